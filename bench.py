@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py — Lanczos iterations/s + CSR SpMV GB/s on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over the synthetic input: LambdaLanczos::run() on the configured matrix with a
+fixed window of `--window` Lanczos iterations (max_iteration = window; the cost of an iteration grows with k, so the
+window is part of the metric and is printed in `config`).  value = steps * window / time = Lanczos iterations/s of the
+whole job.  With N > 1 the SAME matrix is row-partitioned over the N GPUs (BASELINE config 4) => "scaling": "strong".
+Inputs are synthetic (SURVEY 8d generators), resident in HBM before the timed region starts.
+
+Extra objects on the JSON line: `roofline` (the CSR SpMV kernel: algorithmic bytes / HIP-event time on the stream
+it is launched on, against the 8 TB/s HBM peak), `roofline_orth` (the Gram-Schmidt kernels of the timed windows) and
+`cpu_baseline` (the real reference — or the oracle port — on the host cores of the same machine, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable copy
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c3band", "c2", "c5"],
+                    help="c3: random symmetric CSR n=1e7 nnz=1.5e8 (metric config); c3band: banded variant; "
+                         "c2: 5-pt Laplacian n=1e6; c5: complex torus n=1e6 (Exponentiator)")
+    ap.add_argument("--n", type=int, default=0, help="override the problem size (grid side for c2/c5)")
+    ap.add_argument("--window", type=int, default=100, help="Lanczos iterations per step (max_iteration)")
+    ap.add_argument("--spmv-reps", type=int, default=20)
+    ap.add_argument("--cpu-window", type=int, default=10, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--orth-mode", type=int, default=0)
+    ap.add_argument("--tridiag-mode", type=int, default=0)
+    return ap.parse_args()
+
+
+def spmv_bytes(n, nnz, complex_):
+    """Algorithmic bytes of one CSR SpMV: values + int32 columns + int32 row_ptr + x once + y once."""
+    s = 16 if complex_ else 8
+    return (s + 4) * nnz + 4 * (n + 1) + 2 * s * n
+
+
+def iter_bytes_minimal(n, nnz, k, complex_):
+    """B_iter(k) of SURVEY 8d, minimal-pass model: SpMV + s*n*(2k + 9)."""
+    s = 16 if complex_ else 8
+    return spmv_bytes(n, nnz, complex_) + s * n * (2 * k + 9)
+
+
+def main():
+    args = parse_args()
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (gloo); the data plane is RCCL inside the library
+
+        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
+        dist.init_process_group("gloo")
+
+    import lambda_lanczos_amd as L
+    from lambda_lanczos_amd import generators as G
+
+    ctx = L.Context(local_rank)
+    if world > 1:
+        box = [L.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.init_comm(box[0], rank, world)
+
+    # ------------------------------------------------------------ synthetic input, resident in HBM
+    t_gen = time.time()
+    wl = args.workload
+    complex_ = wl == "c5"
+    if wl in ("c3", "c3band"):
+        n = args.n or 10_000_000
+        rb, nl = ctx.partition(n)
+        band = 65536 if wl == "c3band" else 0
+        if band and n < 4 * band:
+            band = max(2, n // 8)
+        csr = G.randsym(n, band=band, row_begin=rb, n_local=nl)
+        find_max, offset = True, 0.0
+        name = "random symmetric CSR n=%d nnz=%d fp64%s" % (n, 15 * n, " (banded +-%d)" % band if band else "")
+    elif wl == "c2":
+        side = args.n or 1000
+        n = side * side
+        rb, nl = ctx.partition(n)
+        csr = G.laplace2d(side, rb, nl)
+        find_max, offset = False, -8.0
+        name = "5-point Laplacian %dx%d fp64" % (side, side)
+    else:
+        side = args.n or 1000
+        n = side * side
+        rb, nl = ctx.partition(n)
+        csr = G.torus(side, rb, nl)
+        find_max, offset = False, 0.0
+        name = "complex Hermitian torus %dx%d" % (side, side)
+    dtype = np.complex128 if complex_ else np.float64
+    nnz_local = int(csr[0][-1])
+    nnz = nnz_local
+    if world > 1:
+        import torch
+
+        t = torch.tensor([nnz_local], dtype=torch.int64)
+        dist.all_reduce(t)
+        nnz = int(t.item())
+    op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
+    init = G.start_vector_fast(nl, 1, dtype, rb)
+    t_gen = time.time() - t_gen
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        import torch
+
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------ SpMV kernel: HIP events on its own stream
+    xd = ctx.to_device(init / np.linalg.norm(init))
+    yd = ctx.empty(nl, dtype)
+    for _ in range(3):
+        L.spmv(op, xd, yd)
+    barrier()
+    ctx.timer_start()
+    for _ in range(args.spmv_reps):
+        L.spmv(op, xd, yd)
+    spmv_ms = max_over_ranks(ctx.timer_stop() / args.spmv_reps)
+    b_spmv = spmv_bytes(n, nnz, complex_)
+    spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
+
+    # ------------------------------------------------------------ timed steps
+    ctx.set_profiling(True)
+    itern = []
+    stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0}
+
+    if wl == "c5":
+        eng = L.Exponentiator(op, n)
+        eng.max_iteration = args.window
+
+        def step():
+            out, it = eng.run(-1j * 5.0, init)
+            return it
+    else:
+        eng = L.LambdaLanczos(op, n, find_max, 1)
+        eng.max_iteration = args.window
+        eng.eigenvalue_offset = offset
+        eng.orth_mode = args.orth_mode
+        eng.tridiag_mode = args.tridiag_mode
+        eng.init_vector = lambda v, *_: v.__setitem__(slice(None), init)
+
+        def step():
+            eng.run()
+            return eng.getIterationCounts()[0]
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        itern.append(step())
+        for key in stats_acc:
+            stats_acc[key] += eng.last_stats[key]
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    total_iters = int(sum(itern))
+    value = total_iters / elapsed
+
+    # Gram-Schmidt kernels of the timed windows: algorithmic bytes (minimal-pass model minus the SpMV) / device time
+    s = 16 if complex_ else 8
+    if wl == "c5":
+        orth_bytes = sum(s * n * 9 for it in itern for _k in range(1, it + 1))
+    else:
+        orth_bytes = sum(s * n * (2 * k + 9) for it in itern for k in range(1, it + 1))
+    orth_s = max_over_ranks(stats_acc["seconds_orth"])
+    spmv_loop_s = max_over_ranks(stats_acc["seconds_spmv"])
+
+    # ------------------------------------------------------------ CPU baseline (rank 0, N = 1 only; bounded sample)
+    cpu = None
+    if world == 1 and args.cpu_window > 0 and wl != "c5":
+        import oracle_lib
+
+        kind = "reference" if oracle_lib.have_reference() else "port"
+        chk = oracle_lib.reference() if kind == "reference" else oracle_lib.oracle()
+        full = (csr[0], csr[1], csr[2])
+        r = chk.lanczos(full, init, find_max, max_iteration=args.cpu_window, offset=offset, trace=False)
+        cpu_its = r["iter_counts"][0]
+        # the same window on the GPU, for a like-for-like ratio
+        eng.max_iteration = args.cpu_window
+        step()
+        barrier()
+        tg = time.perf_counter()
+        step()
+        barrier()
+        tg = time.perf_counter() - tg
+        cpu = {
+            "value": cpu_its / r["t_total"],
+            "unit": "Lanczos iterations/s",
+            "cores": 1,
+            "kind": kind,
+            "sample": "same matrix and start vector, LambdaLanczos::run with max_iteration=%d (mean k=%.1f), "
+                      "single thread like the reference" % (args.cpu_window, (args.cpu_window + 1) / 2),
+            "seconds": r["t_total"],
+            "spmv_GBps": b_spmv * cpu_its / max(r["t_mv"], 1e-12) / 1e9,
+            "gpu_same_window_value": cpu_its / tg,
+            "host_cores_available": os.cpu_count(),
+        }
+
+    if rank == 0:
+        line = {
+            "metric": "Lanczos iterations/sec (fixed window) + CSR SpMV GB/s, fp64",
+            "value": value,
+            "unit": "Lanczos iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "c128" if complex_ else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": name,
+                "n": n,
+                "nnz": nnz,
+                "step": "one LambdaLanczos::run with max_iteration=%d (k = 1..%d, mean k = %.1f), nroot=%s"
+                        % (args.window, args.window, (args.window + 1) / 2, "n/a" if wl == "c5" else "5"),
+                "iterations_per_step": total_iters / max(args.steps, 1),
+                "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL all-gather of x" % world,
+                "orth_mode": args.orth_mode,
+                "tridiag_mode": args.tridiag_mode,
+            },
+            "spmv": {"GBps": spmv_gbs, "ms": spmv_ms, "algorithmic_bytes": b_spmv, "frac_of_8TBps": spmv_gbs / HBM_PEAK_GBS},
+            "roofline": {
+                "kernel": "spmv_stream",
+                "bound": "hbm",
+                "achieved": spmv_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": spmv_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+            },
+            "roofline_orth": {
+                "kernel": "mdot+maxpy+scale (three-term, Gram-Schmidt, norm, normalise)",
+                "bound": "hbm",
+                "achieved": orth_bytes / max(orth_s, 1e-12) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": orth_bytes / max(orth_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
+                "model": "s*n*(2k+9) bytes per iteration (SURVEY 8d minimal-pass model)",
+            },
+            "phases": {
+                "device_s_operator": spmv_loop_s,
+                "device_s_orth": orth_s,
+                "host_s_tridiag": stats_acc["seconds_host_tridiag"],
+                "wall_s": elapsed,
+                "setup_s_generate_upload": t_gen,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+    op.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

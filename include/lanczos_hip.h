@@ -1,0 +1,281 @@
+/*
+ * lanczos_hip.h — C ABI of the MI355X-native Lanczos hot path (liblanczos_hip.so).
+ *
+ * This is the drop-in boundary.  The reference (mrcdr/lambda-lanczos) is a
+ * header-only C++ template library, so its "FFI" is the template API itself; templates cannot cross a
+ * C ABI, therefore every entry point exists per scalar type with the BLAS-style suffixes
+ *     _d  = double                  (reference T = double)
+ *     _z  = double complex          (reference T = std::complex<double>, interleaved re,im)
+ * and the C++ facade include/lambda_lanczos_hip/{lambda_lanczos,exponentiator}.hpp re-creates
+ * lambda_lanczos::LambdaLanczos<T> / Exponentiator<T> on top by tag dispatch.
+ *
+ * Reference citations (paths relative to the reference repository root):
+ *   LL  = include/lambda_lanczos/lambda_lanczos.hpp
+ *   EX  = include/lambda_lanczos/exponentiator.hpp
+ *   LA  = include/lambda_lanczos/util/linear_algebra.hpp
+ *   TRI = include/lambda_lanczos/lambda_lanczos_tridiagonal_impl.hpp
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = LL_OK, otherwise an LL_ERR_* code; ll_last_error()
+ *     returns a thread-local human readable message for the last failure.  (The reference has no error
+ *     channel at all: asserts only, LA:31, EX:88 — this is additive.)
+ *   - pointers named *_dev are device (HBM) pointers owned by the caller (ll_malloc or any HIP
+ *     allocation on the context's device); pointers named *_host are host memory.
+ *   - all device work is enqueued on the context's HIP stream; primitive calls are asynchronous unless
+ *     they return a host scalar, whole-loop calls (ll_lanczos_run_*, ll_expo_run_*) are synchronous.
+ *   - a context is not re-entrant; one context per host thread (the reference is single threaded and has
+ *     no globals, SURVEY 8b "Threading").
+ *   - no CPU fallback exists: without a HIP device every call that touches the device fails with
+ *     LL_ERR_HIP.
+ */
+#ifndef LANCZOS_HIP_H_
+#define LANCZOS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LL_VERSION_MAJOR 0
+#define LL_VERSION_MINOR 1
+
+enum {
+  LL_OK = 0,
+  LL_ERR_INVALID = 1, /* bad argument */
+  LL_ERR_HIP = 2,     /* a HIP runtime call failed (or no device) */
+  LL_ERR_RCCL = 3,    /* RCCL missing or a collective failed */
+  LL_ERR_ALLOC = 4,   /* out of device or host memory */
+  LL_ERR_CALLBACK = 5 /* a user callback reported failure */
+};
+
+typedef struct ll_context ll_context; /* device + stream + workspace (+ RCCL communicator) */
+typedef struct ll_operator ll_operator; /* the mv_mul plugin: device CSR, host callback or device callback */
+
+/* ------------------------------------------------------------------ library / context */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* ll_last_error(void);
+/* LL_VERSION_MAJOR * 1000 + LL_VERSION_MINOR */
+int ll_version(void);
+
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int ll_ctx_create(int device, ll_context** out);
+/* Same, but enqueue on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * null stream.  The stream stays owned by the caller. */
+int ll_ctx_create_on_stream(int device, void* hip_stream, ll_context** out);
+int ll_ctx_destroy(ll_context* ctx);
+/* hipStream_t of the context (for callers that enqueue their own work in between). */
+int ll_ctx_stream(ll_context* ctx, void** hip_stream_out);
+/* Block until the context's stream is idle. */
+int ll_ctx_synchronize(ll_context* ctx);
+
+/* Device-side stopwatch: HIP events recorded on the context's stream (what bench.py uses to time a kernel on the
+ * stream it is launched on).  ll_timer_stop waits for the stream and returns the milliseconds since ll_timer_start. */
+int ll_timer_start(ll_context* ctx);
+int ll_timer_stop(ll_context* ctx, double* ms_out);
+
+/* ------------------------------------------------------------------ multi-GPU
+ * One process per GPU.  Rows of A and every n-vector are partitioned 1-D and contiguously:
+ * rank r owns rows [row_begin, row_begin + n_local).  The library talks RCCL directly on the context's
+ * stream: one all-gather of the current Lanczos vector per SpMV and small all-reduces for the dot products.
+ * librccl is loaded lazily (dlopen), single-GPU use needs no RCCL. */
+
+#define LL_UNIQUE_ID_BYTES 128
+/* Rank 0 creates the id and distributes the 128 bytes by any host mechanism (MPI, torch.distributed, file). */
+int ll_comm_unique_id(void* id_out_128);
+/* Collective over all ranks. After it, operators created on this context are row shards. */
+int ll_comm_init(ll_context* ctx, const void* id_128, int rank, int n_ranks);
+int ll_comm_rank(ll_context* ctx, int* rank, int* n_ranks);
+/* The contiguous row range of `rank`: shards of ceil(n / n_ranks) rows (the last ones may be shorter or empty).
+ * Sharded operators and vectors must use exactly these ranges (the all-gather relies on equal shard strides). */
+int ll_partition(int64_t n, int n_ranks, int rank, int64_t* row_begin, int64_t* n_local);
+
+/* ------------------------------------------------------------------ device memory helpers */
+
+int ll_malloc(ll_context* ctx, size_t bytes, void** dev_out);
+int ll_free(ll_context* ctx, void* dev);
+int ll_memcpy_h2d(ll_context* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+int ll_memcpy_d2h(ll_context* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
+int ll_memset(ll_context* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* ------------------------------------------------------------------ the operator plugin: mv_mul (LL:120-126, EX:35-41)
+ *
+ * Reference contract: std::function<void(const vector<T>& in, vector<T>& out)>, `out` zero-filled on entry,
+ * accumulate or overwrite both legal, called once per Lanczos iteration with the unit-norm u[k-1]
+ * (LL:242-243, EX:107-108).  Three realisations: */
+
+/* (1) device-resident CSR (the reference ships no sparse format; this is the new operator of SURVEY 8a-a1).
+ *     n_rows_local rows [row_begin, row_begin+n_rows_local) of a global n_cols x n_cols symmetric/Hermitian
+ *     matrix; column indices are GLOBAL.  Single GPU: row_begin = 0, n_rows_local = n_cols.
+ *     row_ptr_host has n_rows_local+1 entries starting at 0.  Host arrays stay owned by the caller and may be
+ *     freed after the call; the library keeps device copies until ll_op_destroy. */
+int ll_op_create_csr_d(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                       const int64_t* row_ptr_host, const int32_t* col_host, const double* val_host,
+                       ll_operator** out);
+int ll_op_create_csr_z(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                       const int64_t* row_ptr_host, const int32_t* col_host, const void* val_host /* re,im pairs */,
+                       ll_operator** out);
+/*     Same with arrays that already live on the device (e.g. built by a GPU generator). */
+int ll_op_create_csr_dev_d(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                           const int64_t* row_ptr_dev, const int32_t* col_dev, const double* val_dev,
+                           ll_operator** out);
+int ll_op_create_csr_dev_z(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                           const int64_t* row_ptr_dev, const int32_t* col_dev, const void* val_dev,
+                           ll_operator** out);
+
+/* (2) unmodified user code: a host callback with exactly the reference semantics; costs one D2H + one H2D
+ *     of an n-vector per iteration (SURVEY 8b "Operator contract").  Return non-zero from fn to abort. */
+typedef int (*ll_host_mv_mul_d)(const double* in, double* out_zeroed, int64_t n, void* user);
+typedef int (*ll_host_mv_mul_z)(const void* in, void* out_zeroed, int64_t n, void* user);
+int ll_op_create_host_d(ll_context* ctx, int64_t n, ll_host_mv_mul_d fn, void* user, ll_operator** out);
+int ll_op_create_host_z(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* user, ll_operator** out);
+
+/* (3) a device callback: fn enqueues out += A*in on `hip_stream` for device pointers (out zero-filled). */
+typedef int (*ll_dev_mv_mul)(const void* in_dev, void* out_dev_zeroed, int64_t n_local, void* hip_stream,
+                             void* user);
+int ll_op_create_device_d(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
+int ll_op_create_device_z(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
+
+int ll_op_destroy(ll_operator* op);
+/* Global dimension n, local rows, nnz held locally (0 for callbacks). */
+int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz_local);
+
+/* ------------------------------------------------------------------ hot-path primitives
+ * Exposed so that every kernel can be parity-checked on its own.  Vectors are LOCAL shards (n_local elements);
+ * scalar results are already all-reduced over ranks when a communicator is attached. */
+
+/* a1+a2+a3: y = A x + offset*x ; if dot_host != NULL also returns Re<x, y> (LL:243-248, EX:108-110).
+ * x_dev is the LOCAL shard (the library all-gathers it when sharded). */
+int ll_spmv_d(ll_context* ctx, ll_operator* op, const double* x_dev, double* y_dev, double offset,
+              double* dot_host);
+int ll_spmv_z(ll_context* ctx, ll_operator* op, const void* x_dev, void* y_dev, double offset, double* dot_host);
+
+/* a3: <a,b> = sum conj(a_i) b_i (LA:29-51; conjugate-linear in the FIRST argument).  out_host: 1 double (_d) or
+ * re,im (_z). */
+int ll_dot_d(ll_context* ctx, int64_t n_local, const double* a_dev, const double* b_dev, double* out_host);
+int ll_dot_z(ll_context* ctx, int64_t n_local, const void* a_dev, const void* b_dev, double* out_host_reim);
+/* a7: sqrt(Re<v,v>), unscaled (LA:56-60). */
+int ll_nrm2_d(ll_context* ctx, int64_t n_local, const double* v_dev, double* out_host);
+int ll_nrm2_z(ll_context* ctx, int64_t n_local, const void* v_dev, double* out_host);
+/* a8: v *= a (LA:65-72) with a real factor; normalize = nrm2 + scal(1/nrm2) (LA:77-80). */
+int ll_scal_d(ll_context* ctx, int64_t n_local, double a, double* v_dev);
+int ll_scal_z(ll_context* ctx, int64_t n_local, double a, void* v_dev);
+int ll_normalize_d(ll_context* ctx, int64_t n_local, double* v_dev, double* norm_host /* nullable */);
+int ll_normalize_z(ll_context* ctx, int64_t n_local, void* v_dev, double* norm_host /* nullable */);
+/* a4: w = w - beta*u_prev - alpha*u_cur (LL:251-257, EX:112-118); u_prev_dev may be NULL (k == 1). */
+int ll_three_term_d(ll_context* ctx, int64_t n_local, double* w_dev, const double* u_prev_dev,
+                    const double* u_cur_dev, double beta, double alpha);
+int ll_three_term_z(ll_context* ctx, int64_t n_local, void* w_dev, const void* u_prev_dev, const void* u_cur_dev,
+                    double beta, double alpha);
+/* a5+a6+a7: orthogonalise w against nb orthonormal vectors stored row-major with leading dimension ld
+ * (vector j at basis_dev + j*ld elements) and return ||w|| afterwards (LA:132-144 at LL:259-262, EX:121,145).
+ * mode: LL_ORTH_CGS_DGKS (default, block classical Gram-Schmidt + a second pass when the norm drops below
+ * 1/sqrt(2)), LL_ORTH_CGS2 (always two passes), LL_ORTH_MGS (sequential dot->axpy per vector: the reference's
+ * operation order, 2*nb launches). h_host (nullable) receives the nb projection coefficients summed over passes
+ * (re,im pairs for _z). */
+enum { LL_ORTH_CGS_DGKS = 0, LL_ORTH_CGS2 = 1, LL_ORTH_MGS = 2 };
+int ll_orth_block_d(ll_context* ctx, int64_t n_local, int64_t nb, const double* basis_dev, int64_t ld,
+                    double* w_dev, int mode, double* norm_host, double* h_host);
+int ll_orth_block_z(ll_context* ctx, int64_t n_local, int64_t nb, const void* basis_dev, int64_t ld, void* w_dev,
+                    int mode, double* norm_host, double* h_host);
+/* a9+a10: out_r = sum_{k=m-1..0} coeff[r*m + k] * basis_k for r < nout in ONE pass over the basis
+ * (LL:51-57: Ritz vectors, real coefficients; EX:166-170: exp(aA)v, coefficients of type T).
+ * coeff_host: nout*m values of type T (re,im pairs for _z).  out_dev: nout vectors, leading dimension ld_out. */
+int ll_gemv_basis_d(ll_context* ctx, int64_t n_local, int64_t m, const double* basis_dev, int64_t ld, int64_t nout,
+                    const double* coeff_host, double* out_dev, int64_t ld_out);
+int ll_gemv_basis_z(ll_context* ctx, int64_t n_local, int64_t m, const void* basis_dev, int64_t ld, int64_t nout,
+                    const double* coeff_host_reim, void* out_dev, int64_t ld_out);
+
+/* a11 (host, TRI:290-361): all eigenvalues (ascending) and optionally eigenvectors (q_host row-major m*m,
+ * row j = eigenvector j, nullable) of the symmetric tridiagonal T(alpha[0..m), beta[0..m-1)).
+ * Returns the reference's "unconverged" count through unconverged_out (nullable). */
+int ll_tridiag_eig(int64_t m, const double* alpha_host, const double* beta_host, double* ev_host, double* q_host,
+                   int64_t* unconverged_out);
+/* k-th smallest eigenvalue (k = 0 .. m-1) by Sturm bisection (TRI:22-88, find_mth_eigenvalue); what
+ * LL_TRIDIAG_BISECT / LL_TRIDIAG_AUTO use for the per-iteration stop test. */
+int ll_tridiag_bisect(int64_t m, const double* alpha_host, const double* beta_host, int64_t k, double* out);
+
+/* ------------------------------------------------------------------ whole-loop entry points */
+
+/* Start-vector hook (LL:133 init_vector): fill the LOCAL shard vec_host[0..n_local) holding global rows
+ * [row_begin, row_begin+n_local) (re,im pairs for _z).  Called once per restart pass (LL:231-232).
+ * NULL = the reference's default: nondeterministic uniform [-1,1] (LL:70-104). */
+typedef void (*ll_init_vector_fn)(void* vec_host, int64_t n_local, int64_t row_begin, void* user);
+
+enum { LL_TRIDIAG_QR = 0, LL_TRIDIAG_BISECT = 1, LL_TRIDIAG_AUTO = 2 };
+
+typedef struct ll_lanczos_params {
+  /* --- the reference's public fields, same meaning and defaults (LL:126-181) --- */
+  int64_t matrix_size;            /* LL:136  global n */
+  int64_t max_iteration;          /* LL:138,206  default n */
+  double eps;                     /* LL:150  default 1e3 * DBL_EPSILON */
+  int32_t find_maximum;           /* LL:153 */
+  int32_t reserved0;
+  int64_t num_eigs;               /* LL:156  default 1 */
+  double eigenvalue_offset;       /* LL:165  default 0 */
+  int64_t num_eigs_per_iteration; /* LL:173  default 5 */
+  int64_t initial_vector_size;    /* LL:181  default 200 — initial capacity (vectors) of the device basis slab */
+  /* --- additions (0 = reference-faithful behaviour) --- */
+  int32_t tridiag_mode;           /* LL_TRIDIAG_*: how the per-iteration Ritz values (LL:267-268) are obtained */
+  int32_t orth_mode;              /* LL_ORTH_* */
+  ll_init_vector_fn init_vector;  /* LL:133 */
+  void* init_user;
+} ll_lanczos_params;
+
+/* Fill *p with the reference defaults for an n x n problem (LL:200-208). */
+int ll_lanczos_params_default(ll_lanczos_params* p, int64_t n, int find_maximum, int64_t num_eigs);
+
+typedef struct ll_run_stats {
+  int64_t n_passes;         /* restart passes = getIterationCounts().size() (LL:412-414) */
+  int64_t total_iterations; /* sum of the iteration counts */
+  double seconds_total;     /* wall time of the call */
+  double seconds_host_tridiag; /* host time spent in the tridiagonal eigen-solver (a11/a12) */
+  double seconds_spmv;      /* device time inside the operator (HIP events; 0 unless ll_ctx_set_profiling) */
+  double seconds_orth;      /* device time in three-term + orthogonalisation + norm + scale */
+  int64_t last_alpha_len;   /* entries written to alpha_out/beta_out (last pass) */
+} ll_run_stats;
+int ll_ctx_set_profiling(ll_context* ctx, int enabled);
+
+/* LambdaLanczos<T>::run(eigenvalues, eigenvectors) (LL:330-366): restart loop + EigenPairManager semantics.
+ *   eigvals_host   : num_eigs doubles, comparator order (descending for find_maximum, else ascending; LL:362-365)
+ *   eigvecs_host   : num_eigs * n_local values of T, row-major, LOCAL shard of each eigenvector (nullable)
+ *   n_found        : number of pairs returned (<= num_eigs)
+ *   iter_counts    : capacity iter_cap entries (getIterationCounts, LL:412); nullable
+ *   alpha_out/beta_out : optional traces of the LAST pass (capacity max_iteration each); nullable
+ */
+int ll_lanczos_run_d(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals_host,
+                     double* eigvecs_host, int64_t* n_found, int64_t* iter_counts, int64_t iter_cap,
+                     double* alpha_out, double* beta_out, ll_run_stats* stats);
+int ll_lanczos_run_z(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals_host,
+                     void* eigvecs_host, int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out,
+                     double* beta_out, ll_run_stats* stats);
+
+typedef struct ll_expo_params {
+  /* the reference's public fields (EX:41-71) */
+  int64_t matrix_size;         /* EX:44 */
+  int64_t max_iteration;       /* EX:46,81  default n */
+  double eps;                  /* EX:58  default 1e2 * DBL_EPSILON */
+  int32_t full_orthogonalize;  /* EX:63  default false */
+  int32_t orth_mode;           /* LL_ORTH_* used when full_orthogonalize */
+  int64_t initial_vector_size; /* EX:71  default 200 */
+} ll_expo_params;
+int ll_expo_params_default(ll_expo_params* p, int64_t n);
+
+/* Exponentiator<T>::run(a, input, output) (EX:87-173): output = exp(a*A) input; returns the iteration count
+ * through itern_out.  input/output are LOCAL shards in host memory (n_local values of T). */
+int ll_expo_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const double* input_host,
+                  double* output_host, int64_t* itern_out, ll_run_stats* stats);
+int ll_expo_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                  const void* input_host, void* output_host, int64_t* itern_out, ll_run_stats* stats);
+/* Exponentiator<T>::taylor_run (EX:175-210). */
+int ll_expo_taylor_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a,
+                         const double* input_host, double* output_host, int64_t* nterms_out);
+int ll_expo_taylor_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                         const void* input_host, void* output_host, int64_t* nterms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCZOS_HIP_H_ */

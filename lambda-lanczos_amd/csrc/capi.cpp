@@ -1,0 +1,664 @@
+// extern "C" surface of liblanczos_hip.so: declared in include/lanczos_hip.h, which documents every entry point
+// and cites the reference interface it replaces.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdlib>
+#include <limits>
+#include <memory>
+
+#include "engine.hpp"
+
+namespace ll {
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace ll
+
+using namespace ll;
+
+// ---------------------------------------------------------------- context workspace
+static size_t grow(size_t have, size_t want) { return std::max(want, have + have / 2 + 64); }
+
+void ll_context::ensure_partials(size_t doubles) {
+  if (doubles <= partials_cap) return;
+  if (d_partials) LL_HIP(hipFree(d_partials));
+  d_partials = nullptr;
+  partials_cap = grow(partials_cap, doubles);
+  LL_HIP(hipMalloc((void**)&d_partials, partials_cap * sizeof(double)));
+}
+void ll_context::ensure_h(size_t doubles) {
+  if (doubles <= h_cap) return;
+  if (d_h) LL_HIP(hipFree(d_h));
+  d_h = nullptr;
+  h_cap = grow(h_cap, doubles);
+  LL_HIP(hipMalloc((void**)&d_h, h_cap * sizeof(double)));
+}
+void ll_context::ensure_pinned(size_t doubles) {
+  if (doubles <= pinned_cap) return;
+  if (h_pinned) LL_HIP(hipHostFree(h_pinned));
+  h_pinned = nullptr;
+  pinned_cap = grow(pinned_cap, doubles);
+  // device-mapped, coherent host memory: the publish kernel stores the per-iteration scalars straight into it
+  hipError_t e = hipHostMalloc((void**)&h_pinned, pinned_cap * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    LL_HIP(hipHostMalloc((void**)&h_pinned, pinned_cap * sizeof(double), hipHostMallocDefault));
+  }
+}
+void ll_context::ensure_coeff(size_t bytes) {
+  if (bytes <= coeff_cap) return;
+  if (d_coeff) LL_HIP(hipFree(d_coeff));
+  d_coeff = nullptr;
+  coeff_cap = grow(coeff_cap, bytes);
+  LL_HIP(hipMalloc(&d_coeff, coeff_cap));
+}
+void ll_context::ensure_xfull(size_t bytes) {
+  if (bytes <= xfull_cap) return;
+  if (d_xfull) LL_HIP(hipFree(d_xfull));
+  d_xfull = nullptr;
+  xfull_cap = bytes;
+  LL_HIP(hipMalloc(&d_xfull, xfull_cap));
+}
+void ll_context::sync() { LL_HIP(hipStreamSynchronize(stream)); }
+
+// ---------------------------------------------------------------- exception -> status
+template <typename F> static int guarded(F&& f) {
+  try {
+    f();
+    return LL_OK;
+  } catch (const Failure& e) {
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    set_error("host allocation failed");
+    return LL_ERR_ALLOC;
+  } catch (const std::exception& e) {
+    set_error(std::string("unexpected exception: ") + e.what());
+    return LL_ERR_INVALID;
+  }
+}
+
+static void use(ll_context* ctx) {
+  LL_REQUIRE(ctx != nullptr, "null context");
+  LL_HIP(hipSetDevice(ctx->device));
+}
+
+extern "C" {
+
+const char* ll_last_error(void) { return g_last_error.c_str(); }
+int ll_version(void) { return LL_VERSION_MAJOR * 1000 + LL_VERSION_MINOR; }
+
+static int ctx_create_impl(int device, void* stream, bool own, ll_context** out) {
+  return guarded([&] {
+    LL_REQUIRE(out != nullptr, "null output pointer");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+      set_error(std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                "); this library has no CPU fallback");
+      (void)hipGetLastError();
+      throw Failure{LL_ERR_HIP};
+    }
+    LL_REQUIRE(device >= 0 && device < count, "device index out of range");
+    LL_HIP(hipSetDevice(device));
+    std::unique_ptr<ll_context> c(new ll_context);
+    c->device = device;
+    if (own) {
+      LL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      c->own_stream = true;
+    } else {
+      c->stream = (hipStream_t)stream;
+    }
+    LL_HIP(hipMalloc((void**)&c->d_scal, kScalCount * sizeof(double)));
+    LL_HIP(hipMemset(c->d_scal, 0, kScalCount * sizeof(double)));
+    *out = c.release();
+  });
+}
+int ll_ctx_create(int device, ll_context** out) { return ctx_create_impl(device, nullptr, true, out); }
+int ll_ctx_create_on_stream(int device, void* hip_stream, ll_context** out) {
+  return ctx_create_impl(device, hip_stream, false, out);
+}
+int ll_ctx_destroy(ll_context* ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    comm_destroy(ctx->comm);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_h) (void)hipFree(ctx->d_h);
+    if (ctx->d_scal) (void)hipFree(ctx->d_scal);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_coeff) (void)hipFree(ctx->d_coeff);
+    if (ctx->d_xfull) (void)hipFree(ctx->d_xfull);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+int ll_ctx_stream(ll_context* ctx, void** out) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && out, "null argument");
+    *out = (void*)ctx->stream;
+  });
+}
+int ll_ctx_synchronize(ll_context* ctx) {
+  return guarded([&] {
+    use(ctx);
+    ctx->sync();
+  });
+}
+int ll_ctx_set_profiling(ll_context* ctx, int enabled) {
+  return guarded([&] {
+    LL_REQUIRE(ctx != nullptr, "null context");
+    ctx->profiling = enabled != 0;
+  });
+}
+
+// ---------------------------------------------------------------- device timer (HIP events on the context's stream)
+int ll_timer_start(ll_context* ctx) {
+  return guarded([&] {
+    use(ctx);
+    if (!ctx->t0) {
+      LL_HIP(hipEventCreate(&ctx->t0));
+      LL_HIP(hipEventCreate(&ctx->t1));
+    }
+    LL_HIP(hipEventRecord(ctx->t0, ctx->stream));
+  });
+}
+int ll_timer_stop(ll_context* ctx, double* ms_out) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(ctx->t0 != nullptr && ms_out != nullptr, "timer not started");
+    LL_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    LL_HIP(hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    LL_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    *ms_out = (double)ms;
+  });
+}
+
+// ---------------------------------------------------------------- multi-GPU
+int ll_comm_unique_id(void* id) {
+  return guarded([&] {
+    LL_REQUIRE(id != nullptr, "null id buffer");
+    comm_unique_id(id);
+  });
+}
+int ll_comm_init(ll_context* ctx, const void* id, int rank, int n_ranks) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(id != nullptr, "null id");
+    LL_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank out of range");
+    LL_REQUIRE(ctx->comm == nullptr, "communicator already attached");
+    ctx->comm = comm_create(id, rank, n_ranks, ctx->device);
+    ctx->rank = rank;
+    ctx->nranks = n_ranks;
+  });
+}
+int ll_comm_rank(ll_context* ctx, int* rank, int* n_ranks) {
+  return guarded([&] {
+    LL_REQUIRE(ctx != nullptr, "null context");
+    if (rank) *rank = ctx->rank;
+    if (n_ranks) *n_ranks = ctx->nranks;
+  });
+}
+int ll_partition(int64_t n, int n_ranks, int rank, int64_t* row_begin, int64_t* n_local) {
+  return guarded([&] {
+    LL_REQUIRE(n >= 0 && n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad partition request");
+    const int64_t shard = (n + n_ranks - 1) / n_ranks;
+    const int64_t b = std::min<int64_t>(n, shard * rank), e = std::min<int64_t>(n, shard * (rank + 1));
+    if (row_begin) *row_begin = b;
+    if (n_local) *n_local = e - b;
+  });
+}
+
+// ---------------------------------------------------------------- memory helpers
+int ll_malloc(ll_context* ctx, size_t bytes, void** out) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(out != nullptr, "null output pointer");
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+      set_error(std::string("hipMalloc(") + std::to_string(bytes) + ") failed: " + hipGetErrorString(e));
+      throw Failure{LL_ERR_ALLOC};
+    }
+  });
+}
+int ll_free(ll_context* ctx, void* p) {
+  return guarded([&] {
+    use(ctx);
+    if (p) LL_HIP(hipFree(p));
+  });
+}
+int ll_memcpy_h2d(ll_context* ctx, void* dst, const void* src, size_t bytes) {
+  return guarded([&] {
+    use(ctx);
+    LL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();
+  });
+}
+int ll_memcpy_d2h(ll_context* ctx, void* dst, const void* src, size_t bytes) {
+  return guarded([&] {
+    use(ctx);
+    LL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+  });
+}
+int ll_memset(ll_context* ctx, void* dst, int byte, size_t bytes) {
+  return guarded([&] {
+    use(ctx);
+    LL_HIP(hipMemsetAsync(dst, byte, bytes, ctx->stream));
+  });
+}
+
+// ---------------------------------------------------------------- operators
+extern "C++" {
+namespace {
+
+// SpMV tiles: runs of whole rows with <= kSpmvTileNnz nonzeros and <= kBlock rows; a longer row is alone.
+void build_tiles(const int64_t* rp, int64_t nrows, std::vector<int32_t>& tiles) {
+  tiles.clear();
+  tiles.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t r1 = r;
+    while (r1 < nrows && (r1 - r) < kBlock && rp[r1 + 1] - rp[r] <= kSpmvTileNnz) ++r1;
+    if (r1 == r) r1 = r + 1;
+    tiles.push_back((int32_t)r1);
+    r = r1;
+  }
+}
+
+template <typename T>
+void finish_csr(ll_operator* op, const int64_t* rp_host) {
+  ll_context* ctx = op->ctx;
+  const int64_t nr = op->n_local;
+  std::vector<int32_t> tiles;
+  build_tiles(rp_host, nr, tiles);
+  op->ntiles = (int)tiles.size() - 1;
+  LL_HIP(hipMalloc((void**)&op->d_tile_rows, tiles.size() * sizeof(int32_t)));
+  LL_HIP(hipMemcpy(op->d_tile_rows, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  op->rp64 = op->nnz > (int64_t)0x7fffffff;
+  if (op->rp64) {
+    LL_HIP(hipMalloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int64_t)));
+    LL_HIP(hipMemcpy(op->d_row_ptr, rp_host, (size_t)(nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  } else {
+    std::vector<int32_t> rp32((size_t)nr + 1);
+    for (int64_t i = 0; i <= nr; ++i) rp32[i] = (int32_t)rp_host[i];
+    LL_HIP(hipMalloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int32_t)));
+    LL_HIP(hipMemcpy(op->d_row_ptr, rp32.data(), (size_t)(nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  (void)ctx;
+}
+
+template <typename T>
+void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, const int64_t* rp, const int32_t* ci,
+                const void* va, bool on_device, ll_operator** out) {
+  use(ctx);
+  LL_REQUIRE(out && rp && (ci || nr == 0) && (va || nr == 0), "null argument");
+  LL_REQUIRE(nr >= 0 && nc >= 1 && row_begin >= 0 && row_begin + nr <= nc, "bad shape");
+  LL_REQUIRE(nr < (int64_t)0x7fffffff && nc < (int64_t)0x7fffffff, "dimension exceeds int32 indices");
+  std::vector<int64_t> rp_copy;
+  const int64_t* rp_host = rp;
+  if (on_device) {
+    rp_copy.resize((size_t)nr + 1);
+    LL_HIP(hipMemcpy(rp_copy.data(), rp, (size_t)(nr + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    rp_host = rp_copy.data();
+  }
+  LL_REQUIRE(rp_host[0] == 0, "row_ptr must start at 0");
+  for (int64_t i = 0; i < nr; ++i) LL_REQUIRE(rp_host[i + 1] >= rp_host[i], "row_ptr must be non-decreasing");
+  std::unique_ptr<ll_operator> op(new ll_operator);
+  op->kind = ll_operator::CSR;
+  op->is_complex = scalar_traits<T>::is_complex;
+  op->ctx = ctx;
+  op->n = nc;
+  op->n_local = nr;
+  op->row_begin = row_begin;
+  op->nnz = rp_host[nr];
+  if (ctx->nranks > 1) {
+    op->n_shard = (nc + ctx->nranks - 1) / ctx->nranks;
+    LL_REQUIRE(row_begin == std::min<int64_t>(nc, op->n_shard * ctx->rank) &&
+                   nr == std::min<int64_t>(nc, op->n_shard * (ctx->rank + 1)) - row_begin,
+               "sharded operators must use the ll_partition() row ranges");
+  } else {
+    op->n_shard = nc;
+    LL_REQUIRE(row_begin == 0 && nr == nc, "a single-GPU context needs the whole matrix (row_begin 0, n_rows == n_cols)");
+  }
+  const size_t nnz = (size_t)op->nnz;
+  if (on_device) {
+    op->owns_arrays = false;
+    op->d_col = const_cast<int32_t*>(ci);
+    op->d_val = const_cast<void*>(va);
+  } else {
+    if (!on_device && nnz) {
+      for (size_t p = 0; p < nnz; ++p) LL_REQUIRE(ci[p] >= 0 && ci[p] < nc, "column index out of range");
+    }
+    LL_HIP(hipMalloc((void**)&op->d_col, std::max<size_t>(nnz, 1) * sizeof(int32_t)));
+    LL_HIP(hipMalloc(&op->d_val, std::max<size_t>(nnz, 1) * sizeof(T)));
+    LL_HIP(hipMemcpy(op->d_col, ci, nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    LL_HIP(hipMemcpy(op->d_val, va, nnz * sizeof(T), hipMemcpyHostToDevice));
+  }
+  finish_csr<T>(op.get(), rp_host);
+  *out = op.release();
+}
+
+template <typename T> void create_cb(ll_context* ctx, int64_t n, ll_operator::Kind kind, ll_operator** out) {
+  use(ctx);
+  LL_REQUIRE(out != nullptr && n >= 1, "bad argument");
+  LL_REQUIRE(ctx->nranks == 1, "callback operators are not supported on sharded contexts");
+  ll_operator* op = new ll_operator;
+  op->kind = kind;
+  op->is_complex = scalar_traits<T>::is_complex;
+  op->ctx = ctx;
+  op->n = op->n_local = op->n_shard = n;
+  *out = op;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int ll_op_create_csr_d(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                       const double* va, ll_operator** out) {
+  return guarded([&] { create_csr<double>(ctx, nr, nc, rb, rp, ci, va, false, out); });
+}
+int ll_op_create_csr_z(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                       const void* va, ll_operator** out) {
+  return guarded([&] { create_csr<zc>(ctx, nr, nc, rb, rp, ci, va, false, out); });
+}
+int ll_op_create_csr_dev_d(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const double* va, ll_operator** out) {
+  return guarded([&] { create_csr<double>(ctx, nr, nc, rb, rp, ci, va, true, out); });
+}
+int ll_op_create_csr_dev_z(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const void* va, ll_operator** out) {
+  return guarded([&] { create_csr<zc>(ctx, nr, nc, rb, rp, ci, va, true, out); });
+}
+int ll_op_create_host_d(ll_context* ctx, int64_t n, ll_host_mv_mul_d fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<double>(ctx, n, ll_operator::HOST_CB, out);
+    (*out)->host_d = fn;
+    (*out)->user = user;
+  });
+}
+int ll_op_create_host_z(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<zc>(ctx, n, ll_operator::HOST_CB, out);
+    (*out)->host_z = fn;
+    (*out)->user = user;
+  });
+}
+int ll_op_create_device_d(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<double>(ctx, n, ll_operator::DEV_CB, out);
+    (*out)->dev_fn = fn;
+    (*out)->user = user;
+  });
+}
+int ll_op_create_device_z(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<zc>(ctx, n, ll_operator::DEV_CB, out);
+    (*out)->dev_fn = fn;
+    (*out)->user = user;
+  });
+}
+int ll_op_destroy(ll_operator* op) {
+  return guarded([&] {
+    if (!op) return;
+    if (op->ctx) (void)hipSetDevice(op->ctx->device);
+    if (op->d_row_ptr) (void)hipFree(op->d_row_ptr);
+    if (op->d_tile_rows) (void)hipFree(op->d_tile_rows);
+    if (op->owns_arrays) {
+      if (op->d_col) (void)hipFree(op->d_col);
+      if (op->d_val) (void)hipFree(op->d_val);
+    }
+    delete op;
+  });
+}
+int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr, "null operator");
+    if (n) *n = op->n;
+    if (n_local) *n_local = op->n_local;
+    if (nnz) *nnz = op->nnz;
+  });
+}
+
+// ---------------------------------------------------------------- primitives
+extern "C++" {
+namespace {
+template <typename T> void spmv_impl(ll_context* ctx, ll_operator* op, const T* x, T* y, double offset, double* dot) {
+  use(ctx);
+  LL_REQUIRE(op && op->ctx == ctx && x && y, "bad argument");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  Engine<T> E(ctx, op, op->n_local);
+  E.apply(x, y, offset, dot ? E.S(kScalSpare) : nullptr);
+  if (dot) E.fetch(E.S(kScalSpare), dot, 1);
+}
+template <typename T> void dot_impl(ll_context* ctx, int64_t n, const T* a, const T* b, double* out) {
+  use(ctx);
+  LL_REQUIRE(n >= 0 && a && b && out, "bad argument");
+  Engine<T> E(ctx, nullptr, n);
+  E.dot_dev(a, b, E.S(kScalSpare));
+  E.fetch(E.S(kScalSpare), out, scalar_traits<T>::reals);
+}
+template <typename T> void nrm2_impl(ll_context* ctx, int64_t n, const T* v, double* out) {
+  use(ctx);
+  LL_REQUIRE(n >= 0 && v && out, "bad argument");
+  Engine<T> E(ctx, nullptr, n);
+  E.norm2_dev(v, E.S(kScalSpare));
+  double nn = 0;
+  E.fetch(E.S(kScalSpare), &nn, 1);
+  *out = std::sqrt(nn);
+}
+template <typename T> void normalize_impl(ll_context* ctx, int64_t n, T* v, double* norm_out) {
+  use(ctx);
+  LL_REQUIRE(n >= 0 && v, "bad argument");
+  Engine<T> E(ctx, nullptr, n);
+  E.norm2_dev(v, E.S(kScalSpare));
+  const NormRefs nr = E.plain_norm(E.S(kScalSpare));
+  launch_scale<T>(n, v, 0.0, &nr, ctx->stream);
+  if (norm_out) {
+    double nn = 0;
+    E.fetch(E.S(kScalSpare), &nn, 1);
+    *norm_out = std::sqrt(nn);
+  }
+}
+template <typename T>
+void orth_impl(ll_context* ctx, int64_t n, int64_t nb, const T* basis, int64_t ld, T* w, int mode, double* norm_out,
+               double* h_out) {
+  use(ctx);
+  LL_REQUIRE(n >= 0 && nb >= 0 && w && (basis || nb == 0) && ld >= n, "bad argument");
+  LL_REQUIRE(mode >= LL_ORTH_CGS_DGKS && mode <= LL_ORTH_MGS, "unknown orthogonalisation mode");
+  constexpr int R = scalar_traits<T>::reals;
+  Engine<T> E(ctx, nullptr, n);
+  RunList<T> runs;
+  runs.ld = ld;
+  runs.add(basis, nb);
+  const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
+  double* d_htot = nullptr;
+  if (h_out && nb > 0) LL_HIP(hipMalloc((void**)&d_htot, (size_t)R * nb * sizeof(double)));
+  const NormRefs refs = E.orth(w, runs, mode, no_tt, E.S(kScalScratch), d_htot);
+  ctx->ensure_pinned(16);
+  launch_publish(ctx->h_pinned + 8, nullptr, refs, ctx->stream);
+  ctx->sync();
+  if (norm_out) *norm_out = std::sqrt(ctx->h_pinned[9]);
+  if (d_htot) {
+    LL_HIP(hipMemcpy(h_out, d_htot, (size_t)R * nb * sizeof(double), hipMemcpyDeviceToHost));
+    LL_HIP(hipFree(d_htot));
+  }
+}
+template <typename T>
+void gemv_impl(ll_context* ctx, int64_t n, int64_t m, const T* basis, int64_t ld, int64_t nout, const T* coeff,
+               T* out, int64_t ld_out) {
+  use(ctx);
+  LL_REQUIRE(n >= 0 && m >= 1 && nout >= 1 && basis && coeff && out && ld >= n && ld_out >= n, "bad argument");
+  Engine<T> E(ctx, nullptr, n);
+  RunList<T> runs;
+  runs.ld = ld;
+  runs.add(basis, m);
+  E.gemv(runs, m, (int)nout, coeff, out, ld_out);
+}
+}  // namespace
+}  // extern "C++"
+
+int ll_spmv_d(ll_context* ctx, ll_operator* op, const double* x, double* y, double offset, double* dot) {
+  return guarded([&] { spmv_impl<double>(ctx, op, x, y, offset, dot); });
+}
+int ll_spmv_z(ll_context* ctx, ll_operator* op, const void* x, void* y, double offset, double* dot) {
+  return guarded([&] { spmv_impl<zc>(ctx, op, (const zc*)x, (zc*)y, offset, dot); });
+}
+int ll_dot_d(ll_context* ctx, int64_t n, const double* a, const double* b, double* out) {
+  return guarded([&] { dot_impl<double>(ctx, n, a, b, out); });
+}
+int ll_dot_z(ll_context* ctx, int64_t n, const void* a, const void* b, double* out) {
+  return guarded([&] { dot_impl<zc>(ctx, n, (const zc*)a, (const zc*)b, out); });
+}
+int ll_nrm2_d(ll_context* ctx, int64_t n, const double* v, double* out) {
+  return guarded([&] { nrm2_impl<double>(ctx, n, v, out); });
+}
+int ll_nrm2_z(ll_context* ctx, int64_t n, const void* v, double* out) {
+  return guarded([&] { nrm2_impl<zc>(ctx, n, (const zc*)v, out); });
+}
+int ll_scal_d(ll_context* ctx, int64_t n, double a, double* v) {
+  return guarded([&] {
+    use(ctx);
+    launch_scale<double>(n, v, a, nullptr, ctx->stream);
+  });
+}
+int ll_scal_z(ll_context* ctx, int64_t n, double a, void* v) {
+  return guarded([&] {
+    use(ctx);
+    launch_scale<zc>(n, (zc*)v, a, nullptr, ctx->stream);
+  });
+}
+int ll_normalize_d(ll_context* ctx, int64_t n, double* v, double* norm_out) {
+  return guarded([&] { normalize_impl<double>(ctx, n, v, norm_out); });
+}
+int ll_normalize_z(ll_context* ctx, int64_t n, void* v, double* norm_out) {
+  return guarded([&] { normalize_impl<zc>(ctx, n, (zc*)v, norm_out); });
+}
+int ll_three_term_d(ll_context* ctx, int64_t n, double* w, const double* up, const double* uc, double beta,
+                    double alpha) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(w && uc, "null vector");
+    launch_three_term<double>(n, w, up, uc, beta, alpha, ctx->stream);
+  });
+}
+int ll_three_term_z(ll_context* ctx, int64_t n, void* w, const void* up, const void* uc, double beta, double alpha) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(w && uc, "null vector");
+    launch_three_term<zc>(n, (zc*)w, (const zc*)up, (const zc*)uc, beta, alpha, ctx->stream);
+  });
+}
+int ll_orth_block_d(ll_context* ctx, int64_t n, int64_t nb, const double* basis, int64_t ld, double* w, int mode,
+                    double* norm_out, double* h_out) {
+  return guarded([&] { orth_impl<double>(ctx, n, nb, basis, ld, w, mode, norm_out, h_out); });
+}
+int ll_orth_block_z(ll_context* ctx, int64_t n, int64_t nb, const void* basis, int64_t ld, void* w, int mode,
+                    double* norm_out, double* h_out) {
+  return guarded([&] { orth_impl<zc>(ctx, n, nb, (const zc*)basis, ld, (zc*)w, mode, norm_out, h_out); });
+}
+int ll_gemv_basis_d(ll_context* ctx, int64_t n, int64_t m, const double* basis, int64_t ld, int64_t nout,
+                    const double* coeff, double* out, int64_t ld_out) {
+  return guarded([&] { gemv_impl<double>(ctx, n, m, basis, ld, nout, coeff, out, ld_out); });
+}
+int ll_gemv_basis_z(ll_context* ctx, int64_t n, int64_t m, const void* basis, int64_t ld, int64_t nout,
+                    const double* coeff, void* out, int64_t ld_out) {
+  return guarded([&] { gemv_impl<zc>(ctx, n, m, (const zc*)basis, ld, nout, (const zc*)coeff, (zc*)out, ld_out); });
+}
+int ll_tridiag_eig(int64_t m, const double* alpha, const double* beta, double* ev, double* q, int64_t* unconverged) {
+  return guarded([&] {
+    LL_REQUIRE(m >= 1 && alpha && ev && (beta || m == 1), "bad argument");
+    const int64_t u = tridiag_qr(m, alpha, beta, ev, q);
+    if (unconverged) *unconverged = u;
+  });
+}
+int ll_tridiag_bisect(int64_t m, const double* alpha, const double* beta, int64_t k, double* out) {
+  return guarded([&] {
+    LL_REQUIRE(m >= 1 && alpha && out && k >= 0 && k < m && (beta || m == 1), "bad argument");
+    *out = tridiag_bisect(m, alpha, beta, k);
+  });
+}
+
+// ---------------------------------------------------------------- whole-loop entry points
+int ll_lanczos_params_default(ll_lanczos_params* p, int64_t n, int find_maximum, int64_t num_eigs) {
+  return guarded([&] {
+    LL_REQUIRE(p != nullptr, "null params");
+    std::memset(p, 0, sizeof(*p));
+    p->matrix_size = n;                                           // LL:136
+    p->max_iteration = n;                                         // LL:206
+    p->eps = std::numeric_limits<double>::epsilon() * 1e3;        // LL:150
+    p->find_maximum = find_maximum ? 1 : 0;                       // LL:153
+    p->num_eigs = num_eigs;                                       // LL:156
+    p->eigenvalue_offset = 0.0;                                   // LL:165
+    p->num_eigs_per_iteration = 5;                                // LL:173
+    p->initial_vector_size = 200;                                 // LL:181
+    p->tridiag_mode = LL_TRIDIAG_QR;
+    p->orth_mode = LL_ORTH_CGS_DGKS;
+  });
+}
+int ll_expo_params_default(ll_expo_params* p, int64_t n) {
+  return guarded([&] {
+    LL_REQUIRE(p != nullptr, "null params");
+    std::memset(p, 0, sizeof(*p));
+    p->matrix_size = n;                                           // EX:44
+    p->max_iteration = n;                                         // EX:81
+    p->eps = std::numeric_limits<double>::epsilon() * 1e2;        // EX:58
+    p->full_orthogonalize = 0;                                    // EX:63
+    p->orth_mode = LL_ORTH_CGS_DGKS;
+    p->initial_vector_size = 200;                                 // EX:71
+  });
+}
+
+int ll_lanczos_run_d(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals, double* eigvecs,
+                     int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
+                     ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && eigvals && n_found, "null argument");
+    lanczos_run<double>(ctx, op, *p, eigvals, eigvecs, n_found, iter_counts, iter_cap, alpha_out, beta_out, stats);
+  });
+}
+int ll_lanczos_run_z(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals, void* eigvecs,
+                     int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
+                     ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && eigvals && n_found, "null argument");
+    lanczos_run<zc>(ctx, op, *p, eigvals, (zc*)eigvecs, n_found, iter_counts, iter_cap, alpha_out, beta_out, stats);
+  });
+}
+int ll_expo_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const double* input,
+                  double* output, int64_t* itern, ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && itern, "null argument");
+    expo_run<double>(ctx, op, *p, a, input, output, itern, stats);
+  });
+}
+int ll_expo_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                  const void* input, void* output, int64_t* itern, ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && itern, "null argument");
+    expo_run<zc>(ctx, op, *p, std::complex<double>(a_re, a_im), (const zc*)input, (zc*)output, itern, stats);
+  });
+}
+int ll_expo_taylor_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const double* input,
+                         double* output, int64_t* nterms) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && nterms, "null argument");
+    taylor_run<double>(ctx, op, *p, a, input, output, nterms);
+  });
+}
+int ll_expo_taylor_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                         const void* input, void* output, int64_t* nterms) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && nterms, "null argument");
+    taylor_run<zc>(ctx, op, *p, std::complex<double>(a_re, a_im), (const zc*)input, (zc*)output, nterms);
+  });
+}
+
+}  // extern "C"

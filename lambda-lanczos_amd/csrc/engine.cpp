@@ -1,0 +1,743 @@
+// Host drivers: the device-resident Krylov loop of LambdaLanczos<T>::run (LL:216-366) and Exponentiator<T>::run
+// (EX:87-173).  Everything n-sized stays in HBM; per iteration the host receives four doubles (alpha_k, beta_k^2
+// and two diagnostics) through pinned, device-mapped memory and runs the k x k tridiagonal step (a11/a12) while
+// the device already executes iteration k+1 (lag-1 speculation: a speculative iteration only writes basis slots
+// the results never read, so stopping one iteration "late" on the device is harmless).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <random>
+
+namespace ll {
+
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ================================================================= Basis / RunList
+template <typename T> Basis<T>::~Basis() {
+  for (T* p : chunks) (void)hipFree(p);
+}
+template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_) {
+  ctx = c;
+  n_local = n_local_;
+  ld = ld_;
+  chunk_vecs = chunk_vecs_;
+}
+template <typename T> T* Basis<T>::vec(int64_t k) {
+  const int64_t ci = k / chunk_vecs;
+  while ((int64_t)chunks.size() <= ci) {
+    T* p = nullptr;
+    const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
+    hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e != hipSuccess) {
+      set_error("out of device memory growing the Krylov basis to " + std::to_string((chunks.size() + 1) * chunk_vecs) +
+                " vectors of " + std::to_string(ld * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+      throw Failure{LL_ERR_ALLOC};
+    }
+    chunks.push_back(p);
+  }
+  return chunks[ci] + (k % chunk_vecs) * ld;
+}
+
+template <typename T> std::vector<BasisSegs<T>> RunList<T>::groups(int max_vecs) const {
+  std::vector<BasisSegs<T>> out;
+  BasisSegs<T> cur;
+  cur.nseg = 0;
+  cur.ld = ld;
+  int cur_vecs = 0;
+  auto flush = [&]() {
+    if (cur.nseg > 0) out.push_back(cur);
+    cur.nseg = 0;
+    cur_vecs = 0;
+  };
+  for (auto& r : runs) {
+    const T* base = r.first;
+    int left = r.second;
+    while (left > 0) {
+      if (cur.nseg == kMaxSegs || cur_vecs == max_vecs) flush();
+      const int take = std::min(left, max_vecs - cur_vecs);
+      cur.base[cur.nseg] = base;
+      cur.count[cur.nseg] = take;
+      ++cur.nseg;
+      cur_vecs += take;
+      base += (int64_t)take * ld;
+      left -= take;
+    }
+  }
+  flush();
+  return out;
+}
+
+// ================================================================= Engine
+template <typename T> void Engine<T>::all_reduce(double* d, size_t count) {
+  if (ctx->comm && ctx->nranks > 1) comm_allreduce_sum(ctx->comm, d, count, ctx->stream);
+}
+
+template <typename T> void Engine<T>::fetch(const double* d, double* host, size_t count) {
+  LL_HIP(hipMemcpyAsync(host, d, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LL_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha) {
+  hipStream_t s = ctx->stream;
+  ctx->ensure_partials(kMaxGrid);
+  int nparts = 0;
+  if (op->kind == ll_operator::CSR) {
+    const T* x_full = x_local;
+    if (ctx->comm && ctx->nranks > 1) {
+      // exchange step: every rank needs the whole x for its row block
+      ctx->ensure_xfull((size_t)op->n_shard * ctx->nranks * sizeof(T));
+      comm_allgather(ctx->comm, x_local, ctx->d_xfull, (size_t)op->n_shard * R, s);
+      x_full = (const T*)ctx->d_xfull;
+    }
+    nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+  } else {
+    LL_REQUIRE(!(ctx->comm && ctx->nranks > 1), "callback operators are not supported on sharded contexts");
+    const size_t bytes = (size_t)n_local * sizeof(T);
+    if (op->kind == ll_operator::HOST_CB) {
+      // unmodified user code (LL:120-126): one D2H + one H2D of an n-vector per call
+      op->h_in.resize(bytes);
+      op->h_out.assign(bytes, 0);  // "out" is zero-filled on entry (LL:242, EX:107)
+      LL_HIP(hipMemcpyAsync(op->h_in.data(), x_local, bytes, hipMemcpyDeviceToHost, s));
+      LL_HIP(hipStreamSynchronize(s));
+      int rc = op->is_complex ? op->host_z(op->h_in.data(), op->h_out.data(), n_local, op->user)
+                              : op->host_d((const double*)op->h_in.data(), (double*)op->h_out.data(), n_local,
+                                           op->user);
+      if (rc != 0) {
+        set_error("mv_mul host callback returned " + std::to_string(rc));
+        throw Failure{LL_ERR_CALLBACK};
+      }
+      LL_HIP(hipMemcpyAsync(y, op->h_out.data(), bytes, hipMemcpyHostToDevice, s));
+      LL_HIP(hipStreamSynchronize(s));
+    } else {
+      LL_HIP(hipMemsetAsync(y, 0, bytes, s));
+      int rc = op->dev_fn(x_local, y, n_local, (void*)s, op->user);
+      if (rc != 0) {
+        set_error("mv_mul device callback returned " + std::to_string(rc));
+        throw Failure{LL_ERR_CALLBACK};
+      }
+    }
+    nparts = launch_offset_dot<T>(n_local, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+  }
+  if (d_alpha) {
+    launch_reduce_cols(ctx->d_partials, nparts, 1, d_alpha, nullptr, s);
+    all_reduce(d_alpha, 1);
+  }
+}
+
+template <typename T> void Engine<T>::norm2_dev(const T* v, double* d_out) {
+  ctx->ensure_partials((size_t)kMaxGrid * R);
+  const int grid = launch_dot<T>(n_local, v, v, ctx->d_partials, ctx->stream);
+  ctx->ensure_h(4);
+  if (R == 1) {
+    launch_reduce_cols(ctx->d_partials, grid, 1, d_out, nullptr, ctx->stream);
+  } else {  // real part is column 0
+    launch_reduce_cols(ctx->d_partials, grid, R, ctx->d_h, nullptr, ctx->stream);
+    launch_copy_scalar(d_out, ctx->d_h, ctx->stream);
+  }
+  all_reduce(d_out, 1);
+}
+
+template <typename T> void Engine<T>::dot_dev(const T* a, const T* b, double* d_out) {
+  ctx->ensure_partials((size_t)kMaxGrid * R);
+  const int grid = launch_dot<T>(n_local, a, b, ctx->d_partials, ctx->stream);
+  launch_reduce_cols(ctx->d_partials, grid, R, d_out, nullptr, ctx->stream);
+  all_reduce(d_out, R);
+}
+
+// LDS budget of mdot: 4 waves x ncols doubles <= 48 KiB  =>  ncols <= 1536
+template <typename T> static int max_vecs_per_launch() { return (1536 - 1) / scalar_traits<T>::reals; }
+
+template <typename T>
+NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total) {
+  hipStream_t s = ctx->stream;
+  const int nb = runs.total();
+  const bool sharded = ctx->comm && ctx->nranks > 1;
+  const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
+  ctx->ensure_h((size_t)2 * (R * nb + 2));
+  double* h1 = ctx->d_h;
+  double* h2 = ctx->d_h + (R * nb + 2);
+
+  if (nb == 0) {  // three-term update (if any) + ||w||^2 only
+    BasisSegs<T> none;
+    none.nseg = 0;
+    none.ld = runs.ld;
+    ctx->ensure_partials(kMaxGrid);
+    const int grid = launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, s);
+    launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
+    all_reduce(c + 1, 1);
+    return plain_norm(c + 1);
+  }
+
+  if (mode == LL_ORTH_MGS) {
+    // The reference's operation order (LA:132-144): for every basis vector h = <u,w>; w -= h u, strictly sequential.
+    ctx->ensure_partials((size_t)kMaxGrid * (R + 1));
+    if (tt.u_cur) {
+      BasisSegs<T> none;
+      none.nseg = 0;
+      none.ld = runs.ld;
+      launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, s);
+    }
+    int j = 0, grid = 0;
+    for (auto& r : runs.runs)
+      for (int i = 0; i < r.second; ++i, ++j) {
+        BasisSegs<T> one;
+        one.nseg = 1;
+        one.ld = runs.ld;
+        one.base[0] = r.first + (int64_t)i * runs.ld;
+        one.count[0] = 1;
+        grid = launch_mdot<T>(n_local, w, one, no_tt, nullptr, ctx->d_partials, s);
+        launch_reduce_cols(ctx->d_partials, grid, R + 1, h1 + R * j, S(kScalSpare), s);
+        all_reduce(h1 + R * j, R);
+        grid = launch_maxpy<T>(n_local, w, one, h1 + R * j, nullptr, ctx->d_partials, s);
+      }
+    launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
+    all_reduce(c + 1, 1);
+    if (h_total) LL_HIP(hipMemcpyAsync(h_total, h1, (size_t)R * nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return plain_norm(c + 1);
+  }
+
+  const std::vector<BasisSegs<T>> groups = runs.groups(max_vecs_per_launch<T>());
+  const NormRefs refs{c, c + 1, c + 2, mode == LL_ORTH_CGS2 ? 1 : 0};
+  const NormRefs* pred = mode == LL_ORTH_CGS2 ? nullptr : &refs;
+  auto count_of = [](const BasisSegs<T>& g) {
+    int t = 0;
+    for (int i = 0; i < g.nseg; ++i) t += g.count[i];
+    return t;
+  };
+  size_t max_cols = 1;
+  for (auto& g : groups) max_cols = std::max(max_cols, (size_t)R * count_of(g) + 1);
+  ctx->ensure_partials((size_t)kMaxGrid * max_cols);
+
+  // ---- pass 1: h = U^H w (+ fused three-term update and ||w||^2), then w -= U h (+ fused ||w||^2)
+  int off = 0;
+  for (size_t g = 0; g < groups.size(); ++g) {
+    const int nbg = count_of(groups[g]);
+    const bool last = g + 1 == groups.size();
+    const int grid = launch_mdot<T>(n_local, w, groups[g], g == 0 ? tt : no_tt, nullptr, ctx->d_partials, s);
+    launch_reduce_cols(ctx->d_partials, grid, R * nbg + 1, h1 + R * off, (last && !sharded) ? c : nullptr, s);
+    off += nbg;
+  }
+  if (sharded) {  // one all-reduce for all coefficients and the norm (latency-sized)
+    all_reduce(h1, (size_t)R * nb + 1);
+    launch_copy_scalar(c, h1 + R * nb, s);
+  }
+  off = 0;
+  int grid = 0;
+  for (size_t g = 0; g < groups.size(); ++g) {
+    grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, s);
+    off += count_of(groups[g]);
+  }
+  launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
+  all_reduce(c + 1, 1);
+
+  // ---- pass 2: always (CGS2) or only when ||w|| dropped below ||w_before||/sqrt(2) (DGKS); decided on the device
+  off = 0;
+  for (size_t g = 0; g < groups.size(); ++g) {
+    const int nbg = count_of(groups[g]);
+    const int g2 = launch_mdot<T>(n_local, w, groups[g], no_tt, pred, ctx->d_partials, s);
+    launch_reduce_cols(ctx->d_partials, g2, R * nbg + 1, h2 + R * off, S(kScalSpare), s);
+    off += nbg;
+  }
+  if (sharded) all_reduce(h2, (size_t)R * nb);
+  off = 0;
+  for (size_t g = 0; g < groups.size(); ++g) {
+    grid = launch_maxpy<T>(n_local, w, groups[g], h2 + R * off, pred, ctx->d_partials, s);
+    off += count_of(groups[g]);
+  }
+  launch_reduce_cols(ctx->d_partials, grid, 1, c + 2, nullptr, s);
+  all_reduce(c + 2, 1);
+  if (h_total) {
+    LL_HIP(hipMemcpyAsync(h_total, h1, (size_t)R * nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+    launch_accumulate_h(h_total, h2, R * nb, pred, s);
+  }
+  return refs;
+}
+
+template <typename T>
+void Engine<T>::gemv(const RunList<T>& basis, int64_t m, int nout, const T* coeff_host, T* out, int64_t ld_out) {
+  const std::vector<BasisSegs<T>> groups = basis.groups(512);
+  ctx->ensure_coeff((size_t)nout * m * sizeof(T));
+  LL_HIP(hipMemcpyAsync(ctx->d_coeff, coeff_host, (size_t)nout * m * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  launch_gemv_basis<T>(n_local, m, groups.data(), (int)groups.size(), nout, (const T*)ctx->d_coeff, out, ld_out,
+                       ctx->stream);
+  LL_HIP(hipStreamSynchronize(ctx->stream));  // coeff_host may go away; d_coeff is reused
+}
+
+// ================================================================= helpers shared by the loops
+namespace {
+
+template <typename T> struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  void alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+      throw Failure{LL_ERR_ALLOC};
+    }
+  }
+};
+
+struct EventRing {
+  hipEvent_t ev[4];
+  EventRing() {
+    for (auto& e : ev) LL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  ~EventRing() {
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+struct PhaseTimer {  // optional per-phase device timing (HIP events on the context's stream)
+  bool on;
+  hipStream_t s;
+  std::vector<hipEvent_t> evs;  // triples: start, after operator, end
+  PhaseTimer(bool enabled, hipStream_t st) : on(enabled), s(st) {}
+  ~PhaseTimer() {
+    for (auto e : evs) (void)hipEventDestroy(e);
+  }
+  void mark() {
+    if (!on) return;
+    hipEvent_t e;
+    LL_HIP(hipEventCreate(&e));
+    LL_HIP(hipEventRecord(e, s));
+    evs.push_back(e);
+  }
+  void collect(double& t_op, double& t_rest) {
+    if (!on) return;
+    for (size_t i = 0; i + 3 <= evs.size(); i += 3) {
+      float a = 0, b = 0;
+      if (hipEventElapsedTime(&a, evs[i], evs[i + 1]) == hipSuccess) t_op += a * 1e-3;
+      if (hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]) == hipSuccess) t_rest += b * 1e-3;
+    }
+  }
+};
+
+template <typename T> void default_init(T* v, int64_t n);
+// LL:70-104: std::random_device-seeded mt19937, uniform [-1,1]; complex: both parts.
+template <> void default_init<double>(double* v, int64_t n) {
+  std::random_device dev;
+  std::mt19937 mt(dev());
+  std::uniform_real_distribution<double> r(-1.0, 1.0);
+  for (int64_t i = 0; i < n; ++i) v[i] = r(mt);
+}
+template <> void default_init<zc>(zc* v, int64_t n) {
+  std::random_device dev;
+  std::mt19937 mt(dev());
+  std::uniform_real_distribution<double> r(-1.0, 1.0);
+  for (int64_t i = 0; i < n; ++i) {
+    v[i].re = r(mt);
+    v[i].im = r(mt);
+  }
+}
+
+inline double as_real_coeff(double v, double*) { return v; }
+inline zc as_real_coeff(double v, zc*) { return zc{v, 0.0}; }
+
+int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration) {
+  int64_t want = initial_vector_size > 0 ? initial_vector_size : 200;
+  want = std::min(want, max_iteration + 2);
+  return std::max<int64_t>(want, 4);
+}
+
+}  // namespace
+
+// ================================================================= LambdaLanczos<T>::run
+template <typename T>
+void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, double* eigvals, T* eigvecs,
+                 int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
+                 ll_run_stats* stats) {
+  LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
+  LL_REQUIRE(P.num_eigs >= 1 && P.num_eigs <= P.matrix_size, "num_eigs out of range");
+  LL_REQUIRE(P.max_iteration >= 1, "max_iteration must be >= 1");
+  LL_REQUIRE(P.num_eigs_per_iteration >= 1, "num_eigs_per_iteration must be >= 1");
+  LL_HIP(hipSetDevice(ctx->device));
+  const double t_start = now_s();
+  hipStream_t s = ctx->stream;
+  const int64_t n = op->n, nl = op->n_local;
+  const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
+  const int mode = P.orth_mode;
+  Engine<T> E(ctx, op, nl);
+  constexpr int R = scalar_traits<T>::reals;
+
+  Basis<T> U;
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
+  DevBuf<T> d_locked, d_ritz;
+  if (P.num_eigs > 1) d_locked.alloc((size_t)P.num_eigs * ld);
+  const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
+  d_ritz.alloc((size_t)nroot_max * ld);
+  ctx->ensure_pinned(16);
+  EventRing ring;
+  PhaseTimer timer(ctx->profiling, s);
+
+  // EigenPairManager (EPM:21-80): best num_eigs pairs, ordered by the comparator
+  std::function<bool(double, double)> cmp;
+  if (P.find_maximum) cmp = std::greater<double>(); else cmp = std::less<double>();
+  std::multimap<double, std::vector<T>, std::function<bool(double, double)>> kept(cmp);
+
+  int64_t passes = 0, total_iters = 0;
+  double t_tridiag = 0.0;
+  std::vector<double> alpha, beta;
+  std::vector<T> start((size_t)nl);
+
+  while (true) {  // restart loop LL:334-354
+    const int64_t nroot = std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
+    // ---- start vector (LL:231-234)
+    if (P.init_vector) P.init_vector(start.data(), nl, op->row_begin, P.init_user);
+    else default_init<T>(start.data(), nl);
+    LL_HIP(hipMemcpyAsync(U.vec(0), start.data(), (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+    const int64_t L = (int64_t)kept.size();
+    {
+      int64_t j = 0;
+      for (auto& kv : kept) {  // comparator order, like MapValueIterable (CM:58-74)
+        LL_HIP(hipMemcpyAsync(d_locked.p + j * ld, kv.second.data(), (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+        ++j;
+      }
+    }
+    const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
+    NormRefs refs0;
+    if (L > 0) {
+      RunList<T> lk;
+      lk.ld = ld;
+      lk.add(d_locked.p, L);
+      refs0 = E.orth(U.vec(0), lk, mode, no_tt, E.S(kScalScratch), nullptr);  // LL:233
+    } else {
+      E.norm2_dev(U.vec(0), E.S(kScalScratch) + 1);
+      refs0 = E.plain_norm(E.S(kScalScratch) + 1);
+    }
+    launch_scale<T>(nl, U.vec(0), 0.0, &refs0, s);  // LL:234
+
+    // ---- the Lanczos loop (LL:240-310)
+    alpha.clear();
+    beta.clear();
+    std::vector<double> evs, pevs, all;
+    int64_t itern = P.max_iteration;
+    bool stopped = false;
+    NormRefs refs_prev = refs0;
+
+    auto enqueue = [&](int64_t k) {
+      const int slot = (int)(k % 4);
+      T* x = U.vec(k - 1);
+      T* y = U.vec(k);
+      timer.mark();
+      E.apply(x, y, P.eigenvalue_offset, E.S(kScalAlpha + slot));  // P0-P3
+      timer.mark();
+      const ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // P4
+      RunList<T> runs;
+      runs.ld = ld;
+      runs.add(d_locked.p, L);  // P5
+      runs.add_basis(U, k);     // P6
+      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr);  // ... P7
+      launch_publish(ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), refs, s);
+      LL_HIP(hipEventRecord(ring.ev[slot], s));
+      launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
+      timer.mark();
+      refs_prev = refs;
+    };
+    // host half of iteration j (H1-H4); returns true when the loop must stop after j iterations
+    auto process = [&](int64_t j) -> bool {
+      const int slot = (int)(j % 4);
+      LL_HIP(hipEventSynchronize(ring.ev[slot]));
+      const volatile double* hp = ctx->h_pinned + 4 * slot;
+      const double alpha_j = hp[0], beta2_j = hp[1];
+      alpha.push_back(alpha_j);
+      beta.push_back(std::sqrt(beta2_j));
+      const double t0 = now_s();
+      const int64_t m = (int64_t)alpha.size();
+      const int64_t ncalc = std::min<int64_t>(nroot, m);
+      evs.clear();
+      const bool use_qr = P.tridiag_mode == LL_TRIDIAG_QR || (P.tridiag_mode == LL_TRIDIAG_AUTO && m <= 64);
+      if (use_qr) {
+        all.resize((size_t)m);
+        tridiag_qr(m, alpha.data(), beta.data(), all.data(), nullptr);  // H1 LL:267-268
+        for (int64_t i = 0; i < ncalc; ++i) evs.push_back(P.find_maximum ? all[m - i - 1] : all[i]);  // H2
+      } else {
+        for (int64_t i = 0; i < ncalc; ++i)
+          evs.push_back(tridiag_bisect(m, alpha.data(), beta.data(), P.find_maximum ? m - i - 1 : i));
+      }
+      t_tridiag += now_s() - t0;
+      if (beta.back() < std::numeric_limits<double>::epsilon() * 1e1) return true;  // H3 LL:279-283
+      bool stop = true;  // H4 LL:290-309
+      if (pevs.size() != evs.size()) stop = false;
+      else
+        for (int64_t r = 0; r < nroot; ++r)
+          if (std::abs(evs[r] - pevs[r]) >= std::min(std::abs(evs[r]), std::abs(pevs[r])) * P.eps) { stop = false; break; }
+      if (stop) return true;
+      pevs = evs;
+      return false;
+    };
+
+    for (int64_t k = 1; k <= P.max_iteration; ++k) {
+      enqueue(k);
+      if (k > 1 && process(k - 1)) { itern = k - 1; stopped = true; break; }
+    }
+    if (!stopped) process(P.max_iteration);  // itern stays max_iteration either way (LL:239,312)
+    LL_HIP(hipStreamSynchronize(s));
+
+    // ---- Ritz pairs (LL:312-319, LL:33-62)
+    const int64_t m = (int64_t)alpha.size();  // == itern
+    (void)itern;
+    const int64_t nev = (int64_t)evs.size();
+    std::vector<double> tev((size_t)m), tq((size_t)m * m);
+    {
+      const double t0 = now_s();
+      tridiag_qr(m, alpha.data(), beta.data(), tev.data(), tq.data());  // beta[m-1] is never read (LL:314)
+      t_tridiag += now_s() - t0;
+    }
+    std::vector<T> coeff((size_t)nev * m);
+    for (int64_t r = 0; r < nev; ++r) {
+      const int64_t it = P.find_maximum ? m - r - 1 : r;
+      for (int64_t k = 0; k < m; ++k) coeff[(size_t)r * m + k] = as_real_coeff(tq[(size_t)it * m + k], (T*)nullptr);
+    }
+    RunList<T> basis;
+    basis.ld = ld;
+    basis.add_basis(U, m);
+    E.gemv(basis, m, (int)nev, coeff.data(), d_ritz.p, ld);
+    std::vector<std::vector<T>> xs((size_t)nev, std::vector<T>((size_t)nl));
+    for (int64_t r = 0; r < nev; ++r) {
+      E.norm2_dev(d_ritz.p + r * ld, E.S(kScalScratch) + 1);
+      const NormRefs nr = E.plain_norm(E.S(kScalScratch) + 1);
+      launch_scale<T>(nl, d_ritz.p + r * ld, 0.0, &nr, s);  // LL:58
+      LL_HIP(hipMemcpyAsync(xs[r].data(), d_ritz.p + r * ld, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    LL_HIP(hipStreamSynchronize(s));
+    for (auto& e : evs) e -= P.eigenvalue_offset;  // LL:317-319
+
+    if (passes < iter_cap && iter_counts) iter_counts[passes] = m;
+    ++passes;
+    total_iters += m;
+
+    // ---- EigenPairManager::insertEigenpairs (EPM:52-71)
+    bool nothing_added = true;
+    for (int64_t i = 0; i < nev; ++i) {
+      auto ins = kept.emplace(evs[i], std::move(xs[i]));
+      auto last = kept.end();
+      --last;
+      if ((int64_t)kept.size() > P.num_eigs) {
+        if (ins != last) nothing_added = false;
+        kept.erase(last);
+      } else {
+        nothing_added = false;
+      }
+    }
+    if (nothing_added) break;    // LL:346-348
+    if (P.num_eigs == 1) break;  // LL:350-353
+  }
+
+  int64_t cnt = 0;
+  for (auto& kv : kept) {  // comparator order (LL:356-365)
+    eigvals[cnt] = kv.first;
+    if (eigvecs) std::memcpy(eigvecs + (size_t)cnt * nl, kv.second.data(), (size_t)nl * sizeof(T));
+    ++cnt;
+  }
+  *n_found = cnt;
+  if (alpha_out) std::copy(alpha.begin(), alpha.end(), alpha_out);
+  if (beta_out) std::copy(beta.begin(), beta.end(), beta_out);
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->n_passes = passes;
+    stats->total_iterations = total_iters;
+    stats->seconds_host_tridiag = t_tridiag;
+    stats->last_alpha_len = (int64_t)alpha.size();
+    timer.collect(stats->seconds_spmv, stats->seconds_orth);
+    stats->seconds_total = now_s() - t_start;
+  }
+  (void)R;
+}
+
+template void lanczos_run<double>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, double*, int64_t*,
+                                  int64_t*, int64_t, double*, double*, ll_run_stats*);
+template void lanczos_run<zc>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, zc*, int64_t*, int64_t*,
+                              int64_t, double*, double*, ll_run_stats*);
+
+// ================================================================= Exponentiator<T>::run
+namespace {
+inline void from_std(double v, double* o) { *o = v; }
+inline void from_std(std::complex<double> v, zc* o) { o->re = v.real(); o->im = v.imag(); }
+inline double conj_h(double v) { return v; }
+inline std::complex<double> conj_h(std::complex<double> v) { return std::conj(v); }
+}  // namespace
+
+template <typename T>
+void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typename host_scalar<T>::type a,
+              const T* input, T* output, int64_t* itern_out, ll_run_stats* stats) {
+  typedef typename host_scalar<T>::type H;
+  LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
+  LL_REQUIRE(P.max_iteration >= 1, "max_iteration must be >= 1");
+  LL_HIP(hipSetDevice(ctx->device));
+  const double t_start = now_s();
+  hipStream_t s = ctx->stream;
+  const int64_t nl = op->n_local;
+  const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
+  Engine<T> E(ctx, op, nl);
+  Basis<T> U;
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
+  ctx->ensure_pinned(16);
+  EventRing ring;
+  PhaseTimer timer(ctx->profiling, s);
+  double t_tridiag = 0.0;
+
+  // u[0] = input / ||input||  (EX:100-101); ||input|| is kept for the output scaling (EX:165)
+  LL_HIP(hipMemcpyAsync(U.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+  E.norm2_dev(U.vec(0), E.S(kScalScratch) + 1);
+  double in_norm2 = 0.0;
+  E.fetch(E.S(kScalScratch) + 1, &in_norm2, 1);
+  const double in_norm = std::sqrt(in_norm2);
+  NormRefs refs_prev = E.plain_norm(E.S(kScalScratch) + 1);
+  launch_scale<T>(nl, U.vec(0), 0.0, &refs_prev, s);
+
+  std::vector<double> alpha, beta, ev, p;
+  std::vector<H> coeff, coeff_prev;
+  int64_t itern = P.max_iteration;
+  bool stopped = false;
+
+  auto enqueue = [&](int64_t k) {
+    const int slot = (int)(k % 4);
+    T* x = U.vec(k - 1);
+    T* y = U.vec(k);
+    timer.mark();
+    E.apply(x, y, 0.0, E.S(kScalAlpha + slot));  // EX:107-110
+    timer.mark();
+    const ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // EX:112-118
+    RunList<T> runs;
+    runs.ld = ld;
+    if (P.full_orthogonalize) runs.add_basis(U, k);  // EX:120-122
+    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr);  // EX:145
+    launch_publish(ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), refs, s);
+    LL_HIP(hipEventRecord(ring.ev[slot], s));
+    launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
+    timer.mark();
+    refs_prev = refs;
+  };
+  auto process = [&](int64_t j) -> bool {
+    const int slot = (int)(j % 4);
+    LL_HIP(hipEventSynchronize(ring.ev[slot]));
+    const volatile double* hp = ctx->h_pinned + 4 * slot;
+    const double alpha_j = hp[0], beta2_j = hp[1];
+    alpha.push_back(alpha_j);
+    const double beta_j = std::sqrt(beta2_j);
+    const double t0 = now_s();
+    const int64_t m = (int64_t)alpha.size();
+    ev.resize((size_t)m);
+    p.resize((size_t)m * m);
+    tridiag_qr(m, alpha.data(), beta.data(), ev.data(), p.data());  // EX:124-126 (beta has m-1 entries here)
+    coeff.assign((size_t)m, H(0));
+    for (int64_t i = 0; i < m; ++i)  // EX:128-133: (exp(a T_m) e_1)_i
+      for (int64_t jj = 0; jj < m; ++jj) coeff[i] += p[(size_t)jj * m + i] * std::exp(a * ev[jj]) * p[(size_t)jj * m];
+    t_tridiag += now_s() - t0;
+    beta.push_back(beta_j);  // EX:145
+    H overlap = H(0);
+    for (size_t i = 0; i < coeff_prev.size(); ++i) overlap += conj_h(coeff_prev[i]) * coeff[i];  // EX:147-150
+    coeff_prev = coeff;  // EX:152
+    return std::abs(1.0 - std::abs(overlap)) < P.eps || beta_j < std::numeric_limits<double>::epsilon();  // EX:154-158
+  };
+
+  for (int64_t k = 1; k <= P.max_iteration; ++k) {
+    enqueue(k);
+    if (k > 1 && process(k - 1)) { itern = k - 1; stopped = true; break; }
+  }
+  if (!stopped) process(P.max_iteration);
+  LL_HIP(hipStreamSynchronize(s));
+
+  // output = ||input|| * sum_l coeff_prev[l] u[l]  (EX:163-170)
+  const int64_t m = (int64_t)coeff_prev.size();
+  std::vector<T> c((size_t)m);
+  for (int64_t l = 0; l < m; ++l) from_std(H(in_norm) * coeff_prev[l], &c[l]);
+  DevBuf<T> d_out;
+  d_out.alloc((size_t)ld);
+  RunList<T> basis;
+  basis.ld = ld;
+  basis.add_basis(U, m);
+  E.gemv(basis, m, 1, c.data(), d_out.p, ld);
+  LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  *itern_out = itern;
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->n_passes = 1;
+    stats->total_iterations = itern;
+    stats->seconds_host_tridiag = t_tridiag;
+    stats->last_alpha_len = (int64_t)alpha.size();
+    timer.collect(stats->seconds_spmv, stats->seconds_orth);
+    stats->seconds_total = now_s() - t_start;
+  }
+}
+template void expo_run<double>(ll_context*, ll_operator*, const ll_expo_params&, double, const double*, double*,
+                               int64_t*, ll_run_stats*);
+template void expo_run<zc>(ll_context*, ll_operator*, const ll_expo_params&, std::complex<double>, const zc*, zc*,
+                           int64_t*, ll_run_stats*);
+
+// ================================================================= Exponentiator<T>::taylor_run (EX:175-210)
+template <typename T>
+void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typename host_scalar<T>::type a,
+                const T* input, T* output, int64_t* nterms_out) {
+  typedef typename host_scalar<T>::type H;
+  LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
+  LL_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int64_t nl = op->n_local;
+  if (a == H(0)) {  // EX:179-182
+    std::memcpy(output, input, (size_t)nl * sizeof(T));
+    *nterms_out = 1;
+    return;
+  }
+  const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
+  Engine<T> E(ctx, op, nl);
+  Basis<T> V;
+  V.init(ctx, nl, ld, 32);
+  LL_HIP(hipMemcpyAsync(V.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+  H factor = 1.0;
+  int64_t terms = 1;
+  for (int64_t k = 1;; ++k) {  // EX:187-195
+    factor *= a / H((double)k);
+    E.apply(V.vec(k - 1), V.vec(k), 0.0, nullptr);
+    ++terms;
+    E.norm2_dev(V.vec(k), E.S(kScalScratch) + 1);
+    double nn = 0.0;
+    E.fetch(E.S(kScalScratch) + 1, &nn, 1);
+    if (std::sqrt(nn) * std::abs(factor) < P.eps) break;
+  }
+  std::vector<T> c((size_t)terms);
+  for (int64_t k = terms; k-- > 0;) {  // backward sum with the reference's factor recurrence (EX:198-206)
+    from_std(factor, &c[k]);
+    factor *= H((double)k) / a;
+  }
+  DevBuf<T> d_out;
+  d_out.alloc((size_t)ld);
+  RunList<T> basis;
+  basis.ld = ld;
+  basis.add_basis(V, terms);
+  E.gemv(basis, terms, 1, c.data(), d_out.p, ld);
+  LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  *nterms_out = terms;
+}
+template void taylor_run<double>(ll_context*, ll_operator*, const ll_expo_params&, double, const double*, double*,
+                                 int64_t*);
+template void taylor_run<zc>(ll_context*, ll_operator*, const ll_expo_params&, std::complex<double>, const zc*, zc*,
+                             int64_t*);
+
+template struct Basis<double>;
+template struct Basis<zc>;
+template struct RunList<double>;
+template struct RunList<zc>;
+template struct Engine<double>;
+template struct Engine<zc>;
+
+}  // namespace ll

@@ -1,0 +1,99 @@
+// Host drivers of the device-resident Lanczos loop (templated on the scalar type; instantiated for double and
+// complex<double> in engine.cpp).  See DESIGN.md for the data flow.
+#pragma once
+
+#include <complex>
+#include <functional>
+#include <map>
+
+#include "ll_internal.hpp"
+
+namespace ll {
+
+// Device scalar area (ctx->d_scal, 64 doubles):
+//   [0..4)    alpha ring (slot = k % 4)
+//   [8..20)   norm triples (c0,c1,c2) ring, slot s at 8 + 3*s
+//   [24..27)  scratch triple for one-off orthogonalisations (start vector, primitives)
+//   [32]      spare scalar (dot results)
+//   [63]      constant 0
+constexpr int kScalAlpha = 0, kScalNorms = 8, kScalScratch = 24, kScalSpare = 32, kScalZero = 63, kScalCount = 64;
+
+// ---------------------------------------------------------------- chunked device slab for the Krylov basis
+// The reference keeps one heap std::vector per Lanczos vector (LL:221,250; reserve(200) LL:181).  Here the basis
+// lives in HBM as a few large slabs of `chunk_vecs` vectors with a common leading dimension (multiple of 256
+// elements => every vector is 2 KiB aligned); slabs are appended on demand and reused across restart passes,
+// nothing is allocated per iteration.
+template <typename T> struct Basis {
+  ll_context* ctx = nullptr;
+  int64_t n_local = 0, ld = 0;
+  int64_t chunk_vecs = 0;
+  std::vector<T*> chunks;
+  ~Basis();
+  void init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_);
+  T* vec(int64_t k);  // pointer to vector k, growing the slab list if needed
+};
+
+// A list of (base, count) runs with a common ld, packed into kernel-argument groups.
+template <typename T> struct RunList {
+  std::vector<std::pair<const T*, int>> runs;
+  int64_t ld = 0;
+  int total() const {
+    int t = 0;
+    for (auto& r : runs) t += r.second;
+    return t;
+  }
+  void add(const T* base, int64_t count) {
+    if (count > 0) runs.emplace_back(base, (int)count);
+  }
+  void add_basis(Basis<T>& b, int64_t count) {  // vectors [0, count)
+    ld = b.ld;
+    for (int64_t k = 0; k < count; k += b.chunk_vecs) add(b.vec(k), std::min(b.chunk_vecs, count - k));
+  }
+  // launch groups of at most kMaxSegs runs and max_vecs vectors each (runs are split when needed)
+  std::vector<BasisSegs<T>> groups(int max_vecs) const;
+};
+
+template <typename T> struct Engine {
+  ll_context* ctx;
+  ll_operator* op;  // may be null for pure BLAS-1 use
+  int64_t n_local;
+  static constexpr int R = scalar_traits<T>::reals;
+
+  Engine(ll_context* c, ll_operator* o, int64_t n_local_) : ctx(c), op(o), n_local(n_local_) {}
+
+  double* S(int i) const { return ctx->d_scal + i; }
+  NormRefs plain_norm(double* c1) const { return NormRefs{S(kScalZero), c1, c1, 0}; }
+
+  // y = A x + offset x ; Re<x,y> -> *d_alpha (device scalar, all-reduced over ranks); d_alpha nullable.
+  void apply(const T* x_local, T* y, double offset, double* d_alpha);
+  // Orthogonalise w against the runs with an optional fused three-term update; c = device triple for the norms.
+  // Returns the NormRefs every consumer must use for ||w|| afterwards.  h_total (device, nullable): R*nb doubles.
+  NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total);
+  // ||v||^2 -> *d_out (device, all-reduced)
+  void norm2_dev(const T* v, double* d_out);
+  // <a,b> -> d_out[0..R) (device, all-reduced)
+  void dot_dev(const T* a, const T* b, double* d_out);
+  void all_reduce(double* d, size_t count);
+  // read `count` doubles from the device scalar area (synchronises the stream)
+  void fetch(const double* d, double* host, size_t count);
+  // out_r = sum_k coeff[r*m+k] u_k  (coeff host, type T)
+  void gemv(const RunList<T>& basis, int64_t m, int nout, const T* coeff_host, T* out, int64_t ld_out);
+};
+
+template <typename T> struct host_scalar;
+template <> struct host_scalar<double> { typedef double type; };
+template <> struct host_scalar<zc> { typedef std::complex<double> type; };
+
+// Whole-loop drivers
+template <typename T>
+void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, double* eigvals, T* eigvecs,
+                 int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
+                 ll_run_stats* stats);
+template <typename T>
+void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typename host_scalar<T>::type a,
+              const T* input, T* output, int64_t* itern_out, ll_run_stats* stats);
+template <typename T>
+void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typename host_scalar<T>::type a,
+                const T* input, T* output, int64_t* nterms_out);
+
+}  // namespace ll

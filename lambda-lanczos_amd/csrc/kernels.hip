@@ -1,0 +1,718 @@
+// Hand-written HIP kernels for gfx950 (MI355X / CDNA4): the device side of the Lanczos hot path.
+//
+// Every kernel here is HBM-bandwidth bound (SpMV 0.15 flop/B, BLAS-1 <= 0.25 flop/B, ridge ~10
+// flop/B), so there is no MFMA anywhere; what matters is coalesced 16-byte-per-lane streaming, enough loads
+// in flight per CU, LDS-staged partial sums, 64-wide wavefront reductions and XCD-aware tile placement.
+//
+// Reference rows:
+//   a1/a2/a3  spmv_stream      mv_mul (LL:243, EX:108) + offset update (LL:244-246) + alpha dot (LL:248, EX:110)
+//   a4        mdot (prologue)  three-term update (LL:251-257, EX:112-118)
+//   a5/a6     mdot + maxpy     Gram-Schmidt against locked + Krylov vectors (LA:132-144 at LL:259-260, EX:121)
+//   a7        maxpy (epilogue) ||w||^2 (LA:56-60 at LL:262, EX:145)
+//   a8        scale            normalize (LA:65-80 at LL:285, EX:160)
+//   a9/a10    gemv_basis       Ritz vectors (LL:51-57) / exp(aA)v (EX:166-170)
+#include "ll_internal.hpp"
+
+namespace ll {
+
+// ---------------------------------------------------------------- scalar helpers
+__device__ __forceinline__ double zero_of(double*) { return 0.0; }
+__device__ __forceinline__ zc zero_of(zc*) { return zc{0.0, 0.0}; }
+template <typename T> __device__ __forceinline__ T zero() { return zero_of((T*)nullptr); }
+
+__device__ __forceinline__ double mul(double a, double b) { return a * b; }
+__device__ __forceinline__ zc mul(zc a, zc b) { return zc{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ double add(double a, double b) { return a + b; }
+__device__ __forceinline__ zc add(zc a, zc b) { return zc{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ double sub(double a, double b) { return a - b; }
+__device__ __forceinline__ zc sub(zc a, zc b) { return zc{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ double rmul(double r, double a) { return r * a; }
+__device__ __forceinline__ zc rmul(double r, zc a) { return zc{r * a.re, r * a.im}; }
+// acc += a*b
+__device__ __forceinline__ void fma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void fma_acc(zc& acc, zc a, zc b) {
+  acc.re = fma(a.re, b.re, fma(-a.im, b.im, acc.re));
+  acc.im = fma(a.re, b.im, fma(a.im, b.re, acc.im));
+}
+// acc += conj(a)*b   (inner product is conjugate-linear in its first argument, LA:41,49)
+__device__ __forceinline__ void cfma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void cfma_acc(zc& acc, zc a, zc b) {
+  acc.re = fma(a.re, b.re, fma(a.im, b.im, acc.re));
+  acc.im = fma(a.re, b.im, fma(-a.im, b.re, acc.im));
+}
+// acc -= h*u
+__device__ __forceinline__ void fnma_acc(double& acc, double h, double u) { acc = fma(-h, u, acc); }
+__device__ __forceinline__ void fnma_acc(zc& acc, zc h, zc u) {
+  acc.re = fma(-h.re, u.re, fma(h.im, u.im, acc.re));
+  acc.im = fma(-h.re, u.im, fma(-h.im, u.re, acc.im));
+}
+__device__ __forceinline__ double abs2(double a) { return a * a; }
+__device__ __forceinline__ double abs2(zc a) { return fma(a.re, a.re, a.im * a.im); }
+// Re(conj(a)*b)
+__device__ __forceinline__ double re_cmul(double a, double b) { return a * b; }
+__device__ __forceinline__ double re_cmul(zc a, zc b) { return fma(a.re, b.re, a.im * b.im); }
+
+__device__ __forceinline__ double shfl_down_d(double v, int delta) { return __shfl_down(v, delta, 64); }
+
+// Sum over the 64 lanes of a wavefront; result valid in lane 0.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += shfl_down_d(v, d);
+  return v;
+}
+__device__ __forceinline__ zc wave_sum(zc v) { return zc{wave_sum(v.re), wave_sum(v.im)}; }
+
+// Sum over the workgroup (kBlock = 4 waves); result valid in thread 0. `scratch` holds >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) v = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  return v;
+}
+
+// DGKS selection (see NormRefs in ll_internal.hpp).
+__device__ __forceinline__ bool second_pass_due(const NormRefs& r) { return r.force2 || *r.c1 < 0.5 * *r.c0; }
+__device__ __forceinline__ double final_norm2(const NormRefs& r) { return second_pass_due(r) ? *r.c2 : *r.c1; }
+
+// XCD-aware persistent tile walk: workgroups with equal (blockIdx % 8) share an XCD (and its L2), so each such
+// class walks one contiguous eighth of the tile range; neighbouring tiles (which gather neighbouring parts of x
+// for banded / stencil matrices) then hit the same L2 instead of being fetched by all eight.
+struct TileWalk {
+  int first, step, end;
+  __device__ TileWalk(int ntiles) {
+    const int xcd = blockIdx.x % kXcds, local = blockIdx.x / kXcds, nlocal = gridDim.x / kXcds;
+    const int per = (ntiles + kXcds - 1) / kXcds;
+    first = xcd * per + local;
+    step = nlocal;
+    end = min(ntiles, (xcd + 1) * per);
+  }
+};
+
+// ================================================================= a1/a2/a3: CSR SpMV ("CSR-stream")
+// One tile = a run of whole rows holding <= kSpmvTileNnz nonzeros (built at upload time).  The workgroup streams
+// the tile's (val, col) pairs with perfectly coalesced loads regardless of the row lengths, multiplies by the
+// gathered x entries and stages the products in LDS; then a power-of-two group of lanes per row folds its
+// segment of the LDS array (wavefront shuffles), adds offset*x_i (a2), writes y_i and accumulates
+// Re(conj(x_i) y_i) (a3) — one pass over the matrix, no separate offset or dot sweeps.
+// A row longer than a tile is its own tile and is folded by the whole workgroup.
+template <typename T, typename RP>
+__global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t* __restrict__ tile_rows,
+                                                      const RP* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                      const T* __restrict__ va, const T* __restrict__ xf,
+                                                      const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                      double* __restrict__ dot_partials) {
+  __shared__ T prod[kSpmvTileNnz];
+  __shared__ double red[4 * scalar_traits<T>::reals];
+  const int tid = threadIdx.x;
+  double dot_acc = 0.0;
+
+  for (TileWalk tw(ntiles); tw.first < tw.end; tw.first += tw.step) {
+    const int t = tw.first;
+    const int r0 = tile_rows[t], r1 = tile_rows[t + 1];
+    const long long p0 = (long long)rp[r0], p1 = (long long)rp[r1];
+    const int cnt = (int)min(p1 - p0, (long long)kSpmvTileNnz + 1);
+    const int nr = r1 - r0;
+    if (nr == 1 && p1 - p0 > kSpmvTileNnz) {
+      // long row: the whole workgroup strides over it
+      T acc = zero<T>();
+      for (long long p = p0 + tid; p < p1; p += kBlock) fma_acc(acc, va[p], xf[ci[p]]);
+      T tot;
+      if constexpr (scalar_traits<T>::is_complex) {
+        double a = block_sum(acc.re, red);
+        double b = block_sum(acc.im, red);
+        tot = zc{a, b};
+      } else {
+        tot = block_sum(acc, red);
+      }
+      if (tid == 0) {
+        const T xi = xl[r0];
+        T yi = add(tot, rmul(offset, xi));
+        y[r0] = yi;
+        dot_acc += re_cmul(xi, yi);
+      }
+      continue;
+    }
+    (void)cnt;
+    const int len = (int)(p1 - p0);
+    __syncthreads();  // previous tile's readers are done with prod[]
+#pragma unroll 4
+    for (int i = tid; i < len; i += kBlock) {
+      const long long p = p0 + i;
+      prod[i] = mul(va[p], xf[ci[p]]);
+    }
+    __syncthreads();
+    // lanes per row: largest power of two with nr * lanes <= kBlock, at most 64
+    int lanes = 1;
+    while (lanes < 64 && nr * (lanes << 1) <= kBlock) lanes <<= 1;
+    const int g = tid / lanes, l = tid - g * lanes;
+    T acc = zero<T>();
+    int row = r0 + g;
+    if (g < nr) {
+      const int a = (int)((long long)rp[row] - p0), b = (int)((long long)rp[row + 1] - p0);
+      for (int i = a + l; i < b; i += lanes) acc = add(acc, prod[i]);
+    }
+    for (int d = lanes >> 1; d > 0; d >>= 1) {
+      if constexpr (scalar_traits<T>::is_complex) {
+        acc.re += __shfl_down(acc.re, d, 64);
+        acc.im += __shfl_down(acc.im, d, 64);
+      } else {
+        acc += __shfl_down(acc, d, 64);
+      }
+    }
+    if (g < nr && l == 0) {
+      const T xi = xl[row];
+      T yi = add(acc, rmul(offset, xi));
+      y[row] = yi;
+      dot_acc += re_cmul(xi, yi);
+    }
+  }
+  if (dot_partials) {
+    double tot = block_sum(dot_acc, red);
+    if (tid == 0) dot_partials[blockIdx.x] = tot;
+  }
+}
+
+static int spmv_grid(int ntiles) {
+  int g = ntiles < kMaxGrid ? ((ntiles + kXcds - 1) / kXcds) * kXcds : kMaxGrid;
+  return g < kXcds ? kXcds : g;
+}
+
+template <typename T>
+int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
+                hipStream_t s) {
+  const int grid = spmv_grid(op.ntiles);
+  if (op.rp64)
+    hipLaunchKernelGGL((spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
+                       (const int64_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,
+                       dot_partials);
+  else
+    hipLaunchKernelGGL((spmv_stream<T, int32_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
+                       (const int32_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,
+                       dot_partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+template int launch_spmv<double>(const ll_operator&, const double*, const double*, double*, double, double*,
+                                 hipStream_t);
+template int launch_spmv<zc>(const ll_operator&, const zc*, const zc*, zc*, double, double*, hipStream_t);
+
+// ================================================================= strip geometry of the BLAS-1 kernels
+// A workgroup owns strips of kBlock*EPT consecutive elements; every lane keeps EPT elements of w in registers as
+// 16-byte pieces, so one strip of one basis vector is EPT*sizeof(T)/16 dwordx4 loads per lane.
+template <typename T> struct strip {
+  static constexpr int EPT = scalar_traits<T>::is_complex ? 4 : 8;  // 64 B per lane per vector
+  static constexpr int ELEMS = kBlock * EPT;
+};
+
+static int strip_grid(int64_t n, int elems) {
+  int64_t strips = (n + elems - 1) / elems;
+  if (strips < 1) strips = 1;
+  return (int)(strips < kMaxGrid ? strips : kMaxGrid);
+}
+
+// Vector pieces: a lane's EPT elements are contiguous (EPT*sizeof(T) = 64 B), lanes are adjacent -> every
+// wave-instruction moves 64 lanes x 16 B of consecutive memory when the strip is full.
+template <typename T> struct piece;
+template <> struct piece<double> {
+  static constexpr int PER = 2;  // doubles per 16 B
+};
+template <> struct piece<zc> {
+  static constexpr int PER = 1;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_strip(const T* __restrict__ v, int64_t base, int64_t n, T (&r)[strip<T>::EPT]) {
+  constexpr int EPT = strip<T>::EPT;
+  const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+  if (i0 + EPT <= n) {
+    if constexpr (scalar_traits<T>::is_complex) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) r[e] = v[i0 + e];
+    } else {
+      const double2* p = reinterpret_cast<const double2*>(v + i0);
+#pragma unroll
+      for (int e = 0; e < EPT / 2; ++e) {
+        double2 q = p[e];
+        r[2 * e] = q.x;
+        r[2 * e + 1] = q.y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) r[e] = (i0 + e < n) ? v[i0 + e] : zero<T>();
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int64_t n,
+                                            const T (&r)[strip<T>::EPT]) {
+  constexpr int EPT = strip<T>::EPT;
+  const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+  if (i0 + EPT <= n) {
+    if constexpr (scalar_traits<T>::is_complex) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) v[i0 + e] = r[e];
+    } else {
+      double2* p = reinterpret_cast<double2*>(v + i0);
+#pragma unroll
+      for (int e = 0; e < EPT / 2; ++e) p[e] = make_double2(r[2 * e], r[2 * e + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (i0 + e < n) v[i0 + e] = r[e];
+  }
+}
+
+// ================================================================= a4 + a5/a6 (projection half): multi-dot
+// h_j = <u_j, w> for every vector of the segments, plus ||w||^2, in ONE pass that keeps the strip of w in
+// registers while the basis strips stream through (k+1 vector reads for k dots instead of 2k).  Optionally the
+// three-term update w = w - beta u_prev - alpha u_cur is applied on the fly (saves 3R 1W of a separate sweep).
+// Per-wave partial sums live in LDS ([4][ncols]) across all strips of the workgroup; each workgroup finally writes
+// one row of ncols partials which reduce_cols folds in a fixed order (deterministic, no atomics).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
+                                                      ThreeTerm<T> tt, NormRefs pred, int predicated,
+                                                      double* __restrict__ partials, int ncols) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];  // [4 waves][ncols]
+  if (predicated && !second_pass_due(pred)) return;  // predicated second DGKS pass
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
+  __syncthreads();
+  double* mine = lds + (size_t)wave * ncols;
+
+  double alpha = 0.0, beta = 0.0;
+  const bool do_tt = tt.u_cur != nullptr;
+  if (do_tt) {
+    alpha = *tt.alpha;
+    if (tt.u_prev) beta = sqrt(final_norm2(tt.prev));
+  }
+
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T wr[EPT];
+    load_strip<T>(w, base, n, wr);
+    if (do_tt) {
+      T uc[EPT];
+      load_strip<T>(tt.u_cur, base, n, uc);
+      if (tt.u_prev) {
+        T up[EPT];
+        load_strip<T>(tt.u_prev, base, n, up);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) wr[e] = sub(sub(wr[e], rmul(beta, up[e])), rmul(alpha, uc[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) wr[e] = sub(wr[e], rmul(alpha, uc[e]));
+      }
+      store_strip<T>(w, base, n, wr);
+    }
+    int col = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+#pragma unroll 2
+      for (int j = 0; j < cnt; ++j) {
+        T ur[EPT];
+        load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
+        T acc = zero<T>();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) cfma_acc(acc, ur[e], wr[e]);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+          if constexpr (scalar_traits<T>::is_complex) {
+            mine[col] += acc.re;
+            mine[col + 1] += acc.im;
+          } else {
+            mine[col] += acc;
+          }
+        }
+        col += R;
+      }
+    }
+    double nn = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) nn += abs2(wr[e]);
+    nn = wave_sum(nn);
+    if (lane == 0) mine[ncols - 1] += nn;
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < ncols; i += kBlock)
+    out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
+}
+
+template <typename T>
+int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
+                double* partials, hipStream_t s) {
+  int nb = 0;
+  for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  const int ncols = scalar_traits<T>::reals * nb + 1;
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
+  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
+  hipLaunchKernelGGL((mdot_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr, pred ? 1 : 0,
+                     partials, ncols);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+template int launch_mdot<double>(int64_t, double*, const BasisSegs<double>&, const ThreeTerm<double>&,
+                                 const NormRefs*, double*, hipStream_t);
+template int launch_mdot<zc>(int64_t, zc*, const BasisSegs<zc>&, const ThreeTerm<zc>&, const NormRefs*, double*,
+                             hipStream_t);
+
+// ================================================================= a5/a6 (update half) + a7: multi-axpy
+// w -= sum_j h_j u_j in one pass (w strip in registers, coefficients broadcast from LDS), then ||w||^2 of the
+// result is accumulated while the strip is still in registers (fuses LA:56-60 at LL:262 into the same sweep).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
+                                                       const double* __restrict__ h, int nb, NormRefs pred,
+                                                       int predicated, double* __restrict__ partials) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];  // [R*nb] coefficients, then 4 doubles of reduction scratch
+  if (predicated && !second_pass_due(pred)) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < R * nb; i += kBlock) lds[i] = h[i];
+  __syncthreads();
+  double* red = lds + R * nb;
+  double nn = 0.0;
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T wr[EPT];
+    load_strip<T>(w, base, n, wr);
+    int col = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+#pragma unroll 2
+      for (int j = 0; j < cnt; ++j) {
+        T ur[EPT];
+        load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
+        T hj;
+        if constexpr (scalar_traits<T>::is_complex) hj = zc{lds[col], lds[col + 1]};
+        else hj = lds[col];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) fnma_acc(wr[e], hj, ur[e]);
+        col += R;
+      }
+    }
+    store_strip<T>(w, base, n, wr);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) nn += abs2(wr[e]);
+  }
+  double tot = block_sum(nn, red);
+  if (tid == 0) partials[blockIdx.x] = tot;
+}
+
+template <typename T>
+int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
+                 hipStream_t s) {
+  int nb = 0;
+  for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  const size_t lds_bytes = ((size_t)scalar_traits<T>::reals * nb + 4) * sizeof(double);
+  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
+  hipLaunchKernelGGL((maxpy_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr, pred ? 1 : 0,
+                     partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+template int launch_maxpy<double>(int64_t, double*, const BasisSegs<double>&, const double*, const NormRefs*, double*,
+                                  hipStream_t);
+template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*, const NormRefs*, double*,
+                              hipStream_t);
+
+// ================================================================= deterministic fold of workgroup partials
+// out[j] = sum_b partials[b*ncols + j].  32 columns x 8 row-groups per workgroup; every column is folded in a
+// fixed order, so results are bit-reproducible run to run (no float atomics anywhere in the library).
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const double* __restrict__ partials, int nparts, int ncols,
+                                                          double* __restrict__ out, double* __restrict__ last_out) {
+  __shared__ double sm[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  double acc = 0.0;
+  if (j < ncols)
+    for (int b = ry; b < nparts; b += 8) acc += partials[(size_t)b * ncols + j];
+  sm[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && j < ncols) {
+    double t = ((sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx])) + ((sm[4][cx] + sm[5][cx]) + (sm[6][cx] + sm[7][cx]));
+    if (j == ncols - 1 && last_out) *last_out = t;
+    else out[j] = t;
+  }
+}
+// single column: one workgroup, 256 lanes
+__global__ __launch_bounds__(256) void reduce_one_kernel(const double* __restrict__ partials, int nparts,
+                                                         double* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 256) acc += partials[b];
+  double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+// last_out (nullable): destination of the LAST column (the ||w||^2 column of mdot) instead of out[ncols-1].
+void launch_reduce_cols(const double* partials, int nparts, int ncols, double* out, double* last_out, hipStream_t s) {
+  if (ncols == 1) {
+    hipLaunchKernelGGL(reduce_one_kernel, dim3(1), dim3(256), 0, s, partials, nparts, last_out ? last_out : out);
+  } else {
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, partials, nparts, ncols, out,
+                       last_out);
+  }
+  LL_HIP(hipGetLastError());
+}
+__global__ void copy_scalar_kernel(double* dst, const double* src) { *dst = *src; }
+void launch_copy_scalar(double* dst, const double* src, hipStream_t s) {
+  hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, s, dst, src);
+  LL_HIP(hipGetLastError());
+}
+
+// ================================================================= a8: scale, plain three-term, dot, offset+dot
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_kernel(int64_t n, T* __restrict__ v, double a, NormRefs norms,
+                                                       int use_norms) {
+  constexpr int EPT = strip<T>::EPT;
+  const double f = use_norms ? 1.0 / sqrt(final_norm2(norms)) : a;  // T(1)/norm, LA:77-80
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T r[EPT];
+    load_strip<T>(v, base, n, r);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) r[e] = rmul(f, r[e]);
+    store_strip<T>(v, base, n, r);
+  }
+}
+template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRefs* norms, hipStream_t s) {
+  const NormRefs nr = norms ? *norms : NormRefs{nullptr, nullptr, nullptr, 0};
+  hipLaunchKernelGGL((scale_kernel<T>), dim3(strip_grid(n, strip<T>::ELEMS)), dim3(kBlock), 0, s, n, v, a, nr,
+                     norms ? 1 : 0);
+  LL_HIP(hipGetLastError());
+}
+template void launch_scale<double>(int64_t, double*, double, const NormRefs*, hipStream_t);
+template void launch_scale<zc>(int64_t, zc*, double, const NormRefs*, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void three_term_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ up,
+                                                            const T* __restrict__ uc, double beta, double alpha) {
+  constexpr int EPT = strip<T>::EPT;
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T wr[EPT], c[EPT];
+    load_strip<T>(w, base, n, wr);
+    load_strip<T>(uc, base, n, c);
+    if (up) {
+      T p[EPT];
+      load_strip<T>(up, base, n, p);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) wr[e] = sub(sub(wr[e], rmul(beta, p[e])), rmul(alpha, c[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) wr[e] = sub(wr[e], rmul(alpha, c[e]));
+    }
+    store_strip<T>(w, base, n, wr);
+  }
+}
+template <typename T>
+void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double beta, double alpha, hipStream_t s) {
+  hipLaunchKernelGGL((three_term_kernel<T>), dim3(strip_grid(n, strip<T>::ELEMS)), dim3(kBlock), 0, s, n, w, u_prev,
+                     u_cur, beta, alpha);
+  LL_HIP(hipGetLastError());
+}
+template void launch_three_term<double>(int64_t, double*, const double*, const double*, double, double, hipStream_t);
+template void launch_three_term<zc>(int64_t, zc*, const zc*, const zc*, double, double, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                     double* __restrict__ partials) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int R = scalar_traits<T>::reals;
+  __shared__ double red[4];
+  T acc = zero<T>();
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T x[EPT], y[EPT];
+    load_strip<T>(a, base, n, x);
+    load_strip<T>(b, base, n, y);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) cfma_acc(acc, x[e], y[e]);
+  }
+  if constexpr (scalar_traits<T>::is_complex) {
+    double re = block_sum(acc.re, red);
+    double im = block_sum(acc.im, red);
+    if (threadIdx.x == 0) {
+      partials[(size_t)blockIdx.x * R] = re;
+      partials[(size_t)blockIdx.x * R + 1] = im;
+    }
+  } else {
+    double v = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v;
+  }
+}
+template <typename T> int launch_dot(int64_t n, const T* a, const T* b, double* partials, hipStream_t s) {
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  hipLaunchKernelGGL((dot_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, a, b, partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+template int launch_dot<double>(int64_t, const double*, const double*, double*, hipStream_t);
+template int launch_dot<zc>(int64_t, const zc*, const zc*, double*, hipStream_t);
+
+// y += offset*x ; Re<x,y> partials — the a2/a3 post-pass for callback operators (CSR fuses it into the SpMV).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void offset_dot_kernel(int64_t n, const T* __restrict__ x, T* __restrict__ y,
+                                                            double offset, double* __restrict__ partials) {
+  constexpr int EPT = strip<T>::EPT;
+  __shared__ double red[4];
+  double acc = 0.0;
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T xr[EPT], yr[EPT];
+    load_strip<T>(x, base, n, xr);
+    load_strip<T>(y, base, n, yr);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      yr[e] = add(yr[e], rmul(offset, xr[e]));
+      acc += re_cmul(xr[e], yr[e]);
+    }
+    store_strip<T>(y, base, n, yr);
+  }
+  double tot = block_sum(acc, red);
+  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = tot;
+}
+template <typename T>
+int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_partials, hipStream_t s) {
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  hipLaunchKernelGGL((offset_dot_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, x, y, offset, dot_partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+template int launch_offset_dot<double>(int64_t, const double*, double*, double, double*, hipStream_t);
+template int launch_offset_dot<zc>(int64_t, const zc*, zc*, double, double*, hipStream_t);
+
+// ================================================================= a9/a10: tall-skinny GEMV over the basis
+// out_r = sum_k coeff[r*m + k] u_k for r < NOUT in one pass over the basis: every basis strip is read once and
+// feeds all NOUT accumulators (the reference re-reads the basis per root, LL:51-57).  Vectors are visited in
+// DESCENDING k like the reference (LL:53).  coeff (type T) is staged in LDS.  accumulate: start from out.
+template <typename T, int NOUT>
+__global__ __launch_bounds__(kBlock) void gemv_basis_kernel(int64_t n, BasisSegs<T> segs, int kofs, int m_total,
+                                                            const T* __restrict__ coeff, T* __restrict__ out,
+                                                            int64_t ld_out, int accumulate) {
+  constexpr int EPT = strip<T>::EPT;
+  extern __shared__ double lds_raw[];
+  T* cs = reinterpret_cast<T*>(lds_raw);  // [NOUT][nb]
+  int nb = 0;
+  for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  for (int i = threadIdx.x; i < NOUT * nb; i += kBlock) {
+    const int r = i / nb, k = i - r * nb;
+    cs[i] = coeff[(size_t)r * m_total + kofs + k];
+  }
+  __syncthreads();
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T acc[NOUT][EPT];
+#pragma unroll
+    for (int r = 0; r < NOUT; ++r) {
+      if (accumulate) load_strip<T>(out + (int64_t)r * ld_out, base, n, acc[r]);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc[r][e] = zero<T>();
+      }
+    }
+    int col = nb;
+    for (int sg = segs.nseg - 1; sg >= 0; --sg) {
+      const T* ub = segs.base[sg];
+      for (int j = segs.count[sg] - 1; j >= 0; --j) {
+        --col;
+        T ur[EPT];
+        load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
+#pragma unroll
+        for (int r = 0; r < NOUT; ++r) {
+          const T c = cs[r * nb + col];
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) fma_acc(acc[r][e], c, ur[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NOUT; ++r) store_strip<T>(out + (int64_t)r * ld_out, base, n, acc[r]);
+  }
+}
+
+template <typename T, int NOUT>
+static void gemv_launch_n(int64_t n, const BasisSegs<T>& segs, int kofs, int m_total, const T* coeff, T* out,
+                          int64_t ld_out, int accumulate, hipStream_t s) {
+  int nb = 0;
+  for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  const size_t lds_bytes = (size_t)NOUT * nb * sizeof(T);
+  hipLaunchKernelGGL((gemv_basis_kernel<T, NOUT>), dim3(strip_grid(n, strip<T>::ELEMS)), dim3(kBlock), lds_bytes, s,
+                     n, segs, kofs, m_total, coeff, out, ld_out, accumulate);
+  LL_HIP(hipGetLastError());
+}
+
+// segs[0..nlaunch) cover vectors 0..m_total-1 in order; launches run from the last group to the first so that the
+// overall accumulation order is k = m-1 .. 0.
+template <typename T>
+void launch_gemv_basis(int64_t n, int64_t m_total, const BasisSegs<T>* segs, int nlaunch, int nout, const T* coeff,
+                       T* out, int64_t ld_out, hipStream_t s) {
+  std::vector<int> kofs(nlaunch);
+  int k = 0;
+  for (int i = 0; i < nlaunch; ++i) {
+    kofs[i] = k;
+    for (int g = 0; g < segs[i].nseg; ++g) k += segs[i].count[g];
+  }
+  for (int r0 = 0; r0 < nout; r0 += 4) {  // up to 4 outputs per pass (register budget: 4*EPT accumulators)
+    const int nr = nout - r0 < 4 ? nout - r0 : 4;
+    for (int i = nlaunch - 1; i >= 0; --i) {
+      const int acc = (i != nlaunch - 1);
+      const T* c = coeff + (size_t)r0 * m_total;
+      T* o = out + (int64_t)r0 * ld_out;
+      switch (nr) {
+        case 1: gemv_launch_n<T, 1>(n, segs[i], kofs[i], (int)m_total, c, o, ld_out, acc, s); break;
+        case 2: gemv_launch_n<T, 2>(n, segs[i], kofs[i], (int)m_total, c, o, ld_out, acc, s); break;
+        case 3: gemv_launch_n<T, 3>(n, segs[i], kofs[i], (int)m_total, c, o, ld_out, acc, s); break;
+        default: gemv_launch_n<T, 4>(n, segs[i], kofs[i], (int)m_total, c, o, ld_out, acc, s); break;
+      }
+    }
+  }
+}
+template void launch_gemv_basis<double>(int64_t, int64_t, const BasisSegs<double>*, int, int, const double*, double*,
+                                        int64_t, hipStream_t);
+template void launch_gemv_basis<zc>(int64_t, int64_t, const BasisSegs<zc>*, int, int, const zc*, zc*, int64_t,
+                                    hipStream_t);
+
+// ================================================================= tiny scalar kernels
+__global__ void accumulate_h_kernel(double* h_acc, const double* h_add, int count, NormRefs pred, int predicated) {
+  if (predicated && !second_pass_due(pred)) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) h_acc[i] += h_add[i];
+}
+void launch_accumulate_h(double* h_acc, const double* h_add, int count, const NormRefs* pred, hipStream_t s) {
+  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
+  hipLaunchKernelGGL(accumulate_h_kernel, dim3((count + 255) / 256), dim3(256), 0, s, h_acc, h_add, count, pr,
+                     pred ? 1 : 0);
+  LL_HIP(hipGetLastError());
+}
+// The only per-iteration device->host traffic of the Lanczos loop: four doubles stored straight into pinned,
+// device-mapped host memory (no DMA copy on the critical path).
+__global__ void publish_kernel(double* out, const double* alpha, NormRefs norms) {
+  out[0] = alpha ? *alpha : 0.0;
+  out[1] = final_norm2(norms);
+  out[2] = *norms.c0;
+  out[3] = *norms.c1;
+}
+void launch_publish(double* out_mapped, const double* alpha, const NormRefs& norms, hipStream_t s) {
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, out_mapped, alpha, norms);
+  LL_HIP(hipGetLastError());
+}
+
+}  // namespace ll

@@ -1,0 +1,212 @@
+// Internal declarations shared by the HIP kernels, the host drivers and the C ABI.
+// Not installed; the public surface is include/lanczos_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lanczos_hip.h"
+
+namespace ll {
+
+// ---------------------------------------------------------------- scalar types
+// Device-side complex<double>: interleaved (re, im), 16-byte aligned so that one element is one dwordx4 access.
+struct alignas(16) zc {
+  double re, im;
+};
+
+template <typename T> struct scalar_traits;
+template <> struct scalar_traits<double> {
+  static constexpr bool is_complex = false;
+  static constexpr int reals = 1;
+};
+template <> struct scalar_traits<zc> {
+  static constexpr bool is_complex = true;
+  static constexpr int reals = 2;
+};
+
+// ---------------------------------------------------------------- errors
+void set_error(const std::string& msg);
+struct Failure {
+  int code;
+};
+
+#define LL_HIP(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      ::ll::set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" + __FILE__ + ":" +     \
+                      std::to_string(__LINE__) + ")");                                                       \
+      throw ::ll::Failure{LL_ERR_HIP};                                                                       \
+    }                                                                                                        \
+  } while (0)
+
+#define LL_REQUIRE(cond, msg)                                                      \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      ::ll::set_error(std::string("invalid argument: ") + (msg));                  \
+      throw ::ll::Failure{LL_ERR_INVALID};                                         \
+    }                                                                              \
+  } while (0)
+
+// ---------------------------------------------------------------- launch geometry
+constexpr int kBlock = 256;          // threads per workgroup (4 waves of 64)
+constexpr int kCUs = 256;            // MI355X
+constexpr int kXcds = 8;
+constexpr int kMaxGrid = kCUs * 8;   // persistent grids: at most 8 workgroups per CU (multiple of 8 XCDs)
+constexpr int kSpmvTileNnz = 1024;   // nonzeros staged through LDS per SpMV tile
+constexpr int kMaxSegs = 8;          // basis segments per multi-dot / multi-axpy launch
+
+// A run of basis vectors stored with a common leading dimension: vector j at base + j*ld.
+template <typename T> struct BasisSegs {
+  const T* base[kMaxSegs];
+  int count[kMaxSegs];
+  int nseg;
+  long long ld;
+};
+
+// The three squared norms of one Gram-Schmidt call, as device scalars:
+//   c0 = ||w||^2 before pass 1, c1 = after pass 1, c2 = after pass 2 (valid only if the second pass ran).
+// The second pass runs iff force2 (LL_ORTH_CGS2) or c1 < c0/2 (DGKS "twice is enough" test); every consumer
+// (scale, next three-term update, host read-back) applies the same selection, so no host round trip is needed
+// to decide it.
+struct NormRefs {
+  const double* c0;
+  const double* c1;
+  const double* c2;
+  int force2;
+};
+
+// ---------------------------------------------------------------- communicator (RCCL, lazily loaded)
+struct Comm;
+Comm* comm_create(const void* id128, int rank, int nranks, int device);
+void comm_destroy(Comm*);
+void comm_unique_id(void* id128);
+void comm_allgather(Comm*, const void* send, void* recv, size_t n_doubles, hipStream_t s);
+void comm_allreduce_sum(Comm*, double* buf, size_t n_doubles, hipStream_t s);
+
+}  // namespace ll
+
+// ---------------------------------------------------------------- context
+struct ll_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  ll::Comm* comm = nullptr;
+  int rank = 0, nranks = 1;
+  bool profiling = false;
+  hipEvent_t t0 = nullptr, t1 = nullptr;  // ll_timer_*
+
+  // workspace, all sized lazily
+  double* d_partials = nullptr;  // [grid][ncols] block partial sums
+  size_t partials_cap = 0;       // doubles
+  double* d_h = nullptr;         // reduced projection coefficients / small scalars
+  size_t h_cap = 0;              // doubles
+  double* d_h2 = nullptr;        // second-pass coefficients
+  double* d_scal = nullptr;      // 64 doubles of device scalars (ring slots, flags)
+  double* h_pinned = nullptr;    // pinned host mirror for scalar read-back
+  size_t pinned_cap = 0;         // doubles
+  void* d_coeff = nullptr;       // coefficient upload area for gemv_basis
+  size_t coeff_cap = 0;          // bytes
+  void* d_xfull = nullptr;       // all-gather target (sharded runs)
+  size_t xfull_cap = 0;          // bytes
+
+  void ensure_partials(size_t doubles);
+  void ensure_h(size_t doubles);
+  void ensure_pinned(size_t doubles);
+  void ensure_coeff(size_t bytes);
+  void ensure_xfull(size_t bytes);
+  void sync();
+};
+
+// ---------------------------------------------------------------- operator
+struct ll_operator {
+  enum Kind { CSR, HOST_CB, DEV_CB } kind = CSR;
+  bool is_complex = false;
+  ll_context* ctx = nullptr;
+  int64_t n = 0, n_local = 0, row_begin = 0, nnz = 0;
+  int64_t n_shard = 0;  // padded shard length used by the all-gather (= n when not sharded)
+  // CSR
+  void* d_row_ptr = nullptr;  // int32 or int64
+  bool rp64 = false;
+  int32_t* d_col = nullptr;
+  void* d_val = nullptr;
+  bool owns_arrays = true;
+  int32_t* d_tile_rows = nullptr;  // ntiles+1 row boundaries of the SpMV tiles
+  int ntiles = 0;
+  // callbacks
+  ll_host_mv_mul_d host_d = nullptr;
+  ll_host_mv_mul_z host_z = nullptr;
+  ll_dev_mv_mul dev_fn = nullptr;
+  void* user = nullptr;
+  std::vector<char> h_in, h_out;  // staging for the host callback
+};
+
+namespace ll {
+
+// ---------------------------------------------------------------- kernel launchers (kernels.hip)
+// All launchers enqueue on `s` and return immediately.
+
+// y = A x_full(cols) + offset * x_local ; dot_partials (nullable): one double per workgroup, Re<x_local, y>.
+// Returns the number of partials written.
+template <typename T>
+int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
+                hipStream_t s);
+// y += offset * x ; partials of Re<x,y> (post-pass for callback operators).
+template <typename T>
+int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_partials, hipStream_t s);
+
+// out[j] = sum_b partials[b*ncols + j], j < ncols (deterministic tree, fixed order).
+// last_out (nullable) redirects the last column.
+void launch_reduce_cols(const double* partials, int nparts, int ncols, double* out, double* last_out, hipStream_t s);
+void launch_copy_scalar(double* dst, const double* src, hipStream_t s);
+
+// Multi-dot with optional fused three-term update.
+//   if (three_term) w = w - beta*u_prev - alpha*u_cur   (u_prev nullable; alpha = *alpha_dev; beta = beta_from(norms_prev))
+//   partial columns: for every basis vector j (segments in order): <u_j, w> (1 or 2 doubles), then ||w||^2.
+// pred (nullable): the launch is a no-op unless the second pass is due according to *pred.
+// Returns grid size (= number of partial rows); ncols = reals*nb + 1.
+template <typename T> struct ThreeTerm {
+  const T* u_prev;      // nullable (k == 1)
+  const T* u_cur;       // nullable => no three-term update
+  const double* alpha;  // device scalar
+  NormRefs prev;        // norms of the previous iteration: beta = sqrt(final norm^2)
+};
+template <typename T>
+int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
+                double* partials, hipStream_t s);
+// w -= sum_j h_j u_j over the segments; partial ||w||^2 per workgroup. h: reals*nb doubles on the device.
+template <typename T>
+int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
+                 hipStream_t s);
+// v *= factor, factor = a (host value) when norms == nullptr, else 1/sqrt(final norm^2).
+template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRefs* norms, hipStream_t s);
+// Plain three-term update with host scalars (primitive API).
+template <typename T>
+void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double beta, double alpha, hipStream_t s);
+// partials of <a,b> (reals per workgroup). Returns grid.
+template <typename T> int launch_dot(int64_t n, const T* a, const T* b, double* partials, hipStream_t s);
+// out_r = sum_{k=m-1..0} coeff[r*m+k] * u_k, r < nout (<= 8); coeff on device, type T. scale (nullable device
+// scalar) multiplies every output.
+template <typename T>
+void launch_gemv_basis(int64_t n, int64_t m, const BasisSegs<T>* segs, int nlaunch, int nout, const T* coeff, T* out,
+                       int64_t ld_out, hipStream_t s);
+// small helpers
+// h_acc += h_add when the second pass ran
+void launch_accumulate_h(double* h_acc, const double* h_add, int count, const NormRefs* pred, hipStream_t s);
+// out_host_visible[0] = *alpha (0 if null), [1] = final norm^2, [2] = c0, [3] = c1  (pinned, device-mapped memory)
+void launch_publish(double* out_mapped, const double* alpha, const NormRefs& norms, hipStream_t s);
+
+// ---------------------------------------------------------------- host tridiagonal solver (tridiag_host.cpp)
+// Flat-array implicit-shift QR; same arithmetic as the reference's (TRI:151-343) so that
+// convergence decisions coincide.  q (nullable) row-major m x m, row j = eigenvector j.
+int64_t tridiag_qr(int64_t m, const double* alpha, const double* beta, double* ev, double* q);
+// k-th smallest eigenvalue by Sturm bisection (TRI:22-88).
+double tridiag_bisect(int64_t m, const double* alpha, const double* beta, int64_t k);
+
+}  // namespace ll

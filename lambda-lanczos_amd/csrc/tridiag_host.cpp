@@ -1,0 +1,150 @@
+// Host-side dense math of the Lanczos loop: eigenvalues / eigenvectors of the k x k
+// Lanczos matrix T_k.  Stays on the CPU by design: it is O(k^2) scalar work on k-sized arrays, overlapped with
+// the device's next iteration by the driver.
+//
+// The arithmetic follows the reference's implicit-shift QR formulation step for step (TRI:151-166 Givens with
+// its two special cases, TRI:181-236 sweep, TRI:252-276 deflation test, TRI:290-343 driver with the 50*nsub
+// stagnation guard, CM:141-174 ascending index sort) because the engine's stop decisions (LL:290-309, EX:154)
+// are taken on these numbers: same operations in the same order => same decisions.  The data layout is ours:
+// flat arrays, one contiguous row-major Q, no per-call vector-of-vectors.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "ll_internal.hpp"
+
+namespace ll {
+
+namespace {
+
+struct Rot {
+  double c, s;
+};
+
+inline Rot make_rot(double x, double z) {  // TRI:151-166
+  if (z == 0.0) return {1.0, 0.0};
+  if (x == 0.0) return {0.0, 1.0};
+  const double h = std::sqrt(x * x + z * z);
+  return {x / h, z / h};
+}
+
+inline double sign_pos0(double v) { return v >= 0.0 ? 1.0 : -1.0; }  // CM:194-201
+
+// Rotate rows r and r+1 of the row-major m x m matrix q (TRI:223-231).
+inline void rotate_rows(double* __restrict__ a, double* __restrict__ b, int64_t m, double c, double s) {
+  for (int64_t j = 0; j < m; ++j) {
+    const double v0 = a[j], v1 = b[j];
+    a[j] = c * v0 + s * v1;
+    b[j] = -s * v0 + c * v1;
+  }
+}
+
+// One Wilkinson-shift sweep on the unreduced block [lo, hi] (inclusive), TRI:196-235.
+void sweep(double* al, double* be, double* q, int64_t m, int64_t lo, int64_t hi) {
+  if (hi == lo) return;
+  const double d = (al[hi - 1] - al[hi]) / (2 * be[hi - 1]);
+  const double mu = al[hi] - be[hi - 1] / (d + sign_pos0(d) * std::sqrt(d * d + 1.0));
+  double x = al[lo] - mu;
+  double s = 1.0, c = 1.0, p = 0.0;
+  for (int64_t i = lo; i < hi; ++i) {
+    const double z = s * be[i];
+    const double bprev = c * be[i];
+    const Rot r = make_rot(x, z);
+    c = r.c;
+    s = r.s;
+    if (i > lo) be[i - 1] = std::sqrt(x * x + z * z);
+    const double u = (al[i + 1] - al[i] + p) * s + 2.0 * c * bprev;
+    al[i] = al[i] - p + s * u;
+    p = s * u;
+    x = c * u - bprev;
+    if (q) rotate_rows(q + i * m, q + (i + 1) * m, m, c, s);
+  }
+  al[hi] = al[hi] - p;
+  be[hi - 1] = x;
+}
+
+}  // namespace
+
+int64_t tridiag_qr(int64_t m, const double* alpha, const double* beta, double* ev, double* q) {
+  if (m <= 0) return 0;
+  std::vector<double> al(alpha, alpha + m), be((size_t)m, 0.0);
+  for (int64_t i = 0; i + 1 < m; ++i) be[i] = beta[i];
+  std::vector<double> qw;
+  double* Q = nullptr;
+  if (q) {
+    qw.assign((size_t)m * m, 0.0);
+    for (int64_t i = 0; i < m; ++i) qw[(size_t)i * m + i] = 1.0;
+    Q = qw.data();
+  }
+  const double half_eps = std::numeric_limits<double>::epsilon() * 0.5;
+  const double tiny = std::numeric_limits<double>::min();
+  int64_t unconverged = 0, hi_prev = m - 1, stall = 1;
+  for (;;) {
+    // deflate negligible couplings over the whole matrix (TRI:257-266) ...
+    for (int64_t i = 0; i + 1 < m; ++i)
+      if (std::abs(be[i]) < std::sqrt(std::abs(al[i]) * std::abs(al[i + 1])) * half_eps + tiny) be[i] = 0.0;
+    // ... and locate the trailing unreduced block (TRI:268-275)
+    int64_t hi = hi_prev;
+    while (hi > 0 && be[hi - 1] == 0.0) --hi;
+    int64_t lo = hi;
+    while (lo > 0 && be[lo - 1] != 0.0) --lo;
+    if (hi == 0) break;
+    sweep(al.data(), be.data(), Q, m, lo, hi);
+    const int64_t nsub = hi - lo + 1;
+    if (hi == hi_prev) {
+      if (stall > nsub * 50) {  // forced deflation (TRI:315-331); callers ignore the count (LL:44,268, EX:126)
+        hi_prev = lo;
+        ++unconverged;
+        stall = 1;
+      } else {
+        ++stall;
+      }
+    } else {
+      stall = 1;
+      hi_prev = hi;
+    }
+  }
+  // ascending index sort (CM:141-174: std::sort on (value, index) pairs comparing values only)
+  std::vector<std::pair<double, size_t>> order;
+  order.reserve((size_t)m);
+  for (int64_t i = 0; i < m; ++i) order.emplace_back(al[i], (size_t)i);
+  std::sort(order.begin(), order.end(),
+            [](const std::pair<double, size_t>& a, const std::pair<double, size_t>& b) { return a.first < b.first; });
+  for (int64_t i = 0; i < m; ++i) ev[i] = order[i].first;
+  if (q)
+    for (int64_t i = 0; i < m; ++i) std::copy(Q + order[i].second * m, Q + (order[i].second + 1) * m, q + i * m);
+  return unconverged;
+}
+
+// Sturm-sequence bisection for the k-th smallest eigenvalue (TRI:22-88).  Used by LL_TRIDIAG_BISECT / _AUTO for
+// the per-iteration stop test only: O(m) per probe instead of O(m^2) for a full QR.
+double tridiag_bisect(int64_t m, const double* al, const double* be, int64_t k) {
+  double r = 0.0;  // Gerschgorin-style bound sum|alpha| + 2 sum|beta| (TRI:52-58)
+  for (int64_t i = 0; i < m; ++i) r += std::abs(al[i]);
+  double rb = 0.0;
+  for (int64_t i = 0; i + 1 < m; ++i) rb += std::abs(be[i]);
+  r += 2 * rb;
+  auto count_below = [&](double c) {
+    double qi = al[0] - c;
+    int64_t cnt = qi < 0 ? 1 : 0;
+    for (int64_t i = 1; i < m; ++i) {
+      qi = al[i] - c - be[i - 1] * be[i - 1] / qi;
+      if (qi < 0) ++cnt;
+      if (qi == 0) qi = std::numeric_limits<double>::epsilon();
+    }
+    return cnt;
+  };
+  double lo = -r, up = r, mid, pmid = std::numeric_limits<double>::max();
+  while (up - lo > std::min(std::abs(lo), std::abs(up)) * std::numeric_limits<double>::epsilon()) {
+    mid = (lo + up) * 0.5;
+    if (count_below(mid) >= k + 1) up = mid; else lo = mid;
+    if (mid == pmid) break;
+    pmid = mid;
+  }
+  return lo;
+}
+
+}  // namespace ll

@@ -1,0 +1,446 @@
+"""Host-side mirror of the reference's public interface for the Krylov hot path, on top of the C ABI.
+
+``LambdaLanczos`` / ``Exponentiator`` keep the reference's names, constructor shapes, public fields, defaults and
+return conventions (include/lambda_lanczos/lambda_lanczos.hpp:109-415, exponentiator.hpp:24-211) so that the parity
+tests read like the reference's own tests; the C++ twin of this file is include/lambda_lanczos_hip/*.hpp.
+All numerics run in liblanczos_hip.so on the GPU — there is no CPU path in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import check, lib, ptr
+
+_EPS = float(np.finfo(np.float64).eps)
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "d"
+    if dtype == np.complex128:
+        return "z"
+    raise TypeError("supported scalar types: float64, complex128 (got %s)" % dtype)
+
+
+class DeviceArray:
+    """A device allocation owned by a Context (freed with it or by .free())."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx, self.shape, self.dtype = ctx, tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().ll_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def at(self, elem_offset):
+        return C.c_void_p(self.ptr + int(elem_offset) * self.dtype.itemsize)
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes <= self.nbytes
+        check(lib().ll_memcpy_h2d(self.ctx.handle, self.ptr, ptr(host), host.nbytes))
+        return self
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().ll_memcpy_d2h(self.ctx.handle, ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib().ll_free(self.ctx.handle, self.ptr))
+            self.ptr = None
+
+
+class Context:
+    """Device + HIP stream + workspace (+ RCCL communicator): ll_context."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        if stream is None:
+            check(lib().ll_ctx_create(int(device), C.byref(h)))
+        else:
+            check(lib().ll_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self.rank, self.n_ranks = 0, 1
+
+    # ---- multi-GPU
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * capi.UNIQUE_ID_BYTES)()
+        check(lib().ll_comm_unique_id(buf))
+        return bytes(buf)
+
+    def init_comm(self, unique_id, rank, n_ranks):
+        buf = (C.c_char * capi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().ll_comm_init(self.handle, buf, int(rank), int(n_ranks)))
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+
+    def partition(self, n):
+        return partition(n, self.n_ranks, self.rank)
+
+    # ---- memory
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, host):
+        host = np.ascontiguousarray(host)
+        return DeviceArray(self, host.shape, host.dtype).set(host)
+
+    def synchronize(self):
+        check(lib().ll_ctx_synchronize(self.handle))
+
+    def stream(self):
+        p = C.c_void_p()
+        check(lib().ll_ctx_stream(self.handle, C.byref(p)))
+        return p.value
+
+    def timer_start(self):
+        check(lib().ll_timer_start(self.handle))
+
+    def timer_stop(self):
+        """Milliseconds of device time on this context's stream since timer_start()."""
+        ms = C.c_double()
+        check(lib().ll_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on):
+        check(lib().ll_ctx_set_profiling(self.handle, 1 if on else 0))
+
+    def close(self):
+        if self.handle:
+            check(lib().ll_ctx_destroy(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def partition(n, n_ranks, rank):
+    """(row_begin, n_local) of `rank` in the 1-D contiguous row partition (ll_partition)."""
+    b, c = C.c_int64(), C.c_int64()
+    check(lib().ll_partition(int(n), int(n_ranks), int(rank), C.byref(b), C.byref(c)))
+    return b.value, c.value
+
+
+# ------------------------------------------------------------------ operators (the mv_mul plugin)
+class _Operator:
+    handle = None
+
+    def info(self):
+        n, nl, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().ll_op_info(self.handle, C.byref(n), C.byref(nl), C.byref(nnz)))
+        return n.value, nl.value, nnz.value
+
+    def close(self):
+        if self.handle:
+            check(lib().ll_op_destroy(self.handle))
+            self.handle = None
+
+
+class CsrOperator(_Operator):
+    """Device-resident CSR matrix (rows [row_begin, row_begin+len(row_ptr)-1) of an n_cols x n_cols operator)."""
+
+    def __init__(self, ctx, row_ptr, col, val, n_cols=None, row_begin=0):
+        self.ctx = ctx
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val)
+        self.dtype = val.dtype
+        sfx = _suffix(val.dtype)
+        n_rows = row_ptr.shape[0] - 1
+        self.n = int(n_cols if n_cols is not None else n_rows)
+        self.n_local, self.row_begin = n_rows, int(row_begin)
+        h = C.c_void_p()
+        fn = getattr(lib(), "ll_op_create_csr_" + sfx)
+        check(fn(ctx.handle, n_rows, self.n, self.row_begin, ptr(row_ptr), ptr(col), ptr(val), C.byref(h)))
+        self.handle = h
+        self.nnz = int(row_ptr[-1])
+
+
+class HostOperator(_Operator):
+    """Unmodified user code: mv_mul(in, out) on numpy arrays, `out` zero-filled on entry (LL:120-126)."""
+
+    def __init__(self, ctx, mv_mul, n, dtype=np.float64):
+        self.ctx, self.n, self.n_local, self.row_begin = ctx, int(n), int(n), 0
+        self.dtype = np.dtype(dtype)
+        self.nnz = 0
+        self.calls = 0
+        sfx = _suffix(dtype)
+        dt = self.dtype
+
+        def tramp(in_p, out_p, nn, _user):
+            try:
+                a = np.frombuffer((C.c_char * (nn * dt.itemsize)).from_address(in_p), dtype=dt)
+                b = np.frombuffer((C.c_char * (nn * dt.itemsize)).from_address(out_p), dtype=dt)
+                self.calls += 1
+                mv_mul(a, b)
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the C ABI as LL_ERR_CALLBACK
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._cb = capi.HOST_MV_FN(tramp)  # keep alive
+        h = C.c_void_p()
+        check(getattr(lib(), "ll_op_create_host_" + sfx)(ctx.handle, self.n, self._cb, None, C.byref(h)))
+        self.handle = h
+
+
+# ------------------------------------------------------------------ primitives (one call per kernel family)
+def spmv(op, x_dev, y_dev, offset=0.0, want_dot=False):
+    d = C.c_double()
+    fn = getattr(lib(), "ll_spmv_" + _suffix(op.dtype))
+    check(fn(op.ctx.handle, op.handle, x_dev.ptr, y_dev.ptr, float(offset), C.byref(d) if want_dot else None))
+    return d.value if want_dot else None
+
+
+def dot(ctx, a_dev, b_dev, n=None):
+    sfx = _suffix(a_dev.dtype)
+    n = int(n if n is not None else a_dev.shape[-1])
+    out = (C.c_double * 2)()
+    check(getattr(lib(), "ll_dot_" + sfx)(ctx.handle, n, a_dev.ptr, b_dev.ptr, out))
+    return out[0] if sfx == "d" else complex(out[0], out[1])
+
+
+def nrm2(ctx, v_dev, n=None):
+    n = int(n if n is not None else v_dev.shape[-1])
+    out = C.c_double()
+    check(getattr(lib(), "ll_nrm2_" + _suffix(v_dev.dtype))(ctx.handle, n, v_dev.ptr, C.byref(out)))
+    return out.value
+
+
+def scal(ctx, a, v_dev, n=None):
+    n = int(n if n is not None else v_dev.shape[-1])
+    check(getattr(lib(), "ll_scal_" + _suffix(v_dev.dtype))(ctx.handle, n, float(a), v_dev.ptr))
+
+
+def normalize(ctx, v_dev, n=None):
+    n = int(n if n is not None else v_dev.shape[-1])
+    out = C.c_double()
+    check(getattr(lib(), "ll_normalize_" + _suffix(v_dev.dtype))(ctx.handle, n, v_dev.ptr, C.byref(out)))
+    return out.value
+
+
+def three_term(ctx, w_dev, u_prev_dev, u_cur_dev, beta, alpha, n=None):
+    n = int(n if n is not None else w_dev.shape[-1])
+    fn = getattr(lib(), "ll_three_term_" + _suffix(w_dev.dtype))
+    check(fn(ctx.handle, n, w_dev.ptr, None if u_prev_dev is None else u_prev_dev.ptr, u_cur_dev.ptr, float(beta),
+             float(alpha)))
+
+
+def orth_block(ctx, basis_dev, nb, ld, w_dev, n, mode=capi.ORTH_CGS_DGKS, want_h=False):
+    sfx = _suffix(w_dev.dtype)
+    norm = C.c_double()
+    h = np.zeros(max(nb, 1) * (2 if sfx == "z" else 1), dtype=np.float64) if want_h else None
+    fn = getattr(lib(), "ll_orth_block_" + sfx)
+    check(fn(ctx.handle, int(n), int(nb), None if basis_dev is None else basis_dev.ptr, int(ld), w_dev.ptr, int(mode),
+             C.byref(norm), ptr(h)))
+    if want_h:
+        hh = h[: nb * (2 if sfx == "z" else 1)]
+        return norm.value, (hh.view(np.complex128) if sfx == "z" else hh)
+    return norm.value
+
+
+def gemv_basis(ctx, basis_dev, m, ld, coeff, out_dev, ld_out, n):
+    sfx = _suffix(out_dev.dtype)
+    coeff = np.ascontiguousarray(coeff, dtype=out_dev.dtype)
+    nout = coeff.shape[0] if coeff.ndim == 2 else 1
+    fn = getattr(lib(), "ll_gemv_basis_" + sfx)
+    check(fn(ctx.handle, int(n), int(m), basis_dev.ptr, int(ld), int(nout), ptr(coeff), out_dev.ptr, int(ld_out)))
+
+
+def tridiag_eig(alpha, beta, want_vectors=True):
+    """Host tridiagonal eigen-solver of the library (a11): ascending eigenvalues, rows of q = eigenvectors."""
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    m = alpha.shape[0]
+    beta = np.ascontiguousarray(np.concatenate([np.asarray(beta, dtype=np.float64), np.zeros(1)]))
+    ev = np.empty(m)
+    q = np.empty((m, m)) if want_vectors else None
+    unc = C.c_int64()
+    check(lib().ll_tridiag_eig(m, ptr(alpha), ptr(beta), ptr(ev), ptr(q), C.byref(unc)))
+    return (ev, q, unc.value) if want_vectors else (ev, unc.value)
+
+
+def tridiag_bisect(alpha, beta, k):
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    beta = np.ascontiguousarray(np.concatenate([np.asarray(beta, dtype=np.float64), np.zeros(1)]))
+    out = C.c_double()
+    check(lib().ll_tridiag_bisect(alpha.shape[0], ptr(alpha), ptr(beta), int(k), C.byref(out)))
+    return out.value
+
+
+# ------------------------------------------------------------------ the engines
+_default_context = None
+
+
+def default_context():
+    global _default_context
+    if _default_context is None:
+        _default_context = Context(0)
+    return _default_context
+
+
+def _as_operator(mv_mul, n, dtype, ctx):
+    if isinstance(mv_mul, _Operator):
+        return mv_mul, False
+    if callable(mv_mul):
+        return HostOperator(ctx, mv_mul, n, dtype), True
+    raise TypeError("mv_mul must be a CsrOperator/HostOperator or a callable mv_mul(in, out)")
+
+
+class LambdaLanczos:
+    """lambda_lanczos::LambdaLanczos<T> (LL:109-415) with device-resident Krylov vectors.
+
+    ``mv_mul`` is a device operator (``CsrOperator``) or — for unmodified user code — a callable
+    ``mv_mul(in_array, out_array)`` with the reference's contract (out zero-filled, accumulate or overwrite).
+    Public fields and defaults are the reference's (LL:126-181)."""
+
+    def __init__(self, mv_mul, matrix_size, find_maximum, num_eigs, dtype=None, context=None):
+        self.context = context or (mv_mul.ctx if isinstance(mv_mul, _Operator) else default_context())
+        self.dtype = np.dtype(dtype if dtype is not None else getattr(mv_mul, "dtype", np.float64))
+        self.mv_mul = mv_mul                                     # LL:126
+        self.init_vector = None                                  # LL:133 (None = random default, LL:70-104)
+        self.matrix_size = int(matrix_size)                      # LL:136
+        self.max_iteration = int(matrix_size)                    # LL:138,206
+        self.eps = _EPS * 1e3                                    # LL:150
+        self.find_maximum = bool(find_maximum)                   # LL:153
+        self.num_eigs = int(num_eigs)                            # LL:156
+        self.eigenvalue_offset = 0.0                             # LL:165
+        self.num_eigs_per_iteration = 5                          # LL:173
+        self.initial_vector_size = 200                           # LL:181
+        # additions (0 = reference-faithful)
+        self.tridiag_mode = capi.TRIDIAG_QR
+        self.orth_mode = capi.ORTH_CGS_DGKS
+        self._iter_counts = []
+        self.last_stats = None
+        self.last_alpha = self.last_beta = None
+
+    def _params(self, num_eigs):
+        p = capi.LanczosParams()
+        check(lib().ll_lanczos_params_default(C.byref(p), self.matrix_size, int(self.find_maximum), int(num_eigs)))
+        p.max_iteration = int(self.max_iteration)
+        p.eps = float(self.eps)
+        p.eigenvalue_offset = float(self.eigenvalue_offset)
+        p.num_eigs_per_iteration = int(self.num_eigs_per_iteration)
+        p.initial_vector_size = int(self.initial_vector_size)
+        p.tridiag_mode = int(self.tridiag_mode)
+        p.orth_mode = int(self.orth_mode)
+        return p
+
+    def run(self, num_eigs=None):
+        """Returns (eigenvalues, eigenvectors): eigenvectors[k] is the k-th eigenvector (LL:330-386).
+        For sharded contexts each rank receives its row shard of every eigenvector."""
+        k = int(self.num_eigs if num_eigs is None else num_eigs)
+        op, owned = _as_operator(self.mv_mul, self.matrix_size, self.dtype, self.context)
+        sfx = _suffix(self.dtype)
+        p = self._params(k)
+        keep = None
+        if self.init_vector is not None:
+            dt, user_fn = self.dtype, self.init_vector
+
+            def tramp(vec_p, n_local, row_begin, _user):
+                v = np.frombuffer((C.c_char * (n_local * dt.itemsize)).from_address(vec_p), dtype=dt)
+                try:
+                    user_fn(v, row_begin)
+                except TypeError:
+                    user_fn(v)  # reference signature init_vector(vec) (LL:133)
+
+            keep = capi.INIT_FN(tramp)
+            p.init_vector = keep
+        n_local = op.n_local
+        vals = np.zeros(k, dtype=np.float64)
+        vecs = np.zeros((k, n_local), dtype=self.dtype)
+        n_found = C.c_int64()
+        cap = 4 * k + 64
+        counts = np.zeros(cap, dtype=np.int64)
+        trace_cap = int(min(self.max_iteration, 1 << 24))
+        alpha = np.zeros(trace_cap)
+        beta = np.zeros(trace_cap)
+        stats = capi.RunStats()
+        try:
+            fn = getattr(lib(), "ll_lanczos_run_" + sfx)
+            check(fn(self.context.handle, op.handle, C.byref(p), ptr(vals), ptr(vecs), C.byref(n_found), ptr(counts),
+                     cap, ptr(alpha), ptr(beta), C.byref(stats)))
+        finally:
+            if owned:
+                op.close()
+        del keep
+        nf = n_found.value
+        self._iter_counts = [int(c) for c in counts[: min(stats.n_passes, cap)]]
+        self.last_stats = stats.as_dict()
+        self.last_alpha, self.last_beta = alpha[: stats.last_alpha_len].copy(), beta[: stats.last_alpha_len].copy()
+        return vals[:nf].copy(), vecs[:nf].copy()
+
+    def run_single(self):
+        """run(eigenvalue, eigenvector): one pair regardless of num_eigs (LL:394-407)."""
+        vals, vecs = self.run(num_eigs=1)
+        return vals[0], vecs[0]
+
+    def getIterationCounts(self):  # noqa: N802 - reference name (LL:412-414)
+        return list(self._iter_counts)
+
+
+class Exponentiator:
+    """lambda_lanczos::Exponentiator<T> (EX:24-211): output = exp(a*A) input by Krylov projection."""
+
+    def __init__(self, mv_mul, matrix_size, dtype=None, context=None):
+        self.context = context or (mv_mul.ctx if isinstance(mv_mul, _Operator) else default_context())
+        self.dtype = np.dtype(dtype if dtype is not None else getattr(mv_mul, "dtype", np.float64))
+        self.mv_mul = mv_mul                                     # EX:41
+        self.matrix_size = int(matrix_size)                      # EX:44
+        self.max_iteration = int(matrix_size)                    # EX:46,81
+        self.eps = _EPS * 1e2                                    # EX:58
+        self.full_orthogonalize = False                          # EX:63
+        self.initial_vector_size = 200                           # EX:71
+        self.orth_mode = capi.ORTH_CGS_DGKS
+        self.last_stats = None
+
+    def _params(self):
+        p = capi.ExpoParams()
+        check(lib().ll_expo_params_default(C.byref(p), self.matrix_size))
+        p.max_iteration = int(self.max_iteration)
+        p.eps = float(self.eps)
+        p.full_orthogonalize = int(bool(self.full_orthogonalize))
+        p.orth_mode = int(self.orth_mode)
+        p.initial_vector_size = int(self.initial_vector_size)
+        return p
+
+    def _call(self, name, a, input, want_stats):
+        op, owned = _as_operator(self.mv_mul, self.matrix_size, self.dtype, self.context)
+        sfx = _suffix(self.dtype)
+        inp = np.ascontiguousarray(input, dtype=self.dtype)
+        assert inp.shape[0] == op.n_local, "input size differs from the (local) matrix size (EX:88)"
+        out = np.zeros_like(inp)
+        it = C.c_int64()
+        p = self._params()
+        stats = capi.RunStats()
+        try:
+            fn = getattr(lib(), name + sfx)
+            args = [self.context.handle, op.handle, C.byref(p)]
+            args += [float(a)] if sfx == "d" else [float(np.real(a)), float(np.imag(a))]
+            args += [ptr(inp), ptr(out), C.byref(it)]
+            if want_stats:
+                args.append(C.byref(stats))
+            check(fn(*args))
+        finally:
+            if owned:
+                op.close()
+        if want_stats:
+            self.last_stats = stats.as_dict()
+        return out, it.value
+
+    def run(self, a, input):
+        """Returns (output, iteration_count) (EX:87-173)."""
+        return self._call("ll_expo_run_", a, input, True)
+
+    def taylor_run(self, a, input):
+        """Returns (output, number_of_terms) (EX:175-210)."""
+        return self._call("ll_expo_taylor_run_", a, input, False)

@@ -1,0 +1,252 @@
+"""Whole-loop parity of the HIP path (through the C ABI) with the CPU oracle, the real reference (when
+oracle/_ref/libref.so travelled) and the reference's own known answers (T1/T2), plus size-independent properties
+at BASELINE sizes.
+
+Stated fp64 tolerances:
+  eigenvalue        |l_gpu - l_ref| <= 1e-10 * max(1, |l + offset|)
+  eigenvector       1 - |<v_ref, v_gpu>| <= 1e-8
+  alpha/beta trace  |d alpha_k|, |d beta_k| <= 1e-10 * ||A||_inf for every k
+  iteration count   within +-2 of the oracle when run to convergence
+  exponentiator     1 - overlap <= 10 * eps_engine ; |  ||out||/||in|| - 1 | <= 1e-12 for anti-Hermitian exponents
+"""
+import math
+
+import numpy as np
+import pytest
+
+import cases
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import generators as G
+from util import inf_norm, overlap, residual
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def fixed_init(vec):
+    return lambda v, *_: v.__setitem__(slice(None), vec)
+
+
+def gpu_engine(ctx, csr, find_max, k, **fields):
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, csr[0].shape[0] - 1, find_max, k)
+    for key, val in fields.items():
+        setattr(eng, key, val)
+    return eng, op
+
+
+# ------------------------------------------------------------------ the reference's known-answer tests (T1:128-536)
+@pytest.mark.parametrize("name", sorted(cases.eigen_cases()))
+@pytest.mark.parametrize("orth_mode", [L.ORTH_CGS_DGKS, L.ORTH_MGS])
+def test_reference_known_answers(ctx, oracle, name, orth_mode):
+    case = cases.eigen_cases()[name]
+    csr = case["csr"]
+    n = csr[0].shape[0] - 1
+    dtype = csr[2].dtype
+    init = G.start_vector(n, 1, dtype)
+    eng, op = gpu_engine(ctx, csr, case["find_maximum"], case["num_eigs"], eigenvalue_offset=case["offset"],
+                         init_vector=fixed_init(init), orth_mode=orth_mode)
+    if case["eps"] is not None:
+        eng.eps = case["eps"]
+    vals, vecs = eng.run()
+    eps_eng = eng.eps
+    assert len(vals) == case["num_eigs"]
+    for i, lam in enumerate(case["values"]):
+        tol = case.get("abs_tol") or max(abs(lam) * eps_eng, 1e-8 if eps_eng > 1e-8 else 0.0)    # T1:156,478,532
+        assert abs(vals[i] - lam) <= max(tol, 4 * EPS * abs(lam + case["offset"])), (name, i, vals[i], lam)
+    if case["vectors"] is not None:
+        for i, want in enumerate(case["vectors"]):
+            got = vecs[i]
+            phase = np.vdot(want, got)
+            phase /= abs(phase)                                                                   # T1:150, 396-401
+            tol = max(abs(case["values"][i]) * eps_eng * 10, 5e-8 if eps_eng > 1e-8 else 0.0)
+            assert np.max(np.abs(got - phase * want)) <= max(tol, 1e-12), (name, i)
+    # same problem, same start vector through the oracle: same answers, same iteration counts (+-2 per pass)
+    ora = oracle.lanczos(csr, init, case["find_maximum"], num_eigs=case["num_eigs"], eps=case["eps"],
+                         offset=case["offset"])
+    assert len(ora["eigenvalues"]) == len(vals)
+    assert np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * max(1.0, np.max(np.abs(vals + case["offset"])))
+    if case["num_eigs"] == 1:
+        assert len(eng.getIterationCounts()) == 1                                                # T1:160
+        assert abs(eng.getIterationCounts()[0] - ora["iter_counts"][0]) <= 2
+        assert 1 - overlap(vecs[0], ora["eigenvectors"][0]) <= 1e-8
+    op.close()
+
+
+def test_single_pair_overload_restores_num_eigs(ctx):
+    """run(eigenvalue, eigenvector) computes one pair regardless of num_eigs and leaves it untouched (LL:394-407)."""
+    csr = G.dense_to_csr(cases.M8)
+    eng, op = gpu_engine(ctx, csr, False, 3, eps=1e-7)
+    lam, vec = eng.run_single()
+    assert eng.num_eigs == 3 and vec.shape == (8,)
+    assert abs(lam - cases.M8_VALS[0]) <= 1e-6
+    op.close()
+
+
+def test_default_random_start_vector(ctx):
+    """T1:195-229 (..._NOT_FIX_RANDOM_SEED): the default init_vector is random but the answer is not."""
+    csr = G.dense_to_csr(cases.M3)
+    out = []
+    for _ in range(3):
+        eng, op = gpu_engine(ctx, csr, True, 1, eigenvalue_offset=6.0)
+        vals, vecs = eng.run()
+        out.append(vecs[0])
+        assert abs(vals[0] - 4.0) <= 4.0 * eng.eps
+        assert overlap(vecs[0], np.ones(3)) >= 1 - 1e-12
+        op.close()
+
+
+def test_host_callback_operator_readme_sample(ctx):
+    """BASELINE config 1: the README / sample1 3x3 dense lambda, unmodified user code through the host callback."""
+    calls = []
+
+    def mv_mul(inp, out):  # src/samples/sample1_simple.cpp:22-28 — accumulates into the zero-filled out
+        assert np.all(out == 0)
+        calls.append(1)
+        for i in range(3):
+            for j in range(3):
+                out[i] += cases.M3[i][j] * inp[j]
+
+    eng = L.LambdaLanczos(mv_mul, 3, True, 1, context=ctx)
+    vals, vecs = eng.run()
+    assert abs(vals[0] - 4.0) <= 1e-12 and overlap(vecs[0], np.ones(3)) >= 1 - 1e-12
+    assert len(calls) >= eng.getIterationCounts()[0]
+
+    def mv_overwrite(inp, out):  # sample4_use_Eigen_library.cpp:29 overwrites instead of accumulating
+        out[:] = cases.M3 @ inp
+
+    vals2, _ = L.LambdaLanczos(mv_overwrite, 3, True, 1, context=ctx).run()
+    assert abs(vals2[0] - 4.0) <= 1e-12
+
+
+# ------------------------------------------------------------------ traces and convergence vs oracle / reference
+TRACE_CASES = {
+    "laplace64_fixed40": dict(csr=lambda: G.laplace2d_np(64), find_max=False, offset=-8.0, max_iteration=40),
+    "laplace64_converge": dict(csr=lambda: G.laplace2d_np(64), find_max=False, offset=-8.0, max_iteration=None),
+    "randsym4096": dict(csr=lambda: G.randsym_np(4096), find_max=True, offset=0.0, max_iteration=None),
+    "banded20000_fixed60": dict(csr=lambda: G.randsym_np(20000, band=512), find_max=True, offset=0.0, max_iteration=60),
+    "torus16_hermitian": dict(csr=lambda: G.torus_np(16), find_max=False, offset=-10.0, max_iteration=None),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TRACE_CASES))
+@pytest.mark.parametrize("tridiag_mode", [L.TRIDIAG_QR, L.TRIDIAG_AUTO])
+def test_traces_match_oracle(ctx, oracle, name, tridiag_mode):
+    spec = TRACE_CASES[name]
+    csr = spec["csr"]()
+    n = csr[0].shape[0] - 1
+    dtype = csr[2].dtype
+    init = G.start_vector(n, 1, dtype)
+    eng, op = gpu_engine(ctx, csr, spec["find_max"], 1, eigenvalue_offset=spec["offset"],
+                         init_vector=fixed_init(init), tridiag_mode=tridiag_mode)
+    if spec["max_iteration"]:
+        eng.max_iteration = spec["max_iteration"]
+    vals, vecs = eng.run()
+    ora = oracle.lanczos(csr, init, spec["find_max"], offset=spec["offset"], max_iteration=spec["max_iteration"])
+    it_gpu, it_ora = eng.getIterationCounts()[0], ora["iter_counts"][0]
+    assert abs(it_gpu - it_ora) <= 2
+    m = min(it_gpu, it_ora)
+    anorm = inf_norm(csr) + abs(spec["offset"])
+    assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"][:m])) <= 1e-10 * anorm
+    assert np.max(np.abs(eng.last_beta[: m - 1] - ora["beta"][: m - 1])) <= 1e-10 * anorm
+    assert abs(vals[0] - ora["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(vals[0] + spec["offset"]))
+    assert 1 - overlap(vecs[0], ora["eigenvectors"][0]) <= 1e-8
+    if not spec["max_iteration"]:
+        assert residual(csr, vals[0], vecs[0]) <= 1e-6 * anorm
+    op.close()
+
+
+def test_matches_real_reference(ctx, reference):
+    """Same seeded problem through the REAL reference headers (oracle/_ref/libref.so, prebuilt)."""
+    csr = G.randsym_np(3000)
+    init = G.start_vector(3000)
+    eng, op = gpu_engine(ctx, csr, True, 2, init_vector=fixed_init(init))
+    vals, vecs = eng.run()
+    ref = reference.lanczos(csr, init, True, num_eigs=2)
+    assert np.max(np.abs(vals - ref["eigenvalues"])) <= 1e-10 * np.max(np.abs(vals))
+    for i in range(2):
+        assert 1 - overlap(vecs[i], ref["eigenvectors"][i]) <= 1e-8
+    assert len(eng.getIterationCounts()) == len(ref["iter_counts"])
+    op.close()
+
+
+# ------------------------------------------------------------------ Exponentiator (T2:31-222)
+@pytest.mark.parametrize("name", sorted(cases.expo_cases()))
+def test_exponentiator_known_answers(ctx, oracle, name):
+    case = cases.expo_cases()[name]
+    csr = case["csr"]
+    n = csr[0].shape[0] - 1
+    op = L.CsrOperator(ctx, *csr)
+    ex = L.Exponentiator(op, n)
+    ex.full_orthogonalize = case["full"]
+    out, itern = ex.run(case["a"], case["input"])
+    assert abs(1 - overlap(case["exact"], out)) <= 10 * ex.eps + 4 * EPS                       # T2:66-72
+    o_out, o_it, _ = oracle.expo(csr, case["a"], case["input"], full_orthogonalize=case["full"])
+    assert abs(itern - o_it) <= 1
+    assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(o_out)
+    t_out, terms = ex.taylor_run(case["a"], case["input"])                                     # T2:74-80
+    assert abs(1 - overlap(case["exact"], t_out)) <= 10 * ex.eps + 4 * EPS
+    ot_out, ot_terms, _ = oracle.expo(csr, case["a"], case["input"], taylor=True)
+    assert terms == ot_terms
+    op.close()
+
+
+@pytest.mark.parametrize("dt", [0.1, 1.0, 5.0])
+def test_exponentiator_torus_unitary(ctx, oracle, dt):
+    """Config 5 in small: complex Hermitian torus, a = -i*dt: norm preserving, matches the oracle."""
+    csr = G.torus_np(32)
+    inp = G.start_vector(1024, 1, np.complex128)
+    op = L.CsrOperator(ctx, *csr)
+    ex = L.Exponentiator(op, 1024)
+    out, itern = ex.run(-1j * dt, inp)
+    o_out, o_it, _ = oracle.expo(csr, -1j * dt, inp)
+    assert abs(itern - o_it) <= 1
+    assert abs(np.linalg.norm(out) / np.linalg.norm(inp) - 1) <= 1e-12
+    assert 1 - overlap(out, o_out) <= 10 * ex.eps
+    assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(inp)
+    op.close()
+
+
+# ------------------------------------------------------------------ BASELINE sizes: size-independent properties
+def test_c2_laplacian_1M_properties(ctx):
+    """Config 2 at full size (n = 1e6): fixed window; Lanczos relation ||A v - theta v|| = beta_m |s_m| and the
+    Ritz value against the analytic spectrum bounds."""
+    N = 1000
+    csr = G.laplace2d(N)
+    n = N * N
+    init = G.start_vector_fast(n, 1)
+    eng, op = gpu_engine(ctx, csr, False, 1, eigenvalue_offset=-8.0, init_vector=fixed_init(init), max_iteration=60)
+    vals, vecs = eng.run()
+    al, be = eng.last_alpha, eng.last_beta
+    t = np.diag(al) + np.diag(be[:-1], 1) + np.diag(be[:-1], -1)
+    w, s = np.linalg.eigh(t)
+    theta = w[0] + 8.0
+    assert abs(vals[0] - theta) <= 1e-10 * 8
+    lam_min = G.laplace2d_lambda_min(N)
+    assert lam_min - 1e-9 <= vals[0] <= 8.0                                  # Ritz values lie inside the spectrum
+    assert abs(np.linalg.norm(vecs[0]) - 1) <= 1e-12
+    res = residual(csr, vals[0], vecs[0])
+    assert abs(res - be[-1] * abs(s[-1, 0])) <= 1e-9 * 8
+    op.close()
+
+
+def test_c3_random_10M_spmv_properties(ctx):
+    """Config 3 at full size (n = 1e7, nnz = 1.5e8): SpMV linearity, symmetry <x,Ay> = <Ax,y> and A*1 = row sums."""
+    n = 10_000_000
+    csr = G.randsym(n)
+    assert csr[0][-1] == 15 * n
+    op = L.CsrOperator(ctx, *csr)
+    x, y = G.start_vector_fast(n, 2), G.start_vector_fast(n, 3)
+    xd, yd, sd = ctx.to_device(x), ctx.to_device(y), ctx.to_device(x + 2.0 * y)
+    ax, ay, as_ = ctx.empty(n), ctx.empty(n), ctx.empty(n)
+    L.spmv(op, xd, ax)
+    L.spmv(op, yd, ay)
+    L.spmv(op, sd, as_)
+    axh, ayh = ax.get(), ay.get()
+    assert np.max(np.abs(as_.get() - (axh + 2.0 * ayh))) <= 200 * EPS * 30
+    assert abs(L.dot(ctx, xd, ay) - L.dot(ctx, ax, yd)) <= 1e-12 * n
+    ones = ctx.to_device(np.ones(n))
+    L.spmv(op, ones, as_)
+    rowsum = np.add.reduceat(csr[2], csr[0][:-1])
+    assert np.max(np.abs(as_.get() - rowsum)) <= 100 * EPS * 30
+    op.close()

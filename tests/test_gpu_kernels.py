@@ -1,0 +1,179 @@
+"""Parity of every HIP kernel family against the CPU oracle, through the C ABI.
+
+Floating point, so tolerance based: the oracle sums left to right, the kernels sum in wavefront trees.
+Tolerances are stated next to each assertion as a multiple of eps * (problem scale)."""
+import numpy as np
+import pytest
+
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import generators as G
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def rnd(n, dtype, seed):
+    return G.start_vector(n, seed, dtype)
+
+
+def csr_cases():
+    cases = {
+        "dense3": G.dense_to_csr(np.array([[2.0, 1, 1], [1, 2, 1], [1, 1, 2]])),
+        "laplace37": G.laplace2d_np(37),
+        "randsym5000": G.randsym_np(5000),
+        "banded5000": G.randsym_np(5000, band=64),
+        "torus24": G.torus_np(24),
+        "ring_complex": G.ring_csr(100, -1.0, np.complex128),
+    }
+    # ragged: empty rows, a row longer than one LDS tile (>1024 nnz), single-entry rows
+    n = 3000
+    rng = np.random.default_rng(7)
+    lens = rng.integers(0, 9, size=n)
+    lens[::17] = 0
+    lens[1234] = 2500
+    lens[2999] = 1500
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ci = rng.integers(0, n, size=rp[-1]).astype(np.int32)
+    cases["ragged"] = (rp, ci, rng.uniform(-1, 1, size=rp[-1]))
+    cases["ragged_z"] = (rp, ci, rng.uniform(-1, 1, size=rp[-1]) + 1j * rng.uniform(-1, 1, size=rp[-1]))
+    return cases
+
+
+CASES = csr_cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("offset", [0.0, -2.5])
+def test_spmv_matches_oracle(ctx, oracle, name, offset):
+    csr = CASES[name]
+    dtype = csr[2].dtype
+    n = csr[0].shape[0] - 1
+    x = rnd(n, dtype, 3)
+    op = L.CsrOperator(ctx, *csr)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    alpha = L.spmv(op, xd, yd, offset=offset, want_dot=True)
+    y = yd.get()
+    y_ref = oracle.spmv(csr, x) + offset * x
+    rp = csr[0]
+    import scipy.sparse as sp
+
+    absrow = sp.csr_matrix((np.abs(csr[2]), csr[1], rp), shape=(n, n)) @ np.abs(x) + abs(offset) * np.abs(x)
+    # |y - y_ref| <= c * nnz_row * eps * sum_j |a_ij||x_j|   (different summation order, fma contraction)
+    assert np.all(np.abs(y - y_ref) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)
+    alpha_ref = np.vdot(x, y_ref).real
+    assert abs(alpha - alpha_ref) <= 1e-13 * max(1.0, np.sum(np.abs(x) * np.abs(y_ref)))
+    # without the fused dot the result must be bit-identical
+    L.spmv(op, xd, yd, offset=offset)
+    assert np.array_equal(yd.get(), y)
+    op.close()
+
+
+def test_inner_product_convention(ctx):
+    """T1:47-59: <(3, 1+3i), (3, 2+4i)> = 23 - 2i — conjugate-linear in the FIRST argument (LA:41,49)."""
+    a = ctx.to_device(np.array([3.0, 1 + 3j]))
+    b = ctx.to_device(np.array([3.0, 2 + 4j]))
+    assert L.dot(ctx, a, b) == complex(23.0, -2.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 100003, 1 << 20])
+def test_blas1(ctx, dtype, n):
+    a, b = rnd(n, dtype, 11), rnd(n, dtype, 12)
+    ad, bd = ctx.to_device(a), ctx.to_device(b)
+    tol = 4 * EPS * n * 2
+    assert abs(L.dot(ctx, ad, bd) - np.vdot(a, b)) <= tol                       # a3  LA:29-51
+    assert abs(L.nrm2(ctx, ad) - np.linalg.norm(a)) <= tol                       # a7  LA:56-60
+    L.scal(ctx, -0.75, bd)                                                       # a8  LA:65-72
+    assert np.array_equal(bd.get(), -0.75 * b)
+    nrm = L.normalize(ctx, ad)                                                   # a8  LA:77-80
+    assert abs(nrm - np.linalg.norm(a)) <= tol
+    assert np.allclose(ad.get(), a * (1.0 / np.linalg.norm(a)), rtol=4 * EPS, atol=0)
+    # a4 three-term update LL:251-257
+    w, up, uc = rnd(n, dtype, 21), rnd(n, dtype, 22), rnd(n, dtype, 23)
+    wd, upd, ucd = ctx.to_device(w), ctx.to_device(up), ctx.to_device(uc)
+    L.three_term(ctx, wd, upd, ucd, 0.3, -1.7)
+    assert np.allclose(wd.get(), w - 0.3 * up - (-1.7) * uc, rtol=0, atol=8 * EPS)
+    wd.set(w)
+    L.three_term(ctx, wd, None, ucd, 0.0, 0.9)                                   # k == 1: no beta term
+    assert np.allclose(wd.get(), w - 0.9 * uc, rtol=0, atol=8 * EPS)
+
+
+def _orthonormal_basis(n, nb, dtype, seed):
+    rng = np.random.default_rng(seed)
+    m = rng.uniform(-1, 1, (n, nb))
+    if np.dtype(dtype) == np.complex128:
+        m = m + 1j * rng.uniform(-1, 1, (n, nb))
+    q, _ = np.linalg.qr(m)
+    return np.ascontiguousarray(q.T)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("mode", [L.ORTH_CGS_DGKS, L.ORTH_CGS2, L.ORTH_MGS])
+@pytest.mark.parametrize("n,nb", [(10, 5), (4099, 1), (100003, 37), (30011, 700)])
+def test_orth_block_matches_mgs_oracle(ctx, oracle, dtype, mode, n, nb):
+    """a5/a6/a7: block Gram-Schmidt vs the reference's sequential MGS (LA:132-144, test T1:61-91)."""
+    basis = _orthonormal_basis(n, nb, dtype, 5)
+    w = rnd(n, dtype, 31) + 3.0 * basis[0] - 2.0 * basis[nb - 1]
+    ld = ((n + 255) // 256) * 256
+    slab = np.zeros((nb, ld), dtype=dtype)
+    slab[:, :n] = basis
+    bd, wd = ctx.to_device(slab), ctx.to_device(w)
+    nrm, h = L.orth_block(ctx, bd, nb, ld, wd, n, mode=mode, want_h=True)
+    got = wd.get()
+    want = oracle.schmidt_orth(basis.astype(np.complex128), w.astype(np.complex128))
+    if np.dtype(dtype) == np.float64:
+        want = want.real
+    scale = np.linalg.norm(w)
+    assert np.linalg.norm(got - want) <= 50 * EPS * scale * np.sqrt(nb)
+    assert abs(nrm - np.linalg.norm(want)) <= 50 * EPS * scale * np.sqrt(nb)
+    # residual overlaps (T1:86-90 uses 1e-15*n on vectors of norm ~30)
+    ov = basis.conj() @ got
+    assert np.max(np.abs(ov)) <= 20 * EPS * scale
+    # the coefficients are the projections
+    assert np.allclose(h, basis.conj() @ w, rtol=0, atol=50 * EPS * scale)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_orth_block_second_pass_triggers(ctx, dtype):
+    """DGKS branch: w almost inside span(U) => the norm collapses and the predicated second pass must run;
+    all three modes must agree on the (tiny) remainder direction to working accuracy."""
+    n, nb = 50021, 12
+    basis = _orthonormal_basis(n, nb + 1, dtype, 9)
+    extra, basis = basis[nb], np.ascontiguousarray(basis[:nb])
+    coeff = np.arange(1, nb + 1, dtype=np.float64)
+    w = coeff @ basis + 1e-9 * extra
+    ld = ((n + 255) // 256) * 256
+    slab = np.zeros((nb, ld), dtype=dtype)
+    slab[:, :n] = basis
+    bd = ctx.to_device(slab)
+    outs = []
+    for mode in (L.ORTH_CGS_DGKS, L.ORTH_CGS2):
+        wd = ctx.to_device(w)
+        nrm = L.orth_block(ctx, bd, nb, ld, wd, n, mode=mode)
+        got = wd.get()
+        assert abs(nrm - 1e-9) <= 1e-6 * 1e-9 + 50 * EPS * np.linalg.norm(w)
+        assert abs(np.linalg.norm(got) - nrm) <= 1e-3 * nrm
+        # after "twice is enough" the remainder is orthogonal to U relative to ITS OWN norm
+        assert np.max(np.abs(basis.conj() @ got)) <= 1e-6 * nrm
+        outs.append(got)
+    assert np.linalg.norm(outs[0] - outs[1]) <= 1e-6 * 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("n,m,nout", [(1000, 3, 1), (100003, 41, 5), (5000, 600, 2)])
+def test_gemv_basis(ctx, dtype, n, m, nout):
+    """a9/a10: out_r = sum_k c[r,k] u_k in one pass (LL:51-57, EX:166-170)."""
+    rng = np.random.default_rng(3)
+    ld = ((n + 255) // 256) * 256
+    slab = np.zeros((m, ld), dtype=dtype)
+    slab[:, :n] = rng.uniform(-1, 1, (m, n))
+    coeff = rng.uniform(-1, 1, (nout, m)).astype(dtype)
+    if np.dtype(dtype) == np.complex128:
+        slab[:, :n] += 1j * rng.uniform(-1, 1, (m, n))
+        coeff = coeff + 1j * rng.uniform(-1, 1, (nout, m))
+    bd = ctx.to_device(slab)
+    od = ctx.empty((nout, ld), dtype)
+    L.gemv_basis(ctx, bd, m, ld, coeff, od, ld, n)
+    got = od.get()[:, :n]
+    want = coeff @ slab[:, :n]
+    assert np.max(np.abs(got - want)) <= 8 * EPS * m * 2
