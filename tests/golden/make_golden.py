@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the REAL reference (oracle/_ref/libref.so = the reference's own headers compiled
+in place by oracle/Makefile).  Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The fixtures are data — inputs (or the recipe + seed of a generator in lambda-lanczos_amd/generators.py) and the
+outputs the reference produced for them.  No reference source is stored.  Cases:
+  reference_tests.json   the reference's own test problems (T1/T2) with its own start vector (mt19937(1), T1:25-45)
+  tridiagonal.json       T1:757-801 inputs and the reference's tridiagonal_eigenpairs outputs (+ random cases)
+  traces.json            alpha/beta traces, iteration counts, Ritz pairs on the SURVEY 8d generators (splitmix start)
+  exponentiator.json     T2 problems + torus 32x32 (config 5 in small)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import cases  # noqa: E402
+import oracle_lib  # noqa: E402
+from lambda_lanczos_amd import generators as G  # noqa: E402
+from util import c2list  # noqa: E402
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, indent=0, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def main():
+    ref = oracle_lib.reference()
+
+    # ---- G1/G2/G5/G6: the reference's own eigen tests with its own seeded initializer
+    out = {}
+    for name, case in cases.eigen_cases().items():
+        csr = case["csr"]
+        n = csr[0].shape[0] - 1
+        dtype = csr[2].dtype
+        init = ref.init_mt19937(1, n, dtype)
+        r = ref.lanczos(csr, init, case["find_maximum"], num_eigs=case["num_eigs"], eps=case["eps"],
+                        offset=case["offset"])
+        out[name] = {
+            "ref": case["ref"],
+            "init_mt19937_seed1": c2list(init),
+            "eigenvalues": r["eigenvalues"].tolist(),
+            "eigenvectors": [c2list(v) for v in r["eigenvectors"]],
+            "iter_counts": r["iter_counts"],
+        }
+    dump("reference_tests.json", out)
+
+    # ---- G3: tridiagonal
+    tri = {}
+    rng = np.random.default_rng(2026)
+    tcases = {
+        "implicit_shift_qr": ([1.0, 2.0, 3.0], [2.0, 2.0]),                                            # T1:758-759
+        "null_eigenvalue": ([6.82333617e-03, 3.09398208e00, 1.89919458e00, 1.28531906e-16],
+                            [1.19582528e-01, -1.37689656e00, 6.16147405e-15]),                          # T1:787-788
+        "random12": (rng.uniform(-2, 2, 12).tolist(), rng.uniform(-1, 1, 11).tolist()),
+        "random40_with_zero_coupling": (rng.uniform(-2, 2, 40).tolist(),
+                                        [0.0 if i == 17 else float(v) for i, v in enumerate(rng.uniform(-1, 1, 39))]),
+        "single": ([2.5], []),
+    }
+    for name, (al, be) in tcases.items():
+        ev, q, unc = ref.tridiag_eig(np.array(al), np.array(be + [0.0]))
+        tri[name] = {"alpha": al, "beta": be, "eigenvalues": ev.tolist(), "eigenvectors_rows": q.tolist(),
+                     "unconverged": unc,
+                     "bisection": [ref.mth_eigenvalue(np.array(al), np.array(be), m) for m in range(len(al))]
+                     if len(al) > 1 else []}
+    dump("tridiagonal.json", tri)
+
+    # ---- G8: traces on the SURVEY generators, splitmix64 start vector (seed 1)
+    tr = {}
+    specs = {
+        "laplace64_fixed40": dict(gen="laplace2d_np", args=[64], find_max=False, offset=-8.0, max_iteration=40),
+        "laplace64_converge": dict(gen="laplace2d_np", args=[64], find_max=False, offset=-8.0, max_iteration=None),
+        "randsym4096_converge": dict(gen="randsym_np", args=[4096], find_max=True, offset=0.0, max_iteration=None),
+        "torus16_hermitian": dict(gen="torus_np", args=[16], find_max=False, offset=-10.0, max_iteration=None),
+    }
+    for name, s in specs.items():
+        csr = getattr(G, s["gen"])(*s["args"])
+        n = csr[0].shape[0] - 1
+        init = G.start_vector(n, 1, csr[2].dtype)
+        r = ref.lanczos(csr, init, s["find_max"], offset=s["offset"], max_iteration=s["max_iteration"])
+        tr[name] = dict(s, n=n, start="generators.start_vector(n, seed=1)",
+                        iter_counts=r["iter_counts"], eigenvalues=r["eigenvalues"].tolist(),
+                        alpha=r["alpha"].tolist(), beta=r["beta"][:-1].tolist(),
+                        note="alpha/beta recovered with the instrumented mv_mul of oracle/ref_shim.cpp",
+                        eigenvector=c2list(r["eigenvectors"][0]))
+    dump("traces.json", tr)
+
+    # ---- G7: exponentiator
+    ex = {}
+    for name, case in cases.expo_cases().items():
+        o, it, _ = ref.expo(case["csr"], case["a"], case["input"], full_orthogonalize=case["full"])
+        ot, terms, _ = ref.expo(case["csr"], case["a"], case["input"], taylor=True)
+        ex[name] = {"ref": case["ref"], "a": c2list(np.array([case["a"]], dtype=np.complex128)),
+                    "input": c2list(case["input"]), "output": c2list(o), "itern": it, "taylor_output": c2list(ot),
+                    "taylor_terms": terms}
+    for dt in (0.1, 1.0, 5.0):
+        csr = G.torus_np(32)
+        inp = G.start_vector(1024, 1, np.complex128)
+        o, it, _ = ref.expo(csr, -1j * dt, inp)
+        ex["torus32_dt%g" % dt] = {"gen": "torus_np(32)", "start": "generators.start_vector(1024, 1, complex128)",
+                                   "a": c2list(np.array([-1j * dt])), "output": c2list(o), "itern": it}
+    dump("exponentiator.json", ex)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/lanczos_hip.h declares, its
+host-only pieces (tridiagonal solver, partitioning, parameter defaults) are right, and anything that needs the
+device FAILS LOUDLY instead of falling back to a CPU path.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import _capi as capi
+from util import load_golden
+
+EPS = np.finfo(np.float64).eps
+
+
+def _no_gpu():
+    import torch
+
+    return torch.cuda.device_count() == 0
+
+
+def test_library_exports_every_declared_symbol():
+    with open(capi.HEADER_PATH) as f:
+        text = f.read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ll_[a-z0-9_]+)\s*\(", text, flags=re.M))
+    assert len(declared) >= 50
+    lib = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    # and the ctypes table binds exactly that set
+    assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
+    assert lib.ll_version() == 1
+
+
+def test_header_cites_the_reference_interface():
+    with open(capi.HEADER_PATH) as f:
+        text = f.read()
+    for cite in ("LL:330-366", "EX:87-173", "LL:120-126", "LA:29-51", "LA:132-144", "TRI:290-361", "LL:133", "EX:175-210"):
+        assert cite in text, cite
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful without a device")
+def test_no_cpu_fallback_without_device():
+    with pytest.raises(L.LanczosHipError) as e:
+        L.Context(0)
+    assert e.value.code == capi.LL_ERR_HIP and "no CPU fallback" in str(e.value)
+    # an engine built on a host callable cannot run either
+    with pytest.raises(L.LanczosHipError):
+        L.LambdaLanczos(lambda a, b: None, 3, True, 1).run()
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: no file of the product package may import / dlopen / link it."""
+    pkg = os.path.dirname(capi.LIB_PATH.replace(os.sep + "lib" + os.sep, os.sep))
+    pkg = os.path.join(os.path.dirname(os.path.dirname(capi.HEADER_PATH)), "lambda-lanczos_amd")
+    bad = re.compile(r"oracle_lib|liboracle|libref|oracle/|_ref/")
+    for root, _dirs, files in os.walk(pkg):
+        if os.sep + "lib" in root:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or fn == "Makefile":
+                with open(os.path.join(root, fn)) as f:
+                    for i, line in enumerate(f, 1):
+                        assert not bad.search(line), "%s:%d mentions the oracle: %s" % (fn, i, line.strip())
+    # the built library has no dynamic dependency on it either
+    import subprocess
+
+    out = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "libref" not in out
+
+
+def test_params_defaults_are_the_reference_defaults():
+    p = capi.LanczosParams()
+    capi.check(capi.lib().ll_lanczos_params_default(C.byref(p), 1234, 1, 3))
+    assert (p.matrix_size, p.max_iteration, p.find_maximum, p.num_eigs) == (1234, 1234, 1, 3)       # LL:200-208
+    assert p.eps == EPS * 1e3 and p.eigenvalue_offset == 0.0                                          # LL:150,165
+    assert p.num_eigs_per_iteration == 5 and p.initial_vector_size == 200                             # LL:173,181
+    assert p.tridiag_mode == capi.TRIDIAG_QR and p.orth_mode == capi.ORTH_CGS_DGKS
+    q = capi.ExpoParams()
+    capi.check(capi.lib().ll_expo_params_default(C.byref(q), 77))
+    assert (q.matrix_size, q.max_iteration, q.full_orthogonalize, q.initial_vector_size) == (77, 77, 0, 200)
+    assert q.eps == EPS * 1e2                                                                         # EX:58
+    eng = L.LambdaLanczos.__new__(L.LambdaLanczos)  # python mirror: same defaults without touching the device
+    L.LambdaLanczos.__init__(eng, object(), 10, False, 2, dtype=np.float64, context=object())
+    assert (eng.max_iteration, eng.eps, eng.num_eigs_per_iteration, eng.initial_vector_size) == (10, EPS * 1e3, 5, 200)
+
+
+@pytest.mark.parametrize("n,p", [(10, 1), (10, 3), (10_000_000, 8), (7, 8), (1, 2)])
+def test_partition_covers_rows_with_equal_strides(n, p):
+    shard = -(-n // p)
+    seen = 0
+    for r in range(p):
+        b, c = L.partition(n, p, r)
+        assert b == min(n, r * shard) and 0 <= c <= shard
+        assert b == seen
+        seen += c
+    assert seen == n
+
+
+@pytest.mark.parametrize("name", ["implicit_shift_qr", "null_eigenvalue", "random12", "random40_with_zero_coupling",
+                                  "single"])
+def test_product_tridiagonal_solver_matches_reference_fixture(name):
+    """a11: the product's own flat-array QR reproduces the reference's eigenvalues/eigenvectors (captured fixture)."""
+    g = load_golden("tridiagonal.json")[name]
+    ev, q, unc = L.tridiag_eig(g["alpha"], g["beta"])
+    want_ev, want_q = np.array(g["eigenvalues"]), np.array(g["eigenvectors_rows"])
+    scale = max(1.0, np.max(np.abs(want_ev)))
+    assert np.max(np.abs(ev - want_ev)) <= 4 * EPS * scale
+    assert np.max(np.abs(q - want_q)) <= 64 * EPS
+    assert unc == g["unconverged"]
+    for m, want in enumerate(g["bisection"]):
+        assert abs(L.tridiag_bisect(g["alpha"], g["beta"], m) - want) <= 4 * EPS * scale
+
+
+def test_product_tridiagonal_solver_matches_oracle_on_lanczos_matrices(oracle):
+    """T_k of real Lanczos runs (clustered Ritz values, tiny couplings): same values as the oracle, every k."""
+    from lambda_lanczos_amd import generators as G
+
+    r = oracle.lanczos(G.laplace2d_np(24), G.start_vector(576), False, offset=-8.0)
+    al, be = r["alpha"], r["beta"]
+    for k in (1, 2, 3, 10, 57, len(al)):
+        ev, q, _ = L.tridiag_eig(al[:k], be[: k - 1])
+        oev, oq, _ = oracle.tridiag_eig(al[:k], be[:k])
+        assert np.max(np.abs(ev - oev)) <= 8 * EPS * 16
+        t = np.diag(al[:k]) + np.diag(be[: k - 1], 1) + np.diag(be[: k - 1], -1)
+        assert np.max(np.abs(q @ t @ q.T - np.diag(ev))) <= 1e-12 * 16
+        lo = L.tridiag_bisect(al[:k], be[: k - 1], 0)
+        assert abs(lo - ev[0]) <= 64 * EPS * 16

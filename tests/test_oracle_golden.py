@@ -1,0 +1,144 @@
+"""Pins the ORACLE (oracle/lanczos_oracle.cpp, our CPU restatement) before anything trusts it:
+  1. against the known answers of the reference's own tests (T1/T2),
+  2. against the fixtures under tests/golden/ captured from the real reference (make_golden.py),
+  3. directly against the real reference whenever oracle/_ref/libref.so is present (same seeded inputs).
+CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+import cases
+from lambda_lanczos_amd import generators as G
+from util import list2c, load_golden, overlap
+
+EPS = np.finfo(np.float64).eps
+
+
+# ------------------------------------------------------------------ unit pins (T1:47-126)
+def test_inner_product_is_conjugate_linear_in_first_argument(oracle):
+    assert oracle.inner_prod([3.0, 1 + 3j], [3.0, 2 + 4j]) == complex(23.0, -2.0)          # T1:47-59
+
+
+def test_manhattan_norm(oracle):
+    assert oracle.m_norm([1 + 3j, -1 - 1j]) == 6.0                                          # T1:93-100
+
+
+def test_schmidt_orthogonalization(oracle):
+    """T1:61-91: five random complex vectors n=10 orthonormalised one after another, residual overlaps < 1e-15*n."""
+    rng = np.random.default_rng(1)
+    n, us = 10, []
+    for _ in range(n // 2):
+        u = rng.uniform(-10, 10, n) + 1j * rng.uniform(-10, 10, n)
+        if us:
+            u = oracle.schmidt_orth(np.array(us), u)
+        us.append(u / np.linalg.norm(u))
+    v = oracle.schmidt_orth(np.array(us), rng.uniform(-10, 10, n) + 1j * rng.uniform(-10, 10, n))
+    for u in us:
+        assert abs(np.vdot(v, u)) <= 1e-15 * n * 2
+
+
+# ------------------------------------------------------------------ tridiagonal (T1:757-801)
+def test_tridiagonal_known_answer(oracle):
+    ev, q, unc = oracle.tridiag_eig([1.0, 2.0, 3.0], [2.0, 2.0])
+    assert np.allclose(ev, [-1, 2, 5], atol=1e-10, rtol=0) and unc == 0
+    want = np.array([[2, -2, 1], [2, 1, -2], [1, 2, 2]], dtype=float) / 3.0
+    for i in range(3):
+        sign = np.sign(q[i][0])
+        assert np.allclose(q[i], sign * want[i] * np.sign(want[i][0]), atol=1e-10, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["implicit_shift_qr", "null_eigenvalue", "random12", "random40_with_zero_coupling",
+                                  "single"])
+def test_tridiagonal_matches_reference_fixture(oracle, name):
+    g = load_golden("tridiagonal.json")[name]
+    ev, q, unc = oracle.tridiag_eig(g["alpha"], g["beta"] + [0.0])
+    # same operations in the same order, same compiler flags: bit for bit
+    assert np.array_equal(ev, np.array(g["eigenvalues"]))
+    assert np.array_equal(q, np.array(g["eigenvectors_rows"]))
+    assert unc == g["unconverged"]
+    for m, want in enumerate(g["bisection"]):
+        assert oracle.mth_eigenvalue(g["alpha"], g["beta"], m) == want
+        assert abs(want - ev[m]) <= 64 * EPS * max(1.0, np.max(np.abs(ev)))     # bisection family agrees with QR
+
+
+# ------------------------------------------------------------------ eigen solver: known answers + fixtures
+@pytest.mark.parametrize("name", sorted(cases.eigen_cases()))
+def test_eigen_known_answers_and_fixture(oracle, name):
+    case = cases.eigen_cases()[name]
+    g = load_golden("reference_tests.json")[name]
+    csr = case["csr"]
+    init = list2c(g["init_mt19937_seed1"]).astype(csr[2].dtype)
+    r = oracle.lanczos(csr, init, case["find_maximum"], num_eigs=case["num_eigs"], eps=case["eps"],
+                       offset=case["offset"])
+    eps_eng = case["eps"] if case["eps"] is not None else EPS * 1e3
+    # (1) the reference's own expectations
+    for i, lam in enumerate(case["values"]):
+        tol = case.get("abs_tol") or abs(lam) * eps_eng
+        assert abs(r["eigenvalues"][i] - lam) <= max(tol, 1e-8 if eps_eng > 1e-8 else 0), (name, i)
+    if case["vectors"] is not None:
+        for i, want in enumerate(case["vectors"]):
+            assert 1 - overlap(r["eigenvectors"][i], want) <= max(100 * eps_eng, 1e-12)
+    # (2) what the real reference produced for the same start vector
+    assert r["iter_counts"] == g["iter_counts"]
+    assert np.allclose(r["eigenvalues"], g["eigenvalues"], rtol=1e-13, atol=1e-13)
+    for i, v in enumerate(g["eigenvectors"]):
+        assert 1 - overlap(r["eigenvectors"][i], list2c(v)) <= 1e-10 or case["num_eigs"] > 3   # degenerate pairs rotate
+
+
+@pytest.mark.parametrize("name", ["laplace64_fixed40", "laplace64_converge", "randsym4096_converge",
+                                  "torus16_hermitian"])
+def test_traces_match_reference_fixture(oracle, name):
+    g = load_golden("traces.json")[name]
+    csr = getattr(G, g["gen"])(*g["args"])
+    n = csr[0].shape[0] - 1
+    init = G.start_vector(n, 1, csr[2].dtype)
+    r = oracle.lanczos(csr, init, g["find_max"], offset=g["offset"], max_iteration=g["max_iteration"])
+    assert r["iter_counts"] == g["iter_counts"]
+    assert np.allclose(r["eigenvalues"], g["eigenvalues"], rtol=1e-13, atol=1e-13)
+    scale = 16.0
+    m = len(g["alpha"])
+    # the fixture's alpha/beta were recovered through the instrumented mv_mul (O(eps*||A||) noise)
+    assert np.max(np.abs(r["alpha"][:m] - np.array(g["alpha"]))) <= 1e-11 * scale
+    assert np.max(np.abs(r["beta"][: len(g["beta"])] - np.array(g["beta"]))) <= 1e-11 * scale
+    assert 1 - overlap(r["eigenvectors"][0], list2c(g["eigenvector"])) <= 1e-10
+
+
+# ------------------------------------------------------------------ exponentiator (T2)
+@pytest.mark.parametrize("name", sorted(cases.expo_cases()))
+def test_exponentiator_known_answers_and_fixture(oracle, name):
+    case = cases.expo_cases()[name]
+    g = load_golden("exponentiator.json")[name]
+    out, it, _ = oracle.expo(case["csr"], case["a"], case["input"], full_orthogonalize=case["full"])
+    assert abs(1 - overlap(case["exact"], out)) <= EPS * 1e2 * 10                          # T2:66-72
+    assert it == g["itern"]
+    assert np.max(np.abs(out - list2c(g["output"]))) <= 1e-13 * max(1.0, np.max(np.abs(out)))
+    t_out, terms, _ = oracle.expo(case["csr"], case["a"], case["input"], taylor=True)
+    assert terms == g["taylor_terms"]
+    assert np.max(np.abs(t_out - list2c(g["taylor_output"]))) <= 1e-13 * max(1.0, np.max(np.abs(t_out)))
+
+
+@pytest.mark.parametrize("dt", [0.1, 1.0, 5.0])
+def test_exponentiator_torus_fixture(oracle, dt):
+    g = load_golden("exponentiator.json")["torus32_dt%g" % dt]
+    csr = G.torus_np(32)
+    inp = G.start_vector(1024, 1, np.complex128)
+    out, it, _ = oracle.expo(csr, -1j * dt, inp)
+    assert it == g["itern"]
+    assert np.max(np.abs(out - list2c(g["output"]))) <= 1e-12
+    assert abs(np.linalg.norm(out) / np.linalg.norm(inp) - 1) <= 1e-12
+
+
+# ------------------------------------------------------------------ live against the real reference (build container)
+def test_live_against_reference(oracle, reference):
+    for csr, fm, off, k in [(G.randsym_np(2000), True, 0.0, 2), (G.laplace2d_np(24), False, -8.0, 1),
+                            (G.torus_np(12), False, -10.0, 3)]:
+        n = csr[0].shape[0] - 1
+        init = G.start_vector(n, 3, csr[2].dtype)
+        a = oracle.lanczos(csr, init, fm, num_eigs=k, offset=off)
+        b = reference.lanczos(csr, init, fm, num_eigs=k, offset=off)
+        assert a["iter_counts"] == b["iter_counts"]
+        assert np.allclose(a["eigenvalues"], b["eigenvalues"], rtol=1e-13, atol=1e-13)
+        for i in range(len(a["eigenvalues"])):
+            assert 1 - overlap(a["eigenvectors"][i], b["eigenvectors"][i]) <= 1e-9
+    assert math.isfinite(a["t_total"])
