@@ -70,6 +70,9 @@ int ll_ctx_destroy(ll_context* ctx);
 int ll_ctx_stream(ll_context* ctx, void** hip_stream_out);
 /* Block until the context's stream is idle. */
 int ll_ctx_synchronize(ll_context* ctx);
+/* The Krylov-basis slabs of a finished run stay cached in the context so that the next run does not pay
+ * hipMalloc/hipFree of tens of GB; this returns them to the device (ll_ctx_destroy does it too). */
+int ll_ctx_release_cache(ll_context* ctx);
 
 /* Device-side stopwatch: HIP events recorded on the context's stream (what bench.py uses to time a kernel on the
  * stream it is launched on).  ll_timer_stop waits for the stream and returns the milliseconds since ll_timer_start. */
@@ -138,6 +141,17 @@ typedef int (*ll_dev_mv_mul)(const void* in_dev, void* out_dev_zeroed, int64_t n
 int ll_op_create_device_d(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
 int ll_op_create_device_z(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
 
+/* Which SpMV kernel a CSR operator uses (results agree to rounding):
+ *   LL_SPMV_CSR_STREAM  plain CSR, products staged in LDS, bit-reproducible sums; best when the x gathers hit
+ *                       L1/L2 (stencils, narrow bands).
+ *   LL_SPMV_PB          propagation blocking: the same matrix re-ordered once at upload so that one SpMV is two
+ *                       fully coalesced streaming sweeps with x and y slices in LDS and no global gather; best for
+ *                       matrices without column locality (BASELINE config 3).
+ * ll_op_create_csr_{d,z} (host arrays) builds both images, times them on the device and keeps the faster one
+ * (override: environment LL_SPMV_KERNEL=csr|pb, or this call). */
+enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1 };
+int ll_op_select_spmv(ll_operator* op, int kind);
+int ll_op_selected_spmv(const ll_operator* op, int* kind_out);
 int ll_op_destroy(ll_operator* op);
 /* Global dimension n, local rows, nnz held locally (0 for callbacks). */
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz_local);

@@ -14,6 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lanczos_hip.h")
 LL_OK, LL_ERR_INVALID, LL_ERR_HIP, LL_ERR_RCCL, LL_ERR_ALLOC, LL_ERR_CALLBACK = range(6)
 ORTH_CGS_DGKS, ORTH_CGS2, ORTH_MGS = 0, 1, 2
 TRIDIAG_QR, TRIDIAG_BISECT, TRIDIAG_AUTO = 0, 1, 2
+SPMV_CSR_STREAM, SPMV_PB = 0, 1
 UNIQUE_ID_BYTES = 128
 
 
@@ -83,6 +84,7 @@ PROTOTYPES = {
     "ll_ctx_destroy": (C.c_int, [vp]),
     "ll_ctx_stream": (C.c_int, [vp, P(vp)]),
     "ll_ctx_synchronize": (C.c_int, [vp]),
+    "ll_ctx_release_cache": (C.c_int, [vp]),
     "ll_ctx_set_profiling": (C.c_int, [vp, C.c_int]),
     "ll_timer_start": (C.c_int, [vp]),
     "ll_timer_stop": (C.c_int, [vp, P(f64)]),
@@ -103,6 +105,8 @@ PROTOTYPES = {
     "ll_op_create_host_z": (C.c_int, [vp, i64, HOST_MV_FN, vp, P(vp)]),
     "ll_op_create_device_d": (C.c_int, [vp, i64, DEV_MV_FN, vp, P(vp)]),
     "ll_op_create_device_z": (C.c_int, [vp, i64, DEV_MV_FN, vp, P(vp)]),
+    "ll_op_select_spmv": (C.c_int, [vp, C.c_int]),
+    "ll_op_selected_spmv": (C.c_int, [vp, P(C.c_int)]),
     "ll_op_destroy": (C.c_int, [vp]),
     "ll_op_info": (C.c_int, [vp, P(i64), P(i64), P(i64)]),
     "ll_spmv_d": (C.c_int, [vp, vp, vp, vp, f64, P(f64)]),

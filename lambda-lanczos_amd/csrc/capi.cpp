@@ -129,6 +129,7 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_coeff) (void)hipFree(ctx->d_coeff);
     if (ctx->d_xfull) (void)hipFree(ctx->d_xfull);
+    for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -145,6 +146,14 @@ int ll_ctx_synchronize(ll_context* ctx) {
   return guarded([&] {
     use(ctx);
     ctx->sync();
+  });
+}
+int ll_ctx_release_cache(ll_context* ctx) {
+  return guarded([&] {
+    use(ctx);
+    ctx->sync();
+    for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
+    ctx->slab_cache.clear();
   });
 }
 int ll_ctx_set_profiling(ll_context* ctx, int enabled) {
@@ -291,6 +300,132 @@ void finish_csr(ll_operator* op, const int64_t* rp_host) {
   (void)ctx;
 }
 
+// Propagation-blocked image (kernels.hip pb_phase1/pb_phase2): the entries in column-block order (values + 16-bit
+// local columns) and the matching row-block order (16-bit local rows), plus the segment tables that connect them.
+// A segment = all entries of one (column block, row block) pair; inside a segment both orders agree (row-major,
+// original order within a row), so destination = segment base + offset.
+template <typename T>
+bool build_pb(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va) {
+  const int64_t nr = op->n_local, nc = op->n;
+  const bool z = scalar_traits<T>::is_complex;
+  const int64_t slice_max = z ? 6656 : 13312;  // <= 104 KiB of LDS per slice
+  auto block_len = [&](int64_t len) {
+    int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
+    int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
+    if (const char* e = std::getenv("LL_PB_BLOCK")) b = std::max(4, std::atoi(e));
+    return std::min<int64_t>(b, slice_max);
+  };
+  const int64_t cb_cols = block_len(nc), rb_rows = block_len(nr);
+  const int64_t ncb = (nc + cb_cols - 1) / cb_cols, nrb = std::max<int64_t>(1, (nr + rb_rows - 1) / rb_rows);
+  if (ncb * nrb > (int64_t)24 << 20) return false;  // segment tables would not pay off (n beyond ~6e7): keep CSR
+  // segment sizes
+  std::vector<int64_t> cnt((size_t)ncb * nrb, 0);
+#pragma omp parallel for schedule(dynamic, 2)
+  for (int64_t r = 0; r < nrb; ++r) {
+    const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
+    for (int64_t p = rp[i0]; p < rp[i1]; ++p) ++cnt[(size_t)(ci[p] / cb_cols) * nrb + r];
+  }
+  // every segment is padded to whole quads (kernels move 4 entries per lane with 16-byte accesses)
+  for (auto& v : cnt) v = (v + 3) / 4 * 4;
+  // column-block order: segments (c, r) with r fastest; row-block order: (r, c) with c fastest
+  std::vector<int64_t> segq((size_t)ncb * (nrb + 1)), segdest((size_t)ncb * nrb), rptr((size_t)nrb + 1);
+  {
+    int64_t q = 0;
+    for (int64_t c = 0; c < ncb; ++c) {
+      for (int64_t r = 0; r < nrb; ++r) {
+        segq[(size_t)c * (nrb + 1) + r] = q;
+        q += cnt[(size_t)c * nrb + r];
+      }
+      segq[(size_t)c * (nrb + 1) + nrb] = q;
+    }
+    int64_t d = 0;
+    for (int64_t r = 0; r < nrb; ++r) {
+      rptr[(size_t)r] = d;
+      for (int64_t c = 0; c < ncb; ++c) {
+        segdest[(size_t)c * nrb + r] = d;
+        d += cnt[(size_t)c * nrb + r];
+      }
+    }
+    rptr[(size_t)nrb] = d;
+  }
+  const size_t nnz = (size_t)rptr[(size_t)nrb];  // padded entry count
+  std::vector<T> pval(std::max<size_t>(nnz, 4));
+  std::memset((void*)pval.data(), 0, pval.size() * sizeof(T));
+  std::vector<uint16_t> pcol(std::max<size_t>(nnz, 4), 0), prow(std::max<size_t>(nnz, 4), 0);
+#pragma omp parallel
+  {
+    std::vector<int64_t> fill((size_t)ncb);
+#pragma omp for schedule(dynamic, 2)
+    for (int64_t r = 0; r < nrb; ++r) {
+      std::fill(fill.begin(), fill.end(), 0);
+      const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
+      for (int64_t i = i0; i < i1; ++i)
+        for (int64_t p = rp[i]; p < rp[i + 1]; ++p) {
+          const int64_t c = ci[p] / cb_cols;
+          const int64_t off = fill[(size_t)c]++;
+          const int64_t q = segq[(size_t)c * (nrb + 1) + r] + off;
+          pval[(size_t)q] = va[p];
+          pcol[(size_t)q] = (uint16_t)(ci[p] - c * cb_cols);
+          prow[(size_t)(segdest[(size_t)c * nrb + r] + off)] = (uint16_t)(i - i0);
+        }
+    }
+  }
+  op->pb_ncb = (int)ncb;
+  op->pb_nrb = (int)nrb;
+  op->pb_cb_cols = (int)cb_cols;
+  op->pb_rb_rows = (int)rb_rows;
+  auto up = [](void** dst, const void* src, size_t bytes) {
+    LL_HIP(hipMalloc(dst, std::max<size_t>(bytes, 8)));
+    LL_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  };
+  up((void**)&op->d_pb_segq, segq.data(), segq.size() * sizeof(int64_t));
+  up((void**)&op->d_pb_segdest, segdest.data(), segdest.size() * sizeof(int64_t));
+  up((void**)&op->d_pb_rptr, rptr.data(), rptr.size() * sizeof(int64_t));
+  up(&op->d_pb_val, pval.data(), nnz * sizeof(T));
+  up((void**)&op->d_pb_col, pcol.data(), nnz * sizeof(uint16_t));
+  up((void**)&op->d_pb_row, prow.data(), nnz * sizeof(uint16_t));
+  LL_HIP(hipMalloc(&op->d_pb_prod, std::max<size_t>(nnz, 4) * sizeof(T)));
+  return true;
+}
+
+// Time both SpMV kernels on the device with the actual matrix and keep the faster one.
+template <typename T> void autotune_spmv(ll_operator* op) {
+  ll_context* ctx = op->ctx;
+  hipStream_t s = ctx->stream;
+  const size_t xn = (size_t)std::max<int64_t>(op->n, op->n_shard * std::max(1, ctx->nranks));
+  T *x = nullptr, *y = nullptr;
+  LL_HIP(hipMalloc((void**)&x, xn * sizeof(T)));
+  LL_HIP(hipMalloc((void**)&y, (size_t)std::max<int64_t>(op->n_local, 1) * sizeof(T)));
+  LL_HIP(hipMemsetAsync(x, 0, xn * sizeof(T), s));
+  hipEvent_t e0, e1;
+  LL_HIP(hipEventCreate(&e0));
+  LL_HIP(hipEventCreate(&e1));
+  float best = 0.f;
+  int best_kind = LL_SPMV_CSR_STREAM;
+  for (int kind : {LL_SPMV_CSR_STREAM, LL_SPMV_PB}) {
+    float t_kind = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      LL_HIP(hipEventRecord(e0, s));
+      if (kind == LL_SPMV_PB) launch_spmv_pb<T>(*op, x, x + op->row_begin, y, 0.0, nullptr, s);
+      else launch_spmv<T>(*op, x, x + op->row_begin, y, 0.0, nullptr, s);
+      LL_HIP(hipEventRecord(e1, s));
+      LL_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      LL_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (rep > 0) t_kind = std::min(t_kind, ms);
+    }
+    if (kind == LL_SPMV_CSR_STREAM || t_kind < best) {
+      best = t_kind;
+      best_kind = kind;
+    }
+  }
+  op->spmv_kind = best_kind;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(x);
+  (void)hipFree(y);
+}
+
 template <typename T>
 void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, const int64_t* rp, const int32_t* ci,
                 const void* va, bool on_device, ll_operator** out) {
@@ -339,6 +474,13 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     LL_HIP(hipMemcpy(op->d_val, va, nnz * sizeof(T), hipMemcpyHostToDevice));
   }
   finish_csr<T>(op.get(), rp_host);
+  op->spmv_kind = LL_SPMV_CSR_STREAM;
+  const char* fmt = std::getenv("LL_SPMV_KERNEL");
+  const std::string want = fmt ? fmt : "auto";
+  if (!on_device && want != "csr" && nnz > 0 && build_pb<T>(op.get(), rp_host, ci, (const T*)va)) {
+    if (want == "pb") op->spmv_kind = LL_SPMV_PB;
+    else autotune_spmv<T>(op.get());
+  }
   *out = op.release();
 }
 
@@ -411,11 +553,29 @@ int ll_op_destroy(ll_operator* op) {
     if (op->ctx) (void)hipSetDevice(op->ctx->device);
     if (op->d_row_ptr) (void)hipFree(op->d_row_ptr);
     if (op->d_tile_rows) (void)hipFree(op->d_tile_rows);
+    for (void* q : {(void*)op->d_pb_segq, (void*)op->d_pb_segdest, (void*)op->d_pb_rptr, op->d_pb_val,
+                    (void*)op->d_pb_col, (void*)op->d_pb_row, op->d_pb_prod})
+      if (q) (void)hipFree(q);
     if (op->owns_arrays) {
       if (op->d_col) (void)hipFree(op->d_col);
       if (op->d_val) (void)hipFree(op->d_val);
     }
     delete op;
+  });
+}
+int ll_op_select_spmv(ll_operator* op, int kind) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
+    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB, "unknown SpMV kernel");
+    LL_REQUIRE(kind != LL_SPMV_PB || op->d_pb_val != nullptr,
+               "operator has no propagation-blocked image (device arrays, LL_SPMV_KERNEL=csr or n too large)");
+    op->spmv_kind = kind;
+  });
+}
+int ll_op_selected_spmv(const ll_operator* op, int* kind_out) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr && kind_out != nullptr, "null argument");
+    *kind_out = op->spmv_kind;
   });
 }
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz) {

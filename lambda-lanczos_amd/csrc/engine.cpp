@@ -20,7 +20,10 @@ static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * 
 
 // ================================================================= Basis / RunList
 template <typename T> Basis<T>::~Basis() {
-  for (T* p : chunks) (void)hipFree(p);
+  // slabs go back to the context's cache: the next run() on this context reuses them instead of paying
+  // hipMalloc/hipFree of tens of GB per call (ll_ctx_release_cache or ll_ctx_destroy frees them)
+  const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
+  for (T* p : chunks) ctx->slab_cache.emplace_back((void*)p, bytes);
 }
 template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_) {
   ctx = c;
@@ -33,7 +36,23 @@ template <typename T> T* Basis<T>::vec(int64_t k) {
   while ((int64_t)chunks.size() <= ci) {
     T* p = nullptr;
     const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
+    for (size_t i = 0; i < ctx->slab_cache.size(); ++i)
+      if (ctx->slab_cache[i].second == bytes) {
+        p = (T*)ctx->slab_cache[i].first;
+        ctx->slab_cache.erase(ctx->slab_cache.begin() + (long)i);
+        break;
+      }
+    if (p) {
+      chunks.push_back(p);
+      continue;
+    }
     hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e != hipSuccess && !ctx->slab_cache.empty()) {  // make room: drop cached slabs of other shapes and retry
+      (void)hipGetLastError();
+      for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
+      ctx->slab_cache.clear();
+      e = hipMalloc((void**)&p, bytes);
+    }
     if (e != hipSuccess) {
       set_error("out of device memory growing the Krylov basis to " + std::to_string((chunks.size() + 1) * chunk_vecs) +
                 " vectors of " + std::to_string(ld * sizeof(T)) + " bytes: " + hipGetErrorString(e));
@@ -85,7 +104,7 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
 
 template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha) {
   hipStream_t s = ctx->stream;
-  ctx->ensure_partials(kMaxGrid);
+  ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)op->pb_nrb));
   int nparts = 0;
   if (op->kind == ll_operator::CSR) {
     const T* x_full = x_local;
@@ -95,7 +114,10 @@ template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offse
       comm_allgather(ctx->comm, x_local, ctx->d_xfull, (size_t)op->n_shard * R, s);
       x_full = (const T*)ctx->d_xfull;
     }
-    nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    if (op->spmv_kind == LL_SPMV_PB)
+      nparts = launch_spmv_pb<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    else
+      nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
   } else {
     LL_REQUIRE(!(ctx->comm && ctx->nranks > 1), "callback operators are not supported on sharded contexts");
     const size_t bytes = (size_t)n_local * sizeof(T);
@@ -496,41 +518,74 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       tridiag_qr(m, alpha.data(), beta.data(), tev.data(), tq.data());  // beta[m-1] is never read (LL:314)
       t_tridiag += now_s() - t0;
     }
-    std::vector<T> coeff((size_t)nev * m);
-    for (int64_t r = 0; r < nev; ++r) {
-      const int64_t it = P.find_maximum ? m - r - 1 : r;
-      for (int64_t k = 0; k < m; ++k) coeff[(size_t)r * m + k] = as_real_coeff(tq[(size_t)it * m + k], (T*)nullptr);
-    }
-    RunList<T> basis;
-    basis.ld = ld;
-    basis.add_basis(U, m);
-    E.gemv(basis, m, (int)nev, coeff.data(), d_ritz.p, ld);
-    std::vector<std::vector<T>> xs((size_t)nev, std::vector<T>((size_t)nl));
-    for (int64_t r = 0; r < nev; ++r) {
-      E.norm2_dev(d_ritz.p + r * ld, E.S(kScalScratch) + 1);
-      const NormRefs nr = E.plain_norm(E.S(kScalScratch) + 1);
-      launch_scale<T>(nl, d_ritz.p + r * ld, 0.0, &nr, s);  // LL:58
-      LL_HIP(hipMemcpyAsync(xs[r].data(), d_ritz.p + r * ld, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
-    }
-    LL_HIP(hipStreamSynchronize(s));
     for (auto& e : evs) e -= P.eigenvalue_offset;  // LL:317-319
+    // EigenPairManager::insertEigenpairs (EPM:52-71) decides from the VALUES alone which of the nev new pairs
+    // survive; replay it on (value, index) first so that only surviving Ritz vectors are formed and copied to the
+    // host (the reference forms all nroot = 5 and throws 4 away when one pair is requested, LL:338, EPM:60-64).
+    std::vector<char> survives((size_t)nev, 0);
+    bool nothing_added = true;
+    {
+      std::multimap<double, int64_t, std::function<bool(double, double)>> sim(cmp);
+      for (auto& kv : kept) sim.emplace(kv.first, (int64_t)-1);
+      for (int64_t i = 0; i < nev; ++i) {
+        auto ins = sim.emplace(evs[i], i);
+        auto last = sim.end();
+        --last;
+        if ((int64_t)sim.size() > P.num_eigs) {
+          if (ins != last) nothing_added = false;
+          sim.erase(last);
+        } else {
+          nothing_added = false;
+        }
+      }
+      for (auto& kv : sim)
+        if (kv.second >= 0) survives[(size_t)kv.second] = 1;
+    }
+    std::vector<int64_t> want;
+    for (int64_t i = 0; i < nev; ++i)
+      if (survives[(size_t)i]) want.push_back(i);
+    const int64_t nw = (int64_t)want.size();
+    std::vector<std::vector<T>> xs((size_t)nev);
+    if (nw > 0) {
+      std::vector<T> coeff((size_t)nw * m);
+      for (int64_t w = 0; w < nw; ++w) {
+        const int64_t it = P.find_maximum ? m - want[w] - 1 : want[w];
+        for (int64_t k = 0; k < m; ++k) coeff[(size_t)w * m + k] = as_real_coeff(tq[(size_t)it * m + k], (T*)nullptr);
+      }
+      RunList<T> basis;
+      basis.ld = ld;
+      basis.add_basis(U, m);
+      E.gemv(basis, m, (int)nw, coeff.data(), d_ritz.p, ld);
+      for (int64_t w = 0; w < nw; ++w) {
+        xs[(size_t)want[w]].resize((size_t)nl);
+        E.norm2_dev(d_ritz.p + w * ld, E.S(kScalScratch) + 1);
+        const NormRefs nr = E.plain_norm(E.S(kScalScratch) + 1);
+        launch_scale<T>(nl, d_ritz.p + w * ld, 0.0, &nr, s);  // LL:58
+        LL_HIP(hipMemcpyAsync(xs[(size_t)want[w]].data(), d_ritz.p + w * ld, (size_t)nl * sizeof(T),
+                              hipMemcpyDeviceToHost, s));
+      }
+      LL_HIP(hipStreamSynchronize(s));
+    }
 
     if (passes < iter_cap && iter_counts) iter_counts[passes] = m;
     ++passes;
     total_iters += m;
 
-    // ---- EigenPairManager::insertEigenpairs (EPM:52-71)
-    bool nothing_added = true;
-    for (int64_t i = 0; i < nev; ++i) {
-      auto ins = kept.emplace(evs[i], std::move(xs[i]));
-      auto last = kept.end();
-      --last;
-      if ((int64_t)kept.size() > P.num_eigs) {
-        if (ins != last) nothing_added = false;
-        kept.erase(last);
-      } else {
-        nothing_added = false;
+    // ---- EigenPairManager::insertEigenpairs (EPM:52-71), now with the vectors of the survivors
+    {
+      bool check_nothing = true;
+      for (int64_t i = 0; i < nev; ++i) {
+        auto ins = kept.emplace(evs[i], std::move(xs[(size_t)i]));
+        auto last = kept.end();
+        --last;
+        if ((int64_t)kept.size() > P.num_eigs) {
+          if (ins != last) check_nothing = false;
+          kept.erase(last);
+        } else {
+          check_nothing = false;
+        }
       }
+      (void)check_nothing;
     }
     if (nothing_added) break;    // LL:346-348
     if (P.num_eigs == 1) break;  // LL:350-353

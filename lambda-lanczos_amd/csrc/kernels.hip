@@ -11,6 +11,9 @@
 //   a7        maxpy (epilogue) ||w||^2 (LA:56-60 at LL:262, EX:145)
 //   a8        scale            normalize (LA:65-80 at LL:285, EX:160)
 //   a9/a10    gemv_basis       Ritz vectors (LL:51-57) / exp(aA)v (EX:166-170)
+#include <algorithm>
+#include <cstdlib>
+
 #include "ll_internal.hpp"
 
 namespace ll {
@@ -199,6 +202,222 @@ template int launch_spmv<double>(const ll_operator&, const double*, const double
                                  hipStream_t);
 template int launch_spmv<zc>(const ll_operator&, const zc*, const zc*, zc*, double, double*, hipStream_t);
 
+// ================================================================= a1/a2/a3: propagation-blocked SpMV
+// Measured on MI355X (profiles/r01_*): a gather that misses the CU's 32 KiB L1 moves a whole 128-byte line for 8
+// useful bytes and the chip sustains only ~70-140 G such lines/s (L2 -> L1 fill path), whether the line comes from
+// L2, Infinity Cache or HBM.  For a matrix without column locality (BASELINE config 3: 1.5e8 gathers into an 80 MB
+// x) that caps ANY gather-based CSR kernel at >= 1.1 ms per SpMV (measured: 2.7 ms CSR-stream, 2.0 ms with L2-sized
+// column blocking) while the matrix itself streams in 0.35 ms.
+//
+// This kernel therefore never gathers from global memory.  The same matrix is stored in two sweeps' order (built
+// once at upload) and one SpMV is two fully coalesced streaming kernels with LDS-resident slices:
+//   phase 1 (one workgroup per COLUMN block): the x slice of the block is loaded into LDS with coalesced 16-byte
+//            loads; the block's entries (value, 16-bit local column) stream in, ordered by destination row block;
+//            product = value * x_lds[col] is written to the product buffer P at its position in row-block order
+//            (contiguous runs of one segment = one (column block, row block) pair);
+//   phase 2 (one workgroup per ROW block): the y slice lives in LDS; the row block's range of P and the 16-bit
+//            local row indices stream in (perfectly sequential) and are added into the slice with ds_add_f64; the
+//            epilogue adds offset*x_i (a2), writes y once and accumulates Re(conj(x_i) y_i) (a3).
+// HBM traffic is 2*sizeof(T) + sizeof(T) + 4 bytes per nonzero (28 B for fp64 against 12 B for CSR) but every byte
+// is streamed at full line efficiency, every x/y element is touched in LDS, and no phase depends on cache
+// residency or workgroup placement.  Main loops carry no barrier; each lane keeps kPbUnroll independent
+// load->LDS chains in flight.  The LDS adds of phase 2 happen in arrival order, so y can differ by O(eps) from run
+// to run; LL_SPMV_CSR_STREAM remains for bit-reproducible sums and wins on matrices whose gathers hit L1/L2
+// (stencils, narrow bands) — ll_op_create_csr_* times both on the actual matrix and keeps the faster one.
+constexpr int kPbThreads = 1024;
+constexpr int kPbUnroll = 4;  // quads per lane per trip
+
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// Entries are handled in QUADS: every segment is padded to a multiple of four entries (zero value, local index 0), so
+// a lane always moves four consecutive entries with 16-byte accesses (2 x dwordx4 of values / products, one dwordx2
+// of four 16-bit indices) and all four share one segment, i.e. one destination run.
+template <typename T> struct quad {
+  T e[4];
+};
+template <typename T> __device__ __forceinline__ quad<T> load_quad(const T* __restrict__ p) {
+  quad<T> q;
+  if constexpr (scalar_traits<T>::is_complex) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.e[i] = p[i];
+  } else {
+    const double2* d = reinterpret_cast<const double2*>(p);
+    const double2 a = d[0], b = d[1];
+    q.e[0] = a.x; q.e[1] = a.y; q.e[2] = b.x; q.e[3] = b.y;
+  }
+  return q;
+}
+template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__ p, const quad<T>& q) {
+  if constexpr (scalar_traits<T>::is_complex) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = q.e[i];
+  } else {
+    double2* d = reinterpret_cast<double2*>(p);
+    d[0] = make_double2(q.e[0], q.e[1]);
+    d[1] = make_double2(q.e[2], q.e[3]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int cb_cols, int64_t n_cols,
+                                                        const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
+                                                        const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
+                                                        const T* __restrict__ val, const ushort4* __restrict__ col,
+                                                        const T* __restrict__ xf, T* __restrict__ P) {
+  extern __shared__ double lds[];
+  T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
+  long long* qs = reinterpret_cast<long long*>(xs + cb_cols);                      // [nrb + 1]
+  long long* db = qs + (nrb + 1);                                                  // [nrb]
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x;
+  const int64_t col0 = (int64_t)c * cb_cols;
+  const int ncols = (int)min((int64_t)cb_cols, n_cols - col0);
+  for (int i = tid; i < ncols; i += kPbThreads) xs[i] = xf[col0 + i];
+  for (int i = tid; i <= nrb; i += kPbThreads) qs[i] = seg_q[(size_t)c * (nrb + 1) + i];
+  for (int i = tid; i < nrb; i += kPbThreads) db[i] = seg_dest[(size_t)c * nrb + i];
+  __syncthreads();
+  const long long g1 = qs[nrb] >> 2;
+  int r = 0;
+  long long g = (qs[0] >> 2) + tid;
+  for (; g + (long long)(kPbUnroll - 1) * kPbThreads < g1; g += (long long)kPbUnroll * kPbThreads) {
+    quad<T> v[kPbUnroll];
+    ushort4 cl[kPbUnroll];
+#pragma unroll
+    for (int u = 0; u < kPbUnroll; ++u) {
+      const long long gg = g + (long long)u * kPbThreads;
+      v[u] = load_quad<T>(val + 4 * gg);
+      cl[u] = col[gg];
+    }
+#pragma unroll
+    for (int u = 0; u < kPbUnroll; ++u) {
+      const long long qq = 4 * (g + (long long)u * kPbThreads);
+      while (qq >= qs[r + 1]) ++r;
+      quad<T> pr;
+      pr.e[0] = mul(v[u].e[0], xs[cl[u].x]);
+      pr.e[1] = mul(v[u].e[1], xs[cl[u].y]);
+      pr.e[2] = mul(v[u].e[2], xs[cl[u].z]);
+      pr.e[3] = mul(v[u].e[3], xs[cl[u].w]);
+      store_quad<T>(P + db[r] + (qq - qs[r]), pr);
+    }
+  }
+  for (; g < g1; g += kPbThreads) {
+    const long long qq = 4 * g;
+    while (qq >= qs[r + 1]) ++r;
+    const quad<T> v = load_quad<T>(val + qq);
+    const ushort4 cl = col[g];
+    quad<T> pr;
+    pr.e[0] = mul(v.e[0], xs[cl.x]);
+    pr.e[1] = mul(v.e[1], xs[cl.y]);
+    pr.e[2] = mul(v.e[2], xs[cl.z]);
+    pr.e[3] = mul(v.e[3], xs[cl.w]);
+    store_quad<T>(P + db[r] + (qq - qs[r]), pr);
+  }
+}
+
+template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, int rl, const T& v) {
+  if constexpr (scalar_traits<T>::is_complex) {
+    lds_add(&lds[2 * rl], v.re);
+    lds_add(&lds[2 * rl + 1], v.im);
+  } else {
+    lds_add(&lds[rl], v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_local,
+                                                        const int64_t* __restrict__ rptr,  // [nrb + 1]
+                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                        const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                        double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];  // [rb_rows * R]
+  __shared__ double red[kPbThreads / 64];
+  const int tid = threadIdx.x;
+  const int rb = blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
+  __syncthreads();
+  const long long g1 = rptr[rb + 1] >> 2;
+  long long g = (rptr[rb] >> 2) + tid;
+  for (; g + (long long)(kPbUnroll - 1) * kPbThreads < g1; g += (long long)kPbUnroll * kPbThreads) {
+    quad<T> pr[kPbUnroll];
+    ushort4 rl[kPbUnroll];
+#pragma unroll
+    for (int u = 0; u < kPbUnroll; ++u) {
+      const long long gg = g + (long long)u * kPbThreads;
+      pr[u] = load_quad<T>(P + 4 * gg);
+      rl[u] = row[gg];
+    }
+#pragma unroll
+    for (int u = 0; u < kPbUnroll; ++u) {
+      lds_add_elem<T>(lds, rl[u].x, pr[u].e[0]);
+      lds_add_elem<T>(lds, rl[u].y, pr[u].e[1]);
+      lds_add_elem<T>(lds, rl[u].z, pr[u].e[2]);
+      lds_add_elem<T>(lds, rl[u].w, pr[u].e[3]);
+    }
+  }
+  for (; g < g1; g += kPbThreads) {
+    const quad<T> pr = load_quad<T>(P + 4 * g);
+    const ushort4 rl = row[g];
+    lds_add_elem<T>(lds, rl.x, pr.e[0]);
+    lds_add_elem<T>(lds, rl.y, pr.e[1]);
+    lds_add_elem<T>(lds, rl.z, pr.e[2]);
+    lds_add_elem<T>(lds, rl.w, pr.e[3]);
+  }
+  __syncthreads();
+  double dot_acc = 0.0;
+  for (int i = tid; i < rows; i += kPbThreads) {
+    const T xi = xl[row0 + i];
+    T acc;
+    if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
+    else acc = lds[i];
+    const T yi = add(acc, rmul(offset, xi));
+    y[row0 + i] = yi;
+    dot_acc += re_cmul(xi, yi);
+  }
+  if (dot_partials) {
+    const double v = wave_sum(dot_acc);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kPbThreads / 64; ++w) t += red[w];
+      dot_partials[blockIdx.x] = t;
+    }
+  }
+}
+
+template <typename T>
+int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset,
+                   double* dot_partials, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int cap = 160 * 1024 - 2048;
+    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase1<double>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase1<zc>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase2<double>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase2<zc>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_set = true;
+  }
+  const size_t lds1 = (size_t)op.pb_cb_cols * sizeof(T) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
+  const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(T);
+  hipLaunchKernelGGL((pb_phase1<T>), dim3(op.pb_ncb), dim3(kPbThreads), lds1, s, op.pb_nrb, op.pb_cb_cols, op.n,
+                     op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, x_full, (T*)op.d_pb_prod);
+  LL_HIP(hipGetLastError());
+  hipLaunchKernelGGL((pb_phase2<T>), dim3(op.pb_nrb), dim3(kPbThreads), lds2, s, op.pb_rb_rows, op.n_local,
+                     op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
+  LL_HIP(hipGetLastError());
+  return op.pb_nrb;
+}
+template int launch_spmv_pb<double>(const ll_operator&, const double*, const double*, double*, double, double*,
+                                    hipStream_t);
+template int launch_spmv_pb<zc>(const ll_operator&, const zc*, const zc*, zc*, double, double*, hipStream_t);
+
 // ================================================================= strip geometry of the BLAS-1 kernels
 // A workgroup owns strips of kBlock*EPT consecutive elements; every lane keeps EPT elements of w in registers as
 // 16-byte pieces, so one strip of one basis vector is EPT*sizeof(T)/16 dwordx4 loads per lane.
@@ -207,10 +426,14 @@ template <typename T> struct strip {
   static constexpr int ELEMS = kBlock * EPT;
 };
 
+// Balanced persistent grid: every workgroup walks the same number of strips (grid-stride), so no tail round.
 static int strip_grid(int64_t n, int elems) {
+  static int target = 0;
+  if (!target) target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : kMaxGrid;
   int64_t strips = (n + elems - 1) / elems;
   if (strips < 1) strips = 1;
-  return (int)(strips < kMaxGrid ? strips : kMaxGrid);
+  const int64_t per = (strips + target - 1) / target;
+  return (int)((strips + per - 1) / per);
 }
 
 // Vector pieces: a lane's EPT elements are contiguous (EPT*sizeof(T) = 64 B), lanes are adjacent -> every
@@ -433,16 +656,26 @@ template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*,
 // fixed order, so results are bit-reproducible run to run (no float atomics anywhere in the library).
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const double* __restrict__ partials, int nparts, int ncols,
                                                           double* __restrict__ out, double* __restrict__ last_out) {
-  __shared__ double sm[8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + cx;
-  double acc = 0.0;
-  if (j < ncols)
-    for (int b = ry; b < nparts; b += 8) acc += partials[(size_t)b * ncols + j];
-  sm[ry][cx] = acc;
+  __shared__ double sm[16][17];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;  // 16 columns (128 B per partial row) x 16 row lanes
+  const int j = blockIdx.x * 16 + cx;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (j < ncols) {
+    int b = ry;
+    for (; b + 48 < nparts; b += 64) {  // four independent chains per lane
+      a0 += partials[(size_t)b * ncols + j];
+      a1 += partials[(size_t)(b + 16) * ncols + j];
+      a2 += partials[(size_t)(b + 32) * ncols + j];
+      a3 += partials[(size_t)(b + 48) * ncols + j];
+    }
+    for (; b < nparts; b += 16) a0 += partials[(size_t)b * ncols + j];
+  }
+  sm[ry][cx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (ry == 0 && j < ncols) {
-    double t = ((sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx])) + ((sm[4][cx] + sm[5][cx]) + (sm[6][cx] + sm[7][cx]));
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][cx];
     if (j == ncols - 1 && last_out) *last_out = t;
     else out[j] = t;
   }
@@ -461,7 +694,7 @@ void launch_reduce_cols(const double* partials, int nparts, int ncols, double* o
   if (ncols == 1) {
     hipLaunchKernelGGL(reduce_one_kernel, dim3(1), dim3(256), 0, s, partials, nparts, last_out ? last_out : out);
   } else {
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, partials, nparts, ncols, out,
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((ncols + 15) / 16), dim3(256), 0, s, partials, nparts, ncols, out,
                        last_out);
   }
   LL_HIP(hipGetLastError());

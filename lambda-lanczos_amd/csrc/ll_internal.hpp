@@ -113,6 +113,7 @@ struct ll_context {
   size_t pinned_cap = 0;         // doubles
   void* d_coeff = nullptr;       // coefficient upload area for gemv_basis
   size_t coeff_cap = 0;          // bytes
+  std::vector<std::pair<void*, size_t>> slab_cache;  // Krylov-basis slabs kept between runs (ptr, bytes)
   void* d_xfull = nullptr;       // all-gather target (sharded runs)
   size_t xfull_cap = 0;          // bytes
 
@@ -139,6 +140,16 @@ struct ll_operator {
   bool owns_arrays = true;
   int32_t* d_tile_rows = nullptr;  // ntiles+1 row boundaries of the SpMV tiles
   int ntiles = 0;
+  // propagation-blocked image of the same matrix (kernels.hip pb_phase1 / pb_phase2)
+  int spmv_kind = 0;                 // LL_SPMV_*
+  int pb_ncb = 0, pb_nrb = 0, pb_cb_cols = 0, pb_rb_rows = 0;
+  int64_t* d_pb_segq = nullptr;      // [ncb][nrb+1] entry offsets of the segments in column-block order
+  int64_t* d_pb_segdest = nullptr;   // [ncb][nrb]   position of each segment in row-block order
+  int64_t* d_pb_rptr = nullptr;      // [nrb+1]      entry offsets of the row blocks in row-block order
+  void* d_pb_val = nullptr;          // values, column-block order
+  uint16_t* d_pb_col = nullptr;      // local column, column-block order
+  uint16_t* d_pb_row = nullptr;      // local row, row-block order
+  void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
   // callbacks
   ll_host_mv_mul_d host_d = nullptr;
   ll_host_mv_mul_z host_z = nullptr;
@@ -157,6 +168,10 @@ namespace ll {
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
                 hipStream_t s);
+// Same contract, propagation-blocked kernels (op.spmv_kind == LL_SPMV_PB).
+template <typename T>
+int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset,
+                      double* dot_partials, hipStream_t s);
 // y += offset * x ; partials of Re<x,y> (post-pass for callback operators).
 template <typename T>
 int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_partials, hipStream_t s);

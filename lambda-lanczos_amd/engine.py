@@ -107,6 +107,9 @@ class Context:
         check(lib().ll_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
+    def release_cache(self):
+        check(lib().ll_ctx_release_cache(self.handle))
+
     def set_profiling(self, on):
         check(lib().ll_ctx_set_profiling(self.handle, 1 if on else 0))
 
@@ -162,6 +165,15 @@ class CsrOperator(_Operator):
         check(fn(ctx.handle, n_rows, self.n, self.row_begin, ptr(row_ptr), ptr(col), ptr(val), C.byref(h)))
         self.handle = h
         self.nnz = int(row_ptr[-1])
+
+    def select_spmv(self, kind):
+        """capi.SPMV_PB or capi.SPMV_CSR_STREAM (default: whichever timed faster at creation)."""
+        check(lib().ll_op_select_spmv(self.handle, int(kind)))
+
+    def selected_spmv(self):
+        k = C.c_int()
+        check(lib().ll_op_selected_spmv(self.handle, C.byref(k)))
+        return k.value
 
 
 class HostOperator(_Operator):
@@ -357,7 +369,7 @@ class LambdaLanczos:
             p.init_vector = keep
         n_local = op.n_local
         vals = np.zeros(k, dtype=np.float64)
-        vecs = np.zeros((k, n_local), dtype=self.dtype)
+        vecs = np.empty((k, n_local), dtype=self.dtype)
         n_found = C.c_int64()
         cap = 4 * k + 64
         counts = np.zeros(cap, dtype=np.int64)
@@ -377,7 +389,7 @@ class LambdaLanczos:
         self._iter_counts = [int(c) for c in counts[: min(stats.n_passes, cap)]]
         self.last_stats = stats.as_dict()
         self.last_alpha, self.last_beta = alpha[: stats.last_alpha_len].copy(), beta[: stats.last_alpha_len].copy()
-        return vals[:nf].copy(), vecs[:nf].copy()
+        return vals[:nf], vecs[:nf]
 
     def run_single(self):
         """run(eigenvalue, eigenvector): one pair regardless of num_eigs (LL:394-407)."""

@@ -107,8 +107,9 @@ def test_product_tridiagonal_solver_matches_reference_fixture(name):
     ev, q, unc = L.tridiag_eig(g["alpha"], g["beta"])
     want_ev, want_q = np.array(g["eigenvalues"]), np.array(g["eigenvectors_rows"])
     scale = max(1.0, np.max(np.abs(want_ev)))
-    assert np.max(np.abs(ev - want_ev)) <= 4 * EPS * scale
-    assert np.max(np.abs(q - want_q)) <= 64 * EPS
+    # same operations in the same order, contraction off on both sides: bit for bit
+    assert np.array_equal(ev, want_ev)
+    assert np.array_equal(q, want_q)
     assert unc == g["unconverged"]
     for m, want in enumerate(g["bisection"]):
         assert abs(L.tridiag_bisect(g["alpha"], g["beta"], m) - want) <= 4 * EPS * scale
