@@ -1,0 +1,138 @@
+// lambda_lanczos::LambdaLanczos<T> on MI355X — drop-in for include/lambda_lanczos/lambda_lanczos.hpp:109-415 of
+// mrcdr/lambda-lanczos: same constructor shape (mv_mul, matrix_size, find_maximum, num_eigs), same public data
+// members with the same defaults, same run() overloads and getIterationCounts(), same result order.  The Krylov
+// loop itself (lambda_lanczos.hpp:216-322) runs in liblanczos_hip.so with device-resident Lanczos vectors.
+//
+//   #include <lambda_lanczos_hip/lambda_lanczos.hpp>
+//   using lambda_lanczos::LambdaLanczos;                       // alias of lambda_lanczos_hip (see bottom of file)
+//   LambdaLanczos<double> engine(mv_mul, n, true, 1);          // unmodified user lambda  -> host callback path
+//   LambdaLanczos<double> engine(csr_matrix, n, true, 1);      // lambda_lanczos::CsrMatrix<double> -> all on device
+//   engine.run(eigenvalues, eigenvectors);
+//
+// Supported T: double, std::complex<double> (float variants: SURVEY 8f "next").
+#ifndef LAMBDA_LANCZOS_HIP_LAMBDA_LANCZOS_HPP_
+#define LAMBDA_LANCZOS_HIP_LAMBDA_LANCZOS_HPP_
+
+#include <limits>
+#include <tuple>
+
+#include "common.hpp"
+
+namespace lambda_lanczos_hip {
+
+template <typename T> class LambdaLanczos {
+  static_assert(is_supported<T>::value, "LambdaLanczos<T>: T must be double or std::complex<double>");
+  template <typename n_type> using real_t = util::real_t<n_type>;
+
+ public:
+  // ---- the reference's public data members (lambda_lanczos.hpp:126-181), same names / types / defaults
+  std::function<void(const std::vector<T>& in, std::vector<T>& out)> mv_mul;            // :126
+  std::function<void(std::vector<T>& vec)> init_vector;                                   // :133 (empty = random default, :70-104)
+  size_t matrix_size;                                                                     // :136
+  size_t max_iteration;                                                                   // :138
+  real_t<T> eps = std::numeric_limits<real_t<T>>::epsilon() * 1e3;                        // :150
+  bool find_maximum;                                                                      // :153
+  size_t num_eigs = 1;                                                                    // :156
+  real_t<T> eigenvalue_offset = 0.0;                                                      // :165
+  size_t num_eigs_per_iteration = 5;                                                      // :173
+  size_t initial_vector_size = 200;                                                       // :181
+  // ---- additions (defaults = reference-faithful behaviour)
+  int tridiag_mode = LL_TRIDIAG_QR;   // how the per-iteration Ritz values are obtained (LL_TRIDIAG_*)
+  int orth_mode = LL_ORTH_CGS_DGKS;   // Gram-Schmidt variant (LL_ORTH_*)
+
+  // Reference constructor (lambda_lanczos.hpp:200-208): unmodified user code, host callback operator.
+  LambdaLanczos(std::function<void(const std::vector<T>&, std::vector<T>&)> mv_mul, size_t matrix_size,
+                bool find_maximum, size_t num_eigs, Context ctx = Context::default_context())
+      : mv_mul(mv_mul), matrix_size(matrix_size), max_iteration(matrix_size), find_maximum(find_maximum),
+        num_eigs(num_eigs), ctx_(ctx) {}
+
+  // Same shape with a device-resident operator: nothing n-sized crosses PCIe during the loop.
+  LambdaLanczos(const CsrMatrix<T>& op, size_t matrix_size, bool find_maximum, size_t num_eigs)
+      : matrix_size(matrix_size), max_iteration(matrix_size), find_maximum(find_maximum), num_eigs(num_eigs),
+        ctx_(op.context()), csr_(new CsrMatrix<T>(op)) {}
+
+  // run(eigenvalues, eigenvectors) (lambda_lanczos.hpp:330-366): outputs are resized by the library.
+  void run(std::vector<real_t<T>>& eigenvalues, std::vector<std::vector<T>>& eigenvectors) {
+    const size_t n_local = csr_ ? (size_t)csr_->local_rows() : matrix_size;
+    ll_lanczos_params p;
+    check(ll_lanczos_params_default(&p, (int64_t)matrix_size, find_maximum ? 1 : 0, (int64_t)num_eigs));
+    p.max_iteration = (int64_t)max_iteration;
+    p.eps = (double)eps;
+    p.eigenvalue_offset = (double)eigenvalue_offset;
+    p.num_eigs_per_iteration = (int64_t)num_eigs_per_iteration;
+    p.initial_vector_size = (int64_t)initial_vector_size;
+    p.tridiag_mode = tridiag_mode;
+    p.orth_mode = orth_mode;
+    detail::InitHook<T> hook{init_vector};
+    if (init_vector) {
+      p.init_vector = &detail::InitHook<T>::call;
+      p.init_user = &hook;
+    }
+    detail::HostOp<T> host{mv_mul, {}, {}};
+    ll_operator* op = csr_ ? csr_->get() : detail::make_host_operator<T>(ctx_.get(), (int64_t)matrix_size, &host);
+    std::vector<double> vals(num_eigs);
+    std::vector<T> vecs(num_eigs * n_local);
+    std::vector<int64_t> counts(4 * num_eigs + 64);
+    int64_t found = 0;
+    ll_run_stats st;
+    const int rc = call_run(op, &p, vals.data(), vecs.data(), &found, counts.data(), (int64_t)counts.size(), &st);
+    if (!csr_) ll_op_destroy(op);
+    check(rc);
+    eigenvalues.assign(vals.begin(), vals.begin() + found);
+    eigenvectors.assign((size_t)found, std::vector<T>());
+    for (int64_t i = 0; i < found; ++i)
+      eigenvectors[(size_t)i].assign(vecs.begin() + (size_t)i * n_local, vecs.begin() + (size_t)(i + 1) * n_local);
+    iter_counts_.assign(counts.begin(), counts.begin() + std::min<int64_t>(st.n_passes, (int64_t)counts.size()));
+    last_stats_ = st;
+  }
+
+  // C++17 multiple-value-return overload (lambda_lanczos.hpp:376-386)
+  std::tuple<std::vector<real_t<T>>, std::vector<std::vector<T>>> run() {
+    std::vector<real_t<T>> eigenvalues;
+    std::vector<std::vector<T>> eigenvectors;
+    this->run(eigenvalues, eigenvectors);
+    return std::make_tuple(eigenvalues, eigenvectors);
+  }
+
+  // One eigenpair regardless of num_eigs; num_eigs is restored (lambda_lanczos.hpp:394-407)
+  void run(real_t<T>& eigenvalue, std::vector<T>& eigenvector) {
+    const size_t num_eigs_tmp = this->num_eigs;
+    this->num_eigs = 1;
+    std::vector<real_t<T>> eigenvalues(1);
+    std::vector<std::vector<T>> eigenvectors(1);
+    try {
+      this->run(eigenvalues, eigenvectors);
+    } catch (...) {
+      this->num_eigs = num_eigs_tmp;
+      throw;
+    }
+    this->num_eigs = num_eigs_tmp;
+    eigenvalue = eigenvalues[0];
+    eigenvector = std::move(eigenvectors[0]);
+  }
+
+  // Latest iteration counts, one entry per restart pass (lambda_lanczos.hpp:412-414)
+  const std::vector<size_t>& getIterationCounts() const { return iter_counts_; }
+  const ll_run_stats& getLastStats() const { return last_stats_; }
+
+ private:
+  int call_run(ll_operator* op, const ll_lanczos_params* p, double* vals, T* vecs, int64_t* found, int64_t* counts,
+               int64_t cap, ll_run_stats* st) {
+    if (std::is_same<T, double>::value)
+      return ll_lanczos_run_d(ctx_.get(), op, p, vals, reinterpret_cast<double*>(vecs), found, counts, cap, nullptr,
+                              nullptr, st);
+    return ll_lanczos_run_z(ctx_.get(), op, p, vals, vecs, found, counts, cap, nullptr, nullptr, st);
+  }
+  Context ctx_;
+  std::shared_ptr<CsrMatrix<T>> csr_;
+  std::vector<size_t> iter_counts_;
+  ll_run_stats last_stats_{};
+};
+
+}  // namespace lambda_lanczos_hip
+
+#ifndef LAMBDA_LANCZOS_HIP_NO_ALIAS
+namespace lambda_lanczos = lambda_lanczos_hip;  // drop-in: existing `lambda_lanczos::LambdaLanczos<T>` code compiles unchanged
+#endif
+
+#endif  // LAMBDA_LANCZOS_HIP_LAMBDA_LANCZOS_HPP_

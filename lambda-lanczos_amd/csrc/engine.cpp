@@ -94,7 +94,7 @@ template <typename T> std::vector<BasisSegs<T>> RunList<T>::groups(int max_vecs)
 
 // ================================================================= Engine
 template <typename T> void Engine<T>::all_reduce(double* d, size_t count) {
-  if (ctx->comm && ctx->nranks > 1) comm_allreduce_sum(ctx->comm, d, count, ctx->stream);
+  if (ctx->comm != nullptr) comm_allreduce_sum(ctx->comm, d, count, ctx->stream);
 }
 
 template <typename T> void Engine<T>::fetch(const double* d, double* host, size_t count) {
@@ -108,7 +108,7 @@ template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offse
   int nparts = 0;
   if (op->kind == ll_operator::CSR) {
     const T* x_full = x_local;
-    if (ctx->comm && ctx->nranks > 1) {
+    if (ctx->comm != nullptr) {
       // exchange step: every rank needs the whole x for its row block
       ctx->ensure_xfull((size_t)op->n_shard * ctx->nranks * sizeof(T));
       comm_allgather(ctx->comm, x_local, ctx->d_xfull, (size_t)op->n_shard * R, s);
@@ -119,7 +119,7 @@ template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offse
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
   } else {
-    LL_REQUIRE(!(ctx->comm && ctx->nranks > 1), "callback operators are not supported on sharded contexts");
+    LL_REQUIRE(!(ctx->comm != nullptr), "callback operators are not supported on sharded contexts");
     const size_t bytes = (size_t)n_local * sizeof(T);
     if (op->kind == ll_operator::HOST_CB) {
       // unmodified user code (LL:120-126): one D2H + one H2D of an n-vector per call
@@ -179,7 +179,7 @@ template <typename T>
 NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total) {
   hipStream_t s = ctx->stream;
   const int nb = runs.total();
-  const bool sharded = ctx->comm && ctx->nranks > 1;
+  const bool sharded = ctx->comm != nullptr;
   const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
   ctx->ensure_h((size_t)2 * (R * nb + 2));
   double* h1 = ctx->d_h;

@@ -1,0 +1,71 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharded algorithm (tests/dist_worker.py) against the
+single-process oracle, plus the sharding helpers bench.py uses."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import generators as G
+from util import overlap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_row_shards_stitch_to_the_full_matrix():
+    """Every rank generates only its rows (global column indices); concatenated they are the full CSR."""
+    for n, gen in [(1000, lambda **k: G.randsym(1000, **k)), (1000, lambda **k: G.randsym(1000, band=16, **k)),
+                   (900, lambda **k: G.laplace2d(30, **k)), (400, lambda **k: G.torus(20, **k))]:
+        full = gen()
+        for world in (2, 3, 8):
+            rps, cis, vas = [np.zeros(1, np.int64)], [], []
+            for r in range(world):
+                rb, nl = L.partition(n, world, r)
+                rp, ci, va = gen(row_begin=rb, n_local=nl)
+                rps.append(rp[1:] + rps[-1][-1])
+                cis.append(ci)
+                vas.append(va)
+            assert np.array_equal(np.concatenate(rps), full[0])
+            assert np.array_equal(np.concatenate(cis), full[1])
+            assert np.array_equal(np.concatenate(vas), full[2])
+            # start vector shards too
+            v = np.concatenate([G.start_vector(L.partition(n, world, r)[1], 1, np.float64, L.partition(n, world, r)[0])
+                                for r in range(world)])
+            assert np.array_equal(v, G.start_vector(n, 1))
+
+
+def test_two_rank_gloo_run_matches_single_process_oracle(tmp_path, oracle):
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ranks = [json.load(open(os.path.join(tmp_path, "rank%d.json" % i))) for i in range(2)]
+    specs = {"randsym": (G.randsym_np(3001), True, 0.0), "laplace": (G.laplace2d_np(28), False, -8.0)}
+    for name, (csr, find_max, offset) in specs.items():
+        n = csr[0].shape[0] - 1
+        a, b = ranks[0][name], ranks[1][name]
+        # the partition covers the rows exactly once, with equal strides
+        assert a["row_begin"] == 0 and b["row_begin"] == a["n_local"] and a["n_local"] + b["n_local"] == n
+        assert a["nnz_local"] + b["nnz_local"] == csr[0][-1]
+        # every rank took the same decisions and holds the same scalars
+        assert a["itern"] == b["itern"] and a["lambda"] == b["lambda"]
+        assert a["alpha"] == b["alpha"] and a["beta"] == b["beta"]
+        ora = oracle.lanczos(csr, G.start_vector(n, 1), find_max, offset=offset)
+        assert abs(a["itern"] - ora["iter_counts"][0]) <= 2
+        m = min(a["itern"], ora["iter_counts"][0])
+        assert np.max(np.abs(np.array(a["alpha"])[:m] - ora["alpha"][:m])) <= 1e-10 * 30
+        assert np.max(np.abs(np.array(a["beta"])[: m - 1] - ora["beta"][: m - 1])) <= 1e-10 * 30
+        assert abs(a["lambda"] - ora["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(a["lambda"] + offset))
+        vec = np.concatenate([a["vec"], b["vec"]])
+        assert 1 - overlap(vec, ora["eigenvectors"][0]) <= 1e-8

@@ -250,3 +250,41 @@ def test_c3_random_10M_spmv_properties(ctx):
     rowsum = np.add.reduceat(csr[2], csr[0][:-1])
     assert np.max(np.abs(as_.get() - rowsum)) <= 100 * EPS * 30
     op.close()
+
+
+# ------------------------------------------------------------------ sharded code path on one GPU
+def test_sharded_path_with_single_rank_communicator(oracle):
+    """A 1-rank RCCL communicator drives the whole multi-GPU code path (dlopen of librccl, ncclCommInitRank, the
+    all-gather of x before every SpMV and the all-reduces of alpha / Gram-Schmidt coefficients / norms on the
+    library stream) on the single GPU of the test box: results must equal the communicator-free run."""
+    csr = G.randsym_np(30011)
+    n = 30011
+    init = G.start_vector(n)
+    ctx2 = L.Context(0)
+    ctx2.init_comm(L.Context.unique_id(), 0, 1)
+    assert ctx2.partition(n) == (0, n)
+    out = {}
+    for label, c in (("comm", ctx2), ("plain", L.Context(0))):
+        for kind in (L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB):
+            op = L.CsrOperator(c, *csr)
+            op.select_spmv(kind)
+            eng = L.LambdaLanczos(op, n, True, 2)
+            eng.init_vector = fixed_init(init)
+            vals, vecs = eng.run()
+            out[(label, kind)] = (vals, vecs, eng.getIterationCounts())
+            op.close()
+    ora = oracle.lanczos(csr, init, True, num_eigs=2)
+    for key, (vals, vecs, counts) in out.items():
+        assert np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * np.max(np.abs(vals)), key
+        assert len(counts) == len(ora["iter_counts"]), key
+        for i in range(2):
+            assert 1 - overlap(vecs[i], ora["eigenvectors"][i]) <= 1e-8, key
+    # complex + exponentiator through the communicator as well
+    tcsr = G.torus_np(24)
+    inp = G.start_vector(576, 1, np.complex128)
+    top = L.CsrOperator(ctx2, *tcsr)
+    o1, it1 = L.Exponentiator(top, 576).run(-1j, inp)
+    o2, it2, _ = oracle.expo(tcsr, -1j, inp)
+    assert abs(it1 - it2) <= 1 and np.max(np.abs(o1 - o2)) <= 1e-10 * np.linalg.norm(inp)
+    top.close()
+    ctx2.close()
