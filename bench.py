@@ -60,6 +60,25 @@ def iter_bytes_minimal(n, nnz, k, complex_):
     return spmv_bytes(n, nnz, complex_) + s * n * (2 * k + 9)
 
 
+def pmc_traffic(workload, kernels, dtype_tag):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this workload (tools/pmc_summary.py),
+    or None when no such profile exists.  bench.py cannot collect PMC counters itself; the summary names its source."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % workload)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    total = 0.0
+    for k in kernels:
+        e = d["kernels"].get("%s<%s>" % (k, dtype_tag)) or d["kernels"].get("%s<%s, int>" % (k, dtype_tag))
+        if e is None:
+            return None, None
+        total += e["fetch_bytes_mean"] + e["write_bytes_mean"]
+    return total, os.path.relpath(files[-1], ROOT)
+
+
 def main():
     args = parse_args()
     world = args.gpus
@@ -237,6 +256,10 @@ def main():
             "host_cores_available": os.cpu_count(),
         }
 
+    traffic, traffic_src = (None, None)
+    if world == 1 and not args.n:
+        traffic, traffic_src = pmc_traffic(wl, kernel_names[selected].split("+"), "ll::zc" if complex_ else "double")
+
     if rank == 0:
         line = {
             "metric": "Lanczos iterations/sec (fixed window) + CSR SpMV GB/s, fp64",
@@ -274,7 +297,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": spmv_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "achieved_actual_traffic_GBps": (traffic / (spmv_ms * 1e-3) / 1e9) if traffic else None,
             },
             "roofline_orth": {
                 "kernel": "mdot+maxpy+scale (three-term, Gram-Schmidt, norm, normalise)",

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes into per-kernel HBM traffic per launch (profiles/*_pmc_traffic.json).
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d DIR -o pmc_fetch -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d DIR -o pmc_write -- python3 bench.py ...   (separate pass)
+    python tools/pmc_summary.py DIR OUT.json
+
+Units and corrections (MI355X_MICROARCH.md, "HBM" section): the counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of wide coalesced streaming reads (128-B requests tallied at 64 B), so fetch bytes =
+FETCH_SIZE * 1024 * 2; WRITE_SIZE is exact.  The factor is calibrated in the same pass on scale_kernel, whose traffic
+is known (reads n*8 bytes, writes n*8 bytes): the JSON records the calibration ratio next to the numbers."""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ll::", "")
+        agg[k].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+    fetch, write = load(d + "/pmc_fetch_counter_collection.csv"), load(d + "/pmc_write_counter_collection.csv")
+    res = {"units": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count correction), "
+                    "write = WRITE_SIZE KiB * 1024",
+           "calibration": {}, "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, [0.0])
+        w = write.get(k, [0.0])
+        # the predicated second-pass launches of mdot/maxpy are no-ops: report the maximum (k = window) and the mean
+        res["kernels"][k] = {"launches": len(f), "fetch_bytes_mean": sum(f) / len(f) * 2048, "fetch_bytes_max": max(f) * 2048,
+                             "write_bytes_mean": sum(w) / len(w) * 1024, "write_bytes_max": max(w) * 1024}
+    sk = res["kernels"].get("scale_kernel<double>")
+    if sk:
+        res["calibration"] = {"kernel": "scale_kernel<double> (reads and writes n*8 bytes, n=%d)" % n,
+                              "fetch_corrected_over_known": sk["fetch_bytes_mean"] / (8.0 * n),
+                              "write_over_known": sk["write_bytes_mean"] / (8.0 * n)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res["calibration"]))
+    for k in ("pb_phase1<double>", "pb_phase2<double>", "spmv_stream<double, int>"):
+        if k in res["kernels"]:
+            print(k, res["kernels"][k])
+
+
+if __name__ == "__main__":
+    main()
