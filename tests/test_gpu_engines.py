@@ -288,3 +288,106 @@ def test_sharded_path_with_single_rank_communicator(oracle):
     assert abs(it1 - it2) <= 1 and np.max(np.abs(o1 - o2)) <= 1e-10 * np.linalg.norm(inp)
     top.close()
     ctx2.close()
+
+
+# ------------------------------------------------------------------ other operator forms of the mv_mul plugin
+def test_device_array_csr_and_device_callback_operators(ctx, oracle):
+    """ll_op_create_csr_dev_d (matrix already in HBM) and ll_op_create_device_d (a callback that enqueues
+    out += A*in on the library stream for device pointers, `out` zero-filled) give the same run as the host-array CSR."""
+    import ctypes as C
+
+    from lambda_lanczos_amd import _capi as capi
+    from lambda_lanczos_amd.engine import _Operator
+
+    csr = G.randsym_np(20011)
+    n = 20011
+    init = G.start_vector(n)
+    rp_d, ci_d, va_d = ctx.to_device(csr[0]), ctx.to_device(csr[1]), ctx.to_device(csr[2])
+
+    class DevCsr(_Operator):
+        pass
+
+    dev = DevCsr()
+    dev.ctx, dev.dtype, dev.n, dev.n_local, dev.row_begin, dev.nnz = ctx, np.dtype(np.float64), n, n, 0, int(csr[0][-1])
+    h = C.c_void_p()
+    capi.check(capi.lib().ll_op_create_csr_dev_d(ctx.handle, n, n, 0, rp_d.ptr, ci_d.ptr, va_d.ptr, C.byref(h)))
+    dev.handle = h
+
+    calls = []
+
+    def dev_mv(in_p, out_p, nn, stream, _user):  # user code working on device pointers: here another library call
+        calls.append((nn, stream))
+        tmp = ctx.empty(n)
+        rc = capi.lib().ll_spmv_d(ctx.handle, dev.handle, in_p, tmp.ptr, 0.0, None)
+        if rc:
+            return rc
+        out = L.DeviceArray.__new__(L.DeviceArray)
+        # out += tmp  via three_term:  out = out - 0*prev - (-1)*tmp
+        rc = capi.lib().ll_three_term_d(ctx.handle, nn, out_p, None, tmp.ptr, 0.0, -1.0)
+        ctx.synchronize()
+        tmp.free()
+        return rc
+
+    cb = capi.DEV_MV_FN(dev_mv)
+    cbo = DevCsr()
+    cbo.ctx, cbo.dtype, cbo.n, cbo.n_local, cbo.row_begin, cbo.nnz = ctx, np.dtype(np.float64), n, n, 0, 0
+    h2 = C.c_void_p()
+    capi.check(capi.lib().ll_op_create_device_d(ctx.handle, n, cb, None, C.byref(h2)))
+    cbo.handle = h2
+
+    ora = oracle.lanczos(csr, init, True, max_iteration=25)
+    for op in (dev, cbo):
+        eng = L.LambdaLanczos(op, n, True, 1)
+        eng.max_iteration = 25
+        eng.init_vector = fixed_init(init)
+        vals, vecs = eng.run()
+        assert abs(vals[0] - ora["eigenvalues"][0]) <= 1e-10 * abs(vals[0])
+        assert np.max(np.abs(eng.last_alpha - ora["alpha"])) <= 1e-10 * 30
+        assert 1 - overlap(vecs[0], ora["eigenvectors"][0]) <= 1e-8
+    assert len(calls) >= 25 and calls[0][0] == n and calls[0][1] == ctx.stream()
+    dev.close()
+    cbo.close()
+
+
+def test_error_reporting(ctx):
+    """Bad arguments come back as status codes with a message (the reference only asserts, LA:31, EX:88)."""
+    csr = G.randsym_np(500)
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, 499, True, 1)          # wrong matrix_size
+    with pytest.raises(L.LanczosHipError) as e:
+        eng.run()
+    assert e.value.code == L.capi.LL_ERR_INVALID and "matrix_size" in str(e.value)
+    with pytest.raises(L.LanczosHipError):
+        L.CsrOperator(ctx, csr[0], np.where(csr[1] == 3, 700, csr[1]), csr[2])   # column index out of range
+    zop = L.CsrOperator(ctx, *G.torus_np(8))
+    with pytest.raises(L.LanczosHipError):            # complex operator through the real entry point
+        L.LambdaLanczos(zop, 64, True, 1, dtype=np.float64).run()
+
+    def boom(a, b):
+        raise RuntimeError("user code failed")
+
+    with pytest.raises(L.LanczosHipError) as e2:
+        L.LambdaLanczos(boom, 5, True, 1, context=ctx).run()
+    assert e2.value.code == L.capi.LL_ERR_CALLBACK
+    op.close()
+    zop.close()
+
+
+# ------------------------------------------------------------------ BASELINE config 5 at full size
+@pytest.mark.parametrize("dt,expect_iters", [(0.1, 7), (1.0, 15), (5.0, 38)])
+def test_c5_exponentiator_1M_properties(ctx, dt, expect_iters):
+    """Complex Hermitian torus n = 1e6, a = -i*dt: unitary evolution preserves the norm to 1e-12; the iteration counts
+    are the ones the real reference needed for this input (SURVEY 3.2 probe: 7 / 15 / 38); exp(-iH dt) exp(+iH dt) = 1."""
+    N = 1000
+    csr = G.torus(N)
+    n = N * N
+    inp = G.start_vector_fast(n, 1, np.complex128)
+    op = L.CsrOperator(ctx, *csr)
+    ex = L.Exponentiator(op, n)
+    out, itern = ex.run(-1j * dt, inp)
+    assert abs(itern - expect_iters) <= 1
+    assert abs(np.linalg.norm(out) / np.linalg.norm(inp) - 1) <= 1e-12
+    back, _ = ex.run(+1j * dt, out)
+    # the engine stops on 1 - |<c_prev, c>| < eps = 2.2e-14 (EX:154), i.e. a coefficient error of ~sqrt(2 eps) ~ 2e-7
+    assert np.linalg.norm(back - inp) <= 1e-6 * np.linalg.norm(inp)
+    op.close()
