@@ -39,12 +39,15 @@ def parse_args():
     ap.add_argument("--workload", default="c3", choices=["c3", "c3band", "c2", "c5"],
                     help="c3: random symmetric CSR n=1e7 nnz=1.5e8 (metric config); c3band: banded variant; "
                          "c2: 5-pt Laplacian n=1e6; c5: complex torus n=1e6 (Exponentiator)")
-    ap.add_argument("--n", type=int, default=0, help="override the problem size (grid side for c2/c5)")
+    ap.add_argument("--size", dest="n", type=int, default=0, help="override the problem size (grid side for c2/c5)")
     ap.add_argument("--window", type=int, default=100, help="Lanczos iterations per step (max_iteration)")
     ap.add_argument("--spmv-reps", type=int, default=20)
-    ap.add_argument("--cpu-window", type=int, default=10, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-window", type=int, default=14, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--orth-mode", type=int, default=0)
     ap.add_argument("--tridiag-mode", type=int, default=0)
+    ap.add_argument("--dry-run-dist", action="store_true",
+                    help="CPU-only check of the multi-process plumbing (rendezvous, id broadcast, partition, shard "
+                         "generation, reductions over ranks); no device work, prints one JSON line per job")
     return ap.parse_args()
 
 
@@ -94,11 +97,22 @@ def main():
     import lambda_lanczos_amd as L
     from lambda_lanczos_amd import generators as G
 
-    ctx = L.Context(local_rank)
-    if world > 1:
-        box = [L.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ctx.init_comm(box[0], rank, world)
+    if args.dry_run_dist:
+        class _DryCtx:  # partition() only; everything below the shard generation is skipped
+            def partition(self, n_):
+                return L.partition(n_, world, rank)
+
+        ctx = _DryCtx()
+        box = [os.urandom(128) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    else:
+        ctx = L.Context(local_rank)
+        if world > 1:
+            box = [L.Context.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.init_comm(box[0], rank, world)
 
     # ------------------------------------------------------------ synthetic input, resident in HBM
     t_gen = time.time()
@@ -136,8 +150,23 @@ def main():
         t = torch.tensor([nnz_local], dtype=torch.int64)
         dist.all_reduce(t)
         nnz = int(t.item())
-    op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
     init = G.start_vector_fast(nl, 1, dtype, rb)
+    if args.dry_run_dist:
+        import hashlib
+
+        import torch
+
+        t = torch.tensor([float(nl), float(np.sum(init.real))], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "world": world, "n": n, "nnz": nnz, "rows_total": int(t[0].item()),
+                              "start_vector_sum": float(t[1].item()), "id_sha": hashlib.sha1(uid).hexdigest()}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
     t_gen = time.time() - t_gen
 
     def barrier():
@@ -182,7 +211,8 @@ def main():
     # ------------------------------------------------------------ timed steps
     ctx.set_profiling(True)
     itern = []
-    stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0}
+    stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0, "seconds_host_enqueue": 0.0,
+                 "seconds_host_wait": 0.0, "seconds_setup": 0.0, "seconds_finish": 0.0, "seconds_total": 0.0}
 
     if wl == "c5":
         eng = L.Exponentiator(op, n)
@@ -315,6 +345,11 @@ def main():
                 "device_s_operator": spmv_loop_s,
                 "device_s_orth": orth_s,
                 "host_s_tridiag": stats_acc["seconds_host_tridiag"],
+                "host_s_enqueue": stats_acc["seconds_host_enqueue"],
+                "host_s_wait_scalars": stats_acc["seconds_host_wait"],
+                "host_s_setup": stats_acc["seconds_setup"],
+                "host_s_ritz_finish": stats_acc["seconds_finish"],
+                "library_s_total": stats_acc["seconds_total"],
                 "wall_s": elapsed,
                 "setup_s_generate_upload": t_gen,
             },

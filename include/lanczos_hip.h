@@ -210,6 +210,10 @@ int ll_tridiag_eig(int64_t m, const double* alpha_host, const double* beta_host,
 /* k-th smallest eigenvalue (k = 0 .. m-1) by Sturm bisection (TRI:22-88, find_mth_eigenvalue); what
  * LL_TRIDIAG_BISECT / LL_TRIDIAG_AUTO use for the per-iteration stop test. */
 int ll_tridiag_bisect(int64_t m, const double* alpha_host, const double* beta_host, int64_t k, double* out);
+/* Unit eigenvectors for nw given eigenvalues by inverse iteration, O(m) each (out_host: nw rows of m entries); what
+ * LL_TRIDIAG_AUTO uses for the final Ritz step when m > 256 instead of accumulating all m vectors (LL:44, O(m^3)). */
+int ll_tridiag_eigvecs(int64_t m, const double* alpha_host, const double* beta_host, int64_t nw,
+                       const double* lambdas_host, double* out_host);
 
 /* ------------------------------------------------------------------ whole-loop entry points */
 
@@ -249,6 +253,10 @@ typedef struct ll_run_stats {
   double seconds_spmv;      /* device time inside the operator (HIP events; 0 unless ll_ctx_set_profiling) */
   double seconds_orth;      /* device time in three-term + orthogonalisation + norm + scale */
   int64_t last_alpha_len;   /* entries written to alpha_out/beta_out (last pass) */
+  double seconds_host_enqueue; /* host time spent enqueuing device work inside the loop */
+  double seconds_host_wait;    /* host time spent waiting for the per-iteration scalars */
+  double seconds_setup;        /* start vector, locked vectors (per pass) */
+  double seconds_finish;       /* Ritz step: tridiagonal eigenvectors, GEMV over the basis, copy back */
 } ll_run_stats;
 int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 

@@ -35,6 +35,7 @@ from .engine import (  # noqa: F401
     three_term,
     tridiag_bisect,
     tridiag_eig,
+    tridiag_eigvecs,
 )
 
 __version__ = "0.1"

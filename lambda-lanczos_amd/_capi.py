@@ -68,6 +68,10 @@ class RunStats(C.Structure):
         ("seconds_spmv", f64),
         ("seconds_orth", f64),
         ("last_alpha_len", i64),
+        ("seconds_host_enqueue", f64),
+        ("seconds_host_wait", f64),
+        ("seconds_setup", f64),
+        ("seconds_finish", f64),
     ]
 
     def as_dict(self):
@@ -127,6 +131,7 @@ PROTOTYPES = {
     "ll_gemv_basis_z": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, vp, i64]),
     "ll_tridiag_eig": (C.c_int, [i64, vp, vp, vp, vp, P(i64)]),
     "ll_tridiag_bisect": (C.c_int, [i64, vp, vp, i64, P(f64)]),
+    "ll_tridiag_eigvecs": (C.c_int, [i64, vp, vp, i64, vp, vp]),
     "ll_lanczos_params_default": (C.c_int, [P(LanczosParams), i64, C.c_int, i64]),
     "ll_expo_params_default": (C.c_int, [P(ExpoParams), i64]),
     "ll_lanczos_run_d": (C.c_int, [vp, vp, P(LanczosParams), vp, vp, P(i64), vp, i64, vp, vp, P(RunStats)]),

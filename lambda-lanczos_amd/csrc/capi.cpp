@@ -308,14 +308,17 @@ template <typename T>
 bool build_pb(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va) {
   const int64_t nr = op->n_local, nc = op->n;
   const bool z = scalar_traits<T>::is_complex;
-  const int64_t slice_max = z ? 6656 : 13312;  // <= 104 KiB of LDS per slice
-  auto block_len = [&](int64_t len) {
+  // LDS budget per workgroup (160 KiB): phase 1 holds the x slice + two tables of nrb entries, phase 2 only the y slice
+  const int64_t col_max = z ? 6656 : 13312;   // <= 104 KiB
+  const int64_t row_max = z ? 9728 : 19456;   // <= 152 KiB
+  auto block_len = [&](int64_t len, int64_t slice_max, const char* env) {
     int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
     int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
     if (const char* e = std::getenv("LL_PB_BLOCK")) b = std::max(4, std::atoi(e));
+    if (const char* e = std::getenv(env)) b = std::max(4, std::atoi(e));
     return std::min<int64_t>(b, slice_max);
   };
-  const int64_t cb_cols = block_len(nc), rb_rows = block_len(nr);
+  const int64_t cb_cols = block_len(nc, col_max, "LL_PB_COL_BLOCK"), rb_rows = block_len(nr, row_max, "LL_PB_ROW_BLOCK");
   const int64_t ncb = (nc + cb_cols - 1) / cb_cols, nrb = std::max<int64_t>(1, (nr + rb_rows - 1) / rb_rows);
   if (ncb * nrb > (int64_t)24 << 20) return false;  // segment tables would not pay off (n beyond ~6e7): keep CSR
   // segment sizes
@@ -737,6 +740,13 @@ int ll_tridiag_eig(int64_t m, const double* alpha, const double* beta, double* e
     LL_REQUIRE(m >= 1 && alpha && ev && (beta || m == 1), "bad argument");
     const int64_t u = tridiag_qr(m, alpha, beta, ev, q);
     if (unconverged) *unconverged = u;
+  });
+}
+int ll_tridiag_eigvecs(int64_t m, const double* alpha, const double* beta, int64_t nw, const double* lambdas,
+                       double* out) {
+  return guarded([&] {
+    LL_REQUIRE(m >= 1 && nw >= 1 && alpha && lambdas && out && (beta || m == 1), "bad argument");
+    tridiag_inverse_iteration(m, alpha, beta, nw, lambdas, out);
   });
 }
 int ll_tridiag_bisect(int64_t m, const double* alpha, const double* beta, int64_t k, double* out) {

@@ -410,12 +410,13 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   std::multimap<double, std::vector<T>, std::function<bool(double, double)>> kept(cmp);
 
   int64_t passes = 0, total_iters = 0;
-  double t_tridiag = 0.0;
+  double t_tridiag = 0.0, t_enqueue = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
   std::vector<double> alpha, beta;
   std::vector<T> start((size_t)nl);
 
   while (true) {  // restart loop LL:334-354
     const int64_t nroot = std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
+    const double t_pass0 = now_s();
     // ---- start vector (LL:231-234)
     if (P.init_vector) P.init_vector(start.data(), nl, op->row_begin, P.init_user);
     else default_init<T>(start.data(), nl);
@@ -440,6 +441,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       refs0 = E.plain_norm(E.S(kScalScratch) + 1);
     }
     launch_scale<T>(nl, U.vec(0), 0.0, &refs0, s);  // LL:234
+    t_setup += now_s() - t_pass0;
 
     // ---- the Lanczos loop (LL:240-310)
     alpha.clear();
@@ -450,6 +452,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     NormRefs refs_prev = refs0;
 
     auto enqueue = [&](int64_t k) {
+      const double te0 = now_s();
       const int slot = (int)(k % 4);
       T* x = U.vec(k - 1);
       T* y = U.vec(k);
@@ -467,11 +470,14 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
       timer.mark();
       refs_prev = refs;
+      t_enqueue += now_s() - te0;
     };
     // host half of iteration j (H1-H4); returns true when the loop must stop after j iterations
     auto process = [&](int64_t j) -> bool {
       const int slot = (int)(j % 4);
+      const double tw0 = now_s();
       LL_HIP(hipEventSynchronize(ring.ev[slot]));
+      t_wait += now_s() - tw0;
       const volatile double* hp = ctx->h_pinned + 4 * slot;
       const double alpha_j = hp[0], beta2_j = hp[1];
       alpha.push_back(alpha_j);
@@ -509,15 +515,22 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     LL_HIP(hipStreamSynchronize(s));
 
     // ---- Ritz pairs (LL:312-319, LL:33-62)
+    const double t_fin0 = now_s();
     const int64_t m = (int64_t)alpha.size();  // == itern
     (void)itern;
     const int64_t nev = (int64_t)evs.size();
-    std::vector<double> tev((size_t)m), tq((size_t)m * m);
-    {
+    // Eigenvectors of T_m: the reference accumulates all m of them by QR (LL:44, O(m^3)); LL_TRIDIAG_AUTO switches to
+    // inverse iteration for the few wanted ones once m is large.
+    const bool few_vectors = P.tridiag_mode == LL_TRIDIAG_AUTO && m > 256;
+    std::vector<double> tev, tq;
+    if (!few_vectors) {
+      tev.resize((size_t)m);
+      tq.resize((size_t)m * m);
       const double t0 = now_s();
       tridiag_qr(m, alpha.data(), beta.data(), tev.data(), tq.data());  // beta[m-1] is never read (LL:314)
       t_tridiag += now_s() - t0;
     }
+    const std::vector<double> evs_raw = evs;  // Ritz values of the shifted operator, comparator order
     for (auto& e : evs) e -= P.eigenvalue_offset;  // LL:317-319
     // EigenPairManager::insertEigenpairs (EPM:52-71) decides from the VALUES alone which of the nev new pairs
     // survive; replay it on (value, index) first so that only surviving Ritz vectors are formed and copied to the
@@ -548,9 +561,18 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     std::vector<std::vector<T>> xs((size_t)nev);
     if (nw > 0) {
       std::vector<T> coeff((size_t)nw * m);
-      for (int64_t w = 0; w < nw; ++w) {
-        const int64_t it = P.find_maximum ? m - want[w] - 1 : want[w];
-        for (int64_t k = 0; k < m; ++k) coeff[(size_t)w * m + k] = as_real_coeff(tq[(size_t)it * m + k], (T*)nullptr);
+      if (few_vectors) {
+        std::vector<double> lam((size_t)nw), sv((size_t)nw * m);
+        for (int64_t w = 0; w < nw; ++w) lam[(size_t)w] = evs_raw[(size_t)want[w]];
+        const double t0 = now_s();
+        tridiag_inverse_iteration(m, alpha.data(), beta.data(), nw, lam.data(), sv.data());
+        t_tridiag += now_s() - t0;
+        for (size_t i = 0; i < sv.size(); ++i) coeff[i] = as_real_coeff(sv[i], (T*)nullptr);
+      } else {
+        for (int64_t w = 0; w < nw; ++w) {
+          const int64_t it = P.find_maximum ? m - want[w] - 1 : want[w];
+          for (int64_t k = 0; k < m; ++k) coeff[(size_t)w * m + k] = as_real_coeff(tq[(size_t)it * m + k], (T*)nullptr);
+        }
       }
       RunList<T> basis;
       basis.ld = ld;
@@ -567,6 +589,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       LL_HIP(hipStreamSynchronize(s));
     }
 
+    t_finish += now_s() - t_fin0;
     if (passes < iter_cap && iter_counts) iter_counts[passes] = m;
     ++passes;
     total_iters += m;
@@ -606,6 +629,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     stats->total_iterations = total_iters;
     stats->seconds_host_tridiag = t_tridiag;
     stats->last_alpha_len = (int64_t)alpha.size();
+    stats->seconds_host_enqueue = t_enqueue;
+    stats->seconds_host_wait = t_wait;
+    stats->seconds_setup = t_setup;
+    stats->seconds_finish = t_finish;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     stats->seconds_total = now_s() - t_start;
   }

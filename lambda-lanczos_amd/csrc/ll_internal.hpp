@@ -221,6 +221,9 @@ void launch_publish(double* out_mapped, const double* alpha, const NormRefs& nor
 // Flat-array implicit-shift QR; same arithmetic as the reference's (TRI:151-343) so that
 // convergence decisions coincide.  q (nullable) row-major m x m, row j = eigenvector j.
 int64_t tridiag_qr(int64_t m, const double* alpha, const double* beta, double* ev, double* q);
+// Unit eigenvectors for nw given eigenvalues by inverse iteration (O(m) each); out = nw rows of m entries.
+void tridiag_inverse_iteration(int64_t m, const double* alpha, const double* beta, int64_t nw, const double* lambdas,
+                               double* out);
 // k-th smallest eigenvalue by Sturm bisection (TRI:22-88).
 double tridiag_bisect(int64_t m, const double* alpha, const double* beta, int64_t k);
 

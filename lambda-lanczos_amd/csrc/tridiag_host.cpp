@@ -147,4 +147,83 @@ double tridiag_bisect(int64_t m, const double* al, const double* be, int64_t k) 
   return lo;
 }
 
+
+// Eigenvectors of T(alpha, beta) for a FEW known eigenvalues by inverse iteration (LAPACK dstein-style): Gaussian
+// elimination with partial pivoting on T - lambda I, three solves from a constant start vector, then modified
+// Gram-Schmidt among vectors of (nearly) coincident eigenvalues.  O(m) per vector instead of the O(m^3) of the
+// rotation-accumulating QR (TRI:223-231) — used by LL_TRIDIAG_AUTO for the final Ritz step when m is large, where
+// only nroot <= 5 of the m eigenvectors are needed (LL:51-57).  out: nw rows of m entries, unit norm.
+void tridiag_inverse_iteration(int64_t m, const double* al, const double* be, int64_t nw, const double* lambdas,
+                               double* out) {
+  double tnorm = 0.0;
+  for (int64_t i = 0; i < m; ++i)
+    tnorm = std::max(tnorm, std::abs(al[i]) + (i > 0 ? std::abs(be[i - 1]) : 0.0) + (i + 1 < m ? std::abs(be[i]) : 0.0));
+  if (tnorm == 0.0) tnorm = 1.0;
+  const double eps = std::numeric_limits<double>::epsilon();
+  std::vector<double> d((size_t)m), du((size_t)m), du2((size_t)m), dl((size_t)m), x((size_t)m);
+  std::vector<char> piv((size_t)m);
+  for (int64_t w = 0; w < nw; ++w) {
+    // tiny perturbation keeps the factorisation away from exact singularity and separates equal eigenvalues
+    const double lam = lambdas[w] + (double)(w + 1) * 2.0 * eps * tnorm;
+    for (int64_t i = 0; i < m; ++i) {
+      d[i] = al[i] - lam;
+      du[i] = i + 1 < m ? be[i] : 0.0;
+      dl[i] = i + 1 < m ? be[i] : 0.0;
+      du2[i] = 0.0;
+    }
+    // LU with partial pivoting (rows i, i+1)
+    for (int64_t i = 0; i + 1 < m; ++i) {
+      if (std::abs(d[i]) >= std::abs(dl[i])) {
+        piv[i] = 0;
+        if (d[i] == 0.0) d[i] = eps * tnorm;
+        const double f = dl[i] / d[i];
+        dl[i] = f;
+        d[i + 1] -= f * du[i];
+      } else {
+        piv[i] = 1;
+        const double f = d[i] / dl[i];
+        d[i] = dl[i];
+        dl[i] = f;
+        const double t = d[i + 1];
+        d[i + 1] = du[i] - f * t;
+        du2[i] = i + 2 < m ? du[i + 1] : 0.0;
+        du[i] = t;
+        if (i + 2 < m) du[i + 1] = -f * du[i + 1];
+      }
+    }
+    if (d[m - 1] == 0.0) d[m - 1] = eps * tnorm;
+    // deterministic pseudo-random start, different for every wanted vector (a repeated eigenvalue needs start
+    // vectors with independent components in its eigenspace)
+    uint64_t st = 0x9E3779B97F4A7C15ull * (uint64_t)(w + 1);
+    for (int64_t i = 0; i < m; ++i) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      x[i] = ((double)(st >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
+    }
+    for (int it = 0; it < 3; ++it) {
+      // forward: apply L^-1 with the recorded row exchanges
+      for (int64_t i = 0; i + 1 < m; ++i) {
+        if (piv[i]) std::swap(x[i], x[i + 1]);
+        x[i + 1] -= dl[i] * x[i];
+      }
+      // backward: U has three diagonals (d, du, du2)
+      x[m - 1] /= d[m - 1];
+      if (m > 1) x[m - 2] = (x[m - 2] - du[m - 2] * x[m - 1]) / d[m - 2];
+      for (int64_t i = m - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
+      // orthogonalise against previously computed vectors of close eigenvalues, then normalise
+      for (int64_t v = 0; v < w; ++v)
+        if (std::abs(lambdas[v] - lambdas[w]) <= 1e-3 * tnorm) {
+          const double* o = out + v * m;
+          double h = 0.0;
+          for (int64_t i = 0; i < m; ++i) h += o[i] * x[i];
+          for (int64_t i = 0; i < m; ++i) x[i] -= h * o[i];
+        }
+      double nn = 0.0;
+      for (int64_t i = 0; i < m; ++i) nn += x[i] * x[i];
+      nn = 1.0 / std::sqrt(nn);
+      for (int64_t i = 0; i < m; ++i) x[i] *= nn;
+    }
+    std::copy(x.begin(), x.end(), out + w * m);
+  }
+}
+
 }  // namespace ll

@@ -281,6 +281,16 @@ def tridiag_eig(alpha, beta, want_vectors=True):
     return (ev, q, unc.value) if want_vectors else (ev, unc.value)
 
 
+def tridiag_eigvecs(alpha, beta, lambdas):
+    """Eigenvectors (rows) of T(alpha, beta) for the given eigenvalues by inverse iteration."""
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    beta = np.ascontiguousarray(np.concatenate([np.asarray(beta, dtype=np.float64), np.zeros(1)]))
+    lam = np.ascontiguousarray(np.atleast_1d(lambdas), dtype=np.float64)
+    out = np.empty((lam.shape[0], alpha.shape[0]))
+    check(lib().ll_tridiag_eigvecs(alpha.shape[0], ptr(alpha), ptr(beta), lam.shape[0], ptr(lam), ptr(out)))
+    return out
+
+
 def tridiag_bisect(alpha, beta, k):
     alpha = np.ascontiguousarray(alpha, dtype=np.float64)
     beta = np.ascontiguousarray(np.concatenate([np.asarray(beta, dtype=np.float64), np.zeros(1)]))

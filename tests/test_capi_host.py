@@ -129,3 +129,29 @@ def test_product_tridiagonal_solver_matches_oracle_on_lanczos_matrices(oracle):
         assert np.max(np.abs(q @ t @ q.T - np.diag(ev))) <= 1e-12 * 16
         lo = L.tridiag_bisect(al[:k], be[: k - 1], 0)
         assert abs(lo - ev[0]) <= 64 * EPS * 16
+
+
+def test_inverse_iteration_matches_qr_vectors(oracle):
+    """The O(m) inverse-iteration eigenvectors (LL_TRIDIAG_AUTO, m > 256) against the QR vectors on the T_m of a
+    converged Lanczos run (clustered interior Ritz values, well separated extreme ones) and on a degenerate case."""
+    from lambda_lanczos_amd import generators as G
+
+    r = oracle.lanczos(G.laplace2d_np(40), G.start_vector(1600), False, offset=-8.0)
+    al, be = r["alpha"], r["beta"]
+    m = len(al)
+    assert m > 100
+    ev, q, _ = L.tridiag_eig(al, be[: m - 1])
+    for idx in ([0, 1, 2, 3, 4], [m - 1, m - 2, m - 3, m - 4, m - 5]):
+        vecs = L.tridiag_eigvecs(al, be[: m - 1], ev[idx])
+        for row, i in zip(vecs, idx):
+            assert abs(np.linalg.norm(row) - 1) <= 1e-14
+            assert 1 - abs(row @ q[i]) <= 1e-12, (i, 1 - abs(row @ q[i]))
+            t_row = al * row
+            t_row[:-1] += be[: m - 1] * row[1:]
+            t_row[1:] += be[: m - 1] * row[:-1]
+            assert np.linalg.norm(t_row - ev[i] * row) <= 1e-12 * 16
+    # exactly repeated eigenvalues (two uncoupled copies of the same block): the vectors must still be orthonormal
+    a2 = np.array([1.0, 2.0, 3.0, 1.0, 2.0, 3.0])
+    b2 = np.array([2.0, 2.0, 0.0, 2.0, 2.0])
+    v = L.tridiag_eigvecs(a2, b2, [-1.0, -1.0])
+    assert np.max(np.abs(v @ v.T - np.eye(2))) <= 1e-10

@@ -69,3 +69,23 @@ def test_two_rank_gloo_run_matches_single_process_oracle(tmp_path, oracle):
         assert abs(a["lambda"] - ora["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(a["lambda"] + offset))
         vec = np.concatenate([a["vec"], b["vec"]])
         assert 1 - overlap(vec, ora["eigenvectors"][0]) <= 1e-8
+
+
+def test_bench_launch_contract_world_size_2():
+    """bench.py under `torch.distributed.run --nproc-per-node 2` (the driver's launch line): rendezvous on 127.0.0.1,
+    id broadcast from rank 0, row partition, per-rank shard generation and the reductions over ranks — CPU dry run."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--size", "40000", "--dry-run-dist"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world"] == 2 and d["rows_total"] == 40000 and d["nnz"] == 15 * 40000
+    assert abs(d["start_vector_sum"] - float(np.sum(G.start_vector(40000, 1)))) <= 1e-9
+    # single process: same totals
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "40000", "--dry-run-dist"],
+                        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d1["nnz"] == d["nnz"] and d1["rows_total"] == 40000

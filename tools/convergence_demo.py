@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time-to-convergence on the GPU with the reference's DEFAULT settings (nroot = 5, eps = 1e3*eps_machine) on the
+BASELINE configurations, with eigenpair checks (reported number (3)).
+
+    python tools/convergence_demo.py c3 [tridiag_mode]      # random symmetric n=1e7, largest eigenpair
+    python tools/convergence_demo.py c2 [tridiag_mode]      # 5-point Laplacian n=1e6, smallest, offset -8
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import lambda_lanczos_amd as L  # noqa: E402
+from lambda_lanczos_amd import generators as G  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else L.TRIDIAG_QR
+ctx = L.Context(0)
+if wl == "c3":
+    n = int(os.environ.get("DEMO_N", "10000000"))
+    csr = G.randsym(n)
+    find_max, offset = True, 0.0
+else:
+    side = int(os.environ.get("DEMO_N", "1000"))
+    n = side * side
+    csr = G.laplace2d(side)
+    find_max, offset = False, -8.0
+op = L.CsrOperator(ctx, *csr)
+init = G.start_vector_fast(n, 1)
+eng = L.LambdaLanczos(op, n, find_max, 1)
+eng.eigenvalue_offset = offset
+eng.tridiag_mode = mode
+eng.init_vector = lambda v, *_: np.copyto(v, init)
+ctx.set_profiling(True)
+t0 = time.time()
+vals, vecs = eng.run()
+wall = time.time() - t0
+v = vecs[0]
+xd, yd = ctx.to_device(v), ctx.empty(n)
+L.spmv(op, xd, yd)
+res = float(np.linalg.norm(yd.get() - vals[0] * v))
+out = {"workload": wl, "n": n, "tridiag_mode": mode, "iterations": eng.getIterationCounts(), "eigenvalue": float(vals[0]),
+       "residual_norm": res, "wall_s": wall, "stats": eng.last_stats}
+if wl == "c2":
+    out["analytic_lambda_min"] = G.laplace2d_lambda_min(int(round(n ** 0.5)))
+print(json.dumps(out))

@@ -19,7 +19,7 @@ ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--nocheck", action="store_true")
-ap.add_argument("--geoms", default="0,8192,4096,6511")
+ap.add_argument("--geoms", default="0:0,13021:13021,13021:9766,9766:19456,13021:6511")
 a = ap.parse_args()
 
 if a.workload in ("c3", "c3band"):
@@ -40,11 +40,13 @@ variants["csr_stream"] = L.CsrOperator(ctx, *csr)
 os.environ.pop("LL_SPMV_KERNEL")
 for g in a.geoms.split(","):
     os.environ["LL_SPMV_KERNEL"] = "pb"
-    if int(g):
-        os.environ["LL_PB_BLOCK"] = g
-    else:
-        os.environ.pop("LL_PB_BLOCK", None)
-    variants["pb_block%s" % g] = L.CsrOperator(ctx, *csr)
+    cb, rb = (g.split(":") + ["0"])[:2]
+    for key, val in (("LL_PB_COL_BLOCK", cb), ("LL_PB_ROW_BLOCK", rb)):
+        if int(val):
+            os.environ[key] = val
+        else:
+            os.environ.pop(key, None)
+    variants["pb_col%s_row%s" % (cb, rb)] = L.CsrOperator(ctx, *csr)
 ref = None
 times = {k: [] for k in variants}
 for rnd in range(a.rounds + 1):
