@@ -227,7 +227,7 @@ def main():
         eng.eigenvalue_offset = offset
         eng.orth_mode = args.orth_mode
         eng.tridiag_mode = args.tridiag_mode
-        eng.init_vector = lambda v, *_: v.__setitem__(slice(None), init)
+        eng.init_vector = lambda v, *_: np.copyto(v, init)
 
         def step():
             eng.run()

@@ -128,6 +128,18 @@ int ll_op_create_csr_dev_z(ll_context* ctx, int64_t n_rows_local, int64_t n_cols
                            const int64_t* row_ptr_dev, const int32_t* col_dev, const void* val_dev,
                            ll_operator** out);
 
+/*     {row, col, value} triplets, the format of the reference's sparse sample (src/samples/sample2_sparse.cpp:14-47):
+ *     converted to CSR on the host (stable inside a row, duplicates kept as separate entries); single GPU only. */
+int ll_op_create_coo_d(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows_host, const int32_t* cols_host,
+                       const double* vals_host, ll_operator** out);
+int ll_op_create_coo_z(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows_host, const int32_t* cols_host,
+                       const void* vals_host, ll_operator** out);
+/*     max_i sum_j |a_ij| over the LOCAL rows of a CSR/COO operator created from
+ *     host arrays: a safe eigenvalue_offset bound, the idea of src/determine_eigenvalue_offset/
+ *     determine_eigenvalue_offset.cpp:12-29 (which does not build upstream).  For "smallest" problems use
+ *     eigenvalue_offset = -inf_norm so that the wanted Ritz value is large in magnitude. */
+int ll_op_inf_norm(const ll_operator* op, double* out);
+
 /* (2) unmodified user code: a host callback with exactly the reference semantics; costs one D2H + one H2D
  *     of an n-vector per iteration (SURVEY 8b "Operator contract").  Return non-zero from fn to abort. */
 typedef int (*ll_host_mv_mul_d)(const double* in, double* out_zeroed, int64_t n, void* user);

@@ -105,6 +105,9 @@ PROTOTYPES = {
     "ll_op_create_csr_z": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_create_csr_dev_d": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_create_csr_dev_z": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(vp)]),
+    "ll_op_create_coo_d": (C.c_int, [vp, i64, i64, vp, vp, vp, P(vp)]),
+    "ll_op_create_coo_z": (C.c_int, [vp, i64, i64, vp, vp, vp, P(vp)]),
+    "ll_op_inf_norm": (C.c_int, [vp, P(f64)]),
     "ll_op_create_host_d": (C.c_int, [vp, i64, HOST_MV_FN, vp, P(vp)]),
     "ll_op_create_host_z": (C.c_int, [vp, i64, HOST_MV_FN, vp, P(vp)]),
     "ll_op_create_device_d": (C.c_int, [vp, i64, DEV_MV_FN, vp, P(vp)]),

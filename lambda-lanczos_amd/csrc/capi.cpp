@@ -59,6 +59,14 @@ void ll_context::ensure_xfull(size_t bytes) {
   xfull_cap = bytes;
   LL_HIP(hipMalloc(&d_xfull, xfull_cap));
 }
+void* ll_context::ensure_stage(size_t bytes) {
+  if (bytes <= stage_cap) return h_stage;
+  if (h_stage) LL_HIP(hipHostFree(h_stage));
+  h_stage = nullptr;
+  stage_cap = grow(stage_cap, bytes);
+  LL_HIP(hipHostMalloc(&h_stage, stage_cap, hipHostMallocDefault));
+  return h_stage;
+}
 void ll_context::sync() { LL_HIP(hipStreamSynchronize(stream)); }
 
 // ---------------------------------------------------------------- exception -> status
@@ -127,6 +135,7 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->d_h) (void)hipFree(ctx->d_h);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_coeff) (void)hipFree(ctx->d_coeff);
     if (ctx->d_xfull) (void)hipFree(ctx->d_xfull);
     for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
@@ -463,6 +472,17 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     LL_REQUIRE(row_begin == 0 && nr == nc, "a single-GPU context needs the whole matrix (row_begin 0, n_rows == n_cols)");
   }
   const size_t nnz = (size_t)op->nnz;
+  if (!on_device) {  // max absolute row sum, for ll_op_inf_norm (determine_eigenvalue_offset.cpp:12-29)
+    const T* v = (const T*)va;
+    double mx = 0.0;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+    for (int64_t i = 0; i < nr; ++i) {
+      double rs = 0.0;
+      for (int64_t p = rp_host[i]; p < rp_host[i + 1]; ++p) rs += std::abs(*reinterpret_cast<const typename host_scalar<T>::type*>(&v[p]));
+      mx = std::max(mx, rs);
+    }
+    op->inf_norm = mx;
+  }
   if (on_device) {
     op->owns_arrays = false;
     op->d_col = const_cast<int32_t*>(ci);
@@ -517,6 +537,47 @@ int ll_op_create_csr_dev_d(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, 
 int ll_op_create_csr_dev_z(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
                            const void* va, ll_operator** out) {
   return guarded([&] { create_csr<zc>(ctx, nr, nc, rb, rp, ci, va, true, out); });
+}
+extern "C++" {
+namespace {
+// {row, col, value} triplets (sample2_sparse.cpp:14-47) -> CSR, stable in input order inside a row (duplicates kept).
+template <typename T>
+void create_coo(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows, const int32_t* cols, const void* vals,
+                ll_operator** out) {
+  LL_REQUIRE(n >= 1 && nnz >= 0 && (nnz == 0 || (rows && cols && vals)), "bad argument");
+  std::vector<int64_t> rp((size_t)n + 1, 0);
+  for (int64_t p = 0; p < nnz; ++p) {
+    LL_REQUIRE(rows[p] >= 0 && rows[p] < n, "row index out of range");
+    ++rp[(size_t)rows[p] + 1];
+  }
+  for (int64_t i = 0; i < n; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
+  std::vector<int64_t> cur(rp.begin(), rp.end() - 1);
+  std::vector<int32_t> ci((size_t)std::max<int64_t>(nnz, 1));
+  std::vector<T> va((size_t)std::max<int64_t>(nnz, 1));
+  const T* v = (const T*)vals;
+  for (int64_t p = 0; p < nnz; ++p) {
+    const int64_t q = cur[(size_t)rows[p]]++;
+    ci[(size_t)q] = cols[p];
+    va[(size_t)q] = v[p];
+  }
+  create_csr<T>(ctx, n, n, 0, rp.data(), ci.data(), va.data(), false, out);
+}
+}  // namespace
+}  // extern "C++"
+int ll_op_create_coo_d(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows, const int32_t* cols,
+                       const double* vals, ll_operator** out) {
+  return guarded([&] { create_coo<double>(ctx, n, nnz, rows, cols, vals, out); });
+}
+int ll_op_create_coo_z(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows, const int32_t* cols,
+                       const void* vals, ll_operator** out) {
+  return guarded([&] { create_coo<zc>(ctx, n, nnz, rows, cols, vals, out); });
+}
+int ll_op_inf_norm(const ll_operator* op, double* out) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr && out != nullptr, "null argument");
+    LL_REQUIRE(op->inf_norm >= 0.0, "the infinity norm is only known for CSR/COO operators created from host arrays");
+    *out = op->inf_norm;
+  });
 }
 int ll_op_create_host_d(ll_context* ctx, int64_t n, ll_host_mv_mul_d fn, void* user, ll_operator** out) {
   return guarded([&] {

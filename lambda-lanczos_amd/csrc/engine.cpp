@@ -397,9 +397,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   Basis<T> U;
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
   DevBuf<T> d_locked, d_ritz;
+  int64_t d_ritz_cap = 0;
   if (P.num_eigs > 1) d_locked.alloc((size_t)P.num_eigs * ld);
   const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
-  d_ritz.alloc((size_t)nroot_max * ld);
+  (void)nroot_max;
   ctx->ensure_pinned(16);
   EventRing ring;
   PhaseTimer timer(ctx->profiling, s);
@@ -412,15 +413,20 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   int64_t passes = 0, total_iters = 0;
   double t_tridiag = 0.0, t_enqueue = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
   std::vector<double> alpha, beta;
-  std::vector<T> start((size_t)nl);
+  // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
+  // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
+  // or page-faulted per call.
+  T* stage = (T*)ctx->ensure_stage((size_t)std::max<int64_t>(nl, 1) * sizeof(T));
+  const bool single_pair = P.num_eigs == 1;  // one pass, one survivor: its vector goes stage -> caller directly
+  bool result_in_stage = false;
 
   while (true) {  // restart loop LL:334-354
     const int64_t nroot = std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
     const double t_pass0 = now_s();
     // ---- start vector (LL:231-234)
-    if (P.init_vector) P.init_vector(start.data(), nl, op->row_begin, P.init_user);
-    else default_init<T>(start.data(), nl);
-    LL_HIP(hipMemcpyAsync(U.vec(0), start.data(), (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+    if (P.init_vector) P.init_vector(stage, nl, op->row_begin, P.init_user);
+    else default_init<T>(stage, nl);
+    LL_HIP(hipMemcpyAsync(U.vec(0), stage, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
     const int64_t L = (int64_t)kept.size();
     {
       int64_t j = 0;
@@ -577,16 +583,23 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       RunList<T> basis;
       basis.ld = ld;
       basis.add_basis(U, m);
+      if (!d_ritz.p || d_ritz_cap < nw) {  // only the surviving vectors are formed
+        d_ritz.alloc((size_t)nw * ld);
+        d_ritz_cap = nw;
+      }
       E.gemv(basis, m, (int)nw, coeff.data(), d_ritz.p, ld);
       for (int64_t w = 0; w < nw; ++w) {
-        xs[(size_t)want[w]].resize((size_t)nl);
         E.norm2_dev(d_ritz.p + w * ld, E.S(kScalScratch) + 1);
         const NormRefs nr = E.plain_norm(E.S(kScalScratch) + 1);
         launch_scale<T>(nl, d_ritz.p + w * ld, 0.0, &nr, s);  // LL:58
-        LL_HIP(hipMemcpyAsync(xs[(size_t)want[w]].data(), d_ritz.p + w * ld, (size_t)nl * sizeof(T),
-                              hipMemcpyDeviceToHost, s));
+        LL_HIP(hipMemcpyAsync(stage, d_ritz.p + w * ld, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
+        LL_HIP(hipStreamSynchronize(s));
+        if (single_pair) {
+          result_in_stage = true;  // copied to the caller once, at the end
+        } else {
+          xs[(size_t)want[w]].assign(stage, stage + nl);
+        }
       }
-      LL_HIP(hipStreamSynchronize(s));
     }
 
     t_finish += now_s() - t_fin0;
@@ -617,7 +630,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   int64_t cnt = 0;
   for (auto& kv : kept) {  // comparator order (LL:356-365)
     eigvals[cnt] = kv.first;
-    if (eigvecs) std::memcpy(eigvecs + (size_t)cnt * nl, kv.second.data(), (size_t)nl * sizeof(T));
+    if (eigvecs) {
+      const T* src = (single_pair && result_in_stage) ? stage : kv.second.data();
+      std::memcpy(eigvecs + (size_t)cnt * nl, src, (size_t)nl * sizeof(T));
+    }
     ++cnt;
   }
   *n_found = cnt;

@@ -421,6 +421,8 @@ template int launch_spmv_pb<zc>(const ll_operator&, const zc*, const zc*, zc*, d
 // ================================================================= strip geometry of the BLAS-1 kernels
 // A workgroup owns strips of kBlock*EPT consecutive elements; every lane keeps EPT elements of w in registers as
 // 16-byte pieces, so one strip of one basis vector is EPT*sizeof(T)/16 dwordx4 loads per lane.
+constexpr int kJB = 4;  // basis vectors per trip of the multi-dot / multi-axpy loops
+
 template <typename T> struct strip {
   static constexpr int EPT = scalar_traits<T>::is_complex ? 4 : 8;  // 64 B per lane per vector
   static constexpr int ELEMS = kBlock * EPT;
@@ -429,7 +431,7 @@ template <typename T> struct strip {
 // Balanced persistent grid: every workgroup walks the same number of strips (grid-stride), so no tail round.
 static int strip_grid(int64_t n, int elems) {
   static int target = 0;
-  if (!target) target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : kMaxGrid;
+  if (!target) target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : 1024;
   int64_t strips = (n + elems - 1) / elems;
   if (strips < 1) strips = 1;
   const int64_t per = (strips + target - 1) / target;
@@ -538,8 +540,36 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
     for (int sg = 0; sg < segs.nseg; ++sg) {
       const T* ub = segs.base[sg];
       const int cnt = segs.count[sg];
-#pragma unroll 2
-      for (int j = 0; j < cnt; ++j) {
+      // JB basis vectors per trip: all JB strips are requested before the first one is consumed (JB x EPT x 8 B per lane
+      // in flight), and the JB wavefront reductions interleave
+      int j = 0;
+      for (; j + kJB <= cnt; j += kJB) {
+        T ur[kJB][EPT];
+#pragma unroll
+        for (int b = 0; b < kJB; ++b) load_strip<T>(ub + (int64_t)(j + b) * segs.ld, base, n, ur[b]);
+        T acc[kJB];
+#pragma unroll
+        for (int b = 0; b < kJB; ++b) {
+          acc[b] = zero<T>();
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) cfma_acc(acc[b], ur[b][e], wr[e]);
+        }
+#pragma unroll
+        for (int b = 0; b < kJB; ++b) acc[b] = wave_sum(acc[b]);
+        if (lane == 0) {
+#pragma unroll
+          for (int b = 0; b < kJB; ++b) {
+            if constexpr (scalar_traits<T>::is_complex) {
+              mine[col + 2 * b] += acc[b].re;
+              mine[col + 2 * b + 1] += acc[b].im;
+            } else {
+              mine[col + b] += acc[b];
+            }
+          }
+        }
+        col += R * kJB;
+      }
+      for (; j < cnt; ++j) {
         T ur[EPT];
         load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
         T acc = zero<T>();
@@ -613,8 +643,22 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
     for (int sg = 0; sg < segs.nseg; ++sg) {
       const T* ub = segs.base[sg];
       const int cnt = segs.count[sg];
-#pragma unroll 2
-      for (int j = 0; j < cnt; ++j) {
+      int j = 0;
+      for (; j + kJB <= cnt; j += kJB) {
+        T ur[kJB][EPT];
+#pragma unroll
+        for (int b = 0; b < kJB; ++b) load_strip<T>(ub + (int64_t)(j + b) * segs.ld, base, n, ur[b]);
+#pragma unroll
+        for (int b = 0; b < kJB; ++b) {
+          T hj;
+          if constexpr (scalar_traits<T>::is_complex) hj = zc{lds[col + 2 * b], lds[col + 2 * b + 1]};
+          else hj = lds[col + b];
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) fnma_acc(wr[e], hj, ur[b][e]);
+        }
+        col += R * kJB;
+      }
+      for (; j < cnt; ++j) {
         T ur[EPT];
         load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
         T hj;

@@ -122,6 +122,9 @@ struct ll_context {
   void ensure_pinned(size_t doubles);
   void ensure_coeff(size_t bytes);
   void ensure_xfull(size_t bytes);
+  void* h_stage = nullptr;       // pinned host staging buffer for n-sized transfers (start vector, Ritz vectors)
+  size_t stage_cap = 0;          // bytes
+  void* ensure_stage(size_t bytes);
   void sync();
 };
 
@@ -132,6 +135,7 @@ struct ll_operator {
   ll_context* ctx = nullptr;
   int64_t n = 0, n_local = 0, row_begin = 0, nnz = 0;
   int64_t n_shard = 0;  // padded shard length used by the all-gather (= n when not sharded)
+  double inf_norm = -1.0;  // max absolute row sum of the local rows (-1: unknown)
   // CSR
   void* d_row_ptr = nullptr;  // int32 or int64
   bool rp64 = false;

@@ -166,6 +166,26 @@ class CsrOperator(_Operator):
         self.handle = h
         self.nnz = int(row_ptr[-1])
 
+    @classmethod
+    def from_coo(cls, ctx, n, rows, cols, vals):
+        """{row, col, value} triplets (sample2_sparse.cpp:14-47); conversion to CSR happens in the library."""
+        self = cls.__new__(cls)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        vals = np.ascontiguousarray(vals)
+        self.ctx, self.dtype, self.n, self.n_local, self.row_begin, self.nnz = ctx, vals.dtype, int(n), int(n), 0, len(vals)
+        h = C.c_void_p()
+        fn = getattr(lib(), "ll_op_create_coo_" + _suffix(vals.dtype))
+        check(fn(ctx.handle, int(n), len(vals), ptr(rows), ptr(cols), ptr(vals), C.byref(h)))
+        self.handle = h
+        return self
+
+    def inf_norm(self):
+        """max_i sum_j |a_ij| of the local rows (a safe |eigenvalue_offset|)."""
+        v = C.c_double()
+        check(lib().ll_op_inf_norm(self.handle, C.byref(v)))
+        return v.value
+
     def select_spmv(self, kind):
         """capi.SPMV_PB or capi.SPMV_CSR_STREAM (default: whichever timed faster at creation)."""
         check(lib().ll_op_select_spmv(self.handle, int(kind)))

@@ -391,3 +391,25 @@ def test_c5_exponentiator_1M_properties(ctx, dt, expect_iters):
     # the engine stops on 1 - |<c_prev, c>| < eps = 2.2e-14 (EX:154), i.e. a coefficient error of ~sqrt(2 eps) ~ 2e-7
     assert np.linalg.norm(back - inp) <= 1e-6 * np.linalg.norm(inp)
     op.close()
+
+
+def test_coo_operator_sample2_and_inf_norm_offset(ctx):
+    """src/samples/sample2_sparse.cpp: {r, c, value} list of the 3x3 matrix with eigenvalues {1, 1, -2}, smallest wanted.
+    And the offset helper: with eigenvalue_offset = -inf_norm the "smallest" problem converges."""
+    rows, cols, vals = [0, 0, 1, 1, 2, 2], [1, 2, 0, 2, 0, 1], [1.0, 1.0, 1.0, -1.0, 1.0, -1.0]
+    op = L.CsrOperator.from_coo(ctx, 3, rows, cols, vals)
+    assert op.inf_norm() == 2.0
+    eng = L.LambdaLanczos(op, 3, False, 1)
+    vals_, vecs_ = eng.run()
+    assert abs(vals_[0] + 2.0) <= 1e-12
+    assert overlap(vecs_[0], np.array([1.0, -1.0, -1.0])) >= 1 - 1e-12
+    op.close()
+    csr = G.laplace2d_np(30)
+    lap = L.CsrOperator(ctx, *csr)
+    assert lap.inf_norm() == 8.0
+    e2 = L.LambdaLanczos(lap, 900, False, 1)
+    e2.eigenvalue_offset = -lap.inf_norm()
+    v2, _ = e2.run()
+    assert abs(v2[0] - G.laplace2d_lambda_min(30)) <= 1e-10 * 8
+    assert e2.getIterationCounts()[0] < 900          # converged, did not run to max_iteration
+    lap.close()
