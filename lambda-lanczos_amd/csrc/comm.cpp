@@ -10,6 +10,13 @@
 // alpha and the norms.  xGMI is point to point, so the all-gather is the per-link-bound step; everything else is
 // latency sized.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <random>
 
 #include <rccl/rccl.h>
 
@@ -70,13 +77,63 @@ void check(ncclResult_t r, const char* what) {
 }
 }  // namespace
 
+// A second, host-staged backend (LL_COMM_BACKEND=shm) exists for ONE purpose: to run the sharded engine with several
+// ranks on a single GPU, where RCCL refuses duplicate devices.  Same collective semantics through a POSIX shared-memory
+// segment (device -> host slot, barrier, host -> device); slow, deterministic (sums in rank order), never the default.
+// It lets the multi-rank code path (row shards, global column indexing, padded all-gather, replicated decisions) be
+// verified end to end on the 1-GPU test boxes; production multi-GPU runs use RCCL.
+struct ShmSeg {
+  std::atomic<int> arrived;
+  std::atomic<int> generation;
+  int nranks;
+  int pad;
+  size_t slot_bytes;
+};
+
 struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  // shm backend
+  bool shm = false;
+  ShmSeg* seg = nullptr;
+  char* slots = nullptr;
+  size_t map_bytes = 0;
+  std::string shm_name;
+  void barrier() {
+    const int gen = seg->generation.load(std::memory_order_acquire);
+    if (seg->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
+      seg->arrived.store(0, std::memory_order_relaxed);
+      seg->generation.fetch_add(1, std::memory_order_release);
+    } else {
+      // bounded wait: a peer that died must not hang the others
+      for (long spins = 0; seg->generation.load(std::memory_order_acquire) == gen; ++spins) {
+        if (spins < 20000) continue;  // busy-wait first (collectives are latency sized), then back off
+        usleep(20);
+        if (spins > 520000) {  // ~30 s
+          set_error("shm backend: barrier timed out (a peer rank is gone?)");
+          throw Failure{LL_ERR_RCCL};
+        }
+      }
+    }
+  }
+  char* slot(int r) { return slots + (size_t)r * seg->slot_bytes; }
 };
+
+static bool want_shm() {
+  const char* e = std::getenv("LL_COMM_BACKEND");
+  return e && std::string(e) == "shm";
+}
+static constexpr size_t kShmSlotBytes = (size_t)64 << 20;  // per rank; enough for the test problems
 
 void comm_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == LL_UNIQUE_ID_BYTES, "unique id size");
+  if (want_shm()) {  // the "id" is the name of the shared-memory segment
+    std::random_device rd;
+    char name[LL_UNIQUE_ID_BYTES] = {0};
+    std::snprintf(name, sizeof(name), "/ll_shm_%d_%08x", (int)getpid(), (unsigned)rd());
+    std::memcpy(id128, name, LL_UNIQUE_ID_BYTES);
+    return;
+  }
   ncclUniqueId id;
   check(api().GetUniqueId(&id), "ncclGetUniqueId");
   std::memcpy(id128, &id, sizeof(id));
@@ -89,6 +146,53 @@ Comm* comm_create(const void* id128, int rank, int nranks, int device) {
   Comm* c = new Comm;
   c->rank = rank;
   c->nranks = nranks;
+  if (want_shm()) {
+    c->shm = true;
+    c->shm_name.assign((const char*)id128, strnlen((const char*)id128, LL_UNIQUE_ID_BYTES - 1));
+    c->map_bytes = 4096 + kShmSlotBytes * (size_t)nranks;
+    // rank 0 owns the segment: it removes any stale one of the same name (a crashed earlier run) and creates it
+    // afresh (zero-filled); the other ranks wait for it to appear with its final size
+    int fd = -1;
+    if (rank == 0) {
+      shm_unlink(c->shm_name.c_str());
+      fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd >= 0 && ftruncate(fd, (off_t)c->map_bytes) != 0) {
+        close(fd);
+        fd = -1;
+      }
+    } else {
+      for (int tries = 0; tries < 3000 && fd < 0; ++tries) {  // ~30 s
+        fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+        if (fd >= 0) {
+          off_t sz = lseek(fd, 0, SEEK_END);
+          if (sz < (off_t)c->map_bytes) {
+            close(fd);
+            fd = -1;
+          }
+        }
+        if (fd < 0) usleep(10000);
+      }
+    }
+    if (fd < 0) {
+      set_error("shm backend: cannot open " + c->shm_name);
+      delete c;
+      throw Failure{LL_ERR_RCCL};
+    }
+    void* m = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+      set_error("shm backend: mmap failed");
+      delete c;
+      throw Failure{LL_ERR_RCCL};
+    }
+    c->seg = (ShmSeg*)m;  // a fresh segment is zero-filled: arrived = generation = 0
+    c->slots = (char*)m + 4096;
+    c->seg->nranks = nranks;
+    c->seg->slot_bytes = kShmSlotBytes;
+    // rendezvous: everybody has mapped the segment once `arrived` has counted all ranks
+    c->barrier();
+    return c;
+  }
   try {
     check(api().CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank");
   } catch (...) {
@@ -100,15 +204,55 @@ Comm* comm_create(const void* id128, int rank, int nranks, int device) {
 
 void comm_destroy(Comm* c) {
   if (!c) return;
+  if (c->shm) {
+    if (c->seg) munmap((void*)c->seg, c->map_bytes);
+    if (c->rank == 0) shm_unlink(c->shm_name.c_str());
+    delete c;
+    return;
+  }
   if (c->comm) api().CommDestroy(c->comm);
   delete c;
 }
 
+static void shm_allgather(Comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+  if (bytes > c->seg->slot_bytes) {
+    set_error("shm backend: message larger than the slot (test backend only)");
+    throw Failure{LL_ERR_RCCL};
+  }
+  LL_HIP(hipMemcpyAsync(c->slot(c->rank), send, bytes, hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  c->barrier();
+  for (int r = 0; r < c->nranks; ++r)
+    LL_HIP(hipMemcpyAsync((char*)recv + (size_t)r * bytes, c->slot(r), bytes, hipMemcpyHostToDevice, s));
+  LL_HIP(hipStreamSynchronize(s));
+  c->barrier();
+}
+static void shm_allreduce(Comm* c, double* buf, size_t n, hipStream_t s) {
+  const size_t bytes = n * sizeof(double);
+  if (bytes > c->seg->slot_bytes) {
+    set_error("shm backend: message larger than the slot (test backend only)");
+    throw Failure{LL_ERR_RCCL};
+  }
+  LL_HIP(hipMemcpyAsync(c->slot(c->rank), buf, bytes, hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  c->barrier();
+  std::vector<double> sum(n, 0.0);
+  for (int r = 0; r < c->nranks; ++r) {  // rank order on every rank: identical bits everywhere
+    const double* p = (const double*)c->slot(r);
+    for (size_t i = 0; i < n; ++i) sum[i] += p[i];
+  }
+  LL_HIP(hipMemcpyAsync(buf, sum.data(), bytes, hipMemcpyHostToDevice, s));
+  LL_HIP(hipStreamSynchronize(s));
+  c->barrier();
+}
+
 void comm_allgather(Comm* c, const void* send, void* recv, size_t n_doubles, hipStream_t s) {
+  if (c->shm) return shm_allgather(c, send, recv, n_doubles * sizeof(double), s);
   check(api().AllGather(send, recv, n_doubles, ncclDouble, c->comm, s), "ncclAllGather");
 }
 
 void comm_allreduce_sum(Comm* c, double* buf, size_t n_doubles, hipStream_t s) {
+  if (c->shm) return shm_allreduce(c, buf, n_doubles, s);
   check(api().AllReduce(buf, buf, n_doubles, ncclDouble, ncclSum, c->comm, s), "ncclAllReduce");
 }
 

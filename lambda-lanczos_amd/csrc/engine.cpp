@@ -102,7 +102,8 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
   LL_HIP(hipStreamSynchronize(ctx->stream));
 }
 
-template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha) {
+template <typename T>
+void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded) {
   hipStream_t s = ctx->stream;
   ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)op->pb_nrb));
   int nparts = 0;
@@ -110,8 +111,19 @@ template <typename T> void Engine<T>::apply(const T* x_local, T* y, double offse
     const T* x_full = x_local;
     if (ctx->comm != nullptr) {
       // exchange step: every rank needs the whole x for its row block
-      ctx->ensure_xfull((size_t)op->n_shard * ctx->nranks * sizeof(T));
-      comm_allgather(ctx->comm, x_local, ctx->d_xfull, (size_t)op->n_shard * R, s);
+      // The all-gather sends n_shard elements from every rank (equal strides); the last shard can be shorter.  Basis
+      // vectors are padded to the stride (x_padded); a caller-provided shard of exactly n_local elements is copied
+      // into a padded send buffer first (tail of the gathered buffer beyond n is never referenced).
+      const size_t shard_bytes = (size_t)op->n_shard * sizeof(T);
+      ctx->ensure_xfull(shard_bytes * (size_t)(ctx->nranks + 1));
+      const T* send = x_local;
+      if (!x_padded && op->n_local < op->n_shard) {
+        T* pad = (T*)((char*)ctx->d_xfull + shard_bytes * (size_t)ctx->nranks);
+        LL_HIP(hipMemsetAsync(pad, 0, shard_bytes, s));
+        LL_HIP(hipMemcpyAsync(pad, x_local, (size_t)op->n_local * sizeof(T), hipMemcpyDeviceToDevice, s));
+        send = pad;
+      }
+      comm_allgather(ctx->comm, send, ctx->d_xfull, (size_t)op->n_shard * R, s);
       x_full = (const T*)ctx->d_xfull;
     }
     if (op->spmv_kind == LL_SPMV_PB)
@@ -463,7 +475,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       T* x = U.vec(k - 1);
       T* y = U.vec(k);
       timer.mark();
-      E.apply(x, y, P.eigenvalue_offset, E.S(kScalAlpha + slot));  // P0-P3
+      E.apply(x, y, P.eigenvalue_offset, E.S(kScalAlpha + slot), true);  // P0-P3
       timer.mark();
       const ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // P4
       RunList<T> runs;
@@ -708,7 +720,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     T* x = U.vec(k - 1);
     T* y = U.vec(k);
     timer.mark();
-    E.apply(x, y, 0.0, E.S(kScalAlpha + slot));  // EX:107-110
+    E.apply(x, y, 0.0, E.S(kScalAlpha + slot), true);  // EX:107-110
     timer.mark();
     const ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // EX:112-118
     RunList<T> runs;
@@ -804,7 +816,7 @@ void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typen
   int64_t terms = 1;
   for (int64_t k = 1;; ++k) {  // EX:187-195
     factor *= a / H((double)k);
-    E.apply(V.vec(k - 1), V.vec(k), 0.0, nullptr);
+    E.apply(V.vec(k - 1), V.vec(k), 0.0, nullptr, true);
     ++terms;
     E.norm2_dev(V.vec(k), E.S(kScalScratch) + 1);
     double nn = 0.0;

@@ -65,7 +65,8 @@ template <typename T> struct Engine {
   NormRefs plain_norm(double* c1) const { return NormRefs{S(kScalZero), c1, c1, 0}; }
 
   // y = A x + offset x ; Re<x,y> -> *d_alpha (device scalar, all-reduced over ranks); d_alpha nullable.
-  void apply(const T* x_local, T* y, double offset, double* d_alpha);
+  // x_padded: x_local is readable up to the padded shard length n_shard (true for basis vectors).
+  void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false);
   // Orthogonalise w against the runs with an optional fused three-term update; c = device triple for the norms.
   // Returns the NormRefs every consumer must use for ||w|| afterwards.  h_total (device, nullable): R*nb doubles.
   NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total);

@@ -1,0 +1,76 @@
+"""N > 1 ranks with the REAL kernels: 2 and 3 processes share the test box's single GPU and exchange through the
+library's host-staged test communicator (LL_COMM_BACKEND=shm, csrc/comm.cpp) — RCCL refuses several ranks on one
+device, and the pool has 1-GPU boxes only.  Everything except the transport is the production sharded path:
+ll_partition row shards, global column indices, the padded all-gather before each SpMV (CSR-stream and propagation
+blocking), all-reduced alpha / Gram-Schmidt coefficients / norms, replicated host decisions, sharded locked vectors in
+restart passes, sharded Exponentiator input/output."""
+import json
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+from lambda_lanczos_amd import generators as G
+from util import list2c, overlap
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
+    name = "/ll_shm_test_" + uuid.uuid4().hex[:12]
+    env = dict(os.environ, LL_COMM_BACKEND="shm", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shm_rank_worker.py"), str(r), str(world), name,
+                               str(tmp_path)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-4000:]
+    ranks = [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in range(world)]
+
+    def stitch(key, field, idx=None):
+        parts = []
+        for r in ranks:
+            v = r[key][field]
+            parts.append(np.asarray(v if idx is None else v[idx]))
+        return np.concatenate(parts)
+
+    # ---- random symmetric, two roots
+    n = 9001
+    csr = G.randsym_np(n)
+    init = G.start_vector(n, 1)
+    ora = oracle.lanczos(csr, init, True, num_eigs=2, max_iteration=120)
+    y_ref = oracle.spmv(csr, init) + 0.5 * init
+    for label in ("csr", "pb"):
+        key = "randsym_" + label
+        for r in ranks[1:]:   # replicated scalars and decisions
+            assert r[key]["vals"] == ranks[0][key]["vals"] and r[key]["iters"] == ranks[0][key]["iters"]
+            assert r[key]["alpha"] == ranks[0][key]["alpha"]
+        assert sum(r[key]["n_local"] for r in ranks) == n
+        vals = np.array(ranks[0][key]["vals"])
+        assert np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * np.max(np.abs(vals))
+        assert ranks[0][key]["iters"] == ora["iter_counts"]          # fixed windows: identical pass structure
+        m = len(ora["alpha"])
+        assert np.max(np.abs(np.array(ranks[0][key]["alpha"])[:m] - ora["alpha"])) <= 1e-10 * 30
+        for i in range(2):
+            assert 1 - overlap(stitch(key, "vecs", i), ora["eigenvectors"][i]) <= 1e-8
+        y = stitch("spmv_" + label, "y")
+        assert np.max(np.abs(y - y_ref)) <= 1e-12 * 40
+        assert abs(ranks[0]["spmv_" + label]["dot"] - float(init @ y_ref)) <= 1e-9 * n
+    # ---- Laplacian
+    lap = G.laplace2d_np(24)
+    ora2 = oracle.lanczos(lap, G.start_vector(576, 1), False, offset=-8.0)
+    assert abs(ranks[0]["laplace"]["vals"][0] - ora2["eigenvalues"][0]) <= 1e-10 * 8
+    assert abs(ranks[0]["laplace"]["iters"][0] - ora2["iter_counts"][0]) <= 2
+    assert 1 - overlap(stitch("laplace", "vecs", 0), ora2["eigenvectors"][0]) <= 1e-8
+    # ---- complex Exponentiator
+    tcsr = G.torus_np(24)
+    inp = G.start_vector(576, 1, np.complex128)
+    o_out, o_it, _ = oracle.expo(tcsr, -1j, inp)
+    out = np.concatenate([list2c(r["torus_expo"]["out"]) for r in ranks])
+    assert abs(ranks[0]["torus_expo"]["itern"] - o_it) <= 1
+    assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(inp)
