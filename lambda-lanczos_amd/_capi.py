@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblanczos_hip.so")
+LIB_PATH = os.environ.get("LL_LIB_PATH") or os.path.join(_HERE, "lib", "liblanczos_hip.so")
 GEN_PATH = os.path.join(_HERE, "lib", "libllgen.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lanczos_hip.h")
 

@@ -225,7 +225,7 @@ template int launch_spmv<zc>(const ll_operator&, const zc*, const zc*, zc*, doub
 // to run; LL_SPMV_CSR_STREAM remains for bit-reproducible sums and wins on matrices whose gathers hit L1/L2
 // (stencils, narrow bands) — ll_op_create_csr_* times both on the actual matrix and keeps the faster one.
 constexpr int kPbThreads = 1024;
-constexpr int kPbUnroll = 4;  // quads per lane per trip
+constexpr int kPbUnroll = 2;  // quads per lane per trip (measured: 2 beats 4 and 8 by 1-5 %)
 
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
