@@ -337,8 +337,11 @@ bool build_pb(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va
     const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
     for (int64_t p = rp[i0]; p < rp[i1]; ++p) ++cnt[(size_t)(ci[p] / cb_cols) * nrb + r];
   }
-  // every segment is padded to whole quads (kernels move 4 entries per lane with 16-byte accesses)
-  for (auto& v : cnt) v = (v + 3) / 4 * 4;
+  // every segment is padded to 16 entries: kernels move quads (4 entries per lane, 16-byte accesses) and every run of
+  // products written by phase 1 starts and ends on a 128-byte line (measured 3.5 % faster than quad padding)
+  int64_t pad = 16;
+  if (const char* e = std::getenv("LL_PB_PAD")) pad = std::max(4, std::atoi(e) / 4 * 4);
+  for (auto& v : cnt) v = (v + pad - 1) / pad * pad;
   // column-block order: segments (c, r) with r fastest; row-block order: (r, c) with c fastest
   std::vector<int64_t> segq((size_t)ncb * (nrb + 1)), segdest((size_t)ncb * nrb), rptr((size_t)nrb + 1);
   {

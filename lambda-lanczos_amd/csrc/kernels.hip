@@ -229,7 +229,7 @@ constexpr int kPbUnroll = 2;  // quads per lane per trip (measured: 2 beats 4 an
 
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
-// Entries are handled in QUADS: every segment is padded to a multiple of four entries (zero value, local index 0), so
+// Entries are handled in QUADS: every segment is padded to a multiple of 16 entries (zero value, local index 0), so
 // a lane always moves four consecutive entries with 16-byte accesses (2 x dwordx4 of values / products, one dwordx2
 // of four 16-bit indices) and all four share one segment, i.e. one destination run.
 template <typename T> struct quad {
