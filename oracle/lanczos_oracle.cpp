@@ -39,7 +39,16 @@
 #include <random>
 #include <vector>
 
+#include <omp.h>
+
 namespace oracle {
+
+// Thread count of the "all cores" courtesy variant (bench.py cpu_baseline_all_cores).  1 = the reference's own
+// behaviour: single thread, strict left-to-right sums (the stdpar path of the reference is dead code).
+// With t > 1 every n-sized loop below is split over t threads; dot products then sum per-thread chunks in thread
+// order (deterministic for a given t, rounding differs from t = 1).
+static int g_threads = 1;
+#define ORACLE_PAR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)")
 
 template <typename T> struct real_of { typedef T type; };                       // CM:80-102
 template <typename R> struct real_of<std::complex<R>> { typedef R type; };
@@ -56,15 +65,31 @@ template <typename R> inline R re(const std::complex<R>& v) { return v.real(); }
 
 // <a,b> = sum conj(a_i) b_i, strict left fold (LA:29-51; conjugate-linear in arg 1, T1:47-59).
 template <typename T> T inner_prod(const std::vector<T>& a, const std::vector<T>& b) {
+  if (g_threads <= 1) {
+    T acc = T();
+    for (size_t i = 0; i < a.size(); ++i) acc = acc + cj(a[i]) * b[i];
+    return acc;
+  }
+  std::vector<T> part((size_t)g_threads, T());
+#pragma omp parallel num_threads(g_threads)
+  {
+    const size_t t = (size_t)omp_get_thread_num(), nt = (size_t)omp_get_num_threads(), n = a.size();
+    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+    T acc = T();
+    for (size_t i = lo; i < hi; ++i) acc = acc + cj(a[i]) * b[i];
+    part[t] = acc;
+  }
   T acc = T();
-  for (size_t i = 0; i < a.size(); ++i) acc = acc + cj(a[i]) * b[i];
+  for (auto& p : part) acc = acc + p;
   return acc;
 }
 // sqrt(Re<v,v>), unscaled (LA:56-60).
 template <typename T> real_t<T> norm2(const std::vector<T>& v) { return std::sqrt(re(inner_prod(v, v))); }
 // v *= a (LA:65-72).
 template <typename S, typename T> void scalar_mul(S a, std::vector<T>& v) {
-  for (auto& e : v) e *= a;
+  const int64_t n = (int64_t)v.size();
+  ORACLE_PAR
+  for (int64_t i = 0; i < n; ++i) v[(size_t)i] *= a;
 }
 // v *= T(1)/norm(v) (LA:77-80).
 template <typename T> void normalize(std::vector<T>& v) { scalar_mul(T(1) / norm2(v), v); }
@@ -85,7 +110,9 @@ template <typename T, typename It> void schmidt_orth(std::vector<T>& w, It first
   for (It it = first; it != last; ++it) {
     const std::vector<T>& u = *it;
     T h = inner_prod(u, w);
-    for (size_t i = 0; i < w.size(); ++i) w[i] -= h * u[i];
+    const int64_t n = (int64_t)w.size();
+    ORACLE_PAR
+    for (int64_t i = 0; i < n; ++i) w[(size_t)i] -= h * u[(size_t)i];
   }
 }
 
@@ -220,6 +247,7 @@ template <typename T> struct Csr {
   const T* va;
   // out += A in  (the mv_mul contract LL:120-126: out is pre-zeroed by the engine)
   void apply(const std::vector<T>& in, std::vector<T>& out) const {
+    ORACLE_PAR
     for (int64_t i = 0; i < n; ++i) {
       T acc = T();
       for (int64_t p = rp[i]; p < rp[i + 1]; ++p) acc += va[p] * in[ci[p]];
@@ -264,8 +292,10 @@ std::vector<std::vector<T>> ritz_vectors(const std::vector<real_t<T>>& alpha, co
   std::vector<std::vector<T>> x(nev, std::vector<T>(n));
   for (size_t r = 0; r < nev; ++r) {
     const size_t it = find_max ? m - r - 1 : r;
-    for (size_t k = m; k-- > 0;)                                   // k = m-1 .. 0 (LL:53)
-      for (size_t i = 0; i < n; ++i) x[r][i] += tq[it][k] * u[k][i];
+    for (size_t k = m; k-- > 0;) {                                 // k = m-1 .. 0 (LL:53)
+      ORACLE_PAR
+      for (int64_t i = 0; i < (int64_t)n; ++i) x[r][(size_t)i] += tq[it][k] * u[k][(size_t)i];
+    }
     normalize(x[r]);
   }
   return x;
@@ -290,10 +320,13 @@ size_t lanczos_pass(const Csr<T>& A, const Params& P, const T* init, size_t nroo
     double t0 = tr ? now_s() : 0;
     A.apply(u[k - 1], au);                                         // P1 LL:243
     if (tr && tr->t_mv) *tr->t_mv += now_s() - t0;
-    for (size_t i = 0; i < n; ++i) au[i] += u[k - 1][i] * (R)P.eigenvalue_offset;   // P2 LL:244-246
+    ORACLE_PAR
+    for (int64_t i = 0; i < (int64_t)n; ++i) au[(size_t)i] += u[k - 1][(size_t)i] * (R)P.eigenvalue_offset;   // P2 LL:244-246
     alpha.push_back(re(inner_prod(u[k - 1], au)));                 // P3 LL:248
     u.push_back(std::move(au));
-    for (size_t i = 0; i < n; ++i) {                               // P4 LL:251-257
+    ORACLE_PAR
+    for (int64_t ii = 0; ii < (int64_t)n; ++ii) {                   // P4 LL:251-257
+      const size_t i = (size_t)ii;
       if (k == 1) u[k][i] = u[k][i] - alpha[k - 1] * u[k - 1][i];
       else u[k][i] = u[k][i] - beta[k - 2] * u[k - 2][i] - alpha[k - 1] * u[k - 1][i];
     }
@@ -470,6 +503,12 @@ using namespace oracle;
 typedef std::complex<double> zd;
 
 extern "C" {
+
+// threads <= 0: all host cores.  Returns the count in effect.
+int oracle_set_threads(int threads) {
+  g_threads = threads > 0 ? threads : omp_get_max_threads();
+  return g_threads;
+}
 
 struct oracle_params {  // layout shared with tests/oracle_lib.py
   int64_t matrix_size, max_iteration;

@@ -166,8 +166,14 @@ class Oracle(_Checker):
             build_oracle()
         super().__init__(ORACLE_SO, "oracle_")
         L = self.lib
+        L.oracle_set_threads.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_spmv_d.argtypes = [i64, vp, vp, vp, vp, vp]
         L.oracle_spmv_z.argtypes = [i64, vp, vp, vp, vp, vp]
+
+    def set_threads(self, threads):
+        """1 = the reference's single-threaded behaviour (default); <= 0 = all host cores (courtesy baseline)."""
+        return self.lib.oracle_set_threads(int(threads))
 
     def spmv(self, csr, x):
         rp, ci, va = csr
