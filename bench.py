@@ -270,9 +270,11 @@ def main():
         step()
         barrier()
         tg = time.perf_counter()
-        step()
+        vals_g, vecs_g = eng.run()
         barrier()
         tg = time.perf_counter() - tg
+        d_lam = float(abs(vals_g[0] - r["eigenvalues"][0]))
+        defect = float(1.0 - abs(np.vdot(r["eigenvectors"][0], vecs_g[0])))
         cpu = {
             "value": cpu_its / r["t_total"],
             "unit": "Lanczos iterations/s",
@@ -283,6 +285,10 @@ def main():
             "seconds": r["t_total"],
             "spmv_GBps": b_spmv * cpu_its / max(r["t_mv"], 1e-12) / 1e9,
             "gpu_same_window_value": cpu_its / tg,
+            "parity_same_window": {"eigenvalue_cpu": float(r["eigenvalues"][0]), "eigenvalue_gpu": float(vals_g[0]),
+                                   "abs_diff": d_lam, "eigenvector_one_minus_overlap": defect,
+                                   "tolerance": "|dlambda| <= 1e-10*max(1,|lambda|), 1-|<v_cpu,v_gpu>| <= 1e-8",
+                                   "ok": bool(d_lam <= 1e-10 * max(1.0, abs(vals_g[0])) and defect <= 1e-8)},
             "host_cores_available": os.cpu_count(),
         }
 

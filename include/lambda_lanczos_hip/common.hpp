@@ -36,6 +36,31 @@ inline void check(int status) {
 template <typename T> struct is_supported : std::false_type {};
 template <> struct is_supported<double> : std::true_type {};
 template <> struct is_supported<std::complex<double>> : std::true_type {};
+template <> struct is_supported<float> : std::true_type {};
+template <> struct is_supported<std::complex<float>> : std::true_type {};
+
+// Tag dispatch from T to the _d / _z / _s / _c entry points of the C ABI.
+template <typename T> struct abi;
+#define LL_FACADE_ABI(T, SFX, HOSTFN)                                                                                    \
+  template <> struct abi<T> {                                                                                            \
+    static int create_csr(ll_context* c, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,       \
+                          const T* va, ll_operator** o) {                                                                \
+      return ll_op_create_csr_##SFX(c, nr, nc, rb, rp, ci, va, o);                                                       \
+    }                                                                                                                    \
+    static int create_host(ll_context* c, int64_t n, int (*fn)(const void*, void*, int64_t, void*), void* user,          \
+                           ll_operator** o) {                                                                            \
+      return ll_op_create_host_##SFX(c, n, reinterpret_cast<HOSTFN>(fn), user, o);                                       \
+    }                                                                                                                    \
+    static int run(ll_context* c, ll_operator* op, const ll_lanczos_params* p, double* vals, T* vecs, int64_t* found,    \
+                   int64_t* counts, int64_t cap, ll_run_stats* st) {                                                     \
+      return ll_lanczos_run_##SFX(c, op, p, vals, vecs, found, counts, cap, nullptr, nullptr, st);                       \
+    }                                                                                                                    \
+  };
+LL_FACADE_ABI(double, d, ll_host_mv_mul_d)
+LL_FACADE_ABI(float, s, ll_host_mv_mul_s)
+LL_FACADE_ABI(std::complex<double>, z, ll_host_mv_mul_z)
+LL_FACADE_ABI(std::complex<float>, c, ll_host_mv_mul_z)
+#undef LL_FACADE_ABI
 
 // Device + stream + workspace.  Copyable handle (shared ownership).
 class Context {
@@ -71,7 +96,7 @@ class Context {
 // n_cols x n_cols symmetric/Hermitian operator; the whole matrix on a single GPU).  Accepted by the engines in place
 // of the host std::function; then only scalars cross PCIe per iteration.
 template <typename T> class CsrMatrix {
-  static_assert(is_supported<T>::value, "CsrMatrix<T>: T must be double or std::complex<double>");
+  static_assert(is_supported<T>::value, "CsrMatrix<T>: T must be float, double or std::complex of those");
 
  public:
   CsrMatrix(const std::vector<int64_t>& row_ptr, const std::vector<int32_t>& col, const std::vector<T>& val,
@@ -80,11 +105,7 @@ template <typename T> class CsrMatrix {
     const int64_t n_rows = (int64_t)row_ptr.size() - 1;
     if (n_cols < 0) n_cols = n_rows;
     ll_operator* op = nullptr;
-    if (std::is_same<T, double>::value)
-      check(ll_op_create_csr_d(ctx_.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(),
-                               reinterpret_cast<const double*>(val.data()), &op));
-    else
-      check(ll_op_create_csr_z(ctx_.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(), val.data(), &op));
+    check(abi<T>::create_csr(ctx_.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(), val.data(), &op));
     h_.reset(op, [](ll_operator* p) { ll_op_destroy(p); });
     n_ = n_cols;
     n_local_ = n_rows;
@@ -118,7 +139,6 @@ template <typename T> struct HostOp {
       return 1;
     }
   }
-  static int call_d(const double* in_p, double* out_p, int64_t n, void* user) { return call(in_p, out_p, n, user); }
 };
 
 template <typename T> struct InitHook {
@@ -131,17 +151,9 @@ template <typename T> struct InitHook {
   }
 };
 
-template <typename T> inline ll_operator* make_host_operator(ll_context* ctx, int64_t n, HostOp<T>* h);
-template <> inline ll_operator* make_host_operator<double>(ll_context* ctx, int64_t n, HostOp<double>* h) {
+template <typename T> inline ll_operator* make_host_operator(ll_context* ctx, int64_t n, HostOp<T>* h) {
   ll_operator* op = nullptr;
-  check(ll_op_create_host_d(ctx, n, &HostOp<double>::call_d, h, &op));
-  return op;
-}
-template <>
-inline ll_operator* make_host_operator<std::complex<double>>(ll_context* ctx, int64_t n,
-                                                             HostOp<std::complex<double>>* h) {
-  ll_operator* op = nullptr;
-  check(ll_op_create_host_z(ctx, n, &HostOp<std::complex<double>>::call, h, &op));
+  check(abi<T>::create_host(ctx, n, &HostOp<T>::call, h, &op));
   return op;
 }
 }  // namespace detail

@@ -11,7 +11,7 @@
 namespace lambda_lanczos_hip {
 
 template <typename T> class Exponentiator {
-  static_assert(is_supported<T>::value, "Exponentiator<T>: T must be double or std::complex<double>");
+  static_assert(is_supported<T>::value, "Exponentiator<T>: T must be float, double or std::complex of those");
   template <typename n_type> using real_t = util::real_t<n_type>;
 
  public:
@@ -65,6 +65,16 @@ template <typename T> class Exponentiator {
                std::complex<double>* out, int64_t* count, bool taylor) const {
     return taylor ? ll_expo_taylor_run_z(ctx_.get(), op, p, a.real(), a.imag(), in, out, count)
                   : ll_expo_run_z(ctx_.get(), op, p, a.real(), a.imag(), in, out, count, nullptr);
+  }
+  int dispatch(ll_operator* op, const ll_expo_params* p, const float& a, const float* in, float* out, int64_t* count,
+               bool taylor) const {
+    return taylor ? ll_expo_taylor_run_s(ctx_.get(), op, p, (double)a, in, out, count)
+                  : ll_expo_run_s(ctx_.get(), op, p, (double)a, in, out, count, nullptr);
+  }
+  int dispatch(ll_operator* op, const ll_expo_params* p, const std::complex<float>& a, const std::complex<float>* in,
+               std::complex<float>* out, int64_t* count, bool taylor) const {
+    return taylor ? ll_expo_taylor_run_c(ctx_.get(), op, p, (double)a.real(), (double)a.imag(), in, out, count)
+                  : ll_expo_run_c(ctx_.get(), op, p, (double)a.real(), (double)a.imag(), in, out, count, nullptr);
   }
   Context ctx_;
   std::shared_ptr<CsrMatrix<T>> csr_;

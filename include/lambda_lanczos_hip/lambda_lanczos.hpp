@@ -9,7 +9,7 @@
 //   LambdaLanczos<double> engine(csr_matrix, n, true, 1);      // lambda_lanczos::CsrMatrix<double> -> all on device
 //   engine.run(eigenvalues, eigenvectors);
 //
-// Supported T: double, std::complex<double> (float variants: SURVEY 8f "next").
+// Supported T: float, double, std::complex<float>, std::complex<double> (long double has no device counterpart).
 #ifndef LAMBDA_LANCZOS_HIP_LAMBDA_LANCZOS_HPP_
 #define LAMBDA_LANCZOS_HIP_LAMBDA_LANCZOS_HPP_
 
@@ -21,7 +21,7 @@
 namespace lambda_lanczos_hip {
 
 template <typename T> class LambdaLanczos {
-  static_assert(is_supported<T>::value, "LambdaLanczos<T>: T must be double or std::complex<double>");
+  static_assert(is_supported<T>::value, "LambdaLanczos<T>: T must be float, double or std::complex of those");
   template <typename n_type> using real_t = util::real_t<n_type>;
 
  public:
@@ -118,10 +118,7 @@ template <typename T> class LambdaLanczos {
  private:
   int call_run(ll_operator* op, const ll_lanczos_params* p, double* vals, T* vecs, int64_t* found, int64_t* counts,
                int64_t cap, ll_run_stats* st) {
-    if (std::is_same<T, double>::value)
-      return ll_lanczos_run_d(ctx_.get(), op, p, vals, reinterpret_cast<double*>(vecs), found, counts, cap, nullptr,
-                              nullptr, st);
-    return ll_lanczos_run_z(ctx_.get(), op, p, vals, vecs, found, counts, cap, nullptr, nullptr, st);
+    return abi<T>::run(ctx_.get(), op, p, vals, vecs, found, counts, cap, st);
   }
   Context ctx_;
   std::shared_ptr<CsrMatrix<T>> csr_;

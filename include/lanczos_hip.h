@@ -6,6 +6,11 @@
  * C ABI, therefore every entry point exists per scalar type with the BLAS-style suffixes
  *     _d  = double                  (reference T = double)
  *     _z  = double complex          (reference T = std::complex<double>, interleaved re,im)
+ *     _s  = float                   (reference T = float)
+ *     _c  = float complex           (reference T = std::complex<float>, interleaved re,im)
+ *   (the _s/_c declarations are at the end of this file: same arguments as _d/_z with float data pointers; every
+ *   scalar — offsets, eps, alpha, eigenvalues, norms — stays double, and all reductions are accumulated in double,
+ *   which is at least the accuracy of the reference's float arithmetic.  long double has no device counterpart.)
  * and the C++ facade include/lambda_lanczos_hip/{lambda_lanczos,exponentiator}.hpp re-creates
  * lambda_lanczos::LambdaLanczos<T> / Exponentiator<T> on top by tag dispatch.
  *
@@ -143,7 +148,8 @@ int ll_op_inf_norm(const ll_operator* op, double* out);
 /* (2) unmodified user code: a host callback with exactly the reference semantics; costs one D2H + one H2D
  *     of an n-vector per iteration (SURVEY 8b "Operator contract").  Return non-zero from fn to abort. */
 typedef int (*ll_host_mv_mul_d)(const double* in, double* out_zeroed, int64_t n, void* user);
-typedef int (*ll_host_mv_mul_z)(const void* in, void* out_zeroed, int64_t n, void* user);
+typedef int (*ll_host_mv_mul_z)(const void* in, void* out_zeroed, int64_t n, void* user); /* also used by _c */
+typedef int (*ll_host_mv_mul_s)(const float* in, float* out_zeroed, int64_t n, void* user);
 int ll_op_create_host_d(ll_context* ctx, int64_t n, ll_host_mv_mul_d fn, void* user, ll_operator** out);
 int ll_op_create_host_z(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* user, ll_operator** out);
 
@@ -308,6 +314,65 @@ int ll_expo_taylor_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params*
                          const double* input_host, double* output_host, int64_t* nterms_out);
 int ll_expo_taylor_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
                          const void* input_host, void* output_host, int64_t* nterms_out);
+
+/* ------------------------------------------------------------------ float storage types (_s float, _c complex float)
+ * Same entry points as above; see the comments on the _d / _z versions. */
+int ll_op_create_csr_c(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                       const int64_t* row_ptr_host, const int32_t* col_host, const void* val_host ,
+                       ll_operator** out);
+int ll_op_create_csr_s(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                       const int64_t* row_ptr_host, const int32_t* col_host, const float* val_host ,
+                       ll_operator** out);
+int ll_op_create_csr_dev_c(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                           const int64_t* row_ptr_dev, const int32_t* col_dev, const void* val_dev,
+                           ll_operator** out);
+int ll_op_create_csr_dev_s(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                           const int64_t* row_ptr_dev, const int32_t* col_dev, const float* val_dev,
+                           ll_operator** out);
+int ll_op_create_coo_c(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows_host, const int32_t* cols_host,
+                       const void* vals_host, ll_operator** out);
+int ll_op_create_coo_s(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows_host, const int32_t* cols_host,
+                       const float* vals_host, ll_operator** out);
+int ll_op_create_host_c(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* user, ll_operator** out);
+int ll_op_create_host_s(ll_context* ctx, int64_t n, ll_host_mv_mul_s fn, void* user, ll_operator** out);
+int ll_op_create_device_c(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
+int ll_op_create_device_s(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
+int ll_spmv_c(ll_context* ctx, ll_operator* op, const void* x_dev, void* y_dev, double offset, double* dot_host);
+int ll_spmv_s(ll_context* ctx, ll_operator* op, const float* x_dev, float* y_dev, double offset, double* dot_host);
+int ll_dot_c(ll_context* ctx, int64_t n_local, const void* a_dev, const void* b_dev, double* out_host_reim);
+int ll_dot_s(ll_context* ctx, int64_t n_local, const float* a_dev, const float* b_dev, double* out_host_reim);
+int ll_nrm2_c(ll_context* ctx, int64_t n_local, const void* v_dev, double* out_host);
+int ll_nrm2_s(ll_context* ctx, int64_t n_local, const float* v_dev, double* out_host);
+int ll_scal_c(ll_context* ctx, int64_t n_local, double a, void* v_dev);
+int ll_scal_s(ll_context* ctx, int64_t n_local, double a, float* v_dev);
+int ll_normalize_c(ll_context* ctx, int64_t n_local, void* v_dev, double* norm_host );
+int ll_normalize_s(ll_context* ctx, int64_t n_local, float* v_dev, double* norm_host );
+int ll_three_term_c(ll_context* ctx, int64_t n_local, void* w_dev, const void* u_prev_dev, const void* u_cur_dev,
+                    double beta, double alpha);
+int ll_three_term_s(ll_context* ctx, int64_t n_local, float* w_dev, const float* u_prev_dev, const float* u_cur_dev,
+                    double beta, double alpha);
+int ll_orth_block_c(ll_context* ctx, int64_t n_local, int64_t nb, const void* basis_dev, int64_t ld, void* w_dev,
+                    int mode, double* norm_host, double* h_host);
+int ll_orth_block_s(ll_context* ctx, int64_t n_local, int64_t nb, const float* basis_dev, int64_t ld, float* w_dev,
+                    int mode, double* norm_host, double* h_host);
+int ll_gemv_basis_c(ll_context* ctx, int64_t n_local, int64_t m, const void* basis_dev, int64_t ld, int64_t nout,
+                    const double* coeff_host_reim, void* out_dev, int64_t ld_out);
+int ll_gemv_basis_s(ll_context* ctx, int64_t n_local, int64_t m, const float* basis_dev, int64_t ld, int64_t nout,
+                    const double* coeff_host_reim, float* out_dev, int64_t ld_out);
+int ll_lanczos_run_c(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals_host,
+                     void* eigvecs_host, int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out,
+                     double* beta_out, ll_run_stats* stats);
+int ll_lanczos_run_s(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals_host,
+                     float* eigvecs_host, int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out,
+                     double* beta_out, ll_run_stats* stats);
+int ll_expo_run_c(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                  const void* input_host, void* output_host, int64_t* itern_out, ll_run_stats* stats);
+int ll_expo_run_s(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const float* input_host,
+                  float* output_host, int64_t* itern_out, ll_run_stats* stats);
+int ll_expo_taylor_run_c(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                         const void* input_host, void* output_host, int64_t* nterms_out);
+int ll_expo_taylor_run_s(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a,
+                         const float* input_host, float* output_host, int64_t* nterms_out);
 
 #ifdef __cplusplus
 }

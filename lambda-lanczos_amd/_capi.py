@@ -145,6 +145,13 @@ PROTOTYPES = {
     "ll_expo_taylor_run_z": (C.c_int, [vp, vp, P(ExpoParams), f64, f64, vp, vp, P(i64)]),
 }
 
+# float storage types: _s mirrors _d, _c mirrors _z (data pointers are void* here, scalars stay double)
+for _name in list(PROTOTYPES):
+    if _name.endswith("_d") and _name != "ll_memcpy_h2d":
+        PROTOTYPES[_name[:-2] + "_s"] = PROTOTYPES[_name]
+    elif _name.endswith("_z"):
+        PROTOTYPES[_name[:-2] + "_c"] = PROTOTYPES[_name]
+
 _lib = None
 
 

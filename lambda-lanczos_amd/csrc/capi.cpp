@@ -273,6 +273,11 @@ int ll_memset(ll_context* ctx, void* dst, int byte, size_t bytes) {
 extern "C++" {
 namespace {
 
+inline double abs2_host(double v) { return v * v; }
+inline double abs2_host(float v) { return (double)v * (double)v; }
+inline double abs2_host(zc v) { return v.re * v.re + v.im * v.im; }
+inline double abs2_host(cf v) { return (double)v.re * (double)v.re + (double)v.im * (double)v.im; }
+
 // SpMV tiles: runs of whole rows with <= kSpmvTileNnz nonzeros and <= kBlock rows; a longer row is alone.
 void build_tiles(const int64_t* rp, int64_t nrows, std::vector<int32_t>& tiles) {
   tiles.clear();
@@ -318,8 +323,9 @@ bool build_pb(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va
   const int64_t nr = op->n_local, nc = op->n;
   const bool z = scalar_traits<T>::is_complex;
   // LDS budget per workgroup (160 KiB): phase 1 holds the x slice + two tables of nrb entries, phase 2 only the y slice
-  const int64_t col_max = z ? 6656 : 13312;   // <= 104 KiB
-  const int64_t row_max = z ? 9728 : 19456;   // <= 152 KiB
+  (void)z;
+  const int64_t col_max = std::min<int64_t>(65536, (104 * 1024) / (int64_t)sizeof(T));          // x slice <= 104 KiB
+  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)sizeof(acc_t<T>));   // y slice <= 152 KiB
   auto block_len = [&](int64_t len, int64_t slice_max, const char* env) {
     int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
     int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
@@ -460,6 +466,7 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   std::unique_ptr<ll_operator> op(new ll_operator);
   op->kind = ll_operator::CSR;
   op->is_complex = scalar_traits<T>::is_complex;
+  op->elem_bytes = (int)sizeof(T);
   op->ctx = ctx;
   op->n = nc;
   op->n_local = nr;
@@ -481,7 +488,7 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
 #pragma omp parallel for reduction(max : mx) schedule(static)
     for (int64_t i = 0; i < nr; ++i) {
       double rs = 0.0;
-      for (int64_t p = rp_host[i]; p < rp_host[i + 1]; ++p) rs += std::abs(*reinterpret_cast<const typename host_scalar<T>::type*>(&v[p]));
+      for (int64_t p = rp_host[i]; p < rp_host[i + 1]; ++p) rs += std::sqrt(abs2_host(v[p]));
       mx = std::max(mx, rs);
     }
     op->inf_norm = mx;
@@ -517,6 +524,7 @@ template <typename T> void create_cb(ll_context* ctx, int64_t n, ll_operator::Ki
   ll_operator* op = new ll_operator;
   op->kind = kind;
   op->is_complex = scalar_traits<T>::is_complex;
+  op->elem_bytes = (int)sizeof(T);
   op->ctx = ctx;
   op->n = op->n_local = op->n_shard = n;
   *out = op;
@@ -586,7 +594,7 @@ int ll_op_create_host_d(ll_context* ctx, int64_t n, ll_host_mv_mul_d fn, void* u
   return guarded([&] {
     LL_REQUIRE(fn != nullptr, "null callback");
     create_cb<double>(ctx, n, ll_operator::HOST_CB, out);
-    (*out)->host_d = fn;
+    (*out)->host_fn = reinterpret_cast<ll_host_mv_mul_z>(fn);  // same ABI: only the pointee types differ
     (*out)->user = user;
   });
 }
@@ -594,7 +602,7 @@ int ll_op_create_host_z(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* u
   return guarded([&] {
     LL_REQUIRE(fn != nullptr, "null callback");
     create_cb<zc>(ctx, n, ll_operator::HOST_CB, out);
-    (*out)->host_z = fn;
+    (*out)->host_fn = fn;
     (*out)->user = user;
   });
 }
@@ -660,7 +668,8 @@ namespace {
 template <typename T> void spmv_impl(ll_context* ctx, ll_operator* op, const T* x, T* y, double offset, double* dot) {
   use(ctx);
   LL_REQUIRE(op && op->ctx == ctx && x && y, "bad argument");
-  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
+             "operator scalar type mismatch");
   Engine<T> E(ctx, op, op->n_local);
   E.apply(x, y, offset, dot ? E.S(kScalSpare) : nullptr);
   if (dot) E.fetch(E.S(kScalSpare), dot, 1);
@@ -892,6 +901,185 @@ int ll_expo_taylor_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params*
   return guarded([&] {
     LL_REQUIRE(ctx && p && input && output && nterms, "null argument");
     taylor_run<zc>(ctx, op, *p, std::complex<double>(a_re, a_im), (const zc*)input, (zc*)output, nterms);
+  });
+}
+
+// ---------------------------------------------------------------- float storage types: _s (float), _c (complex float)
+// Mechanical twins of the _z entry points above (scalars stay double; data pointers are float / re,im float pairs).
+int ll_op_create_csr_c(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                       const void* va, ll_operator** out) {
+  return guarded([&] { create_csr<cf>(ctx, nr, nc, rb, rp, ci, va, false, out); });
+}
+int ll_op_create_csr_s(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                       const float* va, ll_operator** out) {
+  return guarded([&] { create_csr<float>(ctx, nr, nc, rb, rp, ci, va, false, out); });
+}
+int ll_op_create_csr_dev_c(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const void* va, ll_operator** out) {
+  return guarded([&] { create_csr<cf>(ctx, nr, nc, rb, rp, ci, va, true, out); });
+}
+int ll_op_create_csr_dev_s(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const float* va, ll_operator** out) {
+  return guarded([&] { create_csr<float>(ctx, nr, nc, rb, rp, ci, va, true, out); });
+}
+int ll_op_create_coo_c(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows, const int32_t* cols,
+                       const void* vals, ll_operator** out) {
+  return guarded([&] { create_coo<cf>(ctx, n, nnz, rows, cols, vals, out); });
+}
+int ll_op_create_coo_s(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows, const int32_t* cols,
+                       const float* vals, ll_operator** out) {
+  return guarded([&] { create_coo<float>(ctx, n, nnz, rows, cols, vals, out); });
+}
+int ll_op_create_host_c(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<cf>(ctx, n, ll_operator::HOST_CB, out);
+    (*out)->host_fn = fn;
+    (*out)->user = user;
+  });
+}
+int ll_op_create_host_s(ll_context* ctx, int64_t n, ll_host_mv_mul_s fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<float>(ctx, n, ll_operator::HOST_CB, out);
+    (*out)->host_fn = reinterpret_cast<ll_host_mv_mul_z>(fn);
+    (*out)->user = user;
+  });
+}
+int ll_op_create_device_c(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<cf>(ctx, n, ll_operator::DEV_CB, out);
+    (*out)->dev_fn = fn;
+    (*out)->user = user;
+  });
+}
+int ll_op_create_device_s(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out) {
+  return guarded([&] {
+    LL_REQUIRE(fn != nullptr, "null callback");
+    create_cb<float>(ctx, n, ll_operator::DEV_CB, out);
+    (*out)->dev_fn = fn;
+    (*out)->user = user;
+  });
+}
+int ll_spmv_c(ll_context* ctx, ll_operator* op, const void* x, void* y, double offset, double* dot) {
+  return guarded([&] { spmv_impl<cf>(ctx, op, (const cf*)x, (cf*)y, offset, dot); });
+}
+int ll_spmv_s(ll_context* ctx, ll_operator* op, const float* x, float* y, double offset, double* dot) {
+  return guarded([&] { spmv_impl<float>(ctx, op, (const float*)x, (float*)y, offset, dot); });
+}
+int ll_dot_c(ll_context* ctx, int64_t n, const void* a, const void* b, double* out) {
+  return guarded([&] { dot_impl<cf>(ctx, n, (const cf*)a, (const cf*)b, out); });
+}
+int ll_dot_s(ll_context* ctx, int64_t n, const float* a, const float* b, double* out) {
+  return guarded([&] { dot_impl<float>(ctx, n, (const float*)a, (const float*)b, out); });
+}
+int ll_nrm2_c(ll_context* ctx, int64_t n, const void* v, double* out) {
+  return guarded([&] { nrm2_impl<cf>(ctx, n, (const cf*)v, out); });
+}
+int ll_nrm2_s(ll_context* ctx, int64_t n, const float* v, double* out) {
+  return guarded([&] { nrm2_impl<float>(ctx, n, (const float*)v, out); });
+}
+int ll_scal_c(ll_context* ctx, int64_t n, double a, void* v) {
+  return guarded([&] {
+    use(ctx);
+    launch_scale<cf>(n, (cf*)v, a, nullptr, ctx->stream);
+  });
+}
+int ll_scal_s(ll_context* ctx, int64_t n, double a, float* v) {
+  return guarded([&] {
+    use(ctx);
+    launch_scale<float>(n, (float*)v, a, nullptr, ctx->stream);
+  });
+}
+int ll_normalize_c(ll_context* ctx, int64_t n, void* v, double* norm_out) {
+  return guarded([&] { normalize_impl<cf>(ctx, n, (cf*)v, norm_out); });
+}
+int ll_normalize_s(ll_context* ctx, int64_t n, float* v, double* norm_out) {
+  return guarded([&] { normalize_impl<float>(ctx, n, (float*)v, norm_out); });
+}
+int ll_three_term_c(ll_context* ctx, int64_t n, void* w, const void* up, const void* uc, double beta, double alpha) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(w && uc, "null vector");
+    launch_three_term<cf>(n, (cf*)w, (const cf*)up, (const cf*)uc, beta, alpha, ctx->stream);
+  });
+}
+int ll_three_term_s(ll_context* ctx, int64_t n, float* w, const float* up, const float* uc, double beta, double alpha) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(w && uc, "null vector");
+    launch_three_term<float>(n, (float*)w, (const float*)up, (const float*)uc, beta, alpha, ctx->stream);
+  });
+}
+int ll_orth_block_c(ll_context* ctx, int64_t n, int64_t nb, const void* basis, int64_t ld, void* w, int mode,
+                    double* norm_out, double* h_out) {
+  return guarded([&] { orth_impl<cf>(ctx, n, nb, (const cf*)basis, ld, (cf*)w, mode, norm_out, h_out); });
+}
+int ll_orth_block_s(ll_context* ctx, int64_t n, int64_t nb, const float* basis, int64_t ld, float* w, int mode,
+                    double* norm_out, double* h_out) {
+  return guarded([&] { orth_impl<float>(ctx, n, nb, (const float*)basis, ld, (float*)w, mode, norm_out, h_out); });
+}
+int ll_gemv_basis_c(ll_context* ctx, int64_t n, int64_t m, const void* basis, int64_t ld, int64_t nout,
+                    const double* coeff, void* out, int64_t ld_out) {
+  return guarded([&] {  // coefficients arrive as doubles (re,im pairs) like every scalar of the _s/_c API
+    LL_REQUIRE(coeff != nullptr && m >= 1 && nout >= 1, "bad argument");
+    std::vector<cf> cc((size_t)(nout * m));
+    for (size_t i = 0; i < cc.size(); ++i) cc[i] = cf{(float)coeff[2 * i], (float)coeff[2 * i + 1]};
+    gemv_impl<cf>(ctx, n, m, (const cf*)basis, ld, nout, cc.data(), (cf*)out, ld_out);
+  });
+}
+int ll_gemv_basis_s(ll_context* ctx, int64_t n, int64_t m, const float* basis, int64_t ld, int64_t nout,
+                    const double* coeff, float* out, int64_t ld_out) {
+  return guarded([&] {
+    LL_REQUIRE(coeff != nullptr && m >= 1 && nout >= 1, "bad argument");
+    std::vector<float> cc((size_t)(nout * m));
+    for (size_t i = 0; i < cc.size(); ++i) cc[i] = (float)coeff[i];
+    gemv_impl<float>(ctx, n, m, (const float*)basis, ld, nout, cc.data(), (float*)out, ld_out);
+  });
+}
+int ll_lanczos_run_c(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals, void* eigvecs,
+                     int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
+                     ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && eigvals && n_found, "null argument");
+    lanczos_run<cf>(ctx, op, *p, eigvals, (cf*)eigvecs, n_found, iter_counts, iter_cap, alpha_out, beta_out, stats);
+  });
+}
+int ll_lanczos_run_s(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals, float* eigvecs,
+                     int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
+                     ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && eigvals && n_found, "null argument");
+    lanczos_run<float>(ctx, op, *p, eigvals, (float*)eigvecs, n_found, iter_counts, iter_cap, alpha_out, beta_out, stats);
+  });
+}
+int ll_expo_run_c(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                  const void* input, void* output, int64_t* itern, ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && itern, "null argument");
+    expo_run<cf>(ctx, op, *p, std::complex<double>(a_re, a_im), (const cf*)input, (cf*)output, itern, stats);
+  });
+}
+int ll_expo_taylor_run_c(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
+                         const void* input, void* output, int64_t* nterms) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && nterms, "null argument");
+    taylor_run<cf>(ctx, op, *p, std::complex<double>(a_re, a_im), (const cf*)input, (cf*)output, nterms);
+  });
+}
+int ll_expo_run_s(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const float* input,
+                  float* output, int64_t* itern, ll_run_stats* stats) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && itern, "null argument");
+    expo_run<float>(ctx, op, *p, a, input, output, itern, stats);
+  });
+}
+int ll_expo_taylor_run_s(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const float* input,
+                         float* output, int64_t* nterms) {
+  return guarded([&] {
+    LL_REQUIRE(ctx && p && input && output && nterms, "null argument");
+    taylor_run<float>(ctx, op, *p, a, input, output, nterms);
   });
 }
 

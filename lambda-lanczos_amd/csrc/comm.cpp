@@ -246,9 +246,9 @@ static void shm_allreduce(Comm* c, double* buf, size_t n, hipStream_t s) {
   c->barrier();
 }
 
-void comm_allgather(Comm* c, const void* send, void* recv, size_t n_doubles, hipStream_t s) {
-  if (c->shm) return shm_allgather(c, send, recv, n_doubles * sizeof(double), s);
-  check(api().AllGather(send, recv, n_doubles, ncclDouble, c->comm, s), "ncclAllGather");
+void comm_allgather(Comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+  if (c->shm) return shm_allgather(c, send, recv, bytes, s);
+  check(api().AllGather(send, recv, bytes, ncclChar, c->comm, s), "ncclAllGather");
 }
 
 void comm_allreduce_sum(Comm* c, double* buf, size_t n_doubles, hipStream_t s) {

@@ -123,7 +123,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         LL_HIP(hipMemcpyAsync(pad, x_local, (size_t)op->n_local * sizeof(T), hipMemcpyDeviceToDevice, s));
         send = pad;
       }
-      comm_allgather(ctx->comm, send, ctx->d_xfull, (size_t)op->n_shard * R, s);
+      comm_allgather(ctx->comm, send, ctx->d_xfull, shard_bytes, s);
       x_full = (const T*)ctx->d_xfull;
     }
     if (op->spmv_kind == LL_SPMV_PB)
@@ -139,9 +139,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       op->h_out.assign(bytes, 0);  // "out" is zero-filled on entry (LL:242, EX:107)
       LL_HIP(hipMemcpyAsync(op->h_in.data(), x_local, bytes, hipMemcpyDeviceToHost, s));
       LL_HIP(hipStreamSynchronize(s));
-      int rc = op->is_complex ? op->host_z(op->h_in.data(), op->h_out.data(), n_local, op->user)
-                              : op->host_d((const double*)op->h_in.data(), (double*)op->h_out.data(), n_local,
-                                           op->user);
+      int rc = op->host_fn(op->h_in.data(), op->h_out.data(), n_local, op->user);
       if (rc != 0) {
         set_error("mv_mul host callback returned " + std::to_string(rc));
         throw Failure{LL_ERR_CALLBACK};
@@ -365,6 +363,21 @@ template <> void default_init<double>(double* v, int64_t n) {
   std::uniform_real_distribution<double> r(-1.0, 1.0);
   for (int64_t i = 0; i < n; ++i) v[i] = r(mt);
 }
+template <> void default_init<float>(float* v, int64_t n) {
+  std::random_device dev;
+  std::mt19937 mt(dev());
+  std::uniform_real_distribution<float> r(-1.0f, 1.0f);
+  for (int64_t i = 0; i < n; ++i) v[i] = r(mt);
+}
+template <> void default_init<cf>(cf* v, int64_t n) {
+  std::random_device dev;
+  std::mt19937 mt(dev());
+  std::uniform_real_distribution<float> r(-1.0f, 1.0f);
+  for (int64_t i = 0; i < n; ++i) {
+    v[i].re = r(mt);
+    v[i].im = r(mt);
+  }
+}
 template <> void default_init<zc>(zc* v, int64_t n) {
   std::random_device dev;
   std::mt19937 mt(dev());
@@ -377,6 +390,8 @@ template <> void default_init<zc>(zc* v, int64_t n) {
 
 inline double as_real_coeff(double v, double*) { return v; }
 inline zc as_real_coeff(double v, zc*) { return zc{v, 0.0}; }
+inline float as_real_coeff(double v, float*) { return (float)v; }
+inline cf as_real_coeff(double v, cf*) { return cf{(float)v, 0.0f}; }
 
 int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration) {
   int64_t want = initial_vector_size > 0 ? initial_vector_size : 200;
@@ -392,7 +407,8 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
                  int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
                  ll_run_stats* stats) {
   LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
-  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
+             "operator scalar type mismatch");
   LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
   LL_REQUIRE(P.num_eigs >= 1 && P.num_eigs <= P.matrix_size, "num_eigs out of range");
   LL_REQUIRE(P.max_iteration >= 1, "max_iteration must be >= 1");
@@ -514,7 +530,8 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
           evs.push_back(tridiag_bisect(m, alpha.data(), beta.data(), P.find_maximum ? m - i - 1 : i));
       }
       t_tridiag += now_s() - t0;
-      if (beta.back() < std::numeric_limits<double>::epsilon() * 1e1) return true;  // H3 LL:279-283
+      // H3 LL:279-283: 10 * machine epsilon of real_t<T> (float storage => the float epsilon, like the reference)
+      if (beta.back() < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon() * 1e1) return true;
       bool stop = true;  // H4 LL:290-309
       if (pevs.size() != evs.size()) stop = false;
       else
@@ -671,11 +688,17 @@ template void lanczos_run<double>(ll_context*, ll_operator*, const ll_lanczos_pa
                                   int64_t*, int64_t, double*, double*, ll_run_stats*);
 template void lanczos_run<zc>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, zc*, int64_t*, int64_t*,
                               int64_t, double*, double*, ll_run_stats*);
+template void lanczos_run<float>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, float*, int64_t*,
+                                 int64_t*, int64_t, double*, double*, ll_run_stats*);
+template void lanczos_run<cf>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, cf*, int64_t*, int64_t*,
+                              int64_t, double*, double*, ll_run_stats*);
 
 // ================================================================= Exponentiator<T>::run
 namespace {
 inline void from_std(double v, double* o) { *o = v; }
 inline void from_std(std::complex<double> v, zc* o) { o->re = v.real(); o->im = v.imag(); }
+inline void from_std(double v, float* o) { *o = (float)v; }
+inline void from_std(std::complex<double> v, cf* o) { o->re = (float)v.real(); o->im = (float)v.imag(); }
 inline double conj_h(double v) { return v; }
 inline std::complex<double> conj_h(std::complex<double> v) { return std::conj(v); }
 }  // namespace
@@ -685,7 +708,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
               const T* input, T* output, int64_t* itern_out, ll_run_stats* stats) {
   typedef typename host_scalar<T>::type H;
   LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
-  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
+             "operator scalar type mismatch");
   LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
   LL_REQUIRE(P.max_iteration >= 1, "max_iteration must be >= 1");
   LL_HIP(hipSetDevice(ctx->device));
@@ -753,7 +777,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     H overlap = H(0);
     for (size_t i = 0; i < coeff_prev.size(); ++i) overlap += conj_h(coeff_prev[i]) * coeff[i];  // EX:147-150
     coeff_prev = coeff;  // EX:152
-    return std::abs(1.0 - std::abs(overlap)) < P.eps || beta_j < std::numeric_limits<double>::epsilon();  // EX:154-158
+    return std::abs(1.0 - std::abs(overlap)) < P.eps ||
+           beta_j < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon();  // EX:154-158
   };
 
   for (int64_t k = 1; k <= P.max_iteration; ++k) {
@@ -790,6 +815,10 @@ template void expo_run<double>(ll_context*, ll_operator*, const ll_expo_params&,
                                int64_t*, ll_run_stats*);
 template void expo_run<zc>(ll_context*, ll_operator*, const ll_expo_params&, std::complex<double>, const zc*, zc*,
                            int64_t*, ll_run_stats*);
+template void expo_run<float>(ll_context*, ll_operator*, const ll_expo_params&, double, const float*, float*, int64_t*,
+                              ll_run_stats*);
+template void expo_run<cf>(ll_context*, ll_operator*, const ll_expo_params&, std::complex<double>, const cf*, cf*,
+                           int64_t*, ll_run_stats*);
 
 // ================================================================= Exponentiator<T>::taylor_run (EX:175-210)
 template <typename T>
@@ -797,7 +826,8 @@ void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typen
                 const T* input, T* output, int64_t* nterms_out) {
   typedef typename host_scalar<T>::type H;
   LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
-  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex, "operator scalar type mismatch");
+  LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
+             "operator scalar type mismatch");
   LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
   LL_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -842,12 +872,22 @@ template void taylor_run<double>(ll_context*, ll_operator*, const ll_expo_params
                                  int64_t*);
 template void taylor_run<zc>(ll_context*, ll_operator*, const ll_expo_params&, std::complex<double>, const zc*, zc*,
                              int64_t*);
+template void taylor_run<float>(ll_context*, ll_operator*, const ll_expo_params&, double, const float*, float*,
+                                int64_t*);
+template void taylor_run<cf>(ll_context*, ll_operator*, const ll_expo_params&, std::complex<double>, const cf*, cf*,
+                             int64_t*);
 
 template struct Basis<double>;
 template struct Basis<zc>;
+template struct Basis<float>;
+template struct Basis<cf>;
 template struct RunList<double>;
 template struct RunList<zc>;
+template struct RunList<float>;
+template struct RunList<cf>;
 template struct Engine<double>;
 template struct Engine<zc>;
+template struct Engine<float>;
+template struct Engine<cf>;
 
 }  // namespace ll

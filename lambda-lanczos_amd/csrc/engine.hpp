@@ -84,6 +84,9 @@ template <typename T> struct Engine {
 template <typename T> struct host_scalar;
 template <> struct host_scalar<double> { typedef double type; };
 template <> struct host_scalar<zc> { typedef std::complex<double> type; };
+// float storage: the k-sized host math (tridiagonal step, exp(a T_k) e_1, coefficients) stays in double
+template <> struct host_scalar<float> { typedef double type; };
+template <> struct host_scalar<cf> { typedef std::complex<double> type; };
 
 // Whole-loop drivers
 template <typename T>

@@ -19,41 +19,86 @@
 namespace ll {
 
 // ---------------------------------------------------------------- scalar helpers
+// Storage types T: double, zc (complex double), float, cf (complex float).  Products of two stored values stay in T;
+// everything that is SUMMED over many elements (dot products, row sums, norms) is carried in acc_t<T> = double / zc.
 __device__ __forceinline__ double zero_of(double*) { return 0.0; }
 __device__ __forceinline__ zc zero_of(zc*) { return zc{0.0, 0.0}; }
+__device__ __forceinline__ float zero_of(float*) { return 0.0f; }
+__device__ __forceinline__ cf zero_of(cf*) { return cf{0.0f, 0.0f}; }
 template <typename T> __device__ __forceinline__ T zero() { return zero_of((T*)nullptr); }
 
+__device__ __forceinline__ double to_acc(double a) { return a; }
+__device__ __forceinline__ double to_acc(float a) { return (double)a; }
+__device__ __forceinline__ zc to_acc(zc a) { return a; }
+__device__ __forceinline__ zc to_acc(cf a) { return zc{(double)a.re, (double)a.im}; }
+__device__ __forceinline__ void from_acc(double a, double* o) { *o = a; }
+__device__ __forceinline__ void from_acc(double a, float* o) { *o = (float)a; }
+__device__ __forceinline__ void from_acc(zc a, zc* o) { *o = a; }
+__device__ __forceinline__ void from_acc(zc a, cf* o) { *o = cf{(float)a.re, (float)a.im}; }
+template <typename T> __device__ __forceinline__ T narrow(acc_t<T> a) {
+  T o;
+  from_acc(a, &o);
+  return o;
+}
+
 __device__ __forceinline__ double mul(double a, double b) { return a * b; }
+__device__ __forceinline__ float mul(float a, float b) { return a * b; }
 __device__ __forceinline__ zc mul(zc a, zc b) { return zc{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cf mul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ double add(double a, double b) { return a + b; }
+__device__ __forceinline__ float add(float a, float b) { return a + b; }
 __device__ __forceinline__ zc add(zc a, zc b) { return zc{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf add(cf a, cf b) { return cf{a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ double sub(double a, double b) { return a - b; }
+__device__ __forceinline__ float sub(float a, float b) { return a - b; }
 __device__ __forceinline__ zc sub(zc a, zc b) { return zc{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf sub(cf a, cf b) { return cf{a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ double rmul(double r, double a) { return r * a; }
+__device__ __forceinline__ float rmul(double r, float a) { return (float)r * a; }
 __device__ __forceinline__ zc rmul(double r, zc a) { return zc{r * a.re, r * a.im}; }
+__device__ __forceinline__ cf rmul(double r, cf a) { return cf{(float)r * a.re, (float)a.im * (float)r}; }
 // acc += a*b
 __device__ __forceinline__ void fma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void fma_acc(float& acc, float a, float b) { acc = fmaf(a, b, acc); }
+__device__ __forceinline__ void fma_acc(double& acc, float a, float b) { acc = fma((double)a, (double)b, acc); }
 __device__ __forceinline__ void fma_acc(zc& acc, zc a, zc b) {
   acc.re = fma(a.re, b.re, fma(-a.im, b.im, acc.re));
   acc.im = fma(a.re, b.im, fma(a.im, b.re, acc.im));
 }
+__device__ __forceinline__ void fma_acc(cf& acc, cf a, cf b) {
+  acc.re = fmaf(a.re, b.re, fmaf(-a.im, b.im, acc.re));
+  acc.im = fmaf(a.re, b.im, fmaf(a.im, b.re, acc.im));
+}
+__device__ __forceinline__ void fma_acc(zc& acc, cf a, cf b) { fma_acc(acc, to_acc(a), to_acc(b)); }
 // acc += conj(a)*b   (inner product is conjugate-linear in its first argument, LA:41,49)
 __device__ __forceinline__ void cfma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void cfma_acc(double& acc, float a, float b) { acc = fma((double)a, (double)b, acc); }
 __device__ __forceinline__ void cfma_acc(zc& acc, zc a, zc b) {
   acc.re = fma(a.re, b.re, fma(a.im, b.im, acc.re));
   acc.im = fma(a.re, b.im, fma(-a.im, b.re, acc.im));
 }
-// acc -= h*u
-__device__ __forceinline__ void fnma_acc(double& acc, double h, double u) { acc = fma(-h, u, acc); }
-__device__ __forceinline__ void fnma_acc(zc& acc, zc h, zc u) {
-  acc.re = fma(-h.re, u.re, fma(h.im, u.im, acc.re));
-  acc.im = fma(-h.re, u.im, fma(-h.im, u.re, acc.im));
+__device__ __forceinline__ void cfma_acc(zc& acc, cf a, cf b) { cfma_acc(acc, to_acc(a), to_acc(b)); }
+// w -= h*u  (h in the accumulator type, w and u stored values)
+__device__ __forceinline__ void fnma_acc(double& w, double h, double u) { w = fma(-h, u, w); }
+__device__ __forceinline__ void fnma_acc(float& w, double h, float u) { w = (float)fma(-h, (double)u, (double)w); }
+__device__ __forceinline__ void fnma_acc(zc& w, zc h, zc u) {
+  w.re = fma(-h.re, u.re, fma(h.im, u.im, w.re));
+  w.im = fma(-h.re, u.im, fma(-h.im, u.re, w.im));
+}
+__device__ __forceinline__ void fnma_acc(cf& w, zc h, cf u) {
+  zc t = to_acc(w);
+  fnma_acc(t, h, to_acc(u));
+  w = cf{(float)t.re, (float)t.im};
 }
 __device__ __forceinline__ double abs2(double a) { return a * a; }
+__device__ __forceinline__ double abs2(float a) { return (double)a * (double)a; }
 __device__ __forceinline__ double abs2(zc a) { return fma(a.re, a.re, a.im * a.im); }
+__device__ __forceinline__ double abs2(cf a) { return fma((double)a.re, (double)a.re, (double)a.im * (double)a.im); }
 // Re(conj(a)*b)
 __device__ __forceinline__ double re_cmul(double a, double b) { return a * b; }
+__device__ __forceinline__ double re_cmul(float a, float b) { return (double)a * (double)b; }
 __device__ __forceinline__ double re_cmul(zc a, zc b) { return fma(a.re, b.re, a.im * b.im); }
+__device__ __forceinline__ double re_cmul(cf a, cf b) { return fma((double)a.re, (double)b.re, (double)a.im * (double)b.im); }
 
 __device__ __forceinline__ double shfl_down_d(double v, int delta) { return __shfl_down(v, delta, 64); }
 
@@ -120,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
     const int nr = r1 - r0;
     if (nr == 1 && p1 - p0 > kSpmvTileNnz) {
       // long row: the whole workgroup strides over it
-      T acc = zero<T>();
+      acc_t<T> acc = zero<acc_t<T>>();
       for (long long p = p0 + tid; p < p1; p += kBlock) fma_acc(acc, va[p], xf[ci[p]]);
-      T tot;
+      acc_t<T> tot;
       if constexpr (scalar_traits<T>::is_complex) {
         double a = block_sum(acc.re, red);
         double b = block_sum(acc.im, red);
@@ -132,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
       }
       if (tid == 0) {
         const T xi = xl[r0];
-        T yi = add(tot, rmul(offset, xi));
+        T yi = add(narrow<T>(tot), rmul(offset, xi));
         y[r0] = yi;
         dot_acc += re_cmul(xi, yi);
       }
@@ -151,11 +196,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
     int lanes = 1;
     while (lanes < 64 && nr * (lanes << 1) <= kBlock) lanes <<= 1;
     const int g = tid / lanes, l = tid - g * lanes;
-    T acc = zero<T>();
+    acc_t<T> acc = zero<acc_t<T>>();
     int row = r0 + g;
     if (g < nr) {
       const int a = (int)((long long)rp[row] - p0), b = (int)((long long)rp[row + 1] - p0);
-      for (int i = a + l; i < b; i += lanes) acc = add(acc, prod[i]);
+      for (int i = a + l; i < b; i += lanes) acc = add(acc, to_acc(prod[i]));
     }
     for (int d = lanes >> 1; d > 0; d >>= 1) {
       if constexpr (scalar_traits<T>::is_complex) {
@@ -167,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
     }
     if (g < nr && l == 0) {
       const T xi = xl[row];
-      T yi = add(acc, rmul(offset, xi));
+      T yi = add(narrow<T>(acc), rmul(offset, xi));
       y[row] = yi;
       dot_acc += re_cmul(xi, yi);
     }
@@ -198,9 +243,8 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_spmv<double>(const ll_operator&, const double*, const double*, double*, double, double*,
-                                 hipStream_t);
-template int launch_spmv<zc>(const ll_operator&, const zc*, const zc*, zc*, double, double*, hipStream_t);
+#define LL_INST_SPMV(T) template int launch_spmv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
+LL_INST_SPMV(double) LL_INST_SPMV(zc) LL_INST_SPMV(float) LL_INST_SPMV(cf)
 
 // ================================================================= a1/a2/a3: propagation-blocked SpMV
 // Measured on MI355X (profiles/r01_*): a gather that misses the CU's 32 KiB L1 moves a whole 128-byte line for 8
@@ -236,26 +280,22 @@ template <typename T> struct quad {
   T e[4];
 };
 template <typename T> __device__ __forceinline__ quad<T> load_quad(const T* __restrict__ p) {
-  quad<T> q;
-  if constexpr (scalar_traits<T>::is_complex) {
+  constexpr int NCH = (int)(4 * sizeof(T) / 16);  // 16-byte pieces of four entries (float: 1, double / cf: 2, zc: 4)
+  const uint4* src = reinterpret_cast<const uint4*>(p);
+  uint4 c[NCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q.e[i] = p[i];
-  } else {
-    const double2* d = reinterpret_cast<const double2*>(p);
-    const double2 a = d[0], b = d[1];
-    q.e[0] = a.x; q.e[1] = a.y; q.e[2] = b.x; q.e[3] = b.y;
-  }
+  for (int i = 0; i < NCH; ++i) c[i] = src[i];
+  quad<T> q;
+  __builtin_memcpy(&q, c, sizeof(q));
   return q;
 }
 template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__ p, const quad<T>& q) {
-  if constexpr (scalar_traits<T>::is_complex) {
+  constexpr int NCH = (int)(4 * sizeof(T) / 16);
+  uint4 c[NCH];
+  __builtin_memcpy(c, &q, sizeof(q));
+  uint4* dst = reinterpret_cast<uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = q.e[i];
-  } else {
-    double2* d = reinterpret_cast<double2*>(p);
-    d[0] = make_double2(q.e[0], q.e[1]);
-    d[1] = make_double2(q.e[2], q.e[3]);
-  }
+  for (int i = 0; i < NCH; ++i) dst[i] = c[i];
 }
 
 template <typename T>
@@ -266,7 +306,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int cb_cols, in
                                                         const T* __restrict__ xf, T* __restrict__ P) {
   extern __shared__ double lds[];
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
-  long long* qs = reinterpret_cast<long long*>(xs + cb_cols);                      // [nrb + 1]
+  long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
+                                              (((size_t)cb_cols * sizeof(T) + 7) & ~(size_t)7));  // [nrb + 1]
   long long* db = qs + (nrb + 1);                                                  // [nrb]
   const int tid = threadIdx.x;
   const int c = blockIdx.x;
@@ -316,10 +357,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int cb_cols, in
 
 template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, int rl, const T& v) {
   if constexpr (scalar_traits<T>::is_complex) {
-    lds_add(&lds[2 * rl], v.re);
-    lds_add(&lds[2 * rl + 1], v.im);
+    lds_add(&lds[2 * rl], (double)v.re);
+    lds_add(&lds[2 * rl + 1], (double)v.im);
   } else {
-    lds_add(&lds[rl], v);
+    lds_add(&lds[rl], (double)v);
   }
 }
 
@@ -369,10 +410,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
   double dot_acc = 0.0;
   for (int i = tid; i < rows; i += kPbThreads) {
     const T xi = xl[row0 + i];
-    T acc;
+    acc_t<T> acc;
     if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
     else acc = lds[i];
-    const T yi = add(acc, rmul(offset, xi));
+    const T yi = add(narrow<T>(acc), rmul(offset, xi));
     y[row0 + i] = yi;
     dot_acc += re_cmul(xi, yi);
   }
@@ -394,18 +435,14 @@ int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* 
   static bool attr_set = false;
   if (!attr_set) {
     const int cap = 160 * 1024 - 2048;
-    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase1<double>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase1<zc>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase2<double>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pb_phase2<zc>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+#define LL_PB_ATTR(K) LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, cap))
+    LL_PB_ATTR(pb_phase1<double>); LL_PB_ATTR(pb_phase1<zc>); LL_PB_ATTR(pb_phase1<float>); LL_PB_ATTR(pb_phase1<cf>);
+    LL_PB_ATTR(pb_phase2<double>); LL_PB_ATTR(pb_phase2<zc>); LL_PB_ATTR(pb_phase2<float>); LL_PB_ATTR(pb_phase2<cf>);
+#undef LL_PB_ATTR
     attr_set = true;
   }
-  const size_t lds1 = (size_t)op.pb_cb_cols * sizeof(T) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
-  const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(T);
+  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 7) & ~(size_t)7) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
+  const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
   hipLaunchKernelGGL((pb_phase1<T>), dim3(op.pb_ncb), dim3(kPbThreads), lds1, s, op.pb_nrb, op.pb_cb_cols, op.n,
                      op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, x_full, (T*)op.d_pb_prod);
   LL_HIP(hipGetLastError());
@@ -414,9 +451,8 @@ int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* 
   LL_HIP(hipGetLastError());
   return op.pb_nrb;
 }
-template int launch_spmv_pb<double>(const ll_operator&, const double*, const double*, double*, double, double*,
-                                    hipStream_t);
-template int launch_spmv_pb<zc>(const ll_operator&, const zc*, const zc*, zc*, double, double*, hipStream_t);
+#define LL_INST_PB(T) template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
+LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)
 
 // ================================================================= strip geometry of the BLAS-1 kernels
 // A workgroup owns strips of kBlock*EPT consecutive elements; every lane keeps EPT elements of w in registers as
@@ -424,7 +460,7 @@ template int launch_spmv_pb<zc>(const ll_operator&, const zc*, const zc*, zc*, d
 constexpr int kJB = 4;  // basis vectors per trip of the multi-dot / multi-axpy loops
 
 template <typename T> struct strip {
-  static constexpr int EPT = scalar_traits<T>::is_complex ? 4 : 8;  // 64 B per lane per vector
+  static constexpr int EPT = (int)(64 / sizeof(T));  // 64 B per lane per vector: 16 float, 8 double / cf, 4 zc
   static constexpr int ELEMS = kBlock * EPT;
 };
 
@@ -438,33 +474,18 @@ static int strip_grid(int64_t n, int elems) {
   return (int)((strips + per - 1) / per);
 }
 
-// Vector pieces: a lane's EPT elements are contiguous (EPT*sizeof(T) = 64 B), lanes are adjacent -> every
-// wave-instruction moves 64 lanes x 16 B of consecutive memory when the strip is full.
-template <typename T> struct piece;
-template <> struct piece<double> {
-  static constexpr int PER = 2;  // doubles per 16 B
-};
-template <> struct piece<zc> {
-  static constexpr int PER = 1;
-};
-
+// A lane's EPT elements are contiguous (64 B = four 16-byte pieces), lanes are adjacent -> every wave-instruction
+// moves 64 lanes x 16 B of consecutive memory when the strip is full.
 template <typename T>
 __device__ __forceinline__ void load_strip(const T* __restrict__ v, int64_t base, int64_t n, T (&r)[strip<T>::EPT]) {
   constexpr int EPT = strip<T>::EPT;
   const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
   if (i0 + EPT <= n) {
-    if constexpr (scalar_traits<T>::is_complex) {
+    const uint4* p = reinterpret_cast<const uint4*>(v + i0);
+    uint4 c[4];
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) r[e] = v[i0 + e];
-    } else {
-      const double2* p = reinterpret_cast<const double2*>(v + i0);
-#pragma unroll
-      for (int e = 0; e < EPT / 2; ++e) {
-        double2 q = p[e];
-        r[2 * e] = q.x;
-        r[2 * e + 1] = q.y;
-      }
-    }
+    for (int e = 0; e < 4; ++e) c[e] = p[e];
+    __builtin_memcpy(&r[0], c, sizeof(c));
   } else {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) r[e] = (i0 + e < n) ? v[i0 + e] : zero<T>();
@@ -476,14 +497,11 @@ __device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int
   constexpr int EPT = strip<T>::EPT;
   const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
   if (i0 + EPT <= n) {
-    if constexpr (scalar_traits<T>::is_complex) {
+    uint4 c[4];
+    __builtin_memcpy(c, &r[0], sizeof(c));
+    uint4* p = reinterpret_cast<uint4*>(v + i0);
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) v[i0 + e] = r[e];
-    } else {
-      double2* p = reinterpret_cast<double2*>(v + i0);
-#pragma unroll
-      for (int e = 0; e < EPT / 2; ++e) p[e] = make_double2(r[2 * e], r[2 * e + 1]);
-    }
+    for (int e = 0; e < 4; ++e) p[e] = c[e];
   } else {
 #pragma unroll
     for (int e = 0; e < EPT; ++e)
@@ -547,10 +565,10 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
         T ur[kJB][EPT];
 #pragma unroll
         for (int b = 0; b < kJB; ++b) load_strip<T>(ub + (int64_t)(j + b) * segs.ld, base, n, ur[b]);
-        T acc[kJB];
+        acc_t<T> acc[kJB];
 #pragma unroll
         for (int b = 0; b < kJB; ++b) {
-          acc[b] = zero<T>();
+          acc[b] = zero<acc_t<T>>();
 #pragma unroll
           for (int e = 0; e < EPT; ++e) cfma_acc(acc[b], ur[b][e], wr[e]);
         }
@@ -572,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
       for (; j < cnt; ++j) {
         T ur[EPT];
         load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
-        T acc = zero<T>();
+        acc_t<T> acc = zero<acc_t<T>>();
 #pragma unroll
         for (int e = 0; e < EPT; ++e) cfma_acc(acc, ur[e], wr[e]);
         acc = wave_sum(acc);
@@ -613,10 +631,10 @@ int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& t
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_mdot<double>(int64_t, double*, const BasisSegs<double>&, const ThreeTerm<double>&,
-                                 const NormRefs*, double*, hipStream_t);
-template int launch_mdot<zc>(int64_t, zc*, const BasisSegs<zc>&, const ThreeTerm<zc>&, const NormRefs*, double*,
-                             hipStream_t);
+template int launch_mdot<double>(int64_t, double*, const BasisSegs<double>&, const ThreeTerm<double>&, const NormRefs*, double*, hipStream_t);
+template int launch_mdot<zc>(int64_t, zc*, const BasisSegs<zc>&, const ThreeTerm<zc>&, const NormRefs*, double*, hipStream_t);
+template int launch_mdot<float>(int64_t, float*, const BasisSegs<float>&, const ThreeTerm<float>&, const NormRefs*, double*, hipStream_t);
+template int launch_mdot<cf>(int64_t, cf*, const BasisSegs<cf>&, const ThreeTerm<cf>&, const NormRefs*, double*, hipStream_t);
 
 // ================================================================= a5/a6 (update half) + a7: multi-axpy
 // w -= sum_j h_j u_j in one pass (w strip in registers, coefficients broadcast from LDS), then ||w||^2 of the
@@ -650,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
         for (int b = 0; b < kJB; ++b) load_strip<T>(ub + (int64_t)(j + b) * segs.ld, base, n, ur[b]);
 #pragma unroll
         for (int b = 0; b < kJB; ++b) {
-          T hj;
+          acc_t<T> hj;
           if constexpr (scalar_traits<T>::is_complex) hj = zc{lds[col + 2 * b], lds[col + 2 * b + 1]};
           else hj = lds[col + b];
 #pragma unroll
@@ -661,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
       for (; j < cnt; ++j) {
         T ur[EPT];
         load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
-        T hj;
+        acc_t<T> hj;
         if constexpr (scalar_traits<T>::is_complex) hj = zc{lds[col], lds[col + 1]};
         else hj = lds[col];
 #pragma unroll
@@ -690,10 +708,10 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_maxpy<double>(int64_t, double*, const BasisSegs<double>&, const double*, const NormRefs*, double*,
-                                  hipStream_t);
-template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*, const NormRefs*, double*,
-                              hipStream_t);
+template int launch_maxpy<double>(int64_t, double*, const BasisSegs<double>&, const double*, const NormRefs*, double*, hipStream_t);
+template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*, const NormRefs*, double*, hipStream_t);
+template int launch_maxpy<float>(int64_t, float*, const BasisSegs<float>&, const double*, const NormRefs*, double*, hipStream_t);
+template int launch_maxpy<cf>(int64_t, cf*, const BasisSegs<cf>&, const double*, const NormRefs*, double*, hipStream_t);
 
 // ================================================================= deterministic fold of workgroup partials
 // out[j] = sum_b partials[b*ncols + j].  32 columns x 8 row-groups per workgroup; every column is folded in a
@@ -773,6 +791,8 @@ template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRef
 }
 template void launch_scale<double>(int64_t, double*, double, const NormRefs*, hipStream_t);
 template void launch_scale<zc>(int64_t, zc*, double, const NormRefs*, hipStream_t);
+template void launch_scale<float>(int64_t, float*, double, const NormRefs*, hipStream_t);
+template void launch_scale<cf>(int64_t, cf*, double, const NormRefs*, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void three_term_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ up,
@@ -804,6 +824,8 @@ void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double 
 }
 template void launch_three_term<double>(int64_t, double*, const double*, const double*, double, double, hipStream_t);
 template void launch_three_term<zc>(int64_t, zc*, const zc*, const zc*, double, double, hipStream_t);
+template void launch_three_term<float>(int64_t, float*, const float*, const float*, double, double, hipStream_t);
+template void launch_three_term<cf>(int64_t, cf*, const cf*, const cf*, double, double, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
@@ -811,7 +833,7 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T* __restr
   constexpr int EPT = strip<T>::EPT;
   constexpr int R = scalar_traits<T>::reals;
   __shared__ double red[4];
-  T acc = zero<T>();
+  acc_t<T> acc = zero<acc_t<T>>();
   const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int64_t base = sidx * strip<T>::ELEMS;
@@ -841,6 +863,8 @@ template <typename T> int launch_dot(int64_t n, const T* a, const T* b, double* 
 }
 template int launch_dot<double>(int64_t, const double*, const double*, double*, hipStream_t);
 template int launch_dot<zc>(int64_t, const zc*, const zc*, double*, hipStream_t);
+template int launch_dot<float>(int64_t, const float*, const float*, double*, hipStream_t);
+template int launch_dot<cf>(int64_t, const cf*, const cf*, double*, hipStream_t);
 
 // y += offset*x ; Re<x,y> partials — the a2/a3 post-pass for callback operators (CSR fuses it into the SpMV).
 template <typename T>
@@ -874,6 +898,8 @@ int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_pa
 }
 template int launch_offset_dot<double>(int64_t, const double*, double*, double, double*, hipStream_t);
 template int launch_offset_dot<zc>(int64_t, const zc*, zc*, double, double*, hipStream_t);
+template int launch_offset_dot<float>(int64_t, const float*, float*, double, double*, hipStream_t);
+template int launch_offset_dot<cf>(int64_t, const cf*, cf*, double, double*, hipStream_t);
 
 // ================================================================= a9/a10: tall-skinny GEMV over the basis
 // out_r = sum_k coeff[r*m + k] u_k for r < NOUT in one pass over the basis: every basis strip is read once and
@@ -962,10 +988,10 @@ void launch_gemv_basis(int64_t n, int64_t m_total, const BasisSegs<T>* segs, int
     }
   }
 }
-template void launch_gemv_basis<double>(int64_t, int64_t, const BasisSegs<double>*, int, int, const double*, double*,
-                                        int64_t, hipStream_t);
-template void launch_gemv_basis<zc>(int64_t, int64_t, const BasisSegs<zc>*, int, int, const zc*, zc*, int64_t,
-                                    hipStream_t);
+template void launch_gemv_basis<double>(int64_t, int64_t, const BasisSegs<double>*, int, int, const double*, double*, int64_t, hipStream_t);
+template void launch_gemv_basis<zc>(int64_t, int64_t, const BasisSegs<zc>*, int, int, const zc*, zc*, int64_t, hipStream_t);
+template void launch_gemv_basis<float>(int64_t, int64_t, const BasisSegs<float>*, int, int, const float*, float*, int64_t, hipStream_t);
+template void launch_gemv_basis<cf>(int64_t, int64_t, const BasisSegs<cf>*, int, int, const cf*, cf*, int64_t, hipStream_t);
 
 // ================================================================= tiny scalar kernels
 __global__ void accumulate_h_kernel(double* h_acc, const double* h_add, int count, NormRefs pred, int predicated) {

@@ -20,15 +20,40 @@ struct alignas(16) zc {
   double re, im;
 };
 
+// Device-side complex<float>: interleaved (re, im), 8-byte aligned.
+struct alignas(8) cf {
+  float re, im;
+};
+
+// `reals` = doubles per REDUCED value (all reductions, coefficients and norms are carried in double / zc whatever the
+// storage type: float inputs are widened at the first accumulation, which is at least the reference's accuracy);
+// `acc` = that accumulator type.
 template <typename T> struct scalar_traits;
 template <> struct scalar_traits<double> {
   static constexpr bool is_complex = false;
   static constexpr int reals = 1;
+  typedef double acc;
+  typedef double real;
 };
 template <> struct scalar_traits<zc> {
   static constexpr bool is_complex = true;
   static constexpr int reals = 2;
+  typedef zc acc;
+  typedef double real;
 };
+template <> struct scalar_traits<float> {
+  static constexpr bool is_complex = false;
+  static constexpr int reals = 1;
+  typedef double acc;
+  typedef float real;
+};
+template <> struct scalar_traits<cf> {
+  static constexpr bool is_complex = true;
+  static constexpr int reals = 2;
+  typedef zc acc;
+  typedef float real;
+};
+template <typename T> using acc_t = typename scalar_traits<T>::acc;
 
 // ---------------------------------------------------------------- errors
 void set_error(const std::string& msg);
@@ -87,7 +112,7 @@ struct Comm;
 Comm* comm_create(const void* id128, int rank, int nranks, int device);
 void comm_destroy(Comm*);
 void comm_unique_id(void* id128);
-void comm_allgather(Comm*, const void* send, void* recv, size_t n_doubles, hipStream_t s);
+void comm_allgather(Comm*, const void* send, void* recv, size_t bytes, hipStream_t s);
 void comm_allreduce_sum(Comm*, double* buf, size_t n_doubles, hipStream_t s);
 
 }  // namespace ll
@@ -132,6 +157,7 @@ struct ll_context {
 struct ll_operator {
   enum Kind { CSR, HOST_CB, DEV_CB } kind = CSR;
   bool is_complex = false;
+  int elem_bytes = 8;  // sizeof(T): 4 float, 8 double / complex float, 16 complex double
   ll_context* ctx = nullptr;
   int64_t n = 0, n_local = 0, row_begin = 0, nnz = 0;
   int64_t n_shard = 0;  // padded shard length used by the all-gather (= n when not sharded)
@@ -155,8 +181,7 @@ struct ll_operator {
   uint16_t* d_pb_row = nullptr;      // local row, row-block order
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
   // callbacks
-  ll_host_mv_mul_d host_d = nullptr;
-  ll_host_mv_mul_z host_z = nullptr;
+  ll_host_mv_mul_z host_fn = nullptr;  // every host callback is stored under the void* signature
   ll_dev_mv_mul dev_fn = nullptr;
   void* user = nullptr;
   std::vector<char> h_in, h_out;  // staging for the host callback

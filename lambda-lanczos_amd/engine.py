@@ -21,7 +21,20 @@ def _suffix(dtype):
         return "d"
     if dtype == np.complex128:
         return "z"
-    raise TypeError("supported scalar types: float64, complex128 (got %s)" % dtype)
+    if dtype == np.float32:
+        return "s"
+    if dtype == np.complex64:
+        return "c"
+    raise TypeError("supported scalar types: float32/64, complex64/128 (got %s)" % dtype)
+
+
+def _is_complex(dtype):
+    return np.dtype(dtype).kind == "c"
+
+
+def _real_eps(dtype):
+    """Machine epsilon of real_t<T> (the reference scales its default tolerances with it, LL:150, EX:58)."""
+    return float(np.finfo(np.dtype(dtype)).eps)
 
 
 class DeviceArray:
@@ -239,7 +252,7 @@ def dot(ctx, a_dev, b_dev, n=None):
     n = int(n if n is not None else a_dev.shape[-1])
     out = (C.c_double * 2)()
     check(getattr(lib(), "ll_dot_" + sfx)(ctx.handle, n, a_dev.ptr, b_dev.ptr, out))
-    return out[0] if sfx == "d" else complex(out[0], out[1])
+    return out[0] if sfx in "ds" else complex(out[0], out[1])
 
 
 def nrm2(ctx, v_dev, n=None):
@@ -271,19 +284,23 @@ def three_term(ctx, w_dev, u_prev_dev, u_cur_dev, beta, alpha, n=None):
 def orth_block(ctx, basis_dev, nb, ld, w_dev, n, mode=capi.ORTH_CGS_DGKS, want_h=False):
     sfx = _suffix(w_dev.dtype)
     norm = C.c_double()
-    h = np.zeros(max(nb, 1) * (2 if sfx == "z" else 1), dtype=np.float64) if want_h else None
+    cplx = sfx in "zc"
+    h = np.zeros(max(nb, 1) * (2 if cplx else 1), dtype=np.float64) if want_h else None
     fn = getattr(lib(), "ll_orth_block_" + sfx)
     check(fn(ctx.handle, int(n), int(nb), None if basis_dev is None else basis_dev.ptr, int(ld), w_dev.ptr, int(mode),
              C.byref(norm), ptr(h)))
     if want_h:
-        hh = h[: nb * (2 if sfx == "z" else 1)]
-        return norm.value, (hh.view(np.complex128) if sfx == "z" else hh)
+        hh = h[: nb * (2 if cplx else 1)]
+        return norm.value, (hh.view(np.complex128) if cplx else hh)
     return norm.value
 
 
 def gemv_basis(ctx, basis_dev, m, ld, coeff, out_dev, ld_out, n):
     sfx = _suffix(out_dev.dtype)
-    coeff = np.ascontiguousarray(coeff, dtype=out_dev.dtype)
+    if sfx in "sc":   # the float entry points take their coefficients as doubles, like every scalar
+        coeff = np.ascontiguousarray(coeff, dtype=np.complex128 if sfx == "c" else np.float64)
+    else:
+        coeff = np.ascontiguousarray(coeff, dtype=out_dev.dtype)
     nout = coeff.shape[0] if coeff.ndim == 2 else 1
     fn = getattr(lib(), "ll_gemv_basis_" + sfx)
     check(fn(ctx.handle, int(n), int(m), basis_dev.ptr, int(ld), int(nout), ptr(coeff), out_dev.ptr, int(ld_out)))
@@ -352,7 +369,7 @@ class LambdaLanczos:
         self.init_vector = None                                  # LL:133 (None = random default, LL:70-104)
         self.matrix_size = int(matrix_size)                      # LL:136
         self.max_iteration = int(matrix_size)                    # LL:138,206
-        self.eps = _EPS * 1e3                                    # LL:150
+        self.eps = _real_eps(self.dtype) * 1e3                   # LL:150 (epsilon of real_t<T>)
         self.find_maximum = bool(find_maximum)                   # LL:153
         self.num_eigs = int(num_eigs)                            # LL:156
         self.eigenvalue_offset = 0.0                             # LL:165
@@ -439,7 +456,7 @@ class Exponentiator:
         self.mv_mul = mv_mul                                     # EX:41
         self.matrix_size = int(matrix_size)                      # EX:44
         self.max_iteration = int(matrix_size)                    # EX:46,81
-        self.eps = _EPS * 1e2                                    # EX:58
+        self.eps = _real_eps(self.dtype) * 1e2                   # EX:58
         self.full_orthogonalize = False                          # EX:63
         self.initial_vector_size = 200                           # EX:71
         self.orth_mode = capi.ORTH_CGS_DGKS
@@ -467,7 +484,7 @@ class Exponentiator:
         try:
             fn = getattr(lib(), name + sfx)
             args = [self.context.handle, op.handle, C.byref(p)]
-            args += [float(a)] if sfx == "d" else [float(np.real(a)), float(np.imag(a))]
+            args += [float(a)] if sfx in "ds" else [float(np.real(a)), float(np.imag(a))]
             args += [ptr(inp), ptr(out), C.byref(it)]
             if want_stats:
                 args.append(C.byref(stats))

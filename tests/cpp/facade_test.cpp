@@ -63,14 +63,14 @@ template <typename T> void run_case(const EigCase<T>& c) {
   engine.num_eigs = c.num_eigs;           // public data members, as in the reference's tests
   engine.eigenvalue_offset = c.offset;
   if (c.eps > 0) engine.eps = c.eps;
-  std::vector<double> values;
+  std::vector<ll::util::real_t<T>> values;   // real_t<T>, as in the reference (lambda_lanczos.hpp:330)
   std::vector<std::vector<T>> vectors;
   engine.run(values, vectors);            // outputs are sized by the library
   expect(values.size() == c.num_eigs && vectors.size() == c.num_eigs, "result count");
   for (size_t r = 0; r < c.values.size() && r < values.size(); ++r) {
-    expect_close(c.values[r], values[r], std::max(std::abs(c.values[r]) * engine.eps, 1e-8 * (engine.eps > 1e-8)), "eigenvalue");
+    expect_close(c.values[r], values[r], std::max(std::abs(c.values[r]) * (double)engine.eps, 1e-8 * (engine.eps > 1e-8)), "eigenvalue");
     expect(vectors[r].size() == n, "eigenvector length");
-    expect(misfit(c.vectors[r], vectors[r]) <= std::max(100 * engine.eps, 1e-12), "eigenvector direction");
+    expect(misfit(c.vectors[r], vectors[r]) <= std::max(100.0 * (double)engine.eps, 1e-12), "eigenvector direction");
   }
   expect(!engine.getIterationCounts().empty(), "iteration counts recorded");
   if (c.num_eigs == 1) expect(engine.getIterationCounts().size() == 1, "one pass for one eigenpair");
@@ -81,6 +81,12 @@ static void eigen_cases() {
   // 3x3 all-ones + identity: eigenvalues {4,1,1} (lambda_lanczos_test.cpp:128-161, README sample)
   run_case<double>({"T1:128 SIMPLE_MATRIX", {{2, 1, 1}, {1, 2, 1}, {1, 1, 2}}, true, 1, 6.0, -1, {4.0}, {{s3, s3, s3}}});
   run_case<cplx>({"T1:310 SIMPLE_MATRIX_USE_COMPLEX_TYPE", {{2, 1, 1}, {1, 2, 1}, {1, 1, 2}}, true, 1, 0.0, -1, {4.0}, {{s3, s3, s3}}});
+  // the same matrix in single precision: default eps = 1e3 * FLT_EPSILON (lambda_lanczos_test.cpp:163-193)
+  const float f3 = 1.0f / std::sqrt(3.0f);
+  run_case<float>({"T1:163 SIMPLE_MATRIX_FLOAT", {{2, 1, 1}, {1, 2, 1}, {1, 1, 2}}, true, 1, 0.0, -1, {4.0}, {{f3, f3, f3}}});
+  run_case<std::complex<float>>({"complex<float> Hermitian 3x3 (data of T1:375)",
+                                 {{0, {0, 1}, 1}, {{0, -1}, 0, {0, 1}}, {1, {0, -1}, 0}}, false, 1, 0.0, -1, {-2.0},
+                                 {{f3, {0, f3}, -f3}}});
   const cplx I(0, 1);
   run_case<cplx>({"T1:375 HERMITIAN_MATRIX", {{0, I, 1}, {-I, 0, I}, {1, -I, 0}}, false, 1, 0.0, -1, {-2.0},
                   {{s3, I * s3, -s3}}});

@@ -47,4 +47,21 @@ out = {"workload": wl, "n": n, "tridiag_mode": mode, "iterations": eng.getIterat
        "residual_norm": res, "wall_s": wall, "stats": eng.last_stats}
 if wl == "c2":
     out["analytic_lambda_min"] = G.laplace2d_lambda_min(int(round(n ** 0.5)))
-print(json.dumps(out))
+print(json.dumps(out), flush=True)
+if os.environ.get("DEMO_ORACLE_THREADS"):
+    # the same run through the CPU oracle (pinned to the real reference; OpenMP variant to keep it to minutes)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    if os.environ.get("DEMO_USE_REFERENCE"):      # the REAL reference headers (single thread, oracle/_ref/libref.so)
+        orc, th = oracle_lib.reference(), 1
+    else:
+        orc = oracle_lib.oracle()
+        th = orc.set_threads(int(os.environ["DEMO_ORACLE_THREADS"]))
+    t0 = time.time()
+    r = orc.lanczos(csr, init, find_max, offset=offset, trace=False)
+    cpu_wall = time.time() - t0
+    ov = abs(np.vdot(r["eigenvectors"][0], v))
+    print(json.dumps({"checker": "reference" if os.environ.get("DEMO_USE_REFERENCE") else "oracle", "oracle_threads": th, "oracle_iterations": r["iter_counts"], "oracle_eigenvalue": float(r["eigenvalues"][0]),
+                      "oracle_wall_s": cpu_wall, "d_lambda": float(abs(r["eigenvalues"][0] - vals[0])),
+                      "one_minus_overlap": float(1 - ov), "gpu_wall_s": wall, "speedup": cpu_wall / wall}), flush=True)
