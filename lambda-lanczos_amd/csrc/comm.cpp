@@ -199,6 +199,9 @@ Comm* comm_create(const void* id128, int rank, int nranks, int device) {
     delete c;
     throw;
   }
+  // RCCL prints its version banner to the C stdout buffer; push it out now so that it cannot surface after whatever
+  // the host program prints last (bench.py's single JSON line).
+  std::fflush(stdout);
   return c;
 }
 
