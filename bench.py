@@ -108,7 +108,8 @@ def main():
             dist.broadcast_object_list(box, src=0)
         uid = box[0]
     else:
-        ctx = L.Context(local_rank)
+        # LL_BENCH_DEVICE: testing hook — several ranks on one GPU with the host-staged test transport (LL_COMM_BACKEND=shm)
+        ctx = L.Context(int(os.environ.get("LL_BENCH_DEVICE", local_rank)))
         if world > 1:
             box = [L.Context.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)

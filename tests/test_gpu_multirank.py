@@ -74,3 +74,26 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
     out = np.concatenate([list2c(r["torus_expo"]["out"]) for r in ranks])
     assert abs(ranks[0]["torus_expo"]["itern"] - o_it) <= 1
     assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(inp)
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, id broadcast,
+    row shards, sharded SpMV timing, timed Lanczos windows, reductions over ranks, one JSON line from rank 0) — with
+    both ranks on the test box's single GPU through the host-staged test transport."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LL_COMM_BACKEND="shm", LL_BENCH_DEVICE="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "300000", "--window", "30", "--spmv-reps", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    d = json.loads(lines[-1])                       # the JSON line is the LAST line of stdout
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["n"] == 300000 and d["config"]["nnz"] == 15 * 300000
+    assert d["value"] > 0 and abs(d["config"]["iterations_per_step"] - 30) < 1e-9
+    assert d["cpu_baseline"] is None                # rank 0 at N = 1 only
