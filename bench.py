@@ -57,12 +57,6 @@ def spmv_bytes(n, nnz, complex_):
     return (s + 4) * nnz + 4 * (n + 1) + 2 * s * n
 
 
-def iter_bytes_minimal(n, nnz, k, complex_):
-    """B_iter(k) of SURVEY 8d, minimal-pass model: SpMV + s*n*(2k + 9)."""
-    s = 16 if complex_ else 8
-    return spmv_bytes(n, nnz, complex_) + s * n * (2 * k + 9)
-
-
 def pmc_traffic(workload, kernels, dtype_tag):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary of this workload (tools/pmc_summary.py),
     or None when no such profile exists.  bench.py cannot collect PMC counters itself; the summary names its source."""

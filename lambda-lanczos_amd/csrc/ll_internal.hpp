@@ -132,7 +132,6 @@ struct ll_context {
   size_t partials_cap = 0;       // doubles
   double* d_h = nullptr;         // reduced projection coefficients / small scalars
   size_t h_cap = 0;              // doubles
-  double* d_h2 = nullptr;        // second-pass coefficients
   double* d_scal = nullptr;      // 64 doubles of device scalars (ring slots, flags)
   double* h_pinned = nullptr;    // pinned host mirror for scalar read-back
   size_t pinned_cap = 0;         // doubles
