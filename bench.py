@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--workload", default="c3", choices=["c3", "c3band", "c2", "c5"],
                     help="c3: random symmetric CSR n=1e7 nnz=1.5e8 (metric config); c3band: banded variant; "
                          "c2: 5-pt Laplacian n=1e6; c5: complex torus n=1e6 (Exponentiator)")
+    ap.add_argument("--operator", default="csr", choices=["csr", "lattice"],
+                    help="c2 only: lattice = the matrix-free lattice operator (halo exchange instead of the all-gather)")
     ap.add_argument("--size", dest="n", type=int, default=0, help="override the problem size (grid side for c2/c5)")
     ap.add_argument("--window", type=int, default=100, help="Lanczos iterations per step (max_iteration)")
     ap.add_argument("--spmv-reps", type=int, default=20)
@@ -161,7 +163,12 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
+    lattice = args.operator == "lattice" and wl == "c2"
+    if lattice:
+        op = L.StencilOperator(ctx, [side, side], diag=4.0, hop=-1.0, row_begin=rb, n_local=nl)
+        name += ", matrix-free lattice operator"
+    else:
+        op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
     t_gen = time.time() - t_gen
 
     def barrier():
@@ -181,14 +188,15 @@ def main():
     # ------------------------------------------------------------ SpMV kernel: HIP events on its own stream
     xd = ctx.to_device(init / np.linalg.norm(init))
     yd = ctx.empty(nl, dtype)
-    b_spmv = spmv_bytes(n, nnz, complex_)
-    selected = op.selected_spmv()
-    kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2"}
+    b_spmv = 2 * 8 * n if lattice else spmv_bytes(n, nnz, complex_)   # lattice: x read once, y written once
+    selected = -1 if lattice else op.selected_spmv()
+    kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2", -1: "stencil_kernel"}
     spmv_variants = {}
     for rnd in range(3):  # interleaved rounds in one process; the median is reported
-        for kind in (L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB):
+        for kind in ((-1,) if lattice else (L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB)):
             try:
-                op.select_spmv(kind)
+                if not lattice:
+                    op.select_spmv(kind)
             except L.LanczosHipError:
                 continue
             L.spmv(op, xd, yd)
@@ -198,7 +206,8 @@ def main():
                 L.spmv(op, xd, yd)
             ms = max_over_ranks(ctx.timer_stop() / args.spmv_reps)
             spmv_variants.setdefault(kernel_names[kind], []).append(ms)
-    op.select_spmv(selected)
+    if not lattice:
+        op.select_spmv(selected)
     spmv_variants = {k: sorted(v)[len(v) // 2] for k, v in spmv_variants.items()}
     spmv_ms = spmv_variants[kernel_names[selected]]
     spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
@@ -288,7 +297,7 @@ def main():
         }
 
     traffic, traffic_src = (None, None)
-    if world == 1 and not args.n:
+    if world == 1 and not args.n and not lattice:
         traffic, traffic_src = pmc_traffic(wl, kernel_names[selected].split("+"), "ll::zc" if complex_ else "double")
 
     cpu_all = None
@@ -338,7 +347,7 @@ def main():
                 "step": "one LambdaLanczos::run with max_iteration=%d (k = 1..%d, mean k = %.1f), nroot=%s"
                         % (args.window, args.window, (args.window + 1) / 2, "n/a" if wl == "c5" else "5"),
                 "iterations_per_step": total_iters / max(args.steps, 1),
-                "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL all-gather of x" % world,
+                "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL %s" % (world, "halo exchange" if lattice else "all-gather of x"),
                 "orth_mode": args.orth_mode,
                 "tridiag_mode": args.tridiag_mode,
             },

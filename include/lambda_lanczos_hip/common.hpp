@@ -47,6 +47,13 @@ template <typename T> struct abi;
                           const T* va, ll_operator** o) {                                                                \
       return ll_op_create_csr_##SFX(c, nr, nc, rb, rp, ci, va, o);                                                       \
     }                                                                                                                    \
+    static int create_dense(ll_context* c, int64_t nr, int64_t nc, int64_t rb, const T* a, ll_operator** o) {            \
+      return ll_op_create_dense_##SFX(c, nr, nc, rb, a, o);                                                              \
+    }                                                                                                                    \
+    static int create_stencil(ll_context* c, const ll_stencil_desc* d, int64_t rb, int64_t nl, const double* onsite,     \
+                              ll_operator** o) {                                                                         \
+      return ll_op_create_stencil_##SFX(c, d, rb, nl, onsite, o);                                                        \
+    }                                                                                                                    \
     static int create_host(ll_context* c, int64_t n, int (*fn)(const void*, void*, int64_t, void*), void* user,          \
                            ll_operator** o) {                                                                            \
       return ll_op_create_host_##SFX(c, n, reinterpret_cast<HOSTFN>(fn), user, o);                                       \
@@ -92,33 +99,97 @@ class Context {
   std::shared_ptr<ll_context> h_;
 };
 
-// The device form of the mv_mul plugin: a CSR matrix resident in HBM (rows [row_begin, row_begin + n_rows) of an
-// n_cols x n_cols symmetric/Hermitian operator; the whole matrix on a single GPU).  Accepted by the engines in place
-// of the host std::function; then only scalars cross PCIe per iteration.
-template <typename T> class CsrMatrix {
-  static_assert(is_supported<T>::value, "CsrMatrix<T>: T must be float, double or std::complex of those");
+// The device forms of the mv_mul plugin.  A DeviceOperator<T> is a shared handle to an operator resident in HBM; the
+// engines accept it in place of the host std::function, and then only scalars cross PCIe per iteration.
+template <typename T> class DeviceOperator {
+  static_assert(is_supported<T>::value, "DeviceOperator<T>: T must be float, double or std::complex of those");
 
  public:
-  CsrMatrix(const std::vector<int64_t>& row_ptr, const std::vector<int32_t>& col, const std::vector<T>& val,
-            Context ctx = Context::default_context(), int64_t n_cols = -1, int64_t row_begin = 0)
-      : ctx_(ctx) {
-    const int64_t n_rows = (int64_t)row_ptr.size() - 1;
-    if (n_cols < 0) n_cols = n_rows;
-    ll_operator* op = nullptr;
-    check(abi<T>::create_csr(ctx_.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(), val.data(), &op));
-    h_.reset(op, [](ll_operator* p) { ll_op_destroy(p); });
-    n_ = n_cols;
-    n_local_ = n_rows;
-  }
   ll_operator* get() const { return h_.get(); }
   const Context& context() const { return ctx_; }
   int64_t size() const { return n_; }
   int64_t local_rows() const { return n_local_; }
+  // max_i sum_j |a_ij| over the local rows: a safe |eigenvalue_offset| (determine_eigenvalue_offset.cpp:12-29)
+  double inf_norm() const {
+    double v = 0;
+    check(ll_op_inf_norm(get(), &v));
+    return v;
+  }
 
- private:
+ protected:
+  DeviceOperator(Context ctx) : ctx_(ctx) {}
+  void adopt(ll_operator* op, int64_t n, int64_t n_local) {
+    h_.reset(op, [](ll_operator* p) { ll_op_destroy(p); });
+    n_ = n;
+    n_local_ = n_local;
+  }
   Context ctx_;
   std::shared_ptr<ll_operator> h_;
   int64_t n_ = 0, n_local_ = 0;
+};
+
+// CSR matrix: rows [row_begin, row_begin + n_rows) of an n_cols x n_cols symmetric/Hermitian operator (the whole
+// matrix on a single GPU).
+template <typename T> class CsrMatrix : public DeviceOperator<T> {
+ public:
+  CsrMatrix(const std::vector<int64_t>& row_ptr, const std::vector<int32_t>& col, const std::vector<T>& val,
+            Context ctx = Context::default_context(), int64_t n_cols = -1, int64_t row_begin = 0)
+      : DeviceOperator<T>(ctx) {
+    const int64_t n_rows = (int64_t)row_ptr.size() - 1;
+    if (n_cols < 0) n_cols = n_rows;
+    ll_operator* op = nullptr;
+    check(abi<T>::create_csr(ctx.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(), val.data(), &op));
+    this->adopt(op, n_cols, n_rows);
+  }
+};
+
+// Dense row-major matrix (the operator of src/samples/sample1_simple.cpp:22-28 without the host loop).
+template <typename T> class DenseMatrix : public DeviceOperator<T> {
+ public:
+  explicit DenseMatrix(const std::vector<std::vector<T>>& rows, Context ctx = Context::default_context(),
+                       int64_t row_begin = 0)
+      : DeviceOperator<T>(ctx) {
+    const int64_t nr = (int64_t)rows.size(), nc = nr ? (int64_t)rows[0].size() : 0;
+    std::vector<T> flat;
+    flat.reserve((size_t)(nr * nc));
+    for (const auto& r : rows) {
+      if ((int64_t)r.size() != nc) throw Error(LL_ERR_INVALID, "DenseMatrix: ragged rows");
+      flat.insert(flat.end(), r.begin(), r.end());
+    }
+    ll_operator* op = nullptr;
+    check(abi<T>::create_dense(ctx.get(), nr, nc, row_begin, flat.data(), &op));
+    this->adopt(op, nc, nr);
+  }
+};
+
+// Matrix-free lattice operator (the family of src/samples/sample3_dynamic.cpp:17-22):
+//   (A x)(r) = (diag + onsite[r]) x(r) + sum_d ( hop[d] x(r + e_d) + conj(hop[d]) x(r - e_d) )
+// on a row-major lattice dims[0] x dims[1] x .. (last index fastest), open or periodic per dimension.
+template <typename T> class LatticeOperator : public DeviceOperator<T> {
+ public:
+  LatticeOperator(const std::vector<int64_t>& dims, double diag, const std::vector<std::complex<double>>& hop,
+                  const std::vector<bool>& periodic, const std::vector<double>& onsite = {},
+                  Context ctx = Context::default_context(), int64_t row_begin = 0, int64_t n_local = -1)
+      : DeviceOperator<T>(ctx) {
+    if (dims.empty() || dims.size() > 3 || hop.size() != dims.size() || periodic.size() != dims.size())
+      throw Error(LL_ERR_INVALID, "LatticeOperator: 1 to 3 dimensions, one hop and one periodic flag per dimension");
+    ll_stencil_desc d = {};
+    d.ndim = (int32_t)dims.size();
+    int64_t n = 1;
+    for (size_t k = 0; k < dims.size(); ++k) {
+      d.dims[k] = dims[k];
+      d.periodic[k] = periodic[k] ? 1 : 0;
+      d.hop_re[k] = hop[k].real();
+      d.hop_im[k] = hop[k].imag();
+      n *= dims[k];
+    }
+    d.diag = diag;
+    if (n_local < 0) n_local = n;
+    if (!onsite.empty() && (int64_t)onsite.size() != n_local) throw Error(LL_ERR_INVALID, "LatticeOperator: onsite size");
+    ll_operator* op = nullptr;
+    check(abi<T>::create_stencil(ctx.get(), &d, row_begin, n_local, onsite.empty() ? nullptr : onsite.data(), &op));
+    this->adopt(op, n, n_local);
+  }
 };
 
 namespace detail {

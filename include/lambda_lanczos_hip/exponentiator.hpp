@@ -26,8 +26,8 @@ template <typename T> class Exponentiator {
   Exponentiator(std::function<void(const std::vector<T>&, std::vector<T>&)> mv_mul, size_t matrix_size,
                 Context ctx = Context::default_context())
       : mv_mul(mv_mul), matrix_size(matrix_size), max_iteration(matrix_size), ctx_(ctx) {}            // :80-81
-  Exponentiator(const CsrMatrix<T>& op, size_t matrix_size)
-      : matrix_size(matrix_size), max_iteration(matrix_size), ctx_(op.context()), csr_(new CsrMatrix<T>(op)) {}
+  Exponentiator(const DeviceOperator<T>& op, size_t matrix_size)
+      : matrix_size(matrix_size), max_iteration(matrix_size), ctx_(op.context()), csr_(new DeviceOperator<T>(op)) {}
 
   // exp(a*A) input -> output (resized by the library, exponentiator_test.cpp:131); returns the iteration count (:87-173)
   size_t run(const T& a, const std::vector<T>& input, std::vector<T>& output) const { return call(a, input, output, false); }
@@ -77,7 +77,7 @@ template <typename T> class Exponentiator {
                   : ll_expo_run_c(ctx_.get(), op, p, (double)a.real(), (double)a.imag(), in, out, count, nullptr);
   }
   Context ctx_;
-  std::shared_ptr<CsrMatrix<T>> csr_;
+  std::shared_ptr<DeviceOperator<T>> csr_;
 };
 
 }  // namespace lambda_lanczos_hip

@@ -47,9 +47,9 @@ template <typename T> class LambdaLanczos {
         num_eigs(num_eigs), ctx_(ctx) {}
 
   // Same shape with a device-resident operator: nothing n-sized crosses PCIe during the loop.
-  LambdaLanczos(const CsrMatrix<T>& op, size_t matrix_size, bool find_maximum, size_t num_eigs)
+  LambdaLanczos(const DeviceOperator<T>& op, size_t matrix_size, bool find_maximum, size_t num_eigs)
       : matrix_size(matrix_size), max_iteration(matrix_size), find_maximum(find_maximum), num_eigs(num_eigs),
-        ctx_(op.context()), csr_(new CsrMatrix<T>(op)) {}
+        ctx_(op.context()), csr_(new DeviceOperator<T>(op)) {}
 
   // run(eigenvalues, eigenvectors) (lambda_lanczos.hpp:330-366): outputs are resized by the library.
   void run(std::vector<real_t<T>>& eigenvalues, std::vector<std::vector<T>>& eigenvectors) {
@@ -121,7 +121,7 @@ template <typename T> class LambdaLanczos {
     return abi<T>::run(ctx_.get(), op, p, vals, vecs, found, counts, cap, st);
   }
   Context ctx_;
-  std::shared_ptr<CsrMatrix<T>> csr_;
+  std::shared_ptr<DeviceOperator<T>> csr_;
   std::vector<size_t> iter_counts_;
   ll_run_stats last_stats_{};
 };

@@ -112,7 +112,7 @@ int ll_memset(ll_context* ctx, void* dst_dev, int byte, size_t bytes);
  *
  * Reference contract: std::function<void(const vector<T>& in, vector<T>& out)>, `out` zero-filled on entry,
  * accumulate or overwrite both legal, called once per Lanczos iteration with the unit-norm u[k-1]
- * (LL:242-243, EX:107-108).  Three realisations: */
+ * (LL:242-243, EX:107-108).  Five realisations: */
 
 /* (1) device-resident CSR (the reference ships no sparse format; this is the new operator of SURVEY 8a-a1).
  *     n_rows_local rows [row_begin, row_begin+n_rows_local) of a global n_cols x n_cols symmetric/Hermitian
@@ -158,6 +158,39 @@ typedef int (*ll_dev_mv_mul)(const void* in_dev, void* out_dev_zeroed, int64_t n
                              void* user);
 int ll_op_create_device_d(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
 int ll_op_create_device_z(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
+
+/* (4) dense row-major matrix, the operator of the reference's first sample and of its small known-answer tests
+ *     (src/samples/sample1_simple.cpp:22-28; T1:130, T1:446-453): a_host holds n_rows_local x n_cols values of T,
+ *     rows [row_begin, row_begin + n_rows_local) of the global matrix.  Sharded exactly like CSR (row block +
+ *     all-gather of x).  One apply streams the matrix once: sizeof(T) * n_rows_local * n_cols bytes. */
+int ll_op_create_dense_d(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                         const double* a_host, ll_operator** out);
+int ll_op_create_dense_z(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                         const void* a_host, ll_operator** out);
+
+/* (5) matrix-free lattice operator: the family of the reference's "dynamic matrix" sample and tests
+ *     (src/samples/sample3_dynamic.cpp:17-22 and T1:265-273: open chain; T2:113-121: periodic ring; BASELINE
+ *     config 2: 5-point Laplacian).  Sites of a row-major lattice dims[0] x .. x dims[ndim-1] (LAST index fastest,
+ *     n = product of dims);
+ *         (A x)(r) = (diag + onsite[r]) x(r) + sum_d ( hop[d] x(r + e_d) + conj(hop[d]) x(r - e_d) )
+ *     with open (periodic[d] = 0: the missing neighbour contributes nothing) or periodic boundaries per dimension.
+ *     No matrix is stored: one apply moves 2 * sizeof(T) * n bytes (+ 8n for onsite) instead of the CSR image.
+ *     Sharded contexts: flattened sites [row_begin, row_begin + n_local) per ll_partition; the exchange step is a
+ *     HALO exchange of one lattice hyperplane (n / dims[0] sites) with the two neighbouring ranks instead of the
+ *     all-gather of x; every shard must hold at least one hyperplane.
+ *     hop_im must be 0 for the real types.  onsite_host_local: n_local real values, NULL = none. */
+typedef struct ll_stencil_desc {
+  int32_t ndim;        /* 1..3 */
+  int32_t periodic[3];
+  int64_t dims[3];
+  double diag;
+  double hop_re[3];
+  double hop_im[3];
+} ll_stencil_desc;
+int ll_op_create_stencil_d(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
+                           const double* onsite_host_local, ll_operator** out);
+int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
+                           const double* onsite_host_local, ll_operator** out);
 
 /* Which SpMV kernel a CSR operator uses (results agree to rounding):
  *   LL_SPMV_CSR_STREAM  plain CSR, products staged in LDS, bit-reproducible sums; best when the x gathers hit
@@ -337,6 +370,14 @@ int ll_op_create_host_c(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* u
 int ll_op_create_host_s(ll_context* ctx, int64_t n, ll_host_mv_mul_s fn, void* user, ll_operator** out);
 int ll_op_create_device_c(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
 int ll_op_create_device_s(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* user, ll_operator** out);
+int ll_op_create_dense_c(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                         const void* a_host, ll_operator** out);
+int ll_op_create_dense_s(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, int64_t row_begin,
+                         const float* a_host, ll_operator** out);
+int ll_op_create_stencil_c(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
+                           const double* onsite_host_local, ll_operator** out);
+int ll_op_create_stencil_s(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
+                           const double* onsite_host_local, ll_operator** out);
 int ll_spmv_c(ll_context* ctx, ll_operator* op, const void* x_dev, void* y_dev, double offset, double* dot_host);
 int ll_spmv_s(ll_context* ctx, ll_operator* op, const float* x_dev, float* y_dev, double offset, double* dot_host);
 int ll_dot_c(ll_context* ctx, int64_t n_local, const void* a_dev, const void* b_dev, double* out_host_reim);

@@ -19,9 +19,11 @@ from ._capi import (  # noqa: F401
 from .engine import (  # noqa: F401
     Context,
     CsrOperator,
+    DenseOperator,
     DeviceArray,
     Exponentiator,
     HostOperator,
+    StencilOperator,
     LambdaLanczos,
     default_context,
     dot,

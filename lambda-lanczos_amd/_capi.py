@@ -59,6 +59,19 @@ class ExpoParams(C.Structure):
     ]
 
 
+class StencilDesc(C.Structure):
+    """ll_stencil_desc"""
+
+    _fields_ = [
+        ("ndim", C.c_int32),
+        ("periodic", C.c_int32 * 3),
+        ("dims", C.c_int64 * 3),
+        ("diag", C.c_double),
+        ("hop_re", C.c_double * 3),
+        ("hop_im", C.c_double * 3),
+    ]
+
+
 class RunStats(C.Structure):
     _fields_ = [
         ("n_passes", i64),
@@ -108,6 +121,10 @@ PROTOTYPES = {
     "ll_op_create_coo_d": (C.c_int, [vp, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_create_coo_z": (C.c_int, [vp, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_inf_norm": (C.c_int, [vp, P(f64)]),
+    "ll_op_create_dense_d": (C.c_int, [vp, i64, i64, i64, vp, P(vp)]),
+    "ll_op_create_dense_z": (C.c_int, [vp, i64, i64, i64, vp, P(vp)]),
+    "ll_op_create_stencil_d": (C.c_int, [vp, P(StencilDesc), i64, i64, vp, P(vp)]),
+    "ll_op_create_stencil_z": (C.c_int, [vp, P(StencilDesc), i64, i64, vp, P(vp)]),
     "ll_op_create_host_d": (C.c_int, [vp, i64, HOST_MV_FN, vp, P(vp)]),
     "ll_op_create_host_z": (C.c_int, [vp, i64, HOST_MV_FN, vp, P(vp)]),
     "ll_op_create_device_d": (C.c_int, [vp, i64, DEV_MV_FN, vp, P(vp)]),

@@ -59,6 +59,13 @@ void ll_context::ensure_xfull(size_t bytes) {
   xfull_cap = bytes;
   LL_HIP(hipMalloc(&d_xfull, xfull_cap));
 }
+void ll_context::ensure_halo(size_t bytes) {
+  if (bytes <= halo_cap) return;
+  if (d_halo) LL_HIP(hipFree(d_halo));
+  d_halo = nullptr;
+  halo_cap = bytes;
+  LL_HIP(hipMalloc(&d_halo, halo_cap));
+}
 void* ll_context::ensure_stage(size_t bytes) {
   if (bytes <= stage_cap) return h_stage;
   if (h_stage) LL_HIP(hipHostFree(h_stage));
@@ -138,6 +145,7 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_coeff) (void)hipFree(ctx->d_coeff);
     if (ctx->d_xfull) (void)hipFree(ctx->d_xfull);
+    if (ctx->d_halo) (void)hipFree(ctx->d_halo);
     for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -517,6 +525,98 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   *out = op.release();
 }
 
+// Row ranges of a sharded operator must be the ll_partition() ones (equal shard strides).
+void set_partition(ll_context* ctx, ll_operator* op, int64_t n, int64_t row_begin, int64_t n_local) {
+  op->n = n;
+  op->n_local = n_local;
+  op->row_begin = row_begin;
+  if (ctx->nranks > 1) {
+    op->n_shard = (n + ctx->nranks - 1) / ctx->nranks;
+    LL_REQUIRE(row_begin == std::min<int64_t>(n, op->n_shard * ctx->rank) &&
+                   n_local == std::min<int64_t>(n, op->n_shard * (ctx->rank + 1)) - row_begin,
+               "sharded operators must use the ll_partition() row ranges");
+  } else {
+    op->n_shard = n;
+    LL_REQUIRE(row_begin == 0 && n_local == n, "a single-GPU context needs the whole operator (row_begin 0, n_local == n)");
+  }
+}
+
+template <typename T>
+void create_dense(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, const void* a, ll_operator** out) {
+  use(ctx);
+  LL_REQUIRE(out && (a || nr == 0), "null argument");
+  LL_REQUIRE(nr >= 0 && nc >= 1 && row_begin >= 0 && row_begin + nr <= nc, "bad shape");
+  std::unique_ptr<ll_operator> op(new ll_operator);
+  op->kind = ll_operator::DENSE;
+  op->is_complex = scalar_traits<T>::is_complex;
+  op->elem_bytes = (int)sizeof(T);
+  op->ctx = ctx;
+  set_partition(ctx, op.get(), nc, row_begin, nr);
+  op->nnz = nr * nc;
+  const T* v = (const T*)a;
+  double mx = 0.0;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+  for (int64_t i = 0; i < nr; ++i) {
+    double rs = 0.0;
+    for (int64_t j = 0; j < nc; ++j) rs += std::sqrt(abs2_host(v[i * nc + j]));
+    mx = std::max(mx, rs);
+  }
+  op->inf_norm = mx;
+  const size_t bytes = (size_t)nr * (size_t)nc * sizeof(T);
+  LL_HIP(hipMalloc(&op->d_dense, std::max<size_t>(bytes, 16)));
+  if (bytes) LL_HIP(hipMemcpy(op->d_dense, a, bytes, hipMemcpyHostToDevice));
+  *out = op.release();
+}
+
+template <typename T>
+void create_stencil(ll_context* ctx, const ll_stencil_desc* d, int64_t row_begin, int64_t n_local, const double* onsite,
+                    ll_operator** out) {
+  use(ctx);
+  LL_REQUIRE(out && d, "null argument");
+  LL_REQUIRE(d->ndim >= 1 && d->ndim <= 3, "ndim must be 1, 2 or 3");
+  int64_t n = 1;
+  for (int k = 0; k < d->ndim; ++k) {
+    LL_REQUIRE(d->dims[k] >= 1, "lattice dimensions must be positive");
+    LL_REQUIRE(n <= ((int64_t)1 << 40) / d->dims[k], "lattice too large");
+    n *= d->dims[k];
+    if (!scalar_traits<T>::is_complex) LL_REQUIRE(d->hop_im[k] == 0.0, "complex hopping needs a complex storage type");
+  }
+  std::unique_ptr<ll_operator> op(new ll_operator);
+  op->kind = ll_operator::STENCIL;
+  op->is_complex = scalar_traits<T>::is_complex;
+  op->elem_bytes = (int)sizeof(T);
+  op->ctx = ctx;
+  set_partition(ctx, op.get(), n, row_begin, n_local);
+  LL_REQUIRE(n_local < (int64_t)0x7fffffff, "shard exceeds 32-bit local indices");
+  op->st = *d;
+  int64_t stride = 1;
+  for (int k = d->ndim - 1; k >= 0; --k) {
+    op->st_stride[k] = stride;
+    stride *= d->dims[k];
+  }
+  op->st_halo = op->st_stride[0];
+  if (ctx->nranks > 1) {
+    const int64_t last = n - op->n_shard * (ctx->nranks - 1);  // the shortest shard
+    LL_REQUIRE(last >= op->st_halo && op->n_shard >= op->st_halo,
+               "lattice operator: every shard must hold at least one hyperplane (n / dims[0] sites); use fewer ranks");
+  }
+  op->nnz = 0;
+  double hops = 0.0;
+  for (int k = 0; k < d->ndim; ++k) hops += 2.0 * std::hypot(d->hop_re[k], d->hop_im[k]);
+  double diag_max = std::abs(d->diag);
+  if (onsite) {
+    diag_max = 0.0;
+    for (int64_t i = 0; i < n_local; ++i) diag_max = std::max(diag_max, std::abs(d->diag + onsite[i]));
+    typedef typename scalar_traits<T>::real R;
+    std::vector<R> tmp((size_t)n_local);
+    for (int64_t i = 0; i < n_local; ++i) tmp[(size_t)i] = (R)onsite[i];
+    LL_HIP(hipMalloc(&op->d_onsite, std::max<size_t>((size_t)n_local * sizeof(R), 16)));
+    LL_HIP(hipMemcpy(op->d_onsite, tmp.data(), (size_t)n_local * sizeof(R), hipMemcpyHostToDevice));
+  }
+  op->inf_norm = diag_max + hops;  // an upper bound of the max absolute row sum (equal to it for interior sites)
+  *out = op.release();
+}
+
 template <typename T> void create_cb(ll_context* ctx, int64_t n, ll_operator::Kind kind, ll_operator** out) {
   use(ctx);
   LL_REQUIRE(out != nullptr && n >= 1, "bad argument");
@@ -586,9 +686,23 @@ int ll_op_create_coo_z(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* r
 int ll_op_inf_norm(const ll_operator* op, double* out) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && out != nullptr, "null argument");
-    LL_REQUIRE(op->inf_norm >= 0.0, "the infinity norm is only known for CSR/COO operators created from host arrays");
+    LL_REQUIRE(op->inf_norm >= 0.0, "the infinity norm is only known for CSR/COO/dense/lattice operators created from host data");
     *out = op->inf_norm;
   });
+}
+int ll_op_create_dense_d(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const double* a, ll_operator** out) {
+  return guarded([&] { create_dense<double>(ctx, nr, nc, rb, a, out); });
+}
+int ll_op_create_stencil_d(ll_context* ctx, const ll_stencil_desc* desc, int64_t rb, int64_t nl, const double* onsite,
+                           ll_operator** out) {
+  return guarded([&] { create_stencil<double>(ctx, desc, rb, nl, onsite, out); });
+}
+int ll_op_create_dense_z(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const void* a, ll_operator** out) {
+  return guarded([&] { create_dense<zc>(ctx, nr, nc, rb, a, out); });
+}
+int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t rb, int64_t nl, const double* onsite,
+                           ll_operator** out) {
+  return guarded([&] { create_stencil<zc>(ctx, desc, rb, nl, onsite, out); });
 }
 int ll_op_create_host_d(ll_context* ctx, int64_t n, ll_host_mv_mul_d fn, void* user, ll_operator** out) {
   return guarded([&] {
@@ -628,6 +742,8 @@ int ll_op_destroy(ll_operator* op) {
     if (op->ctx) (void)hipSetDevice(op->ctx->device);
     if (op->d_row_ptr) (void)hipFree(op->d_row_ptr);
     if (op->d_tile_rows) (void)hipFree(op->d_tile_rows);
+    if (op->d_dense) (void)hipFree(op->d_dense);
+    if (op->d_onsite) (void)hipFree(op->d_onsite);
     for (void* q : {(void*)op->d_pb_segq, (void*)op->d_pb_segdest, (void*)op->d_pb_rptr, op->d_pb_val,
                     (void*)op->d_pb_col, (void*)op->d_pb_row, op->d_pb_prod})
       if (q) (void)hipFree(q);
@@ -929,6 +1045,20 @@ int ll_op_create_coo_c(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* r
 int ll_op_create_coo_s(ll_context* ctx, int64_t n, int64_t nnz, const int32_t* rows, const int32_t* cols,
                        const float* vals, ll_operator** out) {
   return guarded([&] { create_coo<float>(ctx, n, nnz, rows, cols, vals, out); });
+}
+int ll_op_create_dense_s(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const float* a, ll_operator** out) {
+  return guarded([&] { create_dense<float>(ctx, nr, nc, rb, a, out); });
+}
+int ll_op_create_stencil_s(ll_context* ctx, const ll_stencil_desc* desc, int64_t rb, int64_t nl, const double* onsite,
+                           ll_operator** out) {
+  return guarded([&] { create_stencil<float>(ctx, desc, rb, nl, onsite, out); });
+}
+int ll_op_create_dense_c(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const void* a, ll_operator** out) {
+  return guarded([&] { create_dense<cf>(ctx, nr, nc, rb, a, out); });
+}
+int ll_op_create_stencil_c(ll_context* ctx, const ll_stencil_desc* desc, int64_t rb, int64_t nl, const double* onsite,
+                           ll_operator** out) {
+  return guarded([&] { create_stencil<cf>(ctx, desc, rb, nl, onsite, out); });
 }
 int ll_op_create_host_c(ll_context* ctx, int64_t n, ll_host_mv_mul_z fn, void* user, ll_operator** out) {
   return guarded([&] {

@@ -32,6 +32,10 @@ struct Api {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -65,6 +69,10 @@ Api& api() {
   a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
   a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
   a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+  a.Send = (decltype(a.Send))sym("ncclSend");
+  a.Recv = (decltype(a.Recv))sym("ncclRecv");
+  a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+  a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
   a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
   return a;
 }
@@ -247,6 +255,38 @@ static void shm_allreduce(Comm* c, double* buf, size_t n, hipStream_t s) {
   LL_HIP(hipMemcpyAsync(buf, sum.data(), bytes, hipMemcpyHostToDevice, s));
   LL_HIP(hipStreamSynchronize(s));
   c->barrier();
+}
+
+static void shm_halo_exchange(Comm* c, const void* send_prev, void* recv_prev, int prev, const void* send_next,
+                              void* recv_next, int next, size_t bytes, hipStream_t s) {
+  if (2 * bytes > c->seg->slot_bytes) {
+    set_error("shm backend: message larger than the slot (test backend only)");
+    throw Failure{LL_ERR_RCCL};
+  }
+  // own slot = [message for prev | message for next]
+  if (prev >= 0) LL_HIP(hipMemcpyAsync(c->slot(c->rank), send_prev, bytes, hipMemcpyDeviceToHost, s));
+  if (next >= 0) LL_HIP(hipMemcpyAsync(c->slot(c->rank) + bytes, send_next, bytes, hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  c->barrier();
+  if (prev >= 0) LL_HIP(hipMemcpyAsync(recv_prev, c->slot(prev) + bytes, bytes, hipMemcpyHostToDevice, s));
+  if (next >= 0) LL_HIP(hipMemcpyAsync(recv_next, c->slot(next), bytes, hipMemcpyHostToDevice, s));
+  LL_HIP(hipStreamSynchronize(s));
+  c->barrier();
+}
+
+void comm_halo_exchange(Comm* c, const void* send_prev, void* recv_prev, int prev, const void* send_next,
+                        void* recv_next, int next, size_t bytes, hipStream_t s) {
+  if (c->shm) return shm_halo_exchange(c, send_prev, recv_prev, prev, send_next, recv_next, next, bytes, s);
+  // One group = one fused point-to-point step.  Posting order matters when prev == next (two ranks on a ring):
+  // messages between one pair of ranks match in posting order, so "to next" is posted before "to prev" and "from
+  // prev" before "from next" — the peer's first send (its "to next") then lands in this rank's recv_prev.
+  Api& a = api();
+  check(a.GroupStart(), "ncclGroupStart");
+  if (next >= 0) check(a.Send(send_next, bytes, ncclChar, next, c->comm, s), "ncclSend");
+  if (prev >= 0) check(a.Recv(recv_prev, bytes, ncclChar, prev, c->comm, s), "ncclRecv");
+  if (prev >= 0) check(a.Send(send_prev, bytes, ncclChar, prev, c->comm, s), "ncclSend");
+  if (next >= 0) check(a.Recv(recv_next, bytes, ncclChar, next, c->comm, s), "ncclRecv");
+  check(a.GroupEnd(), "ncclGroupEnd");
 }
 
 void comm_allgather(Comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {

@@ -107,7 +107,27 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
   hipStream_t s = ctx->stream;
   ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)op->pb_nrb));
   int nparts = 0;
-  if (op->kind == ll_operator::CSR) {
+  if (op->kind == ll_operator::STENCIL) {
+    // exchange step of the lattice operator: one hyperplane from each ring neighbour instead of the all-gather
+    const int64_t H = op->st_halo;
+    const T *lo, *hi;
+    if (ctx->comm == nullptr) {  // the shard is the whole lattice: the ring neighbours are its own ends
+      lo = x_local + (n_local - H);
+      hi = x_local;
+    } else {
+      const size_t hb = (size_t)H * sizeof(T);
+      ctx->ensure_halo(2 * hb);
+      T* rlo = (T*)ctx->d_halo;
+      T* rhi = rlo + H;
+      const bool ring = op->st.periodic[0] != 0;
+      const int prev = ctx->rank > 0 ? ctx->rank - 1 : (ring ? ctx->nranks - 1 : -1);
+      const int next = ctx->rank + 1 < ctx->nranks ? ctx->rank + 1 : (ring ? 0 : -1);
+      comm_halo_exchange(ctx->comm, x_local, rlo, prev, x_local + (n_local - H), rhi, next, hb, s);
+      lo = rlo;
+      hi = rhi;
+    }
+    nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+  } else if (op->kind == ll_operator::CSR || op->kind == ll_operator::DENSE) {
     const T* x_full = x_local;
     if (ctx->comm != nullptr) {
       // exchange step: every rank needs the whole x for its row block
@@ -126,7 +146,9 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       comm_allgather(ctx->comm, send, ctx->d_xfull, shard_bytes, s);
       x_full = (const T*)ctx->d_xfull;
     }
-    if (op->spmv_kind == LL_SPMV_PB)
+    if (op->kind == ll_operator::DENSE)
+      nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    else if (op->spmv_kind == LL_SPMV_PB)
       nparts = launch_spmv_pb<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);

@@ -901,6 +901,177 @@ template int launch_offset_dot<zc>(int64_t, const zc*, zc*, double, double*, hip
 template int launch_offset_dot<float>(int64_t, const float*, float*, double, double*, hipStream_t);
 template int launch_offset_dot<cf>(int64_t, const cf*, cf*, double, double*, hipStream_t);
 
+// ================================================================= a1/a2/a3: dense row block (sample1's operator)
+// One wavefront per row: the row streams in with coalesced loads, x comes from L2, the 64 partial sums fold with
+// shuffles; offset, y write and the alpha partial are fused like in the CSR kernels.  Bound by the matrix stream
+// (sizeof(T) * n_local * n bytes per apply).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long long ncols, const T* __restrict__ a,
+                                                          const T* __restrict__ xf, const T* __restrict__ xl,
+                                                          T* __restrict__ y, double offset,
+                                                          double* __restrict__ dot_partials) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double dot_acc = 0.0;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < nrows; row += (long long)gridDim.x * 4) {
+    const T* __restrict__ ar = a + row * ncols;
+    acc_t<T> acc = zero<acc_t<T>>();
+#pragma unroll 4
+    for (long long j = lane; j < ncols; j += 64) fma_acc(acc, ar[j], xf[j]);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const T xi = xl[row];
+      const T yi = add(narrow<T>(acc), rmul(offset, xi));
+      y[row] = yi;
+      dot_acc += re_cmul(xi, yi);
+    }
+  }
+  if (dot_partials) {
+    const double tot = block_sum(dot_acc, red);
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = tot;
+  }
+}
+template <typename T>
+int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
+                    hipStream_t s) {
+  const long long want = (op.n_local + 3) / 4;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
+  hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(grid), dim3(kBlock), 0, s, (long long)op.n_local, (long long)op.n,
+                     (const T*)op.d_dense, x_full, x_local, y, offset, dot_partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+#define LL_INST_DENSE(T) \
+  template int launch_dense_mv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
+LL_INST_DENSE(double) LL_INST_DENSE(zc) LL_INST_DENSE(float) LL_INST_DENSE(cf)
+
+// ================================================================= a1/a2/a3: matrix-free lattice operator
+// (A x)(r) = (diag + onsite[r]) x(r) + sum_d ( hop[d] x(r + e_d) + conj(hop[d]) x(r - e_d) ), open or periodic per
+// dimension (sample3_dynamic.cpp:17-22, T1:265-273, T2:113-121, BASELINE config 2).  Nothing but x, y (and onsite)
+// moves: the neighbour reads of one site hit lines that the neighbouring lanes / the previous lattice rows already
+// pulled into L1/L2, so HBM sees one read of x and one write of y.  Terms are added in ascending column order of
+// the equivalent matrix row (lower neighbours slowest dimension first, the diagonal, upper neighbours fastest
+// first), the order of a CSR row with sorted columns.
+struct StencilGeom {
+  int ndim;
+  int periodic[3];
+  long long dims[3];
+  long long stride[3];
+  double diag;
+  double hop_re[3], hop_im[3];
+  long long halo;
+  long long row_begin, n_local;
+};
+__device__ __forceinline__ double hop_value(const StencilGeom& g, int d, bool conj, double*) { return g.hop_re[d]; }
+__device__ __forceinline__ float hop_value(const StencilGeom& g, int d, bool conj, float*) { return (float)g.hop_re[d]; }
+__device__ __forceinline__ zc hop_value(const StencilGeom& g, int d, bool conj, zc*) {
+  return zc{g.hop_re[d], conj ? -g.hop_im[d] : g.hop_im[d]};
+}
+__device__ __forceinline__ cf hop_value(const StencilGeom& g, int d, bool conj, cf*) {
+  return cf{(float)g.hop_re[d], (float)(conj ? -g.hop_im[d] : g.hop_im[d])};
+}
+__device__ __forceinline__ void fma_real(double& acc, double r, double x) { acc = fma(r, x, acc); }
+__device__ __forceinline__ void fma_real(double& acc, double r, float x) { acc = fma(r, (double)x, acc); }
+__device__ __forceinline__ void fma_real(zc& acc, double r, zc x) {
+  acc.re = fma(r, x.re, acc.re);
+  acc.im = fma(r, x.im, acc.im);
+}
+__device__ __forceinline__ void fma_real(zc& acc, double r, cf x) {
+  acc.re = fma(r, (double)x.re, acc.re);
+  acc.im = fma(r, (double)x.im, acc.im);
+}
+
+template <typename T, typename IDX>
+__global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T* __restrict__ xl,
+                                                         const T* __restrict__ lo, const T* __restrict__ hi,
+                                                         const typename scalar_traits<T>::real* __restrict__ onsite,
+                                                         T* __restrict__ y, double offset,
+                                                         double* __restrict__ dot_partials) {
+  __shared__ double red[4];
+  double dot_acc = 0.0;
+  const long long nl = g.n_local, H = g.halo;
+  auto fetch = [&](long long j) -> T { return j < 0 ? lo[H + j] : (j >= nl ? hi[j - nl] : xl[j]); };
+  for (long long li = (long long)blockIdx.x * kBlock + threadIdx.x; li < nl; li += (long long)gridDim.x * kBlock) {
+    // lattice coordinates of the site (IDX = 32-bit when the whole lattice fits, else 64-bit)
+    IDX rem = (IDX)(g.row_begin + li);
+    long long c[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 2; d >= 0; --d) {
+      if (d < g.ndim) {
+        const IDX dim = (IDX)g.dims[d];
+        const IDX q = rem / dim;
+        c[d] = (long long)(rem - q * dim);
+        rem = q;
+      }
+    }
+    acc_t<T> acc = zero<acc_t<T>>();
+    // lower neighbours, slowest dimension first
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < g.ndim) {
+        long long off = 0;
+        bool have = true;
+        if (c[d] > 0) off = -g.stride[d];
+        else if (g.periodic[d]) off = d == 0 ? -g.stride[0] : (g.dims[d] - 1) * g.stride[d];  // dim 0 wraps on the ring
+        else have = false;
+        if (have) fma_acc(acc, hop_value(g, d, true, (T*)nullptr), fetch(li + off));
+      }
+    }
+    const T xi = xl[li];
+    fma_real(acc, g.diag + (onsite ? (double)onsite[li] : 0.0), xi);
+    // upper neighbours, fastest dimension first
+#pragma unroll
+    for (int d = 2; d >= 0; --d) {
+      if (d < g.ndim) {
+        long long off = 0;
+        bool have = true;
+        if (c[d] + 1 < g.dims[d]) off = g.stride[d];
+        else if (g.periodic[d]) off = d == 0 ? g.stride[0] : -(g.dims[d] - 1) * g.stride[d];
+        else have = false;
+        if (have) fma_acc(acc, hop_value(g, d, false, (T*)nullptr), fetch(li + off));
+      }
+    }
+    const T yi = add(narrow<T>(acc), rmul(offset, xi));
+    y[li] = yi;
+    dot_acc += re_cmul(xi, yi);
+  }
+  if (dot_partials) {
+    const double tot = block_sum(dot_acc, red);
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = tot;
+  }
+}
+template <typename T>
+int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, const T* halo_hi, T* y, double offset,
+                   double* dot_partials, hipStream_t s) {
+  StencilGeom g;
+  g.ndim = op.st.ndim;
+  for (int d = 0; d < 3; ++d) {
+    g.periodic[d] = d < g.ndim ? op.st.periodic[d] : 0;
+    g.dims[d] = d < g.ndim ? op.st.dims[d] : 1;
+    g.stride[d] = d < g.ndim ? op.st_stride[d] : 0;
+    g.hop_re[d] = op.st.hop_re[d];
+    g.hop_im[d] = op.st.hop_im[d];
+  }
+  g.diag = op.st.diag;
+  g.halo = op.st_halo;
+  g.row_begin = op.row_begin;
+  g.n_local = op.n_local;
+  const long long want = (op.n_local + kBlock - 1) / kBlock;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
+  typedef typename scalar_traits<T>::real R;
+  if (op.n < ((long long)1 << 31))
+    hipLaunchKernelGGL((stencil_kernel<T, unsigned>), dim3(grid), dim3(kBlock), 0, s, g, x_local, halo_lo, halo_hi,
+                       (const R*)op.d_onsite, y, offset, dot_partials);
+  else
+    hipLaunchKernelGGL((stencil_kernel<T, unsigned long long>), dim3(grid), dim3(kBlock), 0, s, g, x_local, halo_lo,
+                       halo_hi, (const R*)op.d_onsite, y, offset, dot_partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+#define LL_INST_STENCIL(T) \
+  template int launch_stencil<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t);
+LL_INST_STENCIL(double) LL_INST_STENCIL(zc) LL_INST_STENCIL(float) LL_INST_STENCIL(cf)
+
 // ================================================================= a9/a10: tall-skinny GEMV over the basis
 // out_r = sum_k coeff[r*m + k] u_k for r < NOUT in one pass over the basis: every basis strip is read once and
 // feeds all NOUT accumulators (the reference re-reads the basis per root, LL:51-57).  Vectors are visited in

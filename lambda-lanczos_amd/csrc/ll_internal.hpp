@@ -114,6 +114,11 @@ void comm_destroy(Comm*);
 void comm_unique_id(void* id128);
 void comm_allgather(Comm*, const void* send, void* recv, size_t bytes, hipStream_t s);
 void comm_allreduce_sum(Comm*, double* buf, size_t n_doubles, hipStream_t s);
+// Ring halo exchange: `bytes` from send_prev go to rank `prev` (they become its recv_next) and `bytes` from send_next
+// go to rank `next` (its recv_prev); the matching messages arrive in recv_prev / recv_next.  prev / next = -1: no such
+// neighbour (open boundary).  prev == next (two ranks on a ring) and prev == next == own rank are legal.
+void comm_halo_exchange(Comm*, const void* send_prev, void* recv_prev, int prev, const void* send_next, void* recv_next,
+                        int next, size_t bytes, hipStream_t s);
 
 }  // namespace ll
 
@@ -140,12 +145,15 @@ struct ll_context {
   std::vector<std::pair<void*, size_t>> slab_cache;  // Krylov-basis slabs kept between runs (ptr, bytes)
   void* d_xfull = nullptr;       // all-gather target (sharded runs)
   size_t xfull_cap = 0;          // bytes
+  void* d_halo = nullptr;        // received halos of the lattice operator: [from prev | from next]
+  size_t halo_cap = 0;           // bytes
 
   void ensure_partials(size_t doubles);
   void ensure_h(size_t doubles);
   void ensure_pinned(size_t doubles);
   void ensure_coeff(size_t bytes);
   void ensure_xfull(size_t bytes);
+  void ensure_halo(size_t bytes);
   void* h_stage = nullptr;       // pinned host staging buffer for n-sized transfers (start vector, Ritz vectors)
   size_t stage_cap = 0;          // bytes
   void* ensure_stage(size_t bytes);
@@ -154,7 +162,7 @@ struct ll_context {
 
 // ---------------------------------------------------------------- operator
 struct ll_operator {
-  enum Kind { CSR, HOST_CB, DEV_CB } kind = CSR;
+  enum Kind { CSR, HOST_CB, DEV_CB, DENSE, STENCIL } kind = CSR;
   bool is_complex = false;
   int elem_bytes = 8;  // sizeof(T): 4 float, 8 double / complex float, 16 complex double
   ll_context* ctx = nullptr;
@@ -179,6 +187,13 @@ struct ll_operator {
   uint16_t* d_pb_col = nullptr;      // local column, column-block order
   uint16_t* d_pb_row = nullptr;      // local row, row-block order
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
+  // dense row-major block (kind DENSE): n_local x n values of T
+  void* d_dense = nullptr;
+  // lattice operator (kind STENCIL)
+  ll_stencil_desc st = {};
+  int64_t st_stride[3] = {0, 0, 0};  // flattened-index stride of each dimension (last index fastest)
+  int64_t st_halo = 0;               // sites of one hyperplane = reach of the operator in the flattened index
+  void* d_onsite = nullptr;          // n_local on-site terms in the real type of T (nullable)
   // callbacks
   ll_host_mv_mul_z host_fn = nullptr;  // every host callback is stored under the void* signature
   ll_dev_mv_mul dev_fn = nullptr;
@@ -200,6 +215,15 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset,
                       double* dot_partials, hipStream_t s);
+// Same contract for the dense row block (op.kind == DENSE).
+template <typename T>
+int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
+                    hipStream_t s);
+// Lattice operator (op.kind == STENCIL): site li of the shard reads x at li + off, |off| <= op.st_halo, from
+// halo_lo[st_halo + j] for j < 0, x_local[j] for 0 <= j < n_local and halo_hi[j - n_local] beyond.
+template <typename T>
+int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, const T* halo_hi, T* y, double offset,
+                   double* dot_partials, hipStream_t s);
 // y += offset * x ; partials of Re<x,y> (post-pass for callback operators).
 template <typename T>
 int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_partials, hipStream_t s);

@@ -209,6 +209,58 @@ class CsrOperator(_Operator):
         return k.value
 
 
+class DenseOperator(_Operator):
+    """Dense row-major matrix (sample1_simple.cpp:22-28): rows [row_begin, row_begin + a.shape[0]) of an n x n matrix."""
+
+    def __init__(self, ctx, a, row_begin=0):
+        a = np.ascontiguousarray(a)
+        if a.dtype not in (np.float32, np.float64, np.complex64, np.complex128):
+            a = a.astype(np.float64)
+        self.ctx, self.dtype = ctx, a.dtype
+        self.n_local, self.n = int(a.shape[0]), int(a.shape[1])
+        self.row_begin, self.nnz = int(row_begin), int(a.size)
+        h = C.c_void_p()
+        fn = getattr(lib(), "ll_op_create_dense_" + _suffix(a.dtype))
+        check(fn(ctx.handle, self.n_local, self.n, self.row_begin, ptr(a), C.byref(h)))
+        self.handle = h
+
+    inf_norm = CsrOperator.inf_norm
+
+
+class StencilOperator(_Operator):
+    """Matrix-free lattice operator (sample3_dynamic.cpp:17-22, T1:265-273, T2:113-121):
+    (A x)(r) = (diag + onsite[r]) x(r) + sum_d (hop[d] x(r+e_d) + conj(hop[d]) x(r-e_d)) on a row-major lattice
+    `dims` (last index fastest), open or periodic per dimension.  Sharded contexts pass their ll_partition range."""
+
+    def __init__(self, ctx, dims, diag=0.0, hop=-1.0, periodic=False, onsite=None, dtype=np.float64, row_begin=0,
+                 n_local=None):
+        dims = [int(d) for d in np.atleast_1d(dims)]
+        nd = len(dims)
+        if not 1 <= nd <= 3:
+            raise ValueError("the lattice operator supports 1, 2 or 3 dimensions")
+        hop = np.broadcast_to(np.asarray(hop, dtype=np.complex128), (nd,))
+        periodic = np.broadcast_to(np.asarray(periodic, dtype=bool), (nd,))
+        d = capi.StencilDesc()
+        d.ndim = nd
+        for k in range(nd):
+            d.dims[k], d.periodic[k] = dims[k], int(periodic[k])
+            d.hop_re[k], d.hop_im[k] = float(hop[k].real), float(hop[k].imag)
+        d.diag = float(diag)
+        self.ctx, self.dtype = ctx, np.dtype(dtype)
+        self.n = int(np.prod(dims))
+        self.n_local = self.n if n_local is None else int(n_local)
+        self.row_begin, self.nnz = int(row_begin), 0
+        os_ = None if onsite is None else np.ascontiguousarray(onsite, dtype=np.float64)
+        if os_ is not None and os_.shape[0] != self.n_local:
+            raise ValueError("onsite must hold n_local values")
+        h = C.c_void_p()
+        fn = getattr(lib(), "ll_op_create_stencil_" + _suffix(self.dtype))
+        check(fn(ctx.handle, C.byref(d), self.row_begin, self.n_local, ptr(os_), C.byref(h)))
+        self.handle = h
+
+    inf_norm = CsrOperator.inf_norm
+
+
 class HostOperator(_Operator):
     """Unmodified user code: mv_mul(in, out) on numpy arrays, `out` zero-filled on entry (LL:120-126)."""
 

@@ -141,6 +141,45 @@ def chain_csr(n, t=-1.0):
     return coo_to_csr(n, rows, cols, np.full(len(rows), t))
 
 
+def lattice_csr(dims, diag=0.0, hop=-1.0, periodic=False, onsite=None, dtype=np.float64, row_begin=0, n_local=None):
+    """CSR image of the matrix-free lattice operator (ll_op_create_stencil_*): rows [row_begin, row_begin+n_local),
+    entries in the operator's own order (lower neighbours slowest dimension first, diagonal, upper neighbours fastest
+    first); a neighbour reached twice (periodic dimension of length 1 or 2) appears twice."""
+    dims = [int(d) for d in np.atleast_1d(dims)]
+    nd = len(dims)
+    hop = np.broadcast_to(np.asarray(hop, dtype=np.complex128), (nd,))
+    periodic = np.broadcast_to(np.asarray(periodic, dtype=bool), (nd,))
+    n = int(np.prod(dims))
+    n_local = n - row_begin if n_local is None else n_local
+    r = np.arange(row_begin, row_begin + n_local, dtype=np.int64)
+    coords = list(np.unravel_index(r, dims))
+    strides = [int(np.prod(dims[k + 1:])) for k in range(nd)]
+    cols, vals, have = [], [], []
+
+    def neighbour(k, sign):
+        c = coords[k] + sign
+        ok = (c >= 0) & (c < dims[k])
+        if periodic[k]:
+            c, ok = c % dims[k], np.ones_like(ok)
+        cols.append(r + (c - coords[k]) * strides[k])
+        vals.append(np.full(n_local, np.conj(hop[k]) if sign < 0 else hop[k]))
+        have.append(ok)
+
+    for k in range(nd):
+        neighbour(k, -1)
+    cols.append(r.copy())
+    vals.append(np.full(n_local, diag, dtype=np.complex128) + (0 if onsite is None else np.asarray(onsite)))
+    have.append(np.ones(n_local, dtype=bool))
+    for k in range(nd - 1, -1, -1):
+        neighbour(k, +1)
+    cols, vals, have = np.stack(cols, 1), np.stack(vals, 1), np.stack(have, 1)
+    rp = np.concatenate([[0], np.cumsum(have.sum(1))]).astype(np.int64)
+    va = vals[have]
+    if not np.issubdtype(np.dtype(dtype), np.complexfloating):
+        va = va.real
+    return rp, cols[have].astype(np.int32), np.ascontiguousarray(va.astype(dtype))
+
+
 # ------------------------------------------------------------------ C++ versions (BASELINE sizes)
 _gen = None
 

@@ -148,6 +148,60 @@ static void device_operator() {
   expect(vec.size() == (size_t)n, "eigenvector length");
 }
 
+static void operator_zoo() {
+  std::printf("[case] matrix-free LatticeOperator: T1:262 DYNAMIC_MATRIX (open chain n=10), lambda_min = -2cos(pi/11)\n");
+  {
+    const size_t n = 10;
+    ll::LatticeOperator<double> chain({(int64_t)n}, 0.0, {-1.0}, {false});
+    ll::LambdaLanczos<double> engine(chain, n, false, 1);
+    engine.eps = 1e-14;
+    engine.eigenvalue_offset = -chain.inf_norm() * 5;  // the reference's test uses -10
+    double value;
+    std::vector<double> vec;
+    engine.run(value, vec);
+    const double want = -2.0 * std::cos(M_PI / (double)(n + 1));
+    expect_close(want, value, std::abs(want) * engine.eps * 10, "open-chain ground state energy");
+    std::vector<double> sine(n);
+    for (size_t i = 0; i < n; ++i) sine[i] = std::sin((double)(i + 1) * M_PI / (double)(n + 1));
+    double nn = 0;
+    for (double v : sine) nn += v * v;
+    for (double& v : sine) v /= std::sqrt(nn);
+    expect(misfit(sine, vec) <= 1e-13, "open-chain ground state vector");
+  }
+  std::printf("[case] DenseMatrix: T1:442 MULTIPLE_EIGENPAIRS matrix resident on the device\n");
+  {
+    std::vector<std::vector<double>> m = {{6, -3, -3, 0, -1, 1, -1, 1}, {-3, -4, 2, 2, -1, -5, 0, -4},
+                                          {-3, 2, 2, -3, 0, 0, -1, -1}, {0, 2, -3, 0, -3, 3, 2, 2},
+                                          {-1, -1, 0, -3, -2, 0, -5, -4}, {1, -5, 0, 3, 0, -4, 5, 0},
+                                          {-1, 0, -1, 2, -5, 5, -4, 4}, {1, -4, -1, 2, -4, 0, 4, 2}};
+    ll::DenseMatrix<double> A(m);
+    ll::LambdaLanczos<double> engine(A, 8, false, 3);
+    engine.eps = 1e-7;
+    std::vector<double> values;
+    std::vector<std::vector<double>> vectors;
+    engine.run(values, vectors);
+    const double want[3] = {-13.21508597, -8.50033154, -4.26674892};
+    expect(values.size() == 3, "three eigenvalues");
+    for (size_t r = 0; r < values.size() && r < 3; ++r) expect_close(want[r], values[r], 1e-7, "dense eigenvalue");
+  }
+  std::printf("[case] LatticeOperator<complex>: T2:106 ring n=100 as a matrix-free operator, a = 3i\n");
+  {
+    const size_t n = 100;
+    ll::LatticeOperator<cplx> ring({(int64_t)n}, 0.0, {-1.0}, {true});
+    ll::Exponentiator<cplx> ex(ring, n);
+    std::vector<cplx> input(n, 0.0), output;
+    input[0] = input[n - 1] = cplx(1, 2);
+    input[n / 2] = cplx(8, 2);
+    double nn = 0;
+    for (auto& c : input) nn += std::norm(c);
+    for (auto& c : input) c /= std::sqrt(nn);
+    expect(ex.run(cplx(0, 3), input, output) == 19, "iteration count of the reference (tests/golden/exponentiator.json)");
+    double on = 0;
+    for (auto& c : output) on += std::norm(c);
+    expect(std::abs(std::sqrt(on) - 1.0) <= 1e-12, "unitary evolution keeps the norm");
+  }
+}
+
 static void exponentiator() {
   std::printf("[case] T2:106 EXPONENTIATE_LARGE_MATRIX — periodic chain n=100, a = 3i, analytic plane waves\n");
   const size_t n = 100;
@@ -184,6 +238,7 @@ int main() {
     eigen_cases();
     api_shapes();
     device_operator();
+    operator_zoo();
     exponentiator();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());

@@ -61,6 +61,43 @@ def main():
     out, it = L.Exponentiator(top, n3).run(-1j, inp)
     res["torus_expo"] = {"out": c2list(out), "itern": it, "row_begin": rb3}
     top.close()
+    # --- matrix-free lattice operators: halo exchange instead of the all-gather
+    #     (a) open 2-D Laplacian, (b) 3-D complex hops, periodic in every dimension (ring neighbours wrap around)
+    side = 24
+    n4 = side * side
+    rb4, nl4 = ctx.partition(n4)
+    st = L.StencilOperator(ctx, [side, side], diag=4.0, hop=-1.0, row_begin=rb4, n_local=nl4)
+    e4 = L.LambdaLanczos(st, n4, False, 1)
+    e4.eigenvalue_offset = -8.0
+    e4.init_vector = lambda v, row_begin: np.copyto(v, G.start_vector(v.shape[0], 1, np.float64, row_begin))
+    v4, x4 = e4.run()
+    res["stencil_laplace"] = {"vals": v4.tolist(), "vecs": [x4[0].tolist()], "iters": e4.getIterationCounts(),
+                              "alpha": e4.last_alpha.tolist()}
+    st.close()
+    dims = [9, 5, 7]
+    n5 = int(np.prod(dims))
+    rb5, nl5 = ctx.partition(n5)
+    ons = 0.3 * np.cos(np.arange(rb5, rb5 + nl5))
+    st3 = L.StencilOperator(ctx, dims, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=True, onsite=ons,
+                            dtype=np.complex128, row_begin=rb5, n_local=nl5)
+    x5 = G.start_vector(nl5, 3, np.complex128, rb5)
+    xd, yd = ctx.to_device(x5), ctx.empty(nl5, np.complex128)
+    dot5 = L.spmv(st3, xd, yd, offset=-0.5, want_dot=True)
+    out5, it5 = L.Exponentiator(st3, n5).run(-0.7j, x5)
+    res["stencil_3d"] = {"y": c2list(yd.get()), "dot": dot5, "out": c2list(out5), "itern": it5}
+    st3.close()
+    # --- dense row block (all-gather path)
+    n6 = 203
+    rb6, nl6 = ctx.partition(n6)
+    rng = np.random.default_rng(5)
+    a6 = rng.standard_normal((n6, n6))
+    a6 = a6 + a6.T
+    dn = L.DenseOperator(ctx, a6[rb6:rb6 + nl6], row_begin=rb6)
+    e6 = L.LambdaLanczos(dn, n6, True, 1)
+    e6.init_vector = lambda v, row_begin: np.copyto(v, G.start_vector(v.shape[0], 1, np.float64, row_begin))
+    v6, x6 = e6.run()
+    res["dense"] = {"vals": v6.tolist(), "vecs": [x6[0].tolist()], "iters": e6.getIterationCounts()}
+    dn.close()
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
         json.dump(res, f)
     ctx.close()

@@ -74,6 +74,35 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
     out = np.concatenate([list2c(r["torus_expo"]["out"]) for r in ranks])
     assert abs(ranks[0]["torus_expo"]["itern"] - o_it) <= 1
     assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(inp)
+    # ---- matrix-free lattice operators (halo exchange) and the dense row block
+    key = "stencil_laplace"
+    for r in ranks[1:]:
+        assert r[key]["vals"] == ranks[0][key]["vals"] and r[key]["alpha"] == ranks[0][key]["alpha"]
+    assert abs(ranks[0][key]["vals"][0] - ora2["eigenvalues"][0]) <= 1e-10 * 8
+    assert abs(ranks[0][key]["iters"][0] - ora2["iter_counts"][0]) <= 2
+    m = min(len(ora2["alpha"]), len(ranks[0][key]["alpha"]))
+    assert np.max(np.abs(np.array(ranks[0][key]["alpha"])[:m] - ora2["alpha"][:m])) <= 1e-10 * 8
+    assert 1 - overlap(stitch(key, "vecs", 0), ora2["eigenvectors"][0]) <= 1e-8
+    dims = [9, 5, 7]
+    n5 = int(np.prod(dims))
+    c5 = G.lattice_csr(dims, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=True, onsite=0.3 * np.cos(np.arange(n5)),
+                       dtype=np.complex128)
+    x5 = G.start_vector(n5, 3, np.complex128)
+    y5 = oracle.spmv(c5, x5) - 0.5 * x5
+    got = np.concatenate([list2c(r["stencil_3d"]["y"]) for r in ranks])
+    assert np.max(np.abs(got - y5)) <= 1e-13 * 10
+    assert abs(ranks[0]["stencil_3d"]["dot"] - np.vdot(x5, y5).real) <= 1e-11 * n5
+    o5, it5, _ = oracle.expo(c5, -0.7j, x5)
+    out5 = np.concatenate([list2c(r["stencil_3d"]["out"]) for r in ranks])
+    assert abs(ranks[0]["stencil_3d"]["itern"] - it5) <= 1
+    assert np.max(np.abs(out5 - o5)) <= 1e-10 * np.linalg.norm(x5)
+    rng = np.random.default_rng(5)
+    a6 = rng.standard_normal((203, 203))
+    a6 = a6 + a6.T
+    ora6 = oracle.lanczos(G.dense_to_csr(a6), G.start_vector(203, 1), True)
+    assert abs(ranks[0]["dense"]["vals"][0] - ora6["eigenvalues"][0]) <= 1e-10 * np.max(np.abs(ora6["eigenvalues"]))
+    assert abs(ranks[0]["dense"]["iters"][0] - ora6["iter_counts"][0]) <= 2
+    assert 1 - overlap(stitch("dense", "vecs", 0), ora6["eigenvectors"][0]) <= 1e-8
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):

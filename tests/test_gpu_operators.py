@@ -1,0 +1,195 @@
+"""The operator zoo either side of the Krylov loop, through the C ABI on the GPU:
+  * the matrix-free lattice operator ll_op_create_stencil_* — the reference's "dynamic matrix" family
+    (src/samples/sample3_dynamic.cpp:17-22, T1:262-308 open chain; T2:106-162 periodic ring; BASELINE config 2),
+  * the dense row-major operator ll_op_create_dense_* (src/samples/sample1_simple.cpp:22-28; T1:128, T1:442).
+Parity: one apply against the oracle's CSR row loop on the equivalent matrix (generators.lattice_csr / dense_to_csr);
+whole loops against the oracle, the CSR operator of the same matrix and the reference's known answers."""
+import math
+
+import numpy as np
+import pytest
+
+import cases
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import generators as G
+from util import overlap
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+LATTICES = {
+    # name: (dims, diag, hop, periodic, with_onsite)
+    "chain10_open": ([10], 0.0, -1.0, False, False),                      # T1:265-273
+    "ring100": ([100], 0.0, -1.0, True, False),                           # T2:113-121
+    "single_site_ring": ([1], 0.5, -1.0, True, False),
+    "laplace_37x41": ([37, 41], 4.0, -1.0, False, False),                 # BASELINE config 2 at a ragged size
+    "torus_300x257": ([300, 257], 0.0, [-1.0, 0.5], True, True),
+    "mixed_3d": ([5, 6, 7], 0.25, [0.5, -1.0, 0.75], [True, False, True], True),
+    "thin_3d": ([2, 1, 3], 0.0, [1.0, -1.0, 0.5], True, False),           # neighbours reached twice / self neighbours
+    "slab_3d": ([40, 33, 29], -1.0, [-1.0, -0.5, -0.25], [False, True, False], False),
+}
+COMPLEX_HOPS = {"ring100": 0.3 - 1j, "torus_300x257": [-1.0 + 0.2j, 0.5j], "mixed_3d": [0.5 + 1j, -1.0, 0.75j],
+                "thin_3d": [1.0 + 1j, -1j, 0.5], "slab_3d": [-1.0, -0.5 + 0.5j, 0.25j]}
+
+
+def lattice(name, dtype):
+    dims, diag, hop, periodic, with_onsite = LATTICES[name]
+    if np.issubdtype(np.dtype(dtype), np.complexfloating) and name in COMPLEX_HOPS:
+        hop = COMPLEX_HOPS[name]
+    n = int(np.prod(dims))
+    onsite = 0.3 * np.cos(1.7 * np.arange(n)) if with_onsite else None
+    return dims, dict(diag=diag, hop=hop, periodic=periodic, onsite=onsite, dtype=dtype)
+
+
+def rnd(n, dtype, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(-1, 1, n)
+    if np.issubdtype(np.dtype(dtype), np.complexfloating):
+        v = v + 1j * rng.uniform(-1, 1, n)
+    return v.astype(dtype)
+
+
+@pytest.mark.parametrize("name", sorted(LATTICES))
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32, np.complex64])
+@pytest.mark.parametrize("offset", [0.0, -2.5])
+def test_lattice_apply_matches_oracle(ctx, oracle, name, dtype, offset):
+    dims, kw = lattice(name, dtype)
+    n = int(np.prod(dims))
+    wide = np.complex128 if np.issubdtype(np.dtype(dtype), np.complexfloating) else np.float64
+    csr = G.lattice_csr(dims, **dict(kw, dtype=wide))
+    single = np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+    if kw["onsite"] is not None and single:
+        # the device keeps onsite in the real type of T: compare against the float-rounded values
+        csr = G.lattice_csr(dims, **dict(kw, dtype=wide, onsite=kw["onsite"].astype(np.float32).astype(np.float64)))
+    op = L.StencilOperator(ctx, dims, **kw)
+    assert op.info() == (n, n, 0)
+    x = rnd(n, dtype, 11)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    alpha = L.spmv(op, xd, yd, offset=offset, want_dot=True)
+    y = yd.get()
+    xw = x.astype(wide)
+    y_ref = oracle.spmv(csr, xw) + offset * xw
+    tol = 16 * (np.finfo(np.float32).eps if single else EPS)
+    scale = op.inf_norm() + abs(offset)
+    assert np.max(np.abs(y - y_ref)) <= tol * max(scale, 1.0)
+    assert abs(alpha - np.vdot(xw, y_ref).real) <= tol * max(scale, 1.0) * n
+    # row-sum bound reported for eigenvalue_offset
+    rowsum = np.max(np.add.reduceat(np.abs(csr[2]), csr[0][:-1]))
+    assert rowsum <= op.inf_norm() * (1 + (1e-6 if single else 1e-12)) + 1e-12
+    op.close()
+
+
+def test_dynamic_matrix_known_answer(ctx):
+    """T1:262-308 DYNAMIC_MATRIX through the matrix-free operator: lambda_min = -2 cos(pi/(n+1)), sine eigenvector."""
+    n = 10
+    op = L.StencilOperator(ctx, [n], diag=0.0, hop=-1.0)
+    eng = L.LambdaLanczos(op, n, False, 1)
+    eng.eps = 1e-14
+    eng.eigenvalue_offset = -10.0
+    eng.init_vector = lambda v, *_: v.__setitem__(slice(None), G.start_vector(n, 1))
+    vals, vecs = eng.run()
+    want = -2.0 * math.cos(math.pi / (n + 1))
+    assert abs(vals[0] - want) <= abs(want) * eng.eps * 10
+    sine = np.sin((np.arange(n) + 1) * math.pi / (n + 1))
+    assert 1 - overlap(vecs[0], sine) <= 1e-13
+    op.close()
+
+
+@pytest.mark.parametrize("name", ["laplace_37x41", "slab_3d", "torus_300x257"])
+def test_lattice_lanczos_equals_csr_and_oracle(ctx, oracle, name):
+    """Same problem through the lattice operator, the CSR operator and the oracle: same alpha/beta trace, same
+    iteration count, same eigenpair."""
+    dims, kw = lattice(name, np.float64)
+    n = int(np.prod(dims))
+    csr = G.lattice_csr(dims, **kw)
+    init = G.start_vector(n, 1)
+    st = L.StencilOperator(ctx, dims, **kw)
+    cs = L.CsrOperator(ctx, *csr)
+    runs = []
+    for op in (st, cs):
+        eng = L.LambdaLanczos(op, n, False, 1)
+        eng.eigenvalue_offset = -op.inf_norm()
+        eng.max_iteration = 150
+        eng.init_vector = lambda v, *_: v.__setitem__(slice(None), init)
+        vals, vecs = eng.run()
+        runs.append((vals[0], vecs[0], eng.getIterationCounts(), eng.last_alpha, eng.last_beta))
+    ora = oracle.lanczos(csr, init, False, offset=-st.inf_norm(), max_iteration=150)
+    norm = st.inf_norm()
+    for val, vec, iters, alpha, beta in runs:
+        assert iters == ora["iter_counts"]
+        m = len(ora["alpha"])
+        assert np.max(np.abs(alpha[:m] - ora["alpha"])) <= 1e-10 * norm
+        assert np.max(np.abs(beta[:m - 1] - ora["beta"][:m - 1])) <= 1e-10 * norm
+        assert abs(val - ora["eigenvalues"][0]) <= 1e-10 * max(1.0, norm)
+    # the Ritz vector of an unconverged fixed window is still the same vector on all three paths
+    assert 1 - overlap(runs[0][1], runs[1][1]) <= 1e-8
+    assert 1 - overlap(runs[0][1], ora["eigenvectors"][0]) <= 1e-8
+    st.close()
+    cs.close()
+
+
+def test_lattice_exponentiate_large_matrix(ctx):
+    """T2:106-162 EXPONENTIATE_LARGE_MATRIX with the ring as a matrix-free operator: analytic plane waves, 19 iterations."""
+    case = cases.expo_cases()["exponentiate_large"]
+    n = 100
+    op = L.StencilOperator(ctx, [n], hop=-1.0, periodic=True, dtype=np.complex128)
+    ex = L.Exponentiator(op, n)
+    out, itern = ex.run(case["a"], case["input"])
+    assert 1 - overlap(out, case["exact"]) <= ex.eps * 10
+    assert itern == 19
+    tout, terms = ex.taylor_run(case["a"], case["input"])
+    assert terms == 37 and 1 - overlap(tout, case["exact"]) <= ex.eps * 10
+    op.close()
+
+
+def test_lattice_rejects_bad_arguments(ctx):
+    with pytest.raises(L.LanczosHipError):
+        L.StencilOperator(ctx, [4, 4], hop=[1j, 1.0], dtype=np.float64)      # complex hop, real storage
+    with pytest.raises(L.LanczosHipError):
+        L.StencilOperator(ctx, [4, 0])
+    with pytest.raises((L.LanczosHipError, ValueError)):
+        L.StencilOperator(ctx, [2, 2, 2, 2])
+    with pytest.raises(L.LanczosHipError):
+        L.StencilOperator(ctx, [8], n_local=4)                               # a single-GPU context needs the whole lattice
+
+
+# ------------------------------------------------------------------ dense operator
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32, np.complex64])
+@pytest.mark.parametrize("n", [1, 3, 64, 301, 2050])
+def test_dense_apply_matches_oracle(ctx, oracle, dtype, n):
+    rng = np.random.default_rng(n)
+    a = rng.uniform(-1, 1, (n, n))
+    if np.issubdtype(np.dtype(dtype), np.complexfloating):
+        a = a + 1j * rng.uniform(-1, 1, (n, n))
+    a = ((a + a.conj().T) / 2).astype(dtype)
+    wide = np.complex128 if np.issubdtype(np.dtype(dtype), np.complexfloating) else np.float64
+    op = L.DenseOperator(ctx, a)
+    x = rnd(n, dtype, 5)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    alpha = L.spmv(op, xd, yd, offset=0.75, want_dot=True)
+    y_ref = oracle.spmv(G.dense_to_csr(a.astype(wide)), x.astype(wide)) + 0.75 * x.astype(wide)
+    tol = 8 * (np.finfo(np.float32).eps if dtype in (np.float32, np.complex64) else EPS)
+    assert np.max(np.abs(yd.get() - y_ref)) <= tol * (op.inf_norm() + 1.0)
+    assert abs(alpha - np.vdot(x.astype(wide), y_ref).real) <= tol * (op.inf_norm() + 1.0) * n
+    assert abs(op.inf_norm() - np.max(np.sum(np.abs(a.astype(wide)), axis=1))) <= 1e-12 * n
+    op.close()
+
+
+@pytest.mark.parametrize("name", ["simple_matrix", "hermitian_matrix", "multiple_eigenpairs", "single_element"])
+def test_dense_known_answers(ctx, name):
+    """T1:128-161, T1:375-409, T1:442-488, T1:411-440 with the matrix handed over as a dense block."""
+    case = cases.eigen_cases()[name]
+    rp, ci, va = case["csr"]
+    n = rp.shape[0] - 1
+    a = va.reshape(n, n)
+    op = L.DenseOperator(ctx, a)
+    eng = L.LambdaLanczos(op, n, case["find_maximum"], case["num_eigs"])
+    if case["eps"] is not None:
+        eng.eps = case["eps"]
+    eng.eigenvalue_offset = case["offset"]
+    eng.init_vector = lambda v, *_: v.__setitem__(slice(None), G.start_vector(n, 1, va.dtype))
+    vals, vecs = eng.run()
+    for r, want in enumerate(case["values"]):
+        assert abs(vals[r] - want) <= max(abs(want) * eng.eps, 1e-8 if eng.eps > 1e-8 else 0.0)
+        assert 1 - overlap(vecs[r], case["vectors"][r]) <= max(100 * eng.eps, 1e-12)
+    op.close()
