@@ -290,6 +290,30 @@ def test_sharded_path_with_single_rank_communicator(oracle):
     ctx2.close()
 
 
+def test_lattice_halo_exchange_with_single_rank_communicator(oracle):
+    """The lattice operator's exchange step through RCCL itself: with a 1-rank communicator on a ring (periodic
+    slowest dimension) both neighbours are the rank itself, so the grouped ncclSend/ncclRecv pair of
+    comm_halo_exchange runs for real on the test box's single GPU; results must equal the communicator-free path."""
+    dims = [12, 9, 7]
+    n = int(np.prod(dims))
+    kw = dict(diag=0.5, hop=[0.5 + 1j, -1.0, 0.25j], periodic=[True, False, True], dtype=np.complex128)
+    csr = G.lattice_csr(dims, **kw)
+    x = G.start_vector(n, 2, np.complex128)
+    y_ref = oracle.spmv(csr, x)
+    ctx2 = L.Context(0)
+    ctx2.init_comm(L.Context.unique_id(), 0, 1)
+    op = L.StencilOperator(ctx2, dims, **kw)
+    xd, yd = ctx2.to_device(x), ctx2.empty(n, np.complex128)
+    dot = L.spmv(op, xd, yd, want_dot=True)
+    assert np.max(np.abs(yd.get() - y_ref)) <= 1e-13 * 10
+    assert abs(dot - np.vdot(x, y_ref).real) <= 1e-11 * n
+    out, it = L.Exponentiator(op, n).run(-0.5j, x)
+    o2, it2, _ = oracle.expo(csr, -0.5j, x)
+    assert abs(it - it2) <= 1 and np.max(np.abs(out - o2)) <= 1e-10 * np.linalg.norm(x)
+    op.close()
+    ctx2.close()
+
+
 # ------------------------------------------------------------------ other operator forms of the mv_mul plugin
 def test_device_array_csr_and_device_callback_operators(ctx, oracle):
     """ll_op_create_csr_dev_d (matrix already in HBM) and ll_op_create_device_d (a callback that enqueues
