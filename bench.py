@@ -344,8 +344,10 @@ def main():
                 "workload": name,
                 "n": n,
                 "nnz": nnz,
-                "step": "one LambdaLanczos::run with max_iteration=%d (k = 1..%d, mean k = %.1f), nroot=%s"
-                        % (args.window, args.window, (args.window + 1) / 2, "n/a" if wl == "c5" else "5"),
+                "step": "one %s::run with max_iteration=%d; %.0f iterations per run (k = 1..%.0f, mean k = %.1f), nroot=%s"
+                        % ("Exponentiator" if wl == "c5" else "LambdaLanczos", args.window, total_iters / max(args.steps, 1),
+                           total_iters / max(args.steps, 1), (total_iters / max(args.steps, 1) + 1) / 2,
+                           "n/a" if wl == "c5" else "5"),
                 "iterations_per_step": total_iters / max(args.steps, 1),
                 "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL %s" % (world, "halo exchange" if lattice else "all-gather of x"),
                 "orth_mode": args.orth_mode,
