@@ -198,7 +198,7 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  *   LL_SPMV_PB          propagation blocking: the same matrix re-ordered once at upload so that one SpMV is two
  *                       fully coalesced streaming sweeps with x and y slices in LDS and no global gather; best for
  *                       matrices without column locality (BASELINE config 3).
- * ll_op_create_csr_{d,z} (host arrays) builds both images, times them on the device and keeps the faster one
+ * ll_op_create_csr_{d,z} and _csr_dev_ (one copy back to the host) build both images, time them on the device and keep the faster one
  * (override: environment LL_SPMV_KERNEL=csr|pb, or this call). */
 enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1 };
 int ll_op_select_spmv(ll_operator* op, int kind);

@@ -518,9 +518,33 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   op->spmv_kind = LL_SPMV_CSR_STREAM;
   const char* fmt = std::getenv("LL_SPMV_KERNEL");
   const std::string want = fmt ? fmt : "auto";
-  if (!on_device && want != "csr" && nnz > 0 && build_pb<T>(op.get(), rp_host, ci, (const T*)va)) {
-    if (want == "pb") op->spmv_kind = LL_SPMV_PB;
-    else autotune_spmv<T>(op.get());
+  if (want != "csr" && nnz > 0) {
+    // the propagation-blocked image is built on the host; arrays that are already in HBM are copied back once for it
+    std::vector<int32_t> ci_copy;
+    std::vector<T> va_copy;
+    const int32_t* ci_host = ci;
+    const T* va_host = (const T*)va;
+    if (on_device) {
+      ci_copy.resize(nnz);
+      va_copy.resize(nnz);
+      LL_HIP(hipMemcpy(ci_copy.data(), ci, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+      LL_HIP(hipMemcpy(va_copy.data(), va, nnz * sizeof(T), hipMemcpyDeviceToHost));
+      ci_host = ci_copy.data();
+      va_host = va_copy.data();
+      for (size_t p = 0; p < nnz; ++p) LL_REQUIRE(ci_host[p] >= 0 && ci_host[p] < nc, "column index out of range");
+      double mx = 0.0;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+      for (int64_t i = 0; i < nr; ++i) {
+        double rs = 0.0;
+        for (int64_t p = rp_host[i]; p < rp_host[i + 1]; ++p) rs += std::sqrt(abs2_host(va_host[p]));
+        mx = std::max(mx, rs);
+      }
+      op->inf_norm = mx;
+    }
+    if (build_pb<T>(op.get(), rp_host, ci_host, va_host)) {
+      if (want == "pb") op->spmv_kind = LL_SPMV_PB;
+      else autotune_spmv<T>(op.get());
+    }
   }
   *out = op.release();
 }
@@ -759,7 +783,7 @@ int ll_op_select_spmv(ll_operator* op, int kind) {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
     LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB, "unknown SpMV kernel");
     LL_REQUIRE(kind != LL_SPMV_PB || op->d_pb_val != nullptr,
-               "operator has no propagation-blocked image (device arrays, LL_SPMV_KERNEL=csr or n too large)");
+               "operator has no propagation-blocked image (LL_SPMV_KERNEL=csr or n too large)");
     op->spmv_kind = kind;
   });
 }

@@ -757,7 +757,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
   launch_scale<T>(nl, U.vec(0), 0.0, &refs_prev, s);
 
   std::vector<double> alpha, beta, ev, p;
-  std::vector<H> coeff, coeff_prev;
+  std::vector<H> coeff, coeff_prev, expv;
   int64_t itern = P.max_iteration;
   bool stopped = false;
 
@@ -792,8 +792,10 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     p.resize((size_t)m * m);
     tridiag_qr(m, alpha.data(), beta.data(), ev.data(), p.data());  // EX:124-126 (beta has m-1 entries here)
     coeff.assign((size_t)m, H(0));
-    for (int64_t i = 0; i < m; ++i)  // EX:128-133: (exp(a T_m) e_1)_i
-      for (int64_t jj = 0; jj < m; ++jj) coeff[i] += p[(size_t)jj * m + i] * std::exp(a * ev[jj]) * p[(size_t)jj * m];
+    expv.resize((size_t)m);
+    for (int64_t jj = 0; jj < m; ++jj) expv[(size_t)jj] = std::exp(a * ev[jj]);  // m exponentials instead of m^2
+    for (int64_t i = 0; i < m; ++i)  // EX:128-133: (exp(a T_m) e_1)_i, same product order as the reference
+      for (int64_t jj = 0; jj < m; ++jj) coeff[i] += p[(size_t)jj * m + i] * expv[(size_t)jj] * p[(size_t)jj * m];
     t_tridiag += now_s() - t0;
     beta.push_back(beta_j);  // EX:145
     H overlap = H(0);

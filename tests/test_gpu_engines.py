@@ -336,6 +336,11 @@ def test_device_array_csr_and_device_callback_operators(ctx, oracle):
     h = C.c_void_p()
     capi.check(capi.lib().ll_op_create_csr_dev_d(ctx.handle, n, n, 0, rp_d.ptr, ci_d.ptr, va_d.ptr, C.byref(h)))
     dev.handle = h
+    # device arrays get the propagation-blocked image too (built from a one-off copy back) and the row-sum bound
+    capi.check(capi.lib().ll_op_select_spmv(h, capi.SPMV_PB))
+    nrm = C.c_double()
+    capi.check(capi.lib().ll_op_inf_norm(h, C.byref(nrm)))
+    assert abs(nrm.value - inf_norm(csr)) <= 1e-12 * nrm.value
 
     calls = []
 
