@@ -76,6 +76,18 @@ void* ll_context::ensure_stage(size_t bytes) {
 }
 void ll_context::sync() { LL_HIP(hipStreamSynchronize(stream)); }
 
+// ---------------------------------------------------------------- operator storage
+ll_operator::~ll_operator() {
+  if (ctx) (void)hipSetDevice(ctx->device);
+  for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
+                  (void*)d_pb_rptr, d_pb_val, (void*)d_pb_col, (void*)d_pb_row, d_pb_prod})
+    if (q) (void)hipFree(q);
+  if (owns_arrays) {
+    if (d_col) (void)hipFree(d_col);
+    if (d_val) (void)hipFree(d_val);
+  }
+}
+
 // ---------------------------------------------------------------- exception -> status
 template <typename F> static int guarded(F&& f) {
   try {
@@ -761,22 +773,7 @@ int ll_op_create_device_z(ll_context* ctx, int64_t n, ll_dev_mv_mul fn, void* us
   });
 }
 int ll_op_destroy(ll_operator* op) {
-  return guarded([&] {
-    if (!op) return;
-    if (op->ctx) (void)hipSetDevice(op->ctx->device);
-    if (op->d_row_ptr) (void)hipFree(op->d_row_ptr);
-    if (op->d_tile_rows) (void)hipFree(op->d_tile_rows);
-    if (op->d_dense) (void)hipFree(op->d_dense);
-    if (op->d_onsite) (void)hipFree(op->d_onsite);
-    for (void* q : {(void*)op->d_pb_segq, (void*)op->d_pb_segdest, (void*)op->d_pb_rptr, op->d_pb_val,
-                    (void*)op->d_pb_col, (void*)op->d_pb_row, op->d_pb_prod})
-      if (q) (void)hipFree(q);
-    if (op->owns_arrays) {
-      if (op->d_col) (void)hipFree(op->d_col);
-      if (op->d_val) (void)hipFree(op->d_val);
-    }
-    delete op;
-  });
+  return guarded([&] { delete op; });  // ~ll_operator releases the device arrays
 }
 int ll_op_select_spmv(ll_operator* op, int kind) {
   return guarded([&] {

@@ -642,7 +642,7 @@ template int launch_mdot<cf>(int64_t, cf*, const BasisSegs<cf>&, const ThreeTerm
 template <typename T>
 __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
                                                        const double* __restrict__ h, int nb, NormRefs pred,
-                                                       int predicated, double* __restrict__ partials) {
+                                                       int predicated, int reverse, double* __restrict__ partials) {
   constexpr int EPT = strip<T>::EPT;
   constexpr int R = scalar_traits<T>::reals;
   extern __shared__ double lds[];  // [R*nb] coefficients, then 4 doubles of reduction scratch
@@ -653,7 +653,10 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
   double* red = lds + R * nb;
   double nn = 0.0;
   const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
-  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+  // Strips are walked in DESCENDING order: the multi-dot that ran just before walked them ascending, so the basis
+  // strips it touched last are the ones most likely still in the Infinity Cache.
+  for (int64_t sidx0 = blockIdx.x; sidx0 < nstrips; sidx0 += gridDim.x) {
+    const int64_t sidx = reverse ? nstrips - 1 - sidx0 : sidx0;
     const int64_t base = sidx * strip<T>::ELEMS;
     T wr[EPT];
     load_strip<T>(w, base, n, wr);
@@ -703,8 +706,12 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
   const int grid = strip_grid(n, strip<T>::ELEMS);
   const size_t lds_bytes = ((size_t)scalar_traits<T>::reals * nb + 4) * sizeof(double);
   const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
+  static const int reverse = [] {
+    const char* e = std::getenv("LL_MAXPY_REVERSE");
+    return e ? std::atoi(e) : 1;
+  }();
   hipLaunchKernelGGL((maxpy_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr, pred ? 1 : 0,
-                     partials);
+                     reverse, partials);
   LL_HIP(hipGetLastError());
   return grid;
 }

@@ -199,6 +199,10 @@ struct ll_operator {
   ll_dev_mv_mul dev_fn = nullptr;
   void* user = nullptr;
   std::vector<char> h_in, h_out;  // staging for the host callback
+  ll_operator() = default;
+  ll_operator(const ll_operator&) = delete;
+  ll_operator& operator=(const ll_operator&) = delete;
+  ~ll_operator();  // frees every device array the operator owns (capi.cpp)
 };
 
 namespace ll {
