@@ -321,7 +321,8 @@ void finish_csr(ll_operator* op, const int64_t* rp_host) {
   op->ntiles = (int)tiles.size() - 1;
   LL_HIP(hipMalloc((void**)&op->d_tile_rows, tiles.size() * sizeof(int32_t)));
   LL_HIP(hipMemcpy(op->d_tile_rows, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  op->rp64 = op->nnz > (int64_t)0x7fffffff;
+  // 64-bit row offsets once nnz exceeds int32 (LL_FORCE_RP64=1: exercise that kernel variant on small test matrices)
+  op->rp64 = op->nnz > (int64_t)0x7fffffff || (std::getenv("LL_FORCE_RP64") && std::atoi(std::getenv("LL_FORCE_RP64")) != 0);
   if (op->rp64) {
     LL_HIP(hipMalloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int64_t)));
     LL_HIP(hipMemcpy(op->d_row_ptr, rp_host, (size_t)(nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice));

@@ -12,6 +12,7 @@
 //   a8        scale            normalize (LA:65-80 at LL:285, EX:160)
 //   a9/a10    gemv_basis       Ritz vectors (LL:51-57) / exp(aA)v (EX:166-170)
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "ll_internal.hpp"
@@ -432,14 +433,18 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset,
                    double* dot_partials, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the opt-in to > 64 KiB of dynamic LDS is per device: remember which devices have it
+  static std::atomic<unsigned long long> attr_mask{0};
+  int dev = 0;
+  LL_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
     const int cap = 160 * 1024 - 2048;
 #define LL_PB_ATTR(K) LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, cap))
     LL_PB_ATTR(pb_phase1<double>); LL_PB_ATTR(pb_phase1<zc>); LL_PB_ATTR(pb_phase1<float>); LL_PB_ATTR(pb_phase1<cf>);
     LL_PB_ATTR(pb_phase2<double>); LL_PB_ATTR(pb_phase2<zc>); LL_PB_ATTR(pb_phase2<float>); LL_PB_ATTR(pb_phase2<cf>);
 #undef LL_PB_ATTR
-    attr_set = true;
+    attr_mask.fetch_or(bit, std::memory_order_release);
   }
   const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 7) & ~(size_t)7) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
   const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);

@@ -82,6 +82,24 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     op.close()
 
 
+@pytest.mark.parametrize("name", ["randsym5000", "torus24", "ragged", "ragged_z"])
+def test_spmv_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
+    """The int64 row_ptr variant of the CSR-stream kernel (used once nnz exceeds 2^31) on small matrices."""
+    monkeypatch.setenv("LL_FORCE_RP64", "1")
+    csr = CASES[name]
+    dtype = csr[2].dtype
+    n = csr[0].shape[0] - 1
+    x = rnd(n, dtype, 9)
+    op = L.CsrOperator(ctx, *csr)
+    op.select_spmv(L.capi.SPMV_CSR_STREAM)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    alpha = L.spmv(op, xd, yd, offset=0.25, want_dot=True)
+    y_ref = oracle.spmv(csr, x) + 0.25 * x
+    assert np.max(np.abs(yd.get() - y_ref)) <= 1e-13 * 40
+    assert abs(alpha - np.vdot(x, y_ref).real) <= 1e-11 * n
+    op.close()
+
+
 def test_inner_product_convention(ctx):
     """T1:47-59: <(3, 1+3i), (3, 2+4i)> = 23 - 2i — conjugate-linear in the FIRST argument (LA:41,49)."""
     a = ctx.to_device(np.array([3.0, 1 + 3j]))
@@ -123,7 +141,7 @@ def _orthonormal_basis(n, nb, dtype, seed):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
 @pytest.mark.parametrize("mode", [L.ORTH_CGS_DGKS, L.ORTH_CGS2, L.ORTH_MGS])
-@pytest.mark.parametrize("n,nb", [(10, 5), (4099, 1), (100003, 37), (30011, 700)])
+@pytest.mark.parametrize("n,nb", [(10, 5), (4099, 1), (100003, 37), (30011, 700), (4099, 1700)])  # 1700 > one launch
 def test_orth_block_matches_mgs_oracle(ctx, oracle, dtype, mode, n, nb):
     """a5/a6/a7: block Gram-Schmidt vs the reference's sequential MGS (LA:132-144, test T1:61-91)."""
     basis = _orthonormal_basis(n, nb, dtype, 5)
