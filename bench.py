@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--window", type=int, default=100, help="Lanczos iterations per step (max_iteration)")
     ap.add_argument("--spmv-reps", type=int, default=20)
     ap.add_argument("--cpu-window", type=int, default=14, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--eps", type=float, default=None,
+                    help="override the engine's eps (0 = never converge: every run does exactly --window iterations)")
     ap.add_argument("--orth-mode", type=int, default=0)
     ap.add_argument("--tridiag-mode", type=int, default=0)
     ap.add_argument("--dry-run-dist", action="store_true",
@@ -231,6 +233,8 @@ def main():
         eng.eigenvalue_offset = offset
         eng.orth_mode = args.orth_mode
         eng.tridiag_mode = args.tridiag_mode
+        if args.eps is not None:
+            eng.eps = args.eps
         eng.init_vector = lambda v, *_: np.copyto(v, init)
 
         def step():
@@ -352,6 +356,7 @@ def main():
                 "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL %s" % (world, "halo exchange" if lattice else "all-gather of x"),
                 "orth_mode": args.orth_mode,
                 "tridiag_mode": args.tridiag_mode,
+                "eps": "engine default" if args.eps is None else args.eps,
             },
             "spmv": {"GBps": spmv_gbs, "ms": spmv_ms, "algorithmic_bytes": b_spmv, "frac_of_8TBps": spmv_gbs / HBM_PEAK_GBS,
                      "kernel": kernel_names[selected] + " (picked by timing both at upload)",
