@@ -120,3 +120,48 @@ def test_full_krylov_space_many_basis_groups(ctx, oracle, dtype, side):
     assert abs(vals[0] - w[0]) <= 1e-10 * 9
     assert np.linalg.norm(dense @ vecs[0] - vals[0] * vecs[0]) <= 1e-8 * 9
     op.close()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_lattice_operator_matches_oracle(ctx, oracle, seed):
+    """Random lattices (1-3 dimensions, open/periodic mix, lengths from 1 up, complex hops, on-site terms, all four
+    storage types): one apply of the matrix-free operator against the oracle's CSR row loop on the equivalent matrix,
+    and a short Exponentiator run through it."""
+    from lambda_lanczos_amd import generators as G
+
+    rng = np.random.default_rng(3000 + seed)
+    nd = int(rng.integers(1, 4))
+    dims = [int(rng.choice([1, 2, 3, 5, 8, 13, 31])) for _ in range(nd)]
+    dtype = [np.float64, np.complex128, np.float32, np.complex64][seed % 4]
+    cplx = np.issubdtype(np.dtype(dtype), np.complexfloating)
+    single = np.dtype(dtype).itemsize == (8 if cplx else 4)
+    wide = np.complex128 if cplx else np.float64
+    hop = rng.uniform(-1, 1, nd) + (1j * rng.uniform(-1, 1, nd) if cplx else 0)
+    periodic = [bool(b) for b in rng.integers(0, 2, nd)]
+    n = int(np.prod(dims))
+    onsite = rng.uniform(-1, 1, n) if rng.integers(2) else None
+    if onsite is not None and single:
+        onsite = onsite.astype(np.float32).astype(np.float64)
+    hop_dev = hop.astype(np.complex64).astype(np.complex128) if single else hop   # what a float operator can hold
+    diag = float(np.float32(rng.uniform(-2, 2)))
+    kw = dict(diag=diag, hop=list(hop_dev), periodic=periodic, onsite=onsite)
+    csr = G.lattice_csr(dims, dtype=wide, **kw)
+    op = L.StencilOperator(ctx, dims, dtype=dtype, **kw)
+    x = (rng.uniform(-1, 1, n) + (1j * rng.uniform(-1, 1, n) if cplx else 0)).astype(dtype)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    alpha = L.spmv(op, xd, yd, offset=0.5, want_dot=True)
+    xw = x.astype(wide)
+    y_ref = oracle.spmv(csr, xw) + 0.5 * xw
+    tol = 32 * (np.finfo(np.float32).eps if single else np.finfo(np.float64).eps)
+    scale = op.inf_norm() + 1.5
+    assert np.max(np.abs(yd.get() - y_ref)) <= tol * scale, (seed, dims, periodic)
+    assert abs(alpha - np.vdot(xw, y_ref).real) <= tol * scale * n
+    if not single:
+        a = -0.3j if cplx else -0.3
+        ex = L.Exponentiator(op, n)
+        ex.max_iteration = min(n, 40)   # a real exponent never meets the reference's stop test (EX:154): bound the run
+        out, it = ex.run(a, x)
+        o_ref, it_ref, _ = oracle.expo(csr, a, xw, max_iteration=min(n, 40))
+        assert abs(it - it_ref) <= 1, (seed, it, it_ref)
+        assert np.max(np.abs(out - o_ref)) <= 1e-10 * max(1.0, np.linalg.norm(xw))
+    op.close()
