@@ -62,6 +62,11 @@ template <typename T> struct abi;
                    int64_t* counts, int64_t cap, ll_run_stats* st) {                                                     \
       return ll_lanczos_run_##SFX(c, op, p, vals, vecs, found, counts, cap, nullptr, nullptr, st);                       \
     }                                                                                                                    \
+    static int run_iteration(ll_context* c, ll_operator* op, const ll_lanczos_params* p, int64_t nroot, int64_t n_orth,  \
+                             const T* orth, double* vals, T* vecs, int64_t* found, int64_t* itern, ll_run_stats* st) {   \
+      return ll_lanczos_run_iteration_##SFX(c, op, p, nroot, n_orth, orth, vals, vecs, found, itern, nullptr, nullptr,   \
+                                            st);                                                                         \
+    }                                                                                                                    \
   };
 LL_FACADE_ABI(double, d, ll_host_mv_mul_d)
 LL_FACADE_ABI(float, s, ll_host_mv_mul_s)

@@ -54,15 +54,7 @@ template <typename T> class LambdaLanczos {
   // run(eigenvalues, eigenvectors) (lambda_lanczos.hpp:330-366): outputs are resized by the library.
   void run(std::vector<real_t<T>>& eigenvalues, std::vector<std::vector<T>>& eigenvectors) {
     const size_t n_local = csr_ ? (size_t)csr_->local_rows() : matrix_size;
-    ll_lanczos_params p;
-    check(ll_lanczos_params_default(&p, (int64_t)matrix_size, find_maximum ? 1 : 0, (int64_t)num_eigs));
-    p.max_iteration = (int64_t)max_iteration;
-    p.eps = (double)eps;
-    p.eigenvalue_offset = (double)eigenvalue_offset;
-    p.num_eigs_per_iteration = (int64_t)num_eigs_per_iteration;
-    p.initial_vector_size = (int64_t)initial_vector_size;
-    p.tridiag_mode = tridiag_mode;
-    p.orth_mode = orth_mode;
+    ll_lanczos_params p = make_params(num_eigs);
     detail::InitHook<T> hook{init_vector};
     if (init_vector) {
       p.init_vector = &detail::InitHook<T>::call;
@@ -84,6 +76,44 @@ template <typename T> class LambdaLanczos {
       eigenvectors[(size_t)i].assign(vecs.begin() + (size_t)i * n_local, vecs.begin() + (size_t)(i + 1) * n_local);
     iter_counts_.assign(counts.begin(), counts.begin() + std::min<int64_t>(st.n_passes, (int64_t)counts.size()));
     last_stats_ = st;
+  }
+
+  // run_iteration(eigvalues, eigvecs, nroot, orthogonalizeTo) (lambda_lanczos.hpp:216-322): ONE Lanczos pass that
+  // tracks nroot Ritz pairs; every Lanczos vector is orthogonalised against the vectors of orthogonalizeTo (any
+  // container of std::vector<T> with cbegin()/cend(), like the reference's Iterable).  Returns the iteration count.
+  template <typename Iterable>
+  size_t run_iteration(std::vector<real_t<T>>& eigvalues, std::vector<std::vector<T>>& eigvecs, size_t nroot,
+                       Iterable orthogonalizeTo) {
+    const size_t n_local = csr_ ? (size_t)csr_->local_rows() : matrix_size;
+    ll_lanczos_params p = make_params(1);
+    detail::InitHook<T> hook{init_vector};
+    if (init_vector) {
+      p.init_vector = &detail::InitHook<T>::call;
+      p.init_user = &hook;
+    }
+    std::vector<T> lock;
+    int64_t n_orth = 0;
+    for (auto it = orthogonalizeTo.cbegin(); it != orthogonalizeTo.cend(); ++it, ++n_orth) {
+      const std::vector<T>& v = *it;
+      if (v.size() != n_local) throw Error(LL_ERR_INVALID, "run_iteration: orthogonalizeTo vector of the wrong size");
+      lock.insert(lock.end(), v.begin(), v.end());
+    }
+    detail::HostOp<T> host{mv_mul, {}, {}};
+    ll_operator* op = csr_ ? csr_->get() : detail::make_host_operator<T>(ctx_.get(), (int64_t)matrix_size, &host);
+    std::vector<double> vals(nroot);
+    std::vector<T> vecs(nroot * n_local);
+    int64_t found = 0, itern = 0;
+    ll_run_stats st;
+    const int rc = abi<T>::run_iteration(ctx_.get(), op, &p, (int64_t)nroot, n_orth, lock.empty() ? nullptr : lock.data(),
+                                         vals.data(), vecs.data(), &found, &itern, &st);
+    if (!csr_) ll_op_destroy(op);
+    check(rc);
+    eigvalues.assign(vals.begin(), vals.begin() + found);
+    eigvecs.assign((size_t)found, std::vector<T>());
+    for (int64_t i = 0; i < found; ++i)
+      eigvecs[(size_t)i].assign(vecs.begin() + (size_t)i * n_local, vecs.begin() + (size_t)(i + 1) * n_local);
+    last_stats_ = st;
+    return (size_t)itern;
   }
 
   // C++17 multiple-value-return overload (lambda_lanczos.hpp:376-386)
@@ -116,6 +146,18 @@ template <typename T> class LambdaLanczos {
   const ll_run_stats& getLastStats() const { return last_stats_; }
 
  private:
+  ll_lanczos_params make_params(size_t k) const {
+    ll_lanczos_params p;
+    check(ll_lanczos_params_default(&p, (int64_t)matrix_size, find_maximum ? 1 : 0, (int64_t)k));
+    p.max_iteration = (int64_t)max_iteration;
+    p.eps = (double)eps;
+    p.eigenvalue_offset = (double)eigenvalue_offset;
+    p.num_eigs_per_iteration = (int64_t)num_eigs_per_iteration;
+    p.initial_vector_size = (int64_t)initial_vector_size;
+    p.tridiag_mode = tridiag_mode;
+    p.orth_mode = orth_mode;
+    return p;
+  }
   int call_run(ll_operator* op, const ll_lanczos_params* p, double* vals, T* vecs, int64_t* found, int64_t* counts,
                int64_t cap, ll_run_stats* st) {
     return abi<T>::run(ctx_.get(), op, p, vals, vecs, found, counts, cap, st);

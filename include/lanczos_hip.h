@@ -325,6 +325,23 @@ int ll_lanczos_run_z(ll_context* ctx, ll_operator* op, const ll_lanczos_params* 
                      void* eigvecs_host, int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out,
                      double* beta_out, ll_run_stats* stats);
 
+/* LambdaLanczos<T>::run_iteration(eigvalues, eigvecs, nroot, orthogonalizeTo) (LL:216-322): ONE Lanczos pass that
+ * tracks `nroot` Ritz pairs, with every Lanczos vector orthogonalised against the caller's n_orth vectors first
+ * (LL:233,259).  No restart loop, no EigenPairManager: every computed pair comes back, in comparator order.
+ *   orth_host      : n_orth * n_local values of T (vector j at orth_host + j*n_local; LOCAL shards); NULL if n_orth = 0
+ *   eigvals_host   : capacity nroot doubles;  eigvecs_host: capacity nroot * n_local values of T (nullable)
+ *   n_found        : pairs returned = min(nroot, iterations done) (LL:264,312)
+ *   itern_out      : the method's return value, the Lanczos-iteration count
+ * p->num_eigs and p->num_eigs_per_iteration are ignored; every other field acts as in ll_lanczos_run_*. */
+int ll_lanczos_run_iteration_d(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const double* orth_host, double* eigvals_host, double* eigvecs_host,
+                               int64_t* n_found, int64_t* itern_out, double* alpha_out, double* beta_out,
+                               ll_run_stats* stats);
+int ll_lanczos_run_iteration_z(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const void* orth_host, double* eigvals_host, void* eigvecs_host,
+                               int64_t* n_found, int64_t* itern_out, double* alpha_out, double* beta_out,
+                               ll_run_stats* stats);
+
 typedef struct ll_expo_params {
   /* the reference's public fields (EX:41-71) */
   int64_t matrix_size;         /* EX:44 */
@@ -406,6 +423,14 @@ int ll_lanczos_run_c(ll_context* ctx, ll_operator* op, const ll_lanczos_params* 
 int ll_lanczos_run_s(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, double* eigvals_host,
                      float* eigvecs_host, int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out,
                      double* beta_out, ll_run_stats* stats);
+int ll_lanczos_run_iteration_c(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const void* orth_host, double* eigvals_host, void* eigvecs_host,
+                               int64_t* n_found, int64_t* itern_out, double* alpha_out, double* beta_out,
+                               ll_run_stats* stats);
+int ll_lanczos_run_iteration_s(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const float* orth_host, double* eigvals_host, float* eigvecs_host,
+                               int64_t* n_found, int64_t* itern_out, double* alpha_out, double* beta_out,
+                               ll_run_stats* stats);
 int ll_expo_run_c(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,
                   const void* input_host, void* output_host, int64_t* itern_out, ll_run_stats* stats);
 int ll_expo_run_s(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const float* input_host,

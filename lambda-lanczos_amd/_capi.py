@@ -156,6 +156,10 @@ PROTOTYPES = {
     "ll_expo_params_default": (C.c_int, [P(ExpoParams), i64]),
     "ll_lanczos_run_d": (C.c_int, [vp, vp, P(LanczosParams), vp, vp, P(i64), vp, i64, vp, vp, P(RunStats)]),
     "ll_lanczos_run_z": (C.c_int, [vp, vp, P(LanczosParams), vp, vp, P(i64), vp, i64, vp, vp, P(RunStats)]),
+    "ll_lanczos_run_iteration_d": (C.c_int, [vp, vp, P(LanczosParams), i64, i64, vp, vp, vp, P(i64), P(i64), vp, vp,
+                                             P(RunStats)]),
+    "ll_lanczos_run_iteration_z": (C.c_int, [vp, vp, P(LanczosParams), i64, i64, vp, vp, vp, P(i64), P(i64), vp, vp,
+                                             P(RunStats)]),
     "ll_expo_run_d": (C.c_int, [vp, vp, P(ExpoParams), f64, vp, vp, P(i64), P(RunStats)]),
     "ll_expo_run_z": (C.c_int, [vp, vp, P(ExpoParams), f64, f64, vp, vp, P(i64), P(RunStats)]),
     "ll_expo_taylor_run_d": (C.c_int, [vp, vp, P(ExpoParams), f64, vp, vp, P(i64)]),

@@ -1013,6 +1013,36 @@ int ll_lanczos_run_z(ll_context* ctx, ll_operator* op, const ll_lanczos_params* 
     lanczos_run<zc>(ctx, op, *p, eigvals, (zc*)eigvecs, n_found, iter_counts, iter_cap, alpha_out, beta_out, stats);
   });
 }
+extern "C++" {
+namespace {
+template <typename T>
+void run_iteration_impl(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot, int64_t n_orth,
+                        const void* orth, double* eigvals, void* eigvecs, int64_t* n_found, int64_t* itern,
+                        double* alpha_out, double* beta_out, ll_run_stats* stats) {
+  LL_REQUIRE(ctx && p && eigvals && n_found, "null argument");
+  ll_lanczos_params q = *p;
+  q.num_eigs = 1;  // unused by the single-pass mode; keep the range check of the common driver happy
+  const IterationSpec<T> spec{nroot, n_orth, (const T*)orth};
+  int64_t count = 0;
+  lanczos_run<T>(ctx, op, q, eigvals, (T*)eigvecs, n_found, &count, 1, alpha_out, beta_out, stats, &spec);
+  if (itern) *itern = count;
+}
+}  // namespace
+}  // extern "C++"
+int ll_lanczos_run_iteration_d(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const double* orth, double* eigvals, double* eigvecs, int64_t* n_found,
+                               int64_t* itern, double* alpha_out, double* beta_out, ll_run_stats* stats) {
+  return guarded([&] {
+    run_iteration_impl<double>(ctx, op, p, nroot, n_orth, orth, eigvals, eigvecs, n_found, itern, alpha_out, beta_out, stats);
+  });
+}
+int ll_lanczos_run_iteration_z(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const void* orth, double* eigvals, void* eigvecs, int64_t* n_found,
+                               int64_t* itern, double* alpha_out, double* beta_out, ll_run_stats* stats) {
+  return guarded([&] {
+    run_iteration_impl<zc>(ctx, op, p, nroot, n_orth, orth, eigvals, eigvecs, n_found, itern, alpha_out, beta_out, stats);
+  });
+}
 int ll_expo_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const double* input,
                   double* output, int64_t* itern, ll_run_stats* stats) {
   return guarded([&] {
@@ -1204,6 +1234,20 @@ int ll_lanczos_run_s(ll_context* ctx, ll_operator* op, const ll_lanczos_params* 
   return guarded([&] {
     LL_REQUIRE(ctx && p && eigvals && n_found, "null argument");
     lanczos_run<float>(ctx, op, *p, eigvals, (float*)eigvecs, n_found, iter_counts, iter_cap, alpha_out, beta_out, stats);
+  });
+}
+int ll_lanczos_run_iteration_s(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const float* orth, double* eigvals, float* eigvecs, int64_t* n_found,
+                               int64_t* itern, double* alpha_out, double* beta_out, ll_run_stats* stats) {
+  return guarded([&] {
+    run_iteration_impl<float>(ctx, op, p, nroot, n_orth, orth, eigvals, eigvecs, n_found, itern, alpha_out, beta_out, stats);
+  });
+}
+int ll_lanczos_run_iteration_c(ll_context* ctx, ll_operator* op, const ll_lanczos_params* p, int64_t nroot,
+                               int64_t n_orth, const void* orth, double* eigvals, void* eigvecs, int64_t* n_found,
+                               int64_t* itern, double* alpha_out, double* beta_out, ll_run_stats* stats) {
+  return guarded([&] {
+    run_iteration_impl<cf>(ctx, op, p, nroot, n_orth, orth, eigvals, eigvecs, n_found, itern, alpha_out, beta_out, stats);
   });
 }
 int ll_expo_run_c(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,

@@ -427,12 +427,16 @@ int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration) {
 template <typename T>
 void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, double* eigvals, T* eigvecs,
                  int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
-                 ll_run_stats* stats) {
+                 ll_run_stats* stats, const IterationSpec<T>* spec) {
   LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
   LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
              "operator scalar type mismatch");
   LL_REQUIRE(P.matrix_size == op->n, "matrix_size differs from the operator dimension");
   LL_REQUIRE(P.num_eigs >= 1 && P.num_eigs <= P.matrix_size, "num_eigs out of range");
+  if (spec) {
+    LL_REQUIRE(spec->nroot >= 1 && spec->nroot <= P.matrix_size, "nroot out of range");
+    LL_REQUIRE(spec->n_orth >= 0 && (spec->n_orth == 0 || spec->orth_host != nullptr), "bad orthogonalizeTo list");
+  }
   LL_REQUIRE(P.max_iteration >= 1, "max_iteration must be >= 1");
   LL_REQUIRE(P.num_eigs_per_iteration >= 1, "num_eigs_per_iteration must be >= 1");
   LL_HIP(hipSetDevice(ctx->device));
@@ -448,7 +452,11 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
   DevBuf<T> d_locked, d_ritz;
   int64_t d_ritz_cap = 0;
-  if (P.num_eigs > 1) d_locked.alloc((size_t)P.num_eigs * ld);
+  if (spec) {
+    if (spec->n_orth > 0) d_locked.alloc((size_t)spec->n_orth * ld);
+  } else if (P.num_eigs > 1) {
+    d_locked.alloc((size_t)P.num_eigs * ld);
+  }
   const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
   (void)nroot_max;
   ctx->ensure_pinned(16);
@@ -467,18 +475,21 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
   // or page-faulted per call.
   T* stage = (T*)ctx->ensure_stage((size_t)std::max<int64_t>(nl, 1) * sizeof(T));
-  const bool single_pair = P.num_eigs == 1;  // one pass, one survivor: its vector goes stage -> caller directly
+  const bool single_pair = P.num_eigs == 1 && !spec;  // one pass, one survivor: its vector goes stage -> caller directly
   bool result_in_stage = false;
 
   while (true) {  // restart loop LL:334-354
-    const int64_t nroot = std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
+    const int64_t nroot = spec ? spec->nroot : std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
     const double t_pass0 = now_s();
     // ---- start vector (LL:231-234)
     if (P.init_vector) P.init_vector(stage, nl, op->row_begin, P.init_user);
     else default_init<T>(stage, nl);
     LL_HIP(hipMemcpyAsync(U.vec(0), stage, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
-    const int64_t L = (int64_t)kept.size();
-    {
+    const int64_t L = spec ? spec->n_orth : (int64_t)kept.size();
+    if (spec) {
+      for (int64_t j = 0; j < L; ++j)  // the caller's orthogonalizeTo, in the caller's order
+        LL_HIP(hipMemcpyAsync(d_locked.p + j * ld, spec->orth_host + j * nl, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+    } else {
       int64_t j = 0;
       for (auto& kv : kept) {  // comparator order, like MapValueIterable (CM:58-74)
         LL_HIP(hipMemcpyAsync(d_locked.p + j * ld, kv.second.data(), (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
@@ -611,6 +622,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       for (auto& kv : sim)
         if (kv.second >= 0) survives[(size_t)kv.second] = 1;
     }
+    if (spec) std::fill(survives.begin(), survives.end(), (char)1);  // run_iteration returns every computed pair
     std::vector<int64_t> want;
     for (int64_t i = 0; i < nev; ++i)
       if (survives[(size_t)i]) want.push_back(i);
@@ -658,6 +670,14 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     ++passes;
     total_iters += m;
 
+    if (spec) {  // LL:312-321: hand the pairs back as they are
+      for (int64_t i = 0; i < nev; ++i) {
+        eigvals[i] = evs[(size_t)i];
+        if (eigvecs) std::memcpy(eigvecs + (size_t)i * nl, xs[(size_t)i].data(), (size_t)nl * sizeof(T));
+      }
+      *n_found = nev;
+      break;
+    }
     // ---- EigenPairManager::insertEigenpairs (EPM:52-71), now with the vectors of the survivors
     {
       bool check_nothing = true;
@@ -678,11 +698,11 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     if (P.num_eigs == 1) break;  // LL:350-353
   }
 
-  int64_t cnt = 0;
-  for (auto& kv : kept) {  // comparator order (LL:356-365)
-    eigvals[cnt] = kv.first;
+  int64_t cnt = spec ? *n_found : 0;
+  for (auto kv = kept.begin(); !spec && kv != kept.end(); ++kv) {  // comparator order (LL:356-365)
+    eigvals[cnt] = kv->first;
     if (eigvecs) {
-      const T* src = (single_pair && result_in_stage) ? stage : kv.second.data();
+      const T* src = (single_pair && result_in_stage) ? stage : kv->second.data();
       std::memcpy(eigvecs + (size_t)cnt * nl, src, (size_t)nl * sizeof(T));
     }
     ++cnt;
@@ -707,13 +727,13 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
 }
 
 template void lanczos_run<double>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, double*, int64_t*,
-                                  int64_t*, int64_t, double*, double*, ll_run_stats*);
+                                  int64_t*, int64_t, double*, double*, ll_run_stats*, const IterationSpec<double>*);
 template void lanczos_run<zc>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, zc*, int64_t*, int64_t*,
-                              int64_t, double*, double*, ll_run_stats*);
+                              int64_t, double*, double*, ll_run_stats*, const IterationSpec<zc>*);
 template void lanczos_run<float>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, float*, int64_t*,
-                                 int64_t*, int64_t, double*, double*, ll_run_stats*);
+                                 int64_t*, int64_t, double*, double*, ll_run_stats*, const IterationSpec<float>*);
 template void lanczos_run<cf>(ll_context*, ll_operator*, const ll_lanczos_params&, double*, cf*, int64_t*, int64_t*,
-                              int64_t, double*, double*, ll_run_stats*);
+                              int64_t, double*, double*, ll_run_stats*, const IterationSpec<cf>*);
 
 // ================================================================= Exponentiator<T>::run
 namespace {

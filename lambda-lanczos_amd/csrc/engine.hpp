@@ -88,11 +88,20 @@ template <> struct host_scalar<zc> { typedef std::complex<double> type; };
 template <> struct host_scalar<float> { typedef double type; };
 template <> struct host_scalar<cf> { typedef std::complex<double> type; };
 
+// LambdaLanczos<T>::run_iteration (LL:216-322) as a mode of lanczos_run: ONE pass with `nroot` Ritz pairs,
+// Gram-Schmidt against n_orth caller-provided vectors (the reference's orthogonalizeTo; host, vector j at
+// orth_host + j*n_local), every computed pair returned in comparator order without EigenPairManager filtering.
+template <typename T> struct IterationSpec {
+  int64_t nroot;
+  int64_t n_orth;
+  const T* orth_host;
+};
+
 // Whole-loop drivers
 template <typename T>
 void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, double* eigvals, T* eigvecs,
                  int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
-                 ll_run_stats* stats);
+                 ll_run_stats* stats, const IterationSpec<T>* spec = nullptr);
 template <typename T>
 void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typename host_scalar<T>::type a,
               const T* input, T* output, int64_t* itern_out, ll_run_stats* stats);

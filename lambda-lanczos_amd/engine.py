@@ -450,9 +450,19 @@ class LambdaLanczos:
         """Returns (eigenvalues, eigenvectors): eigenvectors[k] is the k-th eigenvector (LL:330-386).
         For sharded contexts each rank receives its row shard of every eigenvector."""
         k = int(self.num_eigs if num_eigs is None else num_eigs)
+        vals, vecs, _ = self._drive(k, None, None)
+        return vals, vecs
+
+    def run_iteration(self, nroot, orthogonalize_to=None):
+        """LambdaLanczos<T>::run_iteration(eigvalues, eigvecs, nroot, orthogonalizeTo) (LL:216-322): ONE pass tracking
+        nroot Ritz pairs, every Lanczos vector orthogonalised against the rows of orthogonalize_to first.
+        Returns (eigenvalues, eigenvectors, iteration_count); no restart loop, no EigenPairManager filtering."""
+        return self._drive(int(nroot), int(nroot), orthogonalize_to)
+
+    def _drive(self, k, nroot, orth):
         op, owned = _as_operator(self.mv_mul, self.matrix_size, self.dtype, self.context)
         sfx = _suffix(self.dtype)
-        p = self._params(k)
+        p = self._params(1 if nroot is not None else k)
         keep = None
         if self.init_vector is not None:
             dt, user_fn = self.dtype, self.init_vector
@@ -476,10 +486,22 @@ class LambdaLanczos:
         alpha = np.zeros(trace_cap)
         beta = np.zeros(trace_cap)
         stats = capi.RunStats()
+        itern = C.c_int64()
         try:
-            fn = getattr(lib(), "ll_lanczos_run_" + sfx)
-            check(fn(self.context.handle, op.handle, C.byref(p), ptr(vals), ptr(vecs), C.byref(n_found), ptr(counts),
-                     cap, ptr(alpha), ptr(beta), C.byref(stats)))
+            if nroot is None:
+                fn = getattr(lib(), "ll_lanczos_run_" + sfx)
+                check(fn(self.context.handle, op.handle, C.byref(p), ptr(vals), ptr(vecs), C.byref(n_found), ptr(counts),
+                         cap, ptr(alpha), ptr(beta), C.byref(stats)))
+            else:
+                lock = None
+                n_orth = 0
+                if orth is not None and len(orth):
+                    lock = np.ascontiguousarray(orth, dtype=self.dtype).reshape(-1, n_local)
+                    n_orth = lock.shape[0]
+                fn = getattr(lib(), "ll_lanczos_run_iteration_" + sfx)
+                check(fn(self.context.handle, op.handle, C.byref(p), nroot, n_orth, ptr(lock), ptr(vals), ptr(vecs),
+                         C.byref(n_found), C.byref(itern), ptr(alpha), ptr(beta), C.byref(stats)))
+                counts[0] = itern.value
         finally:
             if owned:
                 op.close()
@@ -488,7 +510,7 @@ class LambdaLanczos:
         self._iter_counts = [int(c) for c in counts[: min(stats.n_passes, cap)]]
         self.last_stats = stats.as_dict()
         self.last_alpha, self.last_beta = alpha[: stats.last_alpha_len].copy(), beta[: stats.last_alpha_len].copy()
-        return vals[:nf], vecs[:nf]
+        return vals[:nf], vecs[:nf], int(itern.value)
 
     def run_single(self):
         """run(eigenvalue, eigenvector): one pair regardless of num_eigs (LL:394-407)."""

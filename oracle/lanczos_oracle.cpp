@@ -496,6 +496,26 @@ static void fixed_init(void* vec, int64_t, void* user) {
   std::memcpy(vec, f->data, f->bytes);
 }
 
+// LambdaLanczos<T>::run_iteration (LL:216-322) on its own: one pass, nroot pairs, caller-provided orthogonalizeTo
+// (n_orth vectors, vector j at orth + j*n).  Returns the iteration count; *n_found pairs are written.
+template <typename T>
+int64_t run_iteration_c(const int64_t* rp, const int32_t* ci, const T* va, const Params& P, const T* init,
+                               int64_t nroot, int64_t n_orth, const T* orth, double* eigvals, T* eigvecs,
+                               int64_t* n_found) {
+  const size_t n = (size_t)P.matrix_size;
+  Csr<T> A{P.matrix_size, rp, ci, va};
+  std::vector<std::vector<T>> lock;
+  for (int64_t j = 0; j < n_orth; ++j) lock.emplace_back(orth + (size_t)j * n, orth + (size_t)(j + 1) * n);
+  std::vector<real_t<T>> ev;
+  std::vector<std::vector<T>> x;
+  const size_t it = lanczos_pass<T>(A, P, init, (size_t)nroot, lock.cbegin(), lock.cend(), ev, x, nullptr);
+  for (size_t i = 0; i < ev.size(); ++i) {
+    eigvals[i] = (double)ev[i];
+    std::memcpy(eigvecs + i * n, x[i].data(), n * sizeof(T));
+  }
+  *n_found = (int64_t)ev.size();
+  return (int64_t)it;
+}
 }  // namespace oracle
 
 // ================================================================= C ABI (ctypes)
@@ -590,6 +610,16 @@ int64_t oracle_lanczos_run_z(const int64_t* rp, const int32_t* ci, const zd* va,
   Csr<zd> A{p->matrix_size, rp, ci, va};
   FixedInit f{init, (size_t)p->matrix_size * sizeof(zd)};
   return lanczos_run<zd>(A, cvt(p), fixed_init, &f, eigvals, eigvecs, iter_counts, n_pass, (Trace*)tr);
+}
+int64_t oracle_run_iteration_d(const int64_t* rp, const int32_t* ci, const double* va, const oracle_params* p,
+                               const double* init, int64_t nroot, int64_t n_orth, const double* orth, double* eigvals,
+                               double* eigvecs, int64_t* n_found) {
+  return run_iteration_c<double>(rp, ci, va, cvt(p), init, nroot, n_orth, orth, eigvals, eigvecs, n_found);
+}
+int64_t oracle_run_iteration_z(const int64_t* rp, const int32_t* ci, const zd* va, const oracle_params* p,
+                               const zd* init, int64_t nroot, int64_t n_orth, const zd* orth, double* eigvals,
+                               zd* eigvecs, int64_t* n_found) {
+  return run_iteration_c<zd>(rp, ci, va, cvt(p), init, nroot, n_orth, orth, eigvals, eigvecs, n_found);
 }
 int64_t oracle_expo_run_d(const int64_t* rp, const int32_t* ci, const double* va, const oracle_params* p, double a,
                           const double* input, double* output, oracle_trace* tr) {

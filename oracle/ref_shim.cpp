@@ -105,6 +105,31 @@ int64_t run_eig(const int64_t* rp, const int32_t* ci, const T* va, const oracle_
   return (int64_t)ev.size();
 }
 
+// The reference's public run_iteration (lambda_lanczos.hpp:216-322) called directly.
+template <typename T>
+int64_t run_iter(const int64_t* rp, const int32_t* ci, const T* va, const oracle_params* p, const T* init, int64_t nroot,
+                 int64_t n_orth, const T* orth, double* eigvals, T* eigvecs, int64_t* n_found) {
+  const int64_t n = p->matrix_size;
+  Tracer<T> op{rp, ci, va, n, p->eigenvalue_offset, nullptr};
+  lambda_lanczos::LambdaLanczos<T> eng([&op](const std::vector<T>& in, std::vector<T>& out) { op(in, out); },
+                                       (size_t)n, p->find_maximum != 0, 1);
+  eng.max_iteration = (size_t)p->max_iteration;
+  eng.eps = p->eps;
+  eng.eigenvalue_offset = p->eigenvalue_offset;
+  eng.init_vector = [init, n](std::vector<T>& v) { std::memcpy(v.data(), init, (size_t)n * sizeof(T)); };
+  std::vector<std::vector<T>> lock;
+  for (int64_t j = 0; j < n_orth; ++j) lock.emplace_back(orth + j * n, orth + (j + 1) * n);
+  std::vector<double> ev;
+  std::vector<std::vector<T>> x;
+  const size_t it = eng.run_iteration(ev, x, (size_t)nroot, lock);
+  for (size_t i = 0; i < ev.size(); ++i) {
+    eigvals[i] = ev[i];
+    std::memcpy(eigvecs + i * (size_t)n, x[i].data(), (size_t)n * sizeof(T));
+  }
+  *n_found = (int64_t)ev.size();
+  return (int64_t)it;
+}
+
 template <typename T>
 int64_t run_expo(const int64_t* rp, const int32_t* ci, const T* va, const oracle_params* p, T a, const T* input,
                  T* output, oracle_trace* tr, bool taylor) {
@@ -135,6 +160,16 @@ int64_t ref_lanczos_run_d(const int64_t* rp, const int32_t* ci, const double* va
 int64_t ref_lanczos_run_z(const int64_t* rp, const int32_t* ci, const zd* va, const oracle_params* p, const zd* init,
                           double* eigvals, zd* eigvecs, int64_t* iter_counts, int64_t* n_pass, oracle_trace* tr) {
   return run_eig<zd>(rp, ci, va, p, init, eigvals, eigvecs, iter_counts, n_pass, tr);
+}
+int64_t ref_run_iteration_d(const int64_t* rp, const int32_t* ci, const double* va, const oracle_params* p,
+                            const double* init, int64_t nroot, int64_t n_orth, const double* orth, double* eigvals,
+                            double* eigvecs, int64_t* n_found) {
+  return run_iter<double>(rp, ci, va, p, init, nroot, n_orth, orth, eigvals, eigvecs, n_found);
+}
+int64_t ref_run_iteration_z(const int64_t* rp, const int32_t* ci, const zd* va, const oracle_params* p, const zd* init,
+                            int64_t nroot, int64_t n_orth, const zd* orth, double* eigvals, zd* eigvecs,
+                            int64_t* n_found) {
+  return run_iter<zd>(rp, ci, va, p, init, nroot, n_orth, orth, eigvals, eigvecs, n_found);
 }
 int64_t ref_expo_run_d(const int64_t* rp, const int32_t* ci, const double* va, const oracle_params* p, double a,
                        const double* input, double* output, oracle_trace* tr) {

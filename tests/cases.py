@@ -81,3 +81,14 @@ def run_eigen_case(engine_cls, make_op, case, init=None):
     if init is not None:
         eng.init_vector = init
     return eng
+
+
+def run_iteration_problem(name):
+    """(csr, init, dtype) of a tests/golden/run_iteration.json case; orthogonalizeTo comes from the fixture itself."""
+    if name.startswith("m8"):
+        return G.dense_to_csr(M8), G.start_vector(8, 1)
+    if name.startswith("randsym600"):
+        return G.randsym_np(600), G.start_vector(600, 1)
+    if name.startswith("torus12"):
+        return G.torus_np(12), G.start_vector(144, 1, np.complex128)
+    raise KeyError(name)

@@ -122,6 +122,28 @@ static void api_shapes() {
   expect_close(1.0, std::get<0>(both)[1], 1e-10, "second eigenvalue");
 }
 
+static void run_iteration_direct() {
+  std::printf("[case] run_iteration called directly with an orthogonalizeTo list (lambda_lanczos.hpp:216-322)\n");
+  // chain matrix tridiag(1, 2, 1): eigenvalues 2 + sqrt2, 2, 2 - sqrt2; the top eigenvector (1, sqrt2, 1)/2 is locked,
+  // so one pass for the two largest remaining pairs must return 2 and 2 - sqrt2
+  std::vector<std::vector<double>> m = {{2, 1, 0}, {1, 2, 1}, {0, 1, 2}};
+  ll::LambdaLanczos<double> engine(dense<double>(m), 3, true, 1);
+  engine.init_vector = [](std::vector<double>& v) { v = {0.3, -0.8, 0.5}; };
+  std::vector<std::vector<double>> locked = {{0.5, std::sqrt(0.5), 0.5}};
+  std::vector<double> values;
+  std::vector<std::vector<double>> vectors;
+  const size_t itern = engine.run_iteration(values, vectors, 2, locked);
+  expect(itern == 2, "two iterations span the deflated space");
+  expect(values.size() == 2 && vectors.size() == 2, "two pairs returned");
+  const double want[2] = {2.0, 2.0 - std::sqrt(2.0)};
+  for (size_t r = 0; r < values.size() && r < 2; ++r) {
+    expect_close(want[r], values[r], 1e-12, "deflated eigenvalue");
+    double dot = 0;
+    for (size_t i = 0; i < 3; ++i) dot += vectors[r][i] * locked[0][i];
+    expect(std::abs(dot) <= 1e-12, "orthogonal to the locked vector");
+  }
+}
+
 static void device_operator() {
   std::printf("[case] device-resident CsrMatrix operator, 5-point Laplacian 40x40 (analytic spectrum)\n");
   const int64_t N = 40, n = N * N;
@@ -237,6 +259,7 @@ int main() {
   try {
     eigen_cases();
     api_shapes();
+    run_iteration_direct();
     device_operator();
     operator_zoo();
     exponentiator();

@@ -10,6 +10,9 @@ outputs the reference produced for them.  No reference source is stored.  Cases 
   tridiagonal.json       T1:757-801 inputs and the reference's tridiagonal_eigenpairs outputs (+ random cases)
   traces.json            alpha/beta traces, iteration counts, Ritz pairs on the SURVEY 8d generators (splitmix start)
   exponentiator.json     T2 problems + torus 32x32 (config 5 in small)
+  run_iteration.json     LambdaLanczos::run_iteration called directly (LL:216-322): nroot pairs, caller's orthogonalizeTo
+
+    python tests/golden/make_golden.py run_iteration      # regenerate one file only
 """
 import json
 import os
@@ -36,8 +39,43 @@ def dump(name, obj):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def run_iteration_cases():
+    """name -> (csr, init, find_maximum, nroot, orth rows or None, offset): shared with the parity tests."""
+    import scipy.sparse as sp
+
+    def eigvecs(csr, idx):
+        n = csr[0].shape[0] - 1
+        w, v = np.linalg.eigh(sp.csr_matrix((csr[2], csr[1], csr[0]), shape=(n, n)).toarray())
+        return np.ascontiguousarray(v[:, idx].T)
+
+    c = {}
+    m8 = G.dense_to_csr(cases.M8)
+    c["m8_three_roots"] = (m8, G.start_vector(8, 1), False, 3, None, 0.0)
+    c["m8_lowest_locked"] = (m8, G.start_vector(8, 1), False, 2, eigvecs(m8, [0]), 0.0)
+    rs = G.randsym_np(600)
+    c["randsym600_top2_locked"] = (rs, G.start_vector(600, 1), True, 3, eigvecs(rs, [-1, -2]), 0.0)
+    to = G.torus_np(12)
+    c["torus12_lowest_locked"] = (to, G.start_vector(144, 1, np.complex128), False, 2, eigvecs(to, [0]), -10.0)
+    return c
+
+
+def make_run_iteration(ref):
+    out = {}
+    for name, (csr, init, find_max, nroot, orth, offset) in run_iteration_cases().items():
+        r = ref.run_iteration(csr, init, find_max, nroot, orth=orth, offset=offset)
+        out[name] = {"nroot": nroot, "find_maximum": find_max, "offset": offset,
+                     "orth": None if orth is None else [c2list(v) for v in orth],
+                     "eigenvalues": r["eigenvalues"].tolist(), "eigenvectors": [c2list(v) for v in r["eigenvectors"]],
+                     "itern": r["itern"]}
+    dump("run_iteration.json", out)
+
+
 def main():
     ref = oracle_lib.reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "run_iteration":
+        make_run_iteration(ref)
+        return
+    make_run_iteration(ref)
 
     # ---- G1/G2/G5/G6: the reference's own eigen tests with its own seeded initializer
     out = {}

@@ -52,6 +52,10 @@ class _Checker:
             f = getattr(L, prefix + "lanczos_run_" + sfx)
             f.restype = i64
             f.argtypes = [vp, vp, vp, C.POINTER(Params), vp, vp, vp, vp, vp, C.POINTER(Trace)]
+        for sfx in "dz":
+            f = getattr(L, prefix + "run_iteration_" + sfx)
+            f.restype = i64
+            f.argtypes = [vp, vp, vp, C.POINTER(Params), vp, i64, i64, vp, vp, vp, vp]
         getattr(L, prefix + "expo_run_d").restype = i64
         getattr(L, prefix + "expo_run_d").argtypes = [vp, vp, vp, C.POINTER(Params), f64, vp, vp, C.POINTER(Trace)]
         getattr(L, prefix + "expo_run_z").restype = i64
@@ -102,6 +106,26 @@ class _Checker:
             "t_mv": float(tmv[0]),
             "t_total": float(ttot[0]),
         }
+
+    def run_iteration(self, csr, init, find_maximum, nroot, orth=None, max_iteration=None, eps=None, offset=0.0):
+        """LambdaLanczos<T>::run_iteration (LL:216-322): one pass, nroot pairs, orthogonalised against the rows of orth."""
+        rp, ci, va = csr
+        rp = np.ascontiguousarray(rp, np.int64)
+        ci = np.ascontiguousarray(ci, np.int32)
+        va = np.ascontiguousarray(va)
+        n = rp.shape[0] - 1
+        init = np.ascontiguousarray(init, dtype=va.dtype)
+        orth = np.zeros((0, n), dtype=va.dtype) if orth is None else np.ascontiguousarray(orth, dtype=va.dtype).reshape(-1, n)
+        p = Params(n, n if max_iteration is None else max_iteration, EPS * 1e3 if eps is None else eps,
+                   int(find_maximum), 0, 1, offset, 5)
+        vals = np.zeros(nroot)
+        vecs = np.zeros((nroot, n), dtype=va.dtype)
+        found = np.zeros(1, dtype=np.int64)
+        fn = getattr(self.lib, self.prefix + "run_iteration_" + ("z" if va.dtype == np.complex128 else "d"))
+        it = fn(_p(rp), _p(ci), _p(va), C.byref(p), _p(init), int(nroot), orth.shape[0], _p(orth), _p(vals), _p(vecs),
+                _p(found))
+        k = int(found[0])
+        return {"eigenvalues": vals[:k].copy(), "eigenvectors": vecs[:k].copy(), "itern": int(it)}
 
     def expo(self, csr, a, input, max_iteration=None, eps=None, full_orthogonalize=False, taylor=False):
         rp, ci, va = csr

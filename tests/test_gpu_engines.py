@@ -252,6 +252,33 @@ def test_c3_random_10M_spmv_properties(ctx):
     op.close()
 
 
+# ------------------------------------------------------------------ run_iteration called directly (LL:216-322)
+@pytest.mark.parametrize("name", ["m8_three_roots", "m8_lowest_locked", "randsym600_top2_locked", "torus12_lowest_locked"])
+@pytest.mark.parametrize("orth_mode", [L.ORTH_CGS_DGKS, L.ORTH_MGS])
+def test_run_iteration_matches_reference_fixture(ctx, oracle, name, orth_mode):
+    """ll_lanczos_run_iteration_*: one pass, nroot pairs, the caller's orthogonalizeTo list — against the real
+    reference's output (tests/golden/run_iteration.json) and the oracle."""
+    from util import list2c, load_golden
+
+    fx = load_golden("run_iteration.json")[name]
+    csr, init = cases.run_iteration_problem(name)
+    orth = None if fx["orth"] is None else np.array([list2c(v) for v in fx["orth"]])
+    eng, op = gpu_engine(ctx, csr, fx["find_maximum"], 1, eigenvalue_offset=fx["offset"], init_vector=fixed_init(init),
+                         orth_mode=orth_mode)
+    vals, vecs, itern = eng.run_iteration(fx["nroot"], orth)
+    want = np.array(fx["eigenvalues"])
+    assert len(vals) == len(want) and abs(itern - fx["itern"]) <= 2
+    assert eng.getIterationCounts() == [itern]
+    assert np.max(np.abs(vals - want)) <= 1e-10 * max(1.0, np.max(np.abs(want + fx["offset"])))
+    for got, ref_v in zip(vecs, fx["eigenvectors"]):
+        assert 1 - overlap(got, list2c(ref_v)) <= 1e-8
+    if orth is not None:
+        assert np.max(np.abs(orth.conj() @ vecs.T)) <= 1e-8
+    ora = oracle.run_iteration(csr, init, fx["find_maximum"], fx["nroot"], orth=orth, offset=fx["offset"])
+    assert abs(itern - ora["itern"]) <= 2 and np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * max(1.0, np.max(np.abs(want)))
+    op.close()
+
+
 # ------------------------------------------------------------------ sharded code path on one GPU
 def test_sharded_path_with_single_rank_communicator(oracle):
     """A 1-rank RCCL communicator drives the whole multi-GPU code path (dlopen of librccl, ncclCommInitRank, the

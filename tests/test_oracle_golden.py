@@ -130,6 +130,26 @@ def test_exponentiator_torus_fixture(oracle, dt):
 
 
 # ------------------------------------------------------------------ live against the real reference (build container)
+RUN_ITERATION = load_golden("run_iteration.json")
+
+
+@pytest.mark.parametrize("name", sorted(RUN_ITERATION))
+def test_run_iteration_matches_reference_fixture(oracle, name):
+    """LambdaLanczos::run_iteration called directly (LL:216-322): nroot pairs of ONE pass with the caller's
+    orthogonalizeTo list; fixture = the real reference's output (tests/golden/make_golden.py)."""
+    fx = RUN_ITERATION[name]
+    csr, init = cases.run_iteration_problem(name)
+    orth = None if fx["orth"] is None else np.array([list2c(v) for v in fx["orth"]])
+    r = oracle.run_iteration(csr, init, fx["find_maximum"], fx["nroot"], orth=orth, offset=fx["offset"])
+    assert r["itern"] == fx["itern"]
+    want = np.array(fx["eigenvalues"])
+    assert np.max(np.abs(r["eigenvalues"] - want)) <= 1e-12 * max(1.0, np.max(np.abs(want + fx["offset"])))
+    for got, ref_v in zip(r["eigenvectors"], fx["eigenvectors"]):
+        assert 1 - overlap(got, list2c(ref_v)) <= 1e-10
+    if orth is not None:   # deflation really happened: every returned vector is orthogonal to the locked ones
+        assert np.max(np.abs(orth.conj() @ r["eigenvectors"].T)) <= 1e-8
+
+
 def test_live_against_reference(oracle, reference):
     for csr, fm, off, k in [(G.randsym_np(2000), True, 0.0, 2), (G.laplace2d_np(24), False, -8.0, 1),
                             (G.torus_np(12), False, -10.0, 3)]:
