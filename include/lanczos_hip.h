@@ -308,6 +308,7 @@ typedef struct ll_run_stats {
   double seconds_host_wait;    /* host time spent waiting for the per-iteration scalars */
   double seconds_setup;        /* start vector, locked vectors (per pass) */
   double seconds_finish;       /* Ritz step: tridiagonal eigenvectors, GEMV over the basis, copy back */
+  int64_t second_passes;       /* iterations whose Gram-Schmidt was repeated (DGKS test decided on the host) */
 } ll_run_stats;
 int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 

@@ -85,6 +85,7 @@ class RunStats(C.Structure):
         ("seconds_host_wait", f64),
         ("seconds_setup", f64),
         ("seconds_finish", f64),
+        ("second_passes", i64),
     ]
 
     def as_dict(self):

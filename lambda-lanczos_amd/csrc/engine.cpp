@@ -208,7 +208,8 @@ template <typename T> void Engine<T>::dot_dev(const T* a, const T* b, double* d_
 template <typename T> static int max_vecs_per_launch() { return (1536 - 1) / scalar_traits<T>::reals; }
 
 template <typename T>
-NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total) {
+NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
+                         bool first_pass_only) {
   hipStream_t s = ctx->stream;
   const int nb = runs.total();
   const bool sharded = ctx->comm != nullptr;
@@ -289,6 +290,10 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   }
   launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
   all_reduce(c + 1, 1);
+  if (first_pass_only && mode == LL_ORTH_CGS_DGKS) {
+    if (h_total) LL_HIP(hipMemcpyAsync(h_total, h1, (size_t)R * nb * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return NormRefs{c, c + 1, c + 1, 0};  // final norm = c1; (c0, c1) go to the host through publish
+  }
 
   // ---- pass 2: always (CGS2) or only when ||w|| dropped below ||w_before||/sqrt(2) (DGKS); decided on the device
   off = 0;
@@ -311,6 +316,15 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     launch_accumulate_h(h_total, h2, R * nb, pred, s);
   }
   return refs;
+}
+
+template <typename T> double Engine<T>::second_pass(T* u, const RunList<T>& runs) {
+  const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
+  const NormRefs r = orth(u, runs, LL_ORTH_CGS_DGKS, no_tt, S(kScalScratch), nullptr, true);
+  launch_scale<T>(n_local, u, 0.0, &r, ctx->stream);
+  double shrink = 0.0;
+  fetch(r.c1, &shrink, 1);
+  return shrink;
 }
 
 template <typename T>
@@ -415,6 +429,13 @@ inline zc as_real_coeff(double v, zc*) { return zc{v, 0.0}; }
 inline float as_real_coeff(double v, float*) { return (float)v; }
 inline cf as_real_coeff(double v, cf*) { return cf{(float)v, 0.0f}; }
 
+// DGKS "twice is enough": a second Gram-Schmidt pass is due when the first one removed more than this fraction of
+// ||w||^2.  LL_DGKS_THRESHOLD overrides the 1/2 (testing: a value > 1 forces the second pass in every iteration).
+double dgks_threshold() {
+  const char* e = std::getenv("LL_DGKS_THRESHOLD");
+  return e ? std::atof(e) : 0.5;
+}
+
 int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration) {
   int64_t want = initial_vector_size > 0 ? initial_vector_size : 200;
   want = std::min(want, max_iteration + 2);
@@ -445,6 +466,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   const int64_t n = op->n, nl = op->n_local;
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   const int mode = P.orth_mode;
+  const double dgks_thr = dgks_threshold();
   Engine<T> E(ctx, op, nl);
   constexpr int R = scalar_traits<T>::reals;
 
@@ -468,7 +490,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   if (P.find_maximum) cmp = std::greater<double>(); else cmp = std::less<double>();
   std::multimap<double, std::vector<T>, std::function<bool(double, double)>> kept(cmp);
 
-  int64_t passes = 0, total_iters = 0;
+  int64_t passes = 0, total_iters = 0, second_passes = 0;
   double t_tridiag = 0.0, t_enqueue = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
@@ -531,7 +553,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       runs.ld = ld;
       runs.add(d_locked.p, L);  // P5
       runs.add_basis(U, k);     // P6
-      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr);  // ... P7
+      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true);  // ... P7
       launch_publish(ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), refs, s);
       LL_HIP(hipEventRecord(ring.ev[slot], s));
       launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
@@ -539,14 +561,37 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       refs_prev = refs;
       t_enqueue += now_s() - te0;
     };
-    // host half of iteration j (H1-H4); returns true when the loop must stop after j iterations
-    auto process = [&](int64_t j) -> bool {
+    // host half of iteration j (H1-H4): kContinue, kStop (the loop ends after j iterations) or kRedone (a second
+    // Gram-Schmidt pass changed u_j: the speculative iteration j+1 must be enqueued again)
+    enum { kContinue = 0, kStop = 1, kRedone = 2 };
+    auto process = [&](int64_t j) -> int {
       const int slot = (int)(j % 4);
       const double tw0 = now_s();
       LL_HIP(hipEventSynchronize(ring.ev[slot]));
       t_wait += now_s() - tw0;
       const volatile double* hp = ctx->h_pinned + 4 * slot;
-      const double alpha_j = hp[0], beta2_j = hp[1];
+      const double alpha_j = hp[0], c0_j = hp[2], c1_j = hp[3];
+      double beta2_j = hp[1];
+      int verdict = kContinue;
+      if (mode == LL_ORTH_CGS_DGKS && c1_j < dgks_thr * c0_j) {
+        // DGKS "twice is enough", decided here from the published norms: the first pass removed more than half of
+        // ||w||^2, so Gram-Schmidt is repeated on u_j (already scaled to unit norm on the device) and beta_j shrinks
+        // by the norm that survives.  Rare (near breakdown / deflation); costs one pipeline drain.
+        if (c1_j > 0.0 && std::isfinite(c1_j)) {
+          RunList<T> again;
+          again.ld = ld;
+          again.add(d_locked.p, L);
+          again.add_basis(U, j);
+          beta2_j = c1_j * E.second_pass(U.vec(j), again);
+          ++second_passes;
+          double* cj = E.S(kScalNorms + 3 * slot);
+          launch_set_scalar(cj + 1, beta2_j, s);  // what the next three-term update reads as beta_j^2
+          refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+          verdict = kRedone;
+        } else {
+          beta2_j = 0.0;  // w vanished exactly: breakdown (H3)
+        }
+      }
       alpha.push_back(alpha_j);
       beta.push_back(std::sqrt(beta2_j));
       const double t0 = now_s();
@@ -564,20 +609,24 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       }
       t_tridiag += now_s() - t0;
       // H3 LL:279-283: 10 * machine epsilon of real_t<T> (float storage => the float epsilon, like the reference)
-      if (beta.back() < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon() * 1e1) return true;
+      if (beta.back() < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon() * 1e1) return kStop;
       bool stop = true;  // H4 LL:290-309
       if (pevs.size() != evs.size()) stop = false;
       else
         for (int64_t r = 0; r < nroot; ++r)
           if (std::abs(evs[r] - pevs[r]) >= std::min(std::abs(evs[r]), std::abs(pevs[r])) * P.eps) { stop = false; break; }
-      if (stop) return true;
+      if (stop) return kStop;
       pevs = evs;
-      return false;
+      return verdict;
     };
 
     for (int64_t k = 1; k <= P.max_iteration; ++k) {
       enqueue(k);
-      if (k > 1 && process(k - 1)) { itern = k - 1; stopped = true; break; }
+      if (k > 1) {
+        const int v = process(k - 1);
+        if (v == kStop) { itern = k - 1; stopped = true; break; }
+        if (v == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
+      }
     }
     if (!stopped) process(P.max_iteration);  // itern stays max_iteration either way (LL:239,312)
     LL_HIP(hipStreamSynchronize(s));
@@ -720,6 +769,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     stats->seconds_host_wait = t_wait;
     stats->seconds_setup = t_setup;
     stats->seconds_finish = t_finish;
+    stats->second_passes = second_passes;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     stats->seconds_total = now_s() - t_start;
   }
@@ -760,6 +810,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
   const int64_t nl = op->n_local;
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   Engine<T> E(ctx, op, nl);
+  const double dgks_thr = dgks_threshold();
   Basis<T> U;
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
   ctx->ensure_pinned(16);
@@ -778,6 +829,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
 
   std::vector<double> alpha, beta, ev, p;
   std::vector<H> coeff, coeff_prev, expv;
+  int64_t second_passes = 0;
   int64_t itern = P.max_iteration;
   bool stopped = false;
 
@@ -792,18 +844,36 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     RunList<T> runs;
     runs.ld = ld;
     if (P.full_orthogonalize) runs.add_basis(U, k);  // EX:120-122
-    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr);  // EX:145
+    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true);  // EX:145
     launch_publish(ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), refs, s);
     LL_HIP(hipEventRecord(ring.ev[slot], s));
     launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
     timer.mark();
     refs_prev = refs;
   };
-  auto process = [&](int64_t j) -> bool {
+  enum { kContinue = 0, kStop = 1, kRedone = 2 };
+  auto process = [&](int64_t j) -> int {
     const int slot = (int)(j % 4);
     LL_HIP(hipEventSynchronize(ring.ev[slot]));
     const volatile double* hp = ctx->h_pinned + 4 * slot;
-    const double alpha_j = hp[0], beta2_j = hp[1];
+    const double alpha_j = hp[0], c0_j = hp[2], c1_j = hp[3];
+    double beta2_j = hp[1];
+    int verdict = kContinue;
+    if (P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS && c1_j < dgks_thr * c0_j) {  // see lanczos_run
+      if (c1_j > 0.0 && std::isfinite(c1_j)) {
+        RunList<T> again;
+        again.ld = ld;
+        again.add_basis(U, j);
+        beta2_j = c1_j * E.second_pass(U.vec(j), again);
+        ++second_passes;
+        double* cj = E.S(kScalNorms + 3 * slot);
+        launch_set_scalar(cj + 1, beta2_j, s);
+        refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+        verdict = kRedone;
+      } else {
+        beta2_j = 0.0;
+      }
+    }
     alpha.push_back(alpha_j);
     const double beta_j = std::sqrt(beta2_j);
     const double t0 = now_s();
@@ -821,13 +891,19 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     H overlap = H(0);
     for (size_t i = 0; i < coeff_prev.size(); ++i) overlap += conj_h(coeff_prev[i]) * coeff[i];  // EX:147-150
     coeff_prev = coeff;  // EX:152
-    return std::abs(1.0 - std::abs(overlap)) < P.eps ||
-           beta_j < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon();  // EX:154-158
+    if (std::abs(1.0 - std::abs(overlap)) < P.eps ||
+        beta_j < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon())  // EX:154-158
+      return kStop;
+    return verdict;
   };
 
   for (int64_t k = 1; k <= P.max_iteration; ++k) {
     enqueue(k);
-    if (k > 1 && process(k - 1)) { itern = k - 1; stopped = true; break; }
+    if (k > 1) {
+      const int v = process(k - 1);
+      if (v == kStop) { itern = k - 1; stopped = true; break; }
+      if (v == kRedone) enqueue(k);
+    }
   }
   if (!stopped) process(P.max_iteration);
   LL_HIP(hipStreamSynchronize(s));
@@ -851,6 +927,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     stats->total_iterations = itern;
     stats->seconds_host_tridiag = t_tridiag;
     stats->last_alpha_len = (int64_t)alpha.size();
+    stats->second_passes = second_passes;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     stats->seconds_total = now_s() - t_start;
   }

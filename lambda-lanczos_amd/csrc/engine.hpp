@@ -69,7 +69,14 @@ template <typename T> struct Engine {
   void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false);
   // Orthogonalise w against the runs with an optional fused three-term update; c = device triple for the norms.
   // Returns the NormRefs every consumer must use for ||w|| afterwards.  h_total (device, nullable): R*nb doubles.
-  NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total);
+  // first_pass_only (whole-loop drivers, LL_ORTH_CGS_DGKS): enqueue pass 1 only and return refs whose final norm is
+  // c1; the driver evaluates the DGKS test on the host from the published (c0, c1) one iteration later and runs the
+  // rare second pass itself (second_pass below) — no predicated no-op launches or collectives per iteration.
+  NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
+                bool first_pass_only = false);
+  // The deferred second pass on the already normalised vector u = w1/||w1||: orthogonalise against `runs` once more,
+  // renormalise, and return ||u'||^2 (the factor by which beta^2 shrinks).  Synchronises the stream.
+  double second_pass(T* u, const RunList<T>& runs);
   // ||v||^2 -> *d_out (device, all-reduced)
   void norm2_dev(const T* v, double* d_out);
   // <a,b> -> d_out[0..R) (device, all-reduced)

@@ -773,6 +773,11 @@ void launch_reduce_cols(const double* partials, int nparts, int ncols, double* o
   }
   LL_HIP(hipGetLastError());
 }
+__global__ void set_scalar_kernel(double* dst, double v) { *dst = v; }
+void launch_set_scalar(double* dst, double v, hipStream_t s) {
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, dst, v);
+  LL_HIP(hipGetLastError());
+}
 __global__ void copy_scalar_kernel(double* dst, const double* src) { *dst = *src; }
 void launch_copy_scalar(double* dst, const double* src, hipStream_t s) {
   hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, s, dst, src);

@@ -236,6 +236,7 @@ int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_pa
 // last_out (nullable) redirects the last column.
 void launch_reduce_cols(const double* partials, int nparts, int ncols, double* out, double* last_out, hipStream_t s);
 void launch_copy_scalar(double* dst, const double* src, hipStream_t s);
+void launch_set_scalar(double* dst, double value, hipStream_t s);
 
 // Multi-dot with optional fused three-term update.
 //   if (three_term) w = w - beta*u_prev - alpha*u_cur   (u_prev nullable; alpha = *alpha_dev; beta = beta_from(norms_prev))

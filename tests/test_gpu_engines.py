@@ -252,6 +252,67 @@ def test_c3_random_10M_spmv_properties(ctx):
     op.close()
 
 
+# ------------------------------------------------------------------ the host-decided second Gram-Schmidt pass
+def test_exhausted_krylov_space_runs_like_the_oracle(ctx, oracle):
+    """An operator with 5 distinct eigenvalues exhausts its Krylov space after 5 iterations: from then on w is rounding
+    noise (beta ~ 1e-15, just above the breakdown threshold) and block Gram-Schmidt with the host-decided DGKS test
+    must carry the run on exactly like the oracle's sequential MGS (same iteration count, same eigenpair)."""
+    rng = np.random.default_rng(4)
+    n = 300
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.repeat([1.0, 2.0, 3.5, 5.0, 9.0], n // 5)
+    a = (q * lam) @ q.T
+    a = (a + a.T) / 2
+    init = G.start_vector(n, 1)
+    op = L.DenseOperator(ctx, a)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.init_vector = fixed_init(init)
+    vals, vecs = eng.run()
+    ora = oracle.lanczos(G.dense_to_csr(a), init, True)
+    assert abs(vals[0] - 9.0) <= 1e-10 and abs(ora["eigenvalues"][0] - 9.0) <= 1e-10
+    assert abs(eng.getIterationCounts()[0] - ora["iter_counts"][0]) <= 1
+    assert eng.last_stats["second_passes"] >= 0   # reported; whether the noise iterations trigger it is data dependent
+    assert np.linalg.norm(a @ vecs[0] - vals[0] * vecs[0]) <= 1e-9
+    op.close()
+
+
+@pytest.mark.parametrize("what", ["lanczos_two_roots", "expo_full_orth", "lanczos_complex"])
+def test_forced_second_pass_every_iteration(ctx, oracle, what, monkeypatch):
+    """LL_DGKS_THRESHOLD > 1 makes the host decide for a second pass in EVERY iteration: the pipeline is drained,
+    Gram-Schmidt is repeated on the normalised vector, beta is rescaled and the speculative next iteration is enqueued
+    again.  A second pass on an already orthogonal vector changes nothing but rounding, so traces, iteration counts and
+    results must still equal the oracle's."""
+    monkeypatch.setenv("LL_DGKS_THRESHOLD", "2.0")
+    if what == "expo_full_orth":
+        csr = G.torus_np(20)
+        inp = G.start_vector(400, 1, np.complex128)
+        op = L.CsrOperator(ctx, *csr)
+        ex = L.Exponentiator(op, 400)
+        ex.full_orthogonalize = True
+        out, it = ex.run(-1j, inp)
+        o_ref, it_ref, _ = oracle.expo(csr, -1j, inp, full_orthogonalize=True)
+        assert it == it_ref and ex.last_stats["second_passes"] == it
+        assert np.max(np.abs(out - o_ref)) <= 1e-11 * np.linalg.norm(inp)
+        op.close()
+        return
+    csr = G.torus_np(24) if what == "lanczos_complex" else G.randsym_np(5000)
+    n = csr[0].shape[0] - 1
+    k = 1 if what == "lanczos_complex" else 2
+    init = G.start_vector(n, 1, csr[2].dtype)
+    eng, op = gpu_engine(ctx, csr, True, k, init_vector=fixed_init(init), max_iteration=60)
+    vals, vecs = eng.run()
+    ora = oracle.lanczos(csr, init, True, num_eigs=k, max_iteration=60)
+    assert eng.getIterationCounts() == ora["iter_counts"]
+    assert eng.last_stats["second_passes"] == sum(ora["iter_counts"])
+    m = len(ora["alpha"])
+    assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"])) <= 1e-10 * inf_norm(csr)
+    assert np.max(np.abs(eng.last_beta[:m - 1] - ora["beta"][:m - 1])) <= 1e-10 * inf_norm(csr)
+    assert np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * np.max(np.abs(vals))
+    for i in range(k):
+        assert 1 - overlap(vecs[i], ora["eigenvectors"][i]) <= 1e-8
+    op.close()
+
+
 # ------------------------------------------------------------------ run_iteration called directly (LL:216-322)
 @pytest.mark.parametrize("name", ["m8_three_roots", "m8_lowest_locked", "randsym600_top2_locked", "torus12_lowest_locked"])
 @pytest.mark.parametrize("orth_mode", [L.ORTH_CGS_DGKS, L.ORTH_MGS])

@@ -20,10 +20,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,forced_second_pass", [(2, False), (3, False), (2, True)])
+def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, forced_second_pass):
     name = "/ll_shm_test_" + uuid.uuid4().hex[:12]
     env = dict(os.environ, LL_COMM_BACKEND="shm", OMP_NUM_THREADS="2")
+    if forced_second_pass:
+        # every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the replicated
+        # decision must keep the ranks' collective sequences aligned, results unchanged up to rounding
+        env["LL_DGKS_THRESHOLD"] = "2.0"
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shm_rank_worker.py"), str(r), str(world), name,
                                str(tmp_path)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
