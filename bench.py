@@ -332,7 +332,10 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Lanczos iterations/sec (fixed window) + CSR SpMV GB/s, fp64",
+            # BASELINE.json's metric string for its own configuration; a descriptive one for the other workloads
+            "metric": ("Lanczos iterations/sec + SpMV GB/s (fp64, n=10M nnz=150M) at 1/2/4/8 GPUs"
+                       if wl == "c3" and not args.n else
+                       "Lanczos iterations/sec (fixed window) + SpMV GB/s, %s" % ("complex fp64" if complex_ else "fp64")),
             "value": value,
             "unit": "Lanczos iterations/s",
             "n_gpus": world,
