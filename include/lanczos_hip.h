@@ -273,6 +273,11 @@ int ll_tridiag_eigvecs(int64_t m, const double* alpha_host, const double* beta_h
  * NULL = the reference's default: nondeterministic uniform [-1,1] (LL:70-104). */
 typedef void (*ll_init_vector_fn)(void* vec_host, int64_t n_local, int64_t row_begin, void* user);
 
+/* LL_TRIDIAG_QR: the reference's implicit-shift QR of all k Ritz values every iteration (O(k^2), TRI:290-361).
+ * LL_TRIDIAG_BISECT: Sturm bisection of the nroot wanted values only (O(k), TRI:22-88).
+ * LL_TRIDIAG_AUTO: QR up to k = 64, bisection beyond, and the reference's QR arithmetic decides whenever a root's
+ *   change comes within 4*eps of the stop threshold: same iteration counts and eigenvalues as LL_TRIDIAG_QR; few Ritz
+ *   vectors by inverse iteration once k > 256.  Recommended for runs of more than a few hundred iterations. */
 enum { LL_TRIDIAG_QR = 0, LL_TRIDIAG_BISECT = 1, LL_TRIDIAG_AUTO = 2 };
 
 typedef struct ll_lanczos_params {

@@ -610,11 +610,35 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       t_tridiag += now_s() - t0;
       // H3 LL:279-283: 10 * machine epsilon of real_t<T> (float storage => the float epsilon, like the reference)
       if (beta.back() < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon() * 1e1) return kStop;
-      bool stop = true;  // H4 LL:290-309
-      if (pevs.size() != evs.size()) stop = false;
-      else
+      // H4 LL:290-309: every tracked root changed by less than eps (relative)
+      auto converged = [&](const std::vector<double>& now, const std::vector<double>& before, double tol) {
+        if (before.size() != now.size()) return false;
         for (int64_t r = 0; r < nroot; ++r)
-          if (std::abs(evs[r] - pevs[r]) >= std::min(std::abs(evs[r]), std::abs(pevs[r])) * P.eps) { stop = false; break; }
+          if (std::abs(now[r] - before[r]) >= std::min(std::abs(now[r]), std::abs(before[r])) * tol) return false;
+        return true;
+      };
+      bool stop;
+      if (use_qr) {
+        stop = converged(evs, pevs, P.eps);
+      } else {
+        // Bisection values differ from the reference's QR values by a few ulp, far less than eps; the decision can only
+        // differ when a root's change sits within that distance of eps.  So: not even within 4*eps => certainly no
+        // stop; otherwise the reference's own arithmetic (QR of T_m and T_{m-1}) takes the decision, and on a stop
+        // its values are the ones returned — iteration counts and eigenvalues equal LL_TRIDIAG_QR's by construction.
+        stop = converged(evs, pevs, 4.0 * P.eps);
+        if (stop) {
+          const double tq0 = now_s();
+          std::vector<double> cur((size_t)m), prev((size_t)(m - 1)), e_now, e_before;
+          tridiag_qr(m, alpha.data(), beta.data(), cur.data(), nullptr);
+          tridiag_qr(m - 1, alpha.data(), beta.data(), prev.data(), nullptr);
+          for (int64_t i = 0; i < ncalc; ++i) e_now.push_back(P.find_maximum ? cur[m - i - 1] : cur[i]);
+          for (int64_t i = 0; i < std::min<int64_t>(nroot, m - 1); ++i)
+            e_before.push_back(P.find_maximum ? prev[m - 2 - i] : prev[i]);
+          t_tridiag += now_s() - tq0;
+          stop = converged(e_now, e_before, P.eps);
+          if (stop) evs = e_now;
+        }
+      }
       if (stop) return kStop;
       pevs = evs;
       return verdict;

@@ -252,6 +252,29 @@ def test_c3_random_10M_spmv_properties(ctx):
     op.close()
 
 
+def test_tridiag_auto_reproduces_qr_decisions(ctx):
+    """LL_TRIDIAG_AUTO (Sturm bisection per iteration, O(k)) hands the stop decision to the reference's QR arithmetic
+    whenever a root's change comes within 4*eps of the threshold: iteration count and returned eigenvalue equal the
+    reference-faithful LL_TRIDIAG_QR mode's exactly, on a run of several hundred iterations (5-point Laplacian
+    200x200: the configuration SURVEY 8d quotes at 708 iterations)."""
+    side = 200
+    n = side * side
+    csr = G.laplace2d_np(side)
+    init = G.start_vector(n, 1)
+    got = {}
+    for mode in (L.TRIDIAG_QR, L.TRIDIAG_AUTO):
+        eng, op = gpu_engine(ctx, csr, False, 1, eigenvalue_offset=-8.0, init_vector=fixed_init(init), tridiag_mode=mode)
+        vals, vecs = eng.run()
+        got[mode] = (eng.getIterationCounts(), float(vals[0]), vecs[0], eng.last_stats["seconds_host_tridiag"])
+        op.close()
+    assert got[L.TRIDIAG_QR][0] == got[L.TRIDIAG_AUTO][0] and got[L.TRIDIAG_QR][0][0] > 300
+    assert got[L.TRIDIAG_QR][1] == got[L.TRIDIAG_AUTO][1]                 # the QR values are returned in both modes
+    assert 1 - overlap(got[L.TRIDIAG_QR][2], got[L.TRIDIAG_AUTO][2]) <= 1e-10
+    lam = G.laplace2d_lambda_min(side)
+    assert abs(got[L.TRIDIAG_AUTO][1] - lam) <= 1e-10 * 8
+    assert got[L.TRIDIAG_AUTO][3] < got[L.TRIDIAG_QR][3]                  # and the host step is cheaper
+
+
 # ------------------------------------------------------------------ the host-decided second Gram-Schmidt pass
 def test_exhausted_krylov_space_runs_like_the_oracle(ctx, oracle):
     """An operator with 5 distinct eigenvalues exhausts its Krylov space after 5 iterations: from then on w is rounding
