@@ -625,8 +625,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
         // differ when a root's change sits within that distance of eps.  So: not even within 4*eps => certainly no
         // stop; otherwise the reference's own arithmetic (QR of T_m and T_{m-1}) takes the decision, and on a stop
         // its values are the ones returned — iteration counts and eigenvalues equal LL_TRIDIAG_QR's by construction.
-        stop = converged(evs, pevs, 4.0 * P.eps);
-        if (stop) {
+        const bool guarded = P.tridiag_mode == LL_TRIDIAG_AUTO;  // LL_TRIDIAG_BISECT: bisection values decide alone
+        stop = converged(evs, pevs, guarded ? 4.0 * P.eps : P.eps);
+        if (stop && guarded) {
           const double tq0 = now_s();
           std::vector<double> cur((size_t)m), prev((size_t)(m - 1)), e_now, e_before;
           tridiag_qr(m, alpha.data(), beta.data(), cur.data(), nullptr);
