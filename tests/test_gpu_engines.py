@@ -489,6 +489,50 @@ def test_device_array_csr_and_device_callback_operators(ctx, oracle):
     cbo.close()
 
 
+def test_no_device_memory_growth_over_many_runs():
+    """Operators, engines and contexts give their device memory back: create/run/destroy cycles (CSR with both SpMV
+    images, lattice, dense; eigen solver with restart passes, Exponentiator) leave the free device memory where it was
+    (40 cycles here; 150 were run once by hand)."""
+    import torch
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    csr = G.randsym_np(20000)
+    init = G.start_vector(20000, 1)
+    tcsr = G.torus_np(40)
+    tin = G.start_vector(1600, 1, np.complex128)
+    dense = np.diag(np.arange(1.0, 301.0)) + 0.01
+
+    def cycle():
+        c = L.Context(0)
+        op = L.CsrOperator(c, *csr)
+        eng = L.LambdaLanczos(op, 20000, True, 3)
+        eng.max_iteration = 30
+        eng.init_vector = fixed_init(init)
+        eng.run()
+        op.close()
+        top = L.CsrOperator(c, *tcsr)
+        L.Exponentiator(top, 1600).run(-0.5j, tin)
+        top.close()
+        st = L.StencilOperator(c, [40, 40], diag=4.0)
+        L.LambdaLanczos(st, 1600, False, 1).run()
+        st.close()
+        dn = L.DenseOperator(c, dense)
+        L.LambdaLanczos(dn, 300, True, 1).run()
+        dn.close()
+        c.close()
+
+    for _ in range(5):   # warm up allocator pools, code objects, RCCL-free paths
+        cycle()
+    before = free_bytes()
+    for _ in range(40):
+        cycle()
+    after = free_bytes()
+    assert before - after <= 64 << 20, (before, after)
+
+
 def test_error_reporting(ctx):
     """Bad arguments come back as status codes with a message (the reference only asserts, LA:31, EX:88)."""
     csr = G.randsym_np(500)
