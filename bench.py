@@ -87,6 +87,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
+        # torch.distributed.run pins OMP_NUM_THREADS=1 per worker; the host-side matrix generation and the PB image build
+        # (one-off, outside the timed region) are OpenMP loops: give every rank its share of the host cores instead
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
         import torch.distributed as dist  # control plane only (gloo); the data plane is RCCL inside the library
 
         assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
