@@ -1057,6 +1057,141 @@ __global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T*
     if (threadIdx.x == 0) dot_partials[blockIdx.x] = tot;
   }
 }
+// Vectorised form: every lane owns V consecutive sites of one lattice row (V * sizeof(T) = 32 bytes), so the
+// coordinate arithmetic is paid once per V sites, the centre / slow-dimension neighbours / on-site terms / results
+// move as 16-byte pieces and only the two fast-dimension end neighbours are scalar loads.  Needs the fastest
+// dimension, the shard start and the shard length to be multiples of V (then no chunk straddles a lattice row or a
+// shard / halo boundary); same accumulation order per site as stencil_kernel, so both give identical bits.
+template <typename T, int V> __device__ __forceinline__ void load_chunk(const T* __restrict__ p, T (&r)[V]) {
+  constexpr int NCH = (int)(V * sizeof(T) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(p);
+  uint4 c[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) c[i] = src[i];
+  __builtin_memcpy(&r[0], c, sizeof(c));
+}
+template <typename T, int V> __device__ __forceinline__ void store_chunk(T* __restrict__ p, const T (&r)[V]) {
+  constexpr int NCH = (int)(V * sizeof(T) / 16);
+  uint4 c[NCH];
+  __builtin_memcpy(c, &r[0], sizeof(c));
+  uint4* dst = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) dst[i] = c[i];
+}
+
+template <typename T, typename IDX, int V>
+__global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, const T* __restrict__ xl,
+                                                             const T* __restrict__ lo, const T* __restrict__ hi,
+                                                             const typename scalar_traits<T>::real* __restrict__ onsite,
+                                                             T* __restrict__ y, double offset,
+                                                             double* __restrict__ dot_partials) {
+  typedef typename scalar_traits<T>::real R;
+  __shared__ double red[4];
+  double dot_acc = 0.0;
+  const long long nl = g.n_local, H = g.halo;
+  const int last = g.ndim - 1;
+  const long long dl = g.dims[last];
+  auto fetch = [&](long long j) -> T { return j < 0 ? lo[H + j] : (j >= nl ? hi[j - nl] : xl[j]); };
+  auto chunk_ptr = [&](long long j) -> const T* { return j < 0 ? lo + (H + j) : (j >= nl ? hi + (j - nl) : xl + j); };
+  const long long nchunks = nl / V;
+  for (long long ch = (long long)blockIdx.x * kBlock + threadIdx.x; ch < nchunks; ch += (long long)gridDim.x * kBlock) {
+    const long long li = ch * V;
+    IDX rem = (IDX)(g.row_begin + li);
+    long long c[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 2; d >= 0; --d) {
+      if (d < g.ndim) {
+        const IDX dim = (IDX)g.dims[d];
+        const IDX q = rem / dim;
+        c[d] = (long long)(rem - q * dim);
+        rem = q;
+      }
+    }
+    T ctr[V];
+    load_chunk<T, V>(xl + li, ctr);
+    acc_t<T> acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = zero<acc_t<T>>();
+    // lower neighbours, slowest dimension first; the fastest dimension comes last and is a shift by one site
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < last) {
+        long long off = 0;
+        bool have = true;
+        if (c[d] > 0) off = -g.stride[d];
+        else if (g.periodic[d]) off = d == 0 ? -g.stride[0] : (g.dims[d] - 1) * g.stride[d];
+        else have = false;
+        if (have) {
+          T nb[V];
+          load_chunk<T, V>(chunk_ptr(li + off), nb);
+          const T hv = hop_value(g, d, true, (T*)nullptr);
+#pragma unroll
+          for (int e = 0; e < V; ++e) fma_acc(acc[e], hv, nb[e]);
+        }
+      } else if (d == last) {
+        const T hv = hop_value(g, d, true, (T*)nullptr);
+        bool have = true;
+        T left = zero<T>();
+        if (c[last] > 0) left = fetch(li - 1);
+        else if (g.periodic[last]) left = fetch(last == 0 ? li - 1 : li + (dl - 1));  // dimension 0 wraps on the ring
+        else have = false;
+        if (have) fma_acc(acc[0], hv, left);
+#pragma unroll
+        for (int e = 1; e < V; ++e) fma_acc(acc[e], hv, ctr[e - 1]);
+      }
+    }
+    if (onsite) {
+      R os[V];
+      load_chunk<R, V>(onsite + li, os);
+#pragma unroll
+      for (int e = 0; e < V; ++e) fma_real(acc[e], g.diag + (double)os[e], ctr[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) fma_real(acc[e], g.diag, ctr[e]);
+    }
+    // upper neighbours, fastest dimension first
+    {
+      const T hv = hop_value(g, last, false, (T*)nullptr);
+#pragma unroll
+      for (int e = 0; e + 1 < V; ++e) fma_acc(acc[e], hv, ctr[e + 1]);
+      bool have = true;
+      T right = zero<T>();
+      if (c[last] + V < dl) right = fetch(li + V);
+      else if (g.periodic[last]) right = fetch(last == 0 ? li + V : li + V - dl);
+      else have = false;
+      if (have) fma_acc(acc[V - 1], hv, right);
+    }
+#pragma unroll
+    for (int d = 2; d >= 0; --d) {
+      if (d < last) {
+        long long off = 0;
+        bool have = true;
+        if (c[d] + 1 < g.dims[d]) off = g.stride[d];
+        else if (g.periodic[d]) off = d == 0 ? g.stride[0] : -(g.dims[d] - 1) * g.stride[d];
+        else have = false;
+        if (have) {
+          T nb[V];
+          load_chunk<T, V>(chunk_ptr(li + off), nb);
+          const T hv = hop_value(g, d, false, (T*)nullptr);
+#pragma unroll
+          for (int e = 0; e < V; ++e) fma_acc(acc[e], hv, nb[e]);
+        }
+      }
+    }
+    T out[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      out[e] = add(narrow<T>(acc[e]), rmul(offset, ctr[e]));
+      dot_acc += re_cmul(ctr[e], out[e]);
+    }
+    store_chunk<T, V>(y + li, out);
+  }
+  if (dot_partials) {
+    const double tot = block_sum(dot_acc, red);
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = tot;
+  }
+}
+
 template <typename T>
 int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, const T* halo_hi, T* y, double offset,
                    double* dot_partials, hipStream_t s) {
@@ -1073,9 +1208,29 @@ int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, co
   g.halo = op.st_halo;
   g.row_begin = op.row_begin;
   g.n_local = op.n_local;
+  typedef typename scalar_traits<T>::real R;
+  constexpr int V = (int)(32 / sizeof(T));
+  static const bool allow_vec = [] {
+    const char* e = std::getenv("LL_STENCIL_VEC");
+    return !e || std::atoi(e) != 0;
+  }();
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool ptrs_ok = aligned16(x_local) && aligned16(y) && (g.ndim == 1 || (aligned16(halo_lo) && aligned16(halo_hi)));
+  if (allow_vec && ptrs_ok && op.n_local >= V && g.dims[g.ndim - 1] % V == 0 && op.row_begin % V == 0 &&
+      op.n_local % V == 0) {
+    const long long chunks = op.n_local / V;
+    const int vgrid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, (chunks + kBlock - 1) / kBlock));
+    if (op.n < ((long long)1 << 31))
+      hipLaunchKernelGGL((stencil_vec_kernel<T, unsigned, V>), dim3(vgrid), dim3(kBlock), 0, s, g, x_local, halo_lo,
+                         halo_hi, (const R*)op.d_onsite, y, offset, dot_partials);
+    else
+      hipLaunchKernelGGL((stencil_vec_kernel<T, unsigned long long, V>), dim3(vgrid), dim3(kBlock), 0, s, g, x_local,
+                         halo_lo, halo_hi, (const R*)op.d_onsite, y, offset, dot_partials);
+    LL_HIP(hipGetLastError());
+    return vgrid;
+  }
   const long long want = (op.n_local + kBlock - 1) / kBlock;
   const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
-  typedef typename scalar_traits<T>::real R;
   if (op.n < ((long long)1 << 31))
     hipLaunchKernelGGL((stencil_kernel<T, unsigned>), dim3(grid), dim3(kBlock), 0, s, g, x_local, halo_lo, halo_hi,
                        (const R*)op.d_onsite, y, offset, dot_partials);

@@ -86,6 +86,17 @@ def main():
     out5, it5 = L.Exponentiator(st3, n5).run(-0.7j, x5)
     res["stencil_3d"] = {"y": c2list(yd.get()), "dot": dot5, "out": c2list(out5), "itern": it5}
     st3.close()
+    # (c) the same with shard boundaries and a fastest dimension that are multiples of 8: the vectorised lattice kernel
+    dims_v = [12, 6, 8]
+    n7 = int(np.prod(dims_v))
+    rb7, nl7 = ctx.partition(n7)
+    stv = L.StencilOperator(ctx, dims_v, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=[True, False, True],
+                            onsite=0.3 * np.cos(np.arange(rb7, rb7 + nl7)), dtype=np.complex128, row_begin=rb7, n_local=nl7)
+    x7 = G.start_vector(nl7, 5, np.complex128, rb7)
+    xd, yd = ctx.to_device(x7), ctx.empty(nl7, np.complex128)
+    dot7 = L.spmv(stv, xd, yd, offset=0.25, want_dot=True)
+    res["stencil_vec"] = {"y": c2list(yd.get()), "dot": dot7}
+    stv.close()
     # --- dense row block (all-gather path)
     n6 = 203
     rb6, nl6 = ctx.partition(n6)

@@ -100,6 +100,15 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, f
     out5 = np.concatenate([list2c(r["stencil_3d"]["out"]) for r in ranks])
     assert abs(ranks[0]["stencil_3d"]["itern"] - it5) <= 1
     assert np.max(np.abs(out5 - o5)) <= 1e-10 * np.linalg.norm(x5)
+    dims_v = [12, 6, 8]
+    n7 = int(np.prod(dims_v))
+    c7 = G.lattice_csr(dims_v, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=[True, False, True],
+                       onsite=0.3 * np.cos(np.arange(n7)), dtype=np.complex128)
+    x7 = G.start_vector(n7, 5, np.complex128)
+    y7 = oracle.spmv(c7, x7) + 0.25 * x7
+    got7 = np.concatenate([list2c(r["stencil_vec"]["y"]) for r in ranks])
+    assert np.max(np.abs(got7 - y7)) <= 1e-13 * 10
+    assert abs(ranks[0]["stencil_vec"]["dot"] - np.vdot(x7, y7).real) <= 1e-11 * n7
     rng = np.random.default_rng(5)
     a6 = rng.standard_normal((203, 203))
     a6 = a6 + a6.T

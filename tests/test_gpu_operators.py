@@ -27,8 +27,16 @@ LATTICES = {
     "mixed_3d": ([5, 6, 7], 0.25, [0.5, -1.0, 0.75], [True, False, True], True),
     "thin_3d": ([2, 1, 3], 0.0, [1.0, -1.0, 0.5], True, False),           # neighbours reached twice / self neighbours
     "slab_3d": ([40, 33, 29], -1.0, [-1.0, -0.5, -0.25], [False, True, False], False),
+    # fastest dimension a multiple of 8: the vectorised kernel (32 bytes of consecutive sites per lane) for every type
+    "vec_ring_4096": ([4096], 0.5, -1.0, True, True),
+    "vec_chain_64": ([64], 0.0, -1.0, False, False),
+    "vec_torus_48x96": ([48, 96], 0.0, [-1.0, 0.5], True, True),
+    "vec_open_33x8": ([33, 8], 4.0, -1.0, False, False),                  # one chunk per lattice row (f32)
+    "vec_mixed_3d": ([12, 10, 16], 0.25, [0.5, -1.0, 0.75], [True, False, True], True),
+    "vec_open_3d": ([9, 7, 24], -1.0, [-1.0, -0.5, -0.25], False, False),
 }
-COMPLEX_HOPS = {"ring100": 0.3 - 1j, "torus_300x257": [-1.0 + 0.2j, 0.5j], "mixed_3d": [0.5 + 1j, -1.0, 0.75j],
+COMPLEX_HOPS = {"vec_ring_4096": 0.3 - 1j, "vec_torus_48x96": [-1.0 + 0.2j, 0.5j], "vec_mixed_3d": [0.5 + 1j, -1.0, 0.75j],
+                "vec_open_3d": [-1.0, -0.5 + 0.5j, 0.25j], "ring100": 0.3 - 1j, "torus_300x257": [-1.0 + 0.2j, 0.5j], "mixed_3d": [0.5 + 1j, -1.0, 0.75j],
                 "thin_3d": [1.0 + 1j, -1j, 0.5], "slab_3d": [-1.0, -0.5 + 0.5j, 0.25j]}
 
 
@@ -77,6 +85,42 @@ def test_lattice_apply_matches_oracle(ctx, oracle, name, dtype, offset):
     rowsum = np.max(np.add.reduceat(np.abs(csr[2]), csr[0][:-1]))
     assert rowsum <= op.inf_norm() * (1 + (1e-6 if single else 1e-12)) + 1e-12
     op.close()
+
+
+@pytest.mark.parametrize("name", ["vec_ring_4096", "vec_torus_48x96", "vec_mixed_3d", "vec_open_3d"])
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32, np.complex64])
+def test_vectorised_lattice_kernel_equals_scalar_kernel(name, dtype):
+    """The vectorised kernel adds every site's terms in the order of the one-site-per-lane kernel: identical bits.
+    (LL_STENCIL_VEC is read once per process, so the scalar run happens in a child process.)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    dims, kw = lattice(name, dtype)
+    n = int(np.prod(dims))
+    x = rnd(n, dtype, 21)
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "x.npy"), x)
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import lambda_lanczos_amd as L; import test_gpu_operators as t\n"
+            "dims, kw = t.lattice(%r, np.dtype(%r).type); c = L.Context(0); op = L.StencilOperator(c, dims, **kw)\n"
+            "x = np.load(%r); xd, yd = c.to_device(x), c.empty(x.shape[0], x.dtype)\n"
+            "a = L.spmv(op, xd, yd, offset=0.5, want_dot=True); np.save(%r, yd.get()); np.save(%r, np.array([a]))\n"
+        )
+        outs = {}
+        for vec in ("1", "0"):
+            y_path, a_path = os.path.join(tmp, "y%s.npy" % vec), os.path.join(tmp, "a%s.npy" % vec)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            src = code % (root, os.path.join(root, "tests"), name, np.dtype(dtype).name, os.path.join(tmp, "x.npy"), y_path,
+                          a_path)
+            r = subprocess.run([sys.executable, "-c", src], env=dict(os.environ, LL_STENCIL_VEC=vec), capture_output=True,
+                               text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            outs[vec] = (np.load(y_path), np.load(a_path))
+    assert np.array_equal(outs["1"][0], outs["0"][0])
+    assert abs(outs["1"][1][0] - outs["0"][1][0]) <= 1e-12 * max(1.0, abs(outs["0"][1][0]))
 
 
 def test_dynamic_matrix_known_answer(ctx):
