@@ -97,9 +97,10 @@ template <typename T> struct BasisSegs {
 
 // The three squared norms of one Gram-Schmidt call, as device scalars:
 //   c0 = ||w||^2 before pass 1, c1 = after pass 1, c2 = after pass 2 (valid only if the second pass ran).
-// The second pass runs iff force2 (LL_ORTH_CGS2) or c1 < c0/2 (DGKS "twice is enough" test); every consumer
-// (scale, next three-term update, host read-back) applies the same selection, so no host round trip is needed
-// to decide it.
+// Device-predicated form (the one-call primitive ll_orth_block_*): the second pass runs iff force2 (LL_ORTH_CGS2) or
+// c1 < c0/2 (DGKS "twice is enough" test) and every consumer (scale, next three-term update, host read-back) applies
+// the same selection.  The whole-loop drivers enqueue pass 1 only (c2 aliases c1, force2 = 0) and take the DGKS
+// decision on the host from the published (c0, c1) one iteration later (engine.hpp, Engine::second_pass).
 struct NormRefs {
   const double* c0;
   const double* c1;
