@@ -155,3 +155,35 @@ def test_inverse_iteration_matches_qr_vectors(oracle):
     b2 = np.array([2.0, 2.0, 0.0, 2.0, 2.0])
     v = L.tridiag_eigvecs(a2, b2, [-1.0, -1.0])
     assert np.max(np.abs(v @ v.T - np.eye(2))) <= 1e-10
+
+
+import subprocess  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C_SRC = os.path.join(ROOT, "tests", "c", "cabi_c99.c")
+C_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "cabi_c99")
+
+
+def _build_c99():
+    os.makedirs(os.path.dirname(C_EXE), exist_ok=True)
+    lib_dir = os.path.join(ROOT, "lambda-lanczos_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), C_SRC,
+                    "-o", C_EXE, "-L" + lib_dir, "-llanczos_hip", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+
+
+def test_header_is_plain_c99_and_links_from_c():
+    """include/lanczos_hip.h compiles as strict C99 and a C program links the library: the boundary is a C ABI."""
+    _build_c99()
+    import torch
+
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([C_EXE], capture_output=True, text=True)
+        assert r.returncode == 2 and "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c99_program_runs_readme_sample():
+    _build_c99()
+    r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "lambda_max = 4.0000" in r.stdout, r.stdout + r.stderr
