@@ -918,6 +918,24 @@ template int launch_offset_dot<zc>(int64_t, const zc*, zc*, double, double*, hip
 template int launch_offset_dot<float>(int64_t, const float*, float*, double, double*, hipStream_t);
 template int launch_offset_dot<cf>(int64_t, const cf*, cf*, double, double*, hipStream_t);
 
+// V consecutive elements (V * sizeof(T) a multiple of 16 bytes) as 16-byte pieces; p must be 16-byte aligned.
+template <typename T, int V> __device__ __forceinline__ void load_chunk(const T* __restrict__ p, T (&r)[V]) {
+  constexpr int NCH = (int)(V * sizeof(T) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(p);
+  uint4 c[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) c[i] = src[i];
+  __builtin_memcpy(&r[0], c, sizeof(c));
+}
+template <typename T, int V> __device__ __forceinline__ void store_chunk(T* __restrict__ p, const T (&r)[V]) {
+  constexpr int NCH = (int)(V * sizeof(T) / 16);
+  uint4 c[NCH];
+  __builtin_memcpy(c, &r[0], sizeof(c));
+  uint4* dst = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) dst[i] = c[i];
+}
+
 // ================================================================= a1/a2/a3: dense row block (sample1's operator)
 // One wavefront per row: the row streams in with coalesced loads, x comes from L2, the 64 partial sums fold with
 // shuffles; offset, y write and the alpha partial are fused like in the CSR kernels.  Bound by the matrix stream
@@ -926,15 +944,27 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long long ncols, const T* __restrict__ a,
                                                           const T* __restrict__ xf, const T* __restrict__ xl,
                                                           T* __restrict__ y, double offset,
-                                                          double* __restrict__ dot_partials) {
+                                                          double* __restrict__ dot_partials, int vec) {
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double dot_acc = 0.0;
   for (long long row = (long long)blockIdx.x * 4 + wave; row < nrows; row += (long long)gridDim.x * 4) {
     const T* __restrict__ ar = a + row * ncols;
     acc_t<T> acc = zero<acc_t<T>>();
+    if (vec) {  // 16-byte loads: V elements per lane per trip (ncols % V == 0, bases 16-byte aligned)
+      constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
 #pragma unroll 4
-    for (long long j = lane; j < ncols; j += 64) fma_acc(acc, ar[j], xf[j]);
+      for (long long j = (long long)lane * V; j < ncols; j += 64 * V) {
+        T av[V], xv[V];
+        load_chunk<T, V>(ar + j, av);
+        load_chunk<T, V>(xf + j, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) fma_acc(acc, av[e], xv[e]);
+      }
+    } else {
+#pragma unroll 4
+      for (long long j = lane; j < ncols; j += 64) fma_acc(acc, ar[j], xf[j]);
+    }
     acc = wave_sum(acc);
     if (lane == 0) {
       const T xi = xl[row];
@@ -953,8 +983,10 @@ int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T*
                     hipStream_t s) {
   const long long want = (op.n_local + 3) / 4;
   const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
+  constexpr long long V = (long long)(16 / sizeof(T)) > 0 ? (long long)(16 / sizeof(T)) : 1;
+  const int vec = op.n % V == 0 && (reinterpret_cast<uintptr_t>(x_full) & 15) == 0 ? 1 : 0;  // rows then start 16-B aligned
   hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(grid), dim3(kBlock), 0, s, (long long)op.n_local, (long long)op.n,
-                     (const T*)op.d_dense, x_full, x_local, y, offset, dot_partials);
+                     (const T*)op.d_dense, x_full, x_local, y, offset, dot_partials, vec);
   LL_HIP(hipGetLastError());
   return grid;
 }
@@ -1062,23 +1094,6 @@ __global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T*
 // move as 16-byte pieces and only the two fast-dimension end neighbours are scalar loads.  Needs the fastest
 // dimension, the shard start and the shard length to be multiples of V (then no chunk straddles a lattice row or a
 // shard / halo boundary); same accumulation order per site as stencil_kernel, so both give identical bits.
-template <typename T, int V> __device__ __forceinline__ void load_chunk(const T* __restrict__ p, T (&r)[V]) {
-  constexpr int NCH = (int)(V * sizeof(T) / 16);
-  const uint4* src = reinterpret_cast<const uint4*>(p);
-  uint4 c[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) c[i] = src[i];
-  __builtin_memcpy(&r[0], c, sizeof(c));
-}
-template <typename T, int V> __device__ __forceinline__ void store_chunk(T* __restrict__ p, const T (&r)[V]) {
-  constexpr int NCH = (int)(V * sizeof(T) / 16);
-  uint4 c[NCH];
-  __builtin_memcpy(c, &r[0], sizeof(c));
-  uint4* dst = reinterpret_cast<uint4*>(p);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) dst[i] = c[i];
-}
-
 template <typename T, typename IDX, int V>
 __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, const T* __restrict__ xl,
                                                              const T* __restrict__ lo, const T* __restrict__ hi,
