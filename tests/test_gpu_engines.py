@@ -374,6 +374,11 @@ def test_sharded_path_with_single_rank_communicator(oracle):
     ctx2 = L.Context(0)
     ctx2.init_comm(L.Context.unique_id(), 0, 1)
     assert ctx2.partition(n) == (0, n)
+    import ctypes as C
+
+    r, w = C.c_int(-1), C.c_int(-1)
+    L.capi.check(L.capi.lib().ll_comm_rank(ctx2.handle, C.byref(r), C.byref(w)))
+    assert (r.value, w.value) == (0, 1)
     out = {}
     for label, c in (("comm", ctx2), ("plain", L.Context(0))):
         for kind in (L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB):

@@ -100,6 +100,20 @@ def test_spmv_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
     op.close()
 
 
+def test_device_memory_helpers(ctx):
+    """ll_malloc / ll_memset / ll_memcpy_{h2d,d2h} / ll_free round trip."""
+    import ctypes as C
+
+    a = ctx.empty(1000)
+    a.set(np.arange(1000.0))
+    L.capi.check(L.capi.lib().ll_memset(ctx.handle, C.c_void_p(a.ptr + 8 * 100), 0, 8 * 300))
+    got = a.get()
+    want = np.arange(1000.0)
+    want[100:400] = 0.0
+    assert np.array_equal(got, want)
+    a.free()
+
+
 def test_inner_product_convention(ctx):
     """T1:47-59: <(3, 1+3i), (3, 2+4i)> = 23 - 2i — conjugate-linear in the FIRST argument (LA:41,49)."""
     a = ctx.to_device(np.array([3.0, 1 + 3j]))
