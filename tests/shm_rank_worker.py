@@ -36,6 +36,11 @@ def main():
         vals, vecs = eng.run()
         res["randsym_" + label] = {"row_begin": rb, "n_local": nl, "vals": vals.tolist(), "vecs": [v.tolist() for v in vecs],
                                    "iters": eng.getIterationCounts(), "alpha": eng.last_alpha.tolist()}
+        if label == "csr":   # run_iteration with a sharded orthogonalizeTo list: the first eigenvector is locked
+            eng.max_iteration = 60
+            rv, rx, rit = eng.run_iteration(2, [vecs[0]])
+            res["run_iteration"] = {"vals": rv.tolist(), "vecs": [v.tolist() for v in rx], "itern": rit}
+            eng.max_iteration = 120
         # SpMV alone on a known vector
         xd, yd = ctx.to_device(init), ctx.empty(nl)
         dot = L.spmv(op, xd, yd, offset=0.5, want_dot=True)

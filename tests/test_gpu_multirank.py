@@ -65,6 +65,15 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, f
         y = stitch("spmv_" + label, "y")
         assert np.max(np.abs(y - y_ref)) <= 1e-12 * 40
         assert abs(ranks[0]["spmv_" + label]["dot"] - float(init @ y_ref)) <= 1e-9 * n
+    # ---- run_iteration with the first eigenvector as a sharded orthogonalizeTo list
+    lock = stitch("randsym_csr", "vecs", 0)
+    ori = oracle.run_iteration(csr, init, True, 2, orth=lock[None, :], max_iteration=60)
+    assert ranks[0]["run_iteration"]["itern"] == ori["itern"]
+    got_vals = np.array(ranks[0]["run_iteration"]["vals"])
+    assert np.max(np.abs(got_vals - ori["eigenvalues"])) <= 1e-9 * np.max(np.abs(got_vals))
+    for i in range(len(got_vals)):
+        v = stitch("run_iteration", "vecs", i)
+        assert abs(np.vdot(lock, v)) <= 1e-8 and 1 - overlap(v, ori["eigenvectors"][i]) <= 1e-6
     # ---- Laplacian
     lap = G.laplace2d_np(24)
     ora2 = oracle.lanczos(lap, G.start_vector(576, 1), False, offset=-8.0)
