@@ -20,17 +20,6 @@ namespace ll {
 
 namespace {
 
-struct Rot {
-  double c, s;
-};
-
-inline Rot make_rot(double x, double z) {  // TRI:151-166
-  if (z == 0.0) return {1.0, 0.0};
-  if (x == 0.0) return {0.0, 1.0};
-  const double h = std::sqrt(x * x + z * z);
-  return {x / h, z / h};
-}
-
 inline double sign_pos0(double v) { return v >= 0.0 ? 1.0 : -1.0; }  // CM:194-201
 
 // Rotate rows r and r+1 of the row-major m x m matrix q (TRI:223-231).
@@ -52,10 +41,12 @@ void sweep(double* al, double* be, double* q, int64_t m, int64_t lo, int64_t hi)
   for (int64_t i = lo; i < hi; ++i) {
     const double z = s * be[i];
     const double bprev = c * be[i];
-    const Rot r = make_rot(x, z);
-    c = r.c;
-    s = r.s;
-    if (i > lo) be[i - 1] = std::sqrt(x * x + z * z);
+    // one square root serves the rotation (TRI:151-166) and the new coupling (TRI:207): same expression, same bits
+    const double h = std::sqrt(x * x + z * z);
+    if (z == 0.0) { c = 1.0; s = 0.0; }
+    else if (x == 0.0) { c = 0.0; s = 1.0; }
+    else { c = x / h; s = z / h; }
+    if (i > lo) be[i - 1] = h;
     const double u = (al[i + 1] - al[i] + p) * s + 2.0 * c * bprev;
     al[i] = al[i] - p + s * u;
     p = s * u;
@@ -82,9 +73,12 @@ int64_t tridiag_qr(int64_t m, const double* alpha, const double* beta, double* e
   const double half_eps = std::numeric_limits<double>::epsilon() * 0.5;
   const double tiny = std::numeric_limits<double>::min();
   int64_t unconverged = 0, hi_prev = m - 1, stall = 1;
+  // The reference re-tests EVERY coupling before every sweep (TRI:257-266).  A sweep only changes al[lo..hi] and
+  // be[lo..hi-1], and be[lo-1] = be[hi] = 0 already, so after the first full scan only the block of the previous sweep
+  // can change its verdict: scanning that block alone zeroes exactly the same couplings at the same times.
+  int64_t scan_lo = 0, scan_hi = m - 1;
   for (;;) {
-    // deflate negligible couplings over the whole matrix (TRI:257-266) ...
-    for (int64_t i = 0; i + 1 < m; ++i)
+    for (int64_t i = scan_lo; i < scan_hi; ++i)
       if (std::abs(be[i]) < std::sqrt(std::abs(al[i]) * std::abs(al[i + 1])) * half_eps + tiny) be[i] = 0.0;
     // ... and locate the trailing unreduced block (TRI:268-275)
     int64_t hi = hi_prev;
@@ -93,6 +87,8 @@ int64_t tridiag_qr(int64_t m, const double* alpha, const double* beta, double* e
     while (lo > 0 && be[lo - 1] != 0.0) --lo;
     if (hi == 0) break;
     sweep(al.data(), be.data(), Q, m, lo, hi);
+    scan_lo = lo;
+    scan_hi = hi;
     const int64_t nsub = hi - lo + 1;
     if (hi == hi_prev) {
       if (stall > nsub * 50) {  // forced deflation (TRI:315-331); callers ignore the count (LL:44,268, EX:126)
