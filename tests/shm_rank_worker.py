@@ -114,6 +114,17 @@ def main():
     v6, x6 = e6.run()
     res["dense"] = {"vals": v6.tolist(), "vecs": [x6[0].tolist()], "iters": e6.getIterationCounts()}
     dn.close()
+    # --- fewer rows than ranks: the last shard(s) are empty
+    tiny = np.array([[2.0, 1.0], [1.0, 3.0]])
+    rb8, nl8 = ctx.partition(2)
+    rp8 = np.arange(nl8 + 1, dtype=np.int64) * 2
+    t_op = L.CsrOperator(ctx, rp8, np.tile(np.arange(2, dtype=np.int32), nl8), tiny[rb8:rb8 + nl8].reshape(-1), n_cols=2,
+                         row_begin=rb8)
+    e8 = L.LambdaLanczos(t_op, 2, True, 1)
+    e8.init_vector = lambda v, row_begin: np.copyto(v, np.array([1.0, 0.5])[row_begin:row_begin + v.shape[0]])
+    v8, x8 = e8.run()
+    res["tiny"] = {"vals": v8.tolist(), "vecs": [x8[0].tolist()], "n_local": nl8}
+    t_op.close()
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
         json.dump(res, f)
     ctx.close()

@@ -109,6 +109,12 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, f
     out5 = np.concatenate([list2c(r["stencil_3d"]["out"]) for r in ranks])
     assert abs(ranks[0]["stencil_3d"]["itern"] - it5) <= 1
     assert np.max(np.abs(out5 - o5)) <= 1e-10 * np.linalg.norm(x5)
+    # ---- 2 x 2 problem on `world` ranks (an empty shard when world = 3)
+    assert [r["tiny"]["n_local"] for r in ranks] == ([1, 1] if world == 2 else [1, 1, 0])
+    lam = (5 + np.sqrt(5)) / 2
+    assert abs(ranks[0]["tiny"]["vals"][0] - lam) <= 1e-12
+    v_t = stitch("tiny", "vecs", 0)
+    assert np.linalg.norm(np.array([[2.0, 1.0], [1.0, 3.0]]) @ v_t - lam * v_t) <= 1e-12
     dims_v = [12, 6, 8]
     n7 = int(np.prod(dims_v))
     c7 = G.lattice_csr(dims_v, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=[True, False, True],
