@@ -87,40 +87,47 @@ def test_lattice_apply_matches_oracle(ctx, oracle, name, dtype, offset):
     op.close()
 
 
-@pytest.mark.parametrize("name", ["vec_ring_4096", "vec_torus_48x96", "vec_mixed_3d", "vec_open_3d"])
-@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32, np.complex64])
-def test_vectorised_lattice_kernel_equals_scalar_kernel(name, dtype):
-    """The vectorised kernel adds every site's terms in the order of the one-site-per-lane kernel: identical bits.
-    (LL_STENCIL_VEC is read once per process, so the scalar run happens in a child process.)"""
+VEC_CASES = [(nm, dt) for nm in ("vec_ring_4096", "vec_torus_48x96", "vec_mixed_3d", "vec_open_3d")
+             for dt in ("float64", "complex128", "float32", "complex64")]
+
+
+def _apply_all_vec_cases(ctx):
+    out = {}
+    for nm, dt in VEC_CASES:
+        dims, kw = lattice(nm, np.dtype(dt).type)
+        n = int(np.prod(dims))
+        op = L.StencilOperator(ctx, dims, **kw)
+        x = rnd(n, np.dtype(dt).type, 21)
+        xd, yd = ctx.to_device(x), ctx.empty(n, x.dtype)
+        a = L.spmv(op, xd, yd, offset=0.5, want_dot=True)
+        out[nm + "/" + dt] = yd.get()
+        out[nm + "/" + dt + "/dot"] = np.array([a])
+        op.close()
+    return out
+
+
+def test_vectorised_lattice_kernel_equals_scalar_kernel(ctx, tmp_path):
+    """The vectorised kernel adds every site's terms in the order of the one-site-per-lane kernel: identical bits for
+    every storage type.  (LL_STENCIL_VEC is read once per process, so the scalar run happens in one child process.)"""
     import os
     import subprocess
     import sys
-    import tempfile
 
-    dims, kw = lattice(name, dtype)
-    n = int(np.prod(dims))
-    x = rnd(n, dtype, 21)
-    with tempfile.TemporaryDirectory() as tmp:
-        np.save(os.path.join(tmp, "x.npy"), x)
-        code = (
-            "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "scalar.npz")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import lambda_lanczos_amd as L; import test_gpu_operators as t\n"
-            "dims, kw = t.lattice(%r, np.dtype(%r).type); c = L.Context(0); op = L.StencilOperator(c, dims, **kw)\n"
-            "x = np.load(%r); xd, yd = c.to_device(x), c.empty(x.shape[0], x.dtype)\n"
-            "a = L.spmv(op, xd, yd, offset=0.5, want_dot=True); np.save(%r, yd.get()); np.save(%r, np.array([a]))\n"
-        )
-        outs = {}
-        for vec in ("1", "0"):
-            y_path, a_path = os.path.join(tmp, "y%s.npy" % vec), os.path.join(tmp, "a%s.npy" % vec)
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            src = code % (root, os.path.join(root, "tests"), name, np.dtype(dtype).name, os.path.join(tmp, "x.npy"), y_path,
-                          a_path)
-            r = subprocess.run([sys.executable, "-c", src], env=dict(os.environ, LL_STENCIL_VEC=vec), capture_output=True,
-                               text=True, timeout=120)
-            assert r.returncode == 0, r.stdout + r.stderr
-            outs[vec] = (np.load(y_path), np.load(a_path))
-    assert np.array_equal(outs["1"][0], outs["0"][0])
-    assert abs(outs["1"][1][0] - outs["0"][1][0]) <= 1e-12 * max(1.0, abs(outs["0"][1][0]))
+            "np.savez(%r, **t._apply_all_vec_cases(L.Context(0)))\n") % (root, os.path.join(root, "tests"), path)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LL_STENCIL_VEC="0"), capture_output=True, text=True,
+                       timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    scalar = np.load(path)
+    vec = _apply_all_vec_cases(ctx)
+    for key, val in vec.items():
+        if key.endswith("/dot"):
+            assert abs(val[0] - scalar[key][0]) <= 1e-12 * max(1.0, abs(scalar[key][0])), key
+        else:
+            assert np.array_equal(val, scalar[key]), key
 
 
 def test_dynamic_matrix_known_answer(ctx):
