@@ -40,7 +40,7 @@ def parse_args():
                     help="c3: random symmetric CSR n=1e7 nnz=1.5e8 (metric config); c3band: banded variant; "
                          "c2: 5-pt Laplacian n=1e6; c5: complex torus n=1e6 (Exponentiator)")
     ap.add_argument("--operator", default="csr", choices=["csr", "lattice"],
-                    help="c2 only: lattice = the matrix-free lattice operator (halo exchange instead of the all-gather)")
+                    help="c2 / c5: lattice = the matrix-free lattice operator (halo exchange instead of the all-gather)")
     ap.add_argument("--size", dest="n", type=int, default=0, help="override the problem size (grid side for c2/c5)")
     ap.add_argument("--window", type=int, default=100, help="Lanczos iterations per step (max_iteration)")
     ap.add_argument("--spmv-reps", type=int, default=20)
@@ -168,9 +168,17 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    lattice = args.operator == "lattice" and wl == "c2"
-    if lattice:
+    lattice = args.operator == "lattice" and wl in ("c2", "c5")
+    if lattice and wl == "c2":
         op = L.StencilOperator(ctx, [side, side], diag=4.0, hop=-1.0, row_begin=rb, n_local=nl)
+        name += ", matrix-free lattice operator"
+    elif lattice:  # config 5: Landau-gauge Peierls phases on the x hops, random on-site terms (generators.torus_np)
+        import math
+
+        onsite = G.u01(np.arange(rb, rb + nl, dtype=np.uint64)) - 0.5
+        op = L.StencilOperator(ctx, [side, side], diag=0.0, hop=[-1.0, -1.0], periodic=True, onsite=onsite,
+                               dtype=np.complex128, row_begin=rb, n_local=nl,
+                               phase_grad=[[0.0, 0.0], [2.0 * math.pi * 3.0 / side, 0.0]])
         name += ", matrix-free lattice operator"
     else:
         op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
@@ -193,7 +201,8 @@ def main():
     # ------------------------------------------------------------ SpMV kernel: HIP events on its own stream
     xd = ctx.to_device(init / np.linalg.norm(init))
     yd = ctx.empty(nl, dtype)
-    b_spmv = 2 * 8 * n if lattice else spmv_bytes(n, nnz, complex_)   # lattice: x read once, y written once
+    # lattice: x read once, y written once (+ the real on-site array of config 5)
+    b_spmv = (2 * (16 if complex_ else 8) * n + (8 * n if complex_ else 0)) if lattice else spmv_bytes(n, nnz, complex_)
     selected = -1 if lattice else op.selected_spmv()
     kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2", -1: "stencil_kernel"}
     spmv_variants = {}

@@ -172,9 +172,12 @@ template <typename T> class DenseMatrix : public DeviceOperator<T> {
 // on a row-major lattice dims[0] x dims[1] x .. (last index fastest), open or periodic per dimension.
 template <typename T> class LatticeOperator : public DeviceOperator<T> {
  public:
+  // phase_grad (optional, complex T): ndim x ndim row-major; the bond r -> r + e_d carries
+  // hop[d] * exp(i * sum_e phase_grad[d*ndim + e] * c_e(r)) — Peierls phases of a magnetic field.
   LatticeOperator(const std::vector<int64_t>& dims, double diag, const std::vector<std::complex<double>>& hop,
                   const std::vector<bool>& periodic, const std::vector<double>& onsite = {},
-                  Context ctx = Context::default_context(), int64_t row_begin = 0, int64_t n_local = -1)
+                  Context ctx = Context::default_context(), int64_t row_begin = 0, int64_t n_local = -1,
+                  const std::vector<double>& phase_grad = {})
       : DeviceOperator<T>(ctx) {
     if (dims.empty() || dims.size() > 3 || hop.size() != dims.size() || periodic.size() != dims.size())
       throw Error(LL_ERR_INVALID, "LatticeOperator: 1 to 3 dimensions, one hop and one periodic flag per dimension");
@@ -189,6 +192,11 @@ template <typename T> class LatticeOperator : public DeviceOperator<T> {
       n *= dims[k];
     }
     d.diag = diag;
+    if (!phase_grad.empty()) {
+      if (phase_grad.size() != dims.size() * dims.size()) throw Error(LL_ERR_INVALID, "LatticeOperator: phase_grad must be ndim x ndim");
+      for (size_t k = 0; k < dims.size(); ++k)
+        for (size_t e = 0; e < dims.size(); ++e) d.phase_grad[k][e] = phase_grad[k * dims.size() + e];
+    }
     if (n_local < 0) n_local = n;
     if (!onsite.empty() && (int64_t)onsite.size() != n_local) throw Error(LL_ERR_INVALID, "LatticeOperator: onsite size");
     ll_operator* op = nullptr;

@@ -172,7 +172,8 @@ int ll_op_create_dense_z(ll_context* ctx, int64_t n_rows_local, int64_t n_cols, 
  *     (src/samples/sample3_dynamic.cpp:17-22 and T1:265-273: open chain; T2:113-121: periodic ring; BASELINE
  *     config 2: 5-point Laplacian).  Sites of a row-major lattice dims[0] x .. x dims[ndim-1] (LAST index fastest,
  *     n = product of dims);
- *         (A x)(r) = (diag + onsite[r]) x(r) + sum_d ( hop[d] x(r + e_d) + conj(hop[d]) x(r - e_d) )
+ *         (A x)(r) = (diag + onsite[r]) x(r) + sum_d ( t_d(r) x(r + e_d) + conj(t_d(r - e_d)) x(r - e_d) ),  t_d = hop[d]
+ *     (times a position-dependent Peierls phase when phase_grad is set, see the struct)
  *     with open (periodic[d] = 0: the missing neighbour contributes nothing) or periodic boundaries per dimension.
  *     No matrix is stored: one apply moves 2 * sizeof(T) * n bytes (+ 8n for onsite) instead of the CSR image.
  *     Sharded contexts: flattened sites [row_begin, row_begin + n_local) per ll_partition; the exchange step is a
@@ -186,6 +187,11 @@ typedef struct ll_stencil_desc {
   double diag;
   double hop_re[3];
   double hop_im[3];
+  /* Peierls phases (complex types only; all 0 = none): the bond r -> r + e_d carries
+   *   hop[d] * exp(i * sum_e phase_grad[d][e] * c_e(r)),   c(r) = lattice coordinates of the bond's lower site r,
+   * and conj of that in the other direction.  Example (BASELINE config 5, Landau gauge on an N x N torus with dims =
+   * {y, x}): hop = {-1, -1}, phase_grad[1][0] = 2 pi 3 / N. */
+  double phase_grad[3][3];
 } ll_stencil_desc;
 int ll_op_create_stencil_d(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
                            const double* onsite_host_local, ll_operator** out);

@@ -69,6 +69,7 @@ class StencilDesc(C.Structure):
         ("diag", C.c_double),
         ("hop_re", C.c_double * 3),
         ("hop_im", C.c_double * 3),
+        ("phase_grad", (C.c_double * 3) * 3),
     ]
 
 

@@ -616,7 +616,10 @@ void create_stencil(ll_context* ctx, const ll_stencil_desc* d, int64_t row_begin
     LL_REQUIRE(d->dims[k] >= 1, "lattice dimensions must be positive");
     LL_REQUIRE(n <= ((int64_t)1 << 40) / d->dims[k], "lattice too large");
     n *= d->dims[k];
-    if (!scalar_traits<T>::is_complex) LL_REQUIRE(d->hop_im[k] == 0.0, "complex hopping needs a complex storage type");
+    if (!scalar_traits<T>::is_complex) {
+      LL_REQUIRE(d->hop_im[k] == 0.0, "complex hopping needs a complex storage type");
+      for (int e = 0; e < 3; ++e) LL_REQUIRE(d->phase_grad[k][e] == 0.0, "Peierls phases need a complex storage type");
+    }
   }
   std::unique_ptr<ll_operator> op(new ll_operator);
   op->kind = ll_operator::STENCIL;

@@ -1008,16 +1008,37 @@ struct StencilGeom {
   long long stride[3];
   double diag;
   double hop_re[3], hop_im[3];
+  // Peierls phases: the bond from site r to r + e_d carries hop[d] * exp(i * sum_e grad[d][e] * c_e(r)) (c = lattice
+  // coordinates of the bond's LOWER site r); the reverse direction carries the conjugate.  has_phase[d]: any grad != 0.
+  double grad[3][3];
+  int has_phase[3];
   long long halo;
   long long row_begin, n_local;
 };
-__device__ __forceinline__ double hop_value(const StencilGeom& g, int d, bool conj, double*) { return g.hop_re[d]; }
-__device__ __forceinline__ float hop_value(const StencilGeom& g, int d, bool conj, float*) { return (float)g.hop_re[d]; }
-__device__ __forceinline__ zc hop_value(const StencilGeom& g, int d, bool conj, zc*) {
-  return zc{g.hop_re[d], conj ? -g.hop_im[d] : g.hop_im[d]};
+__device__ __forceinline__ double hop_value(const StencilGeom& g, int d, bool conj, double phase, double*) {
+  return g.hop_re[d];
 }
-__device__ __forceinline__ cf hop_value(const StencilGeom& g, int d, bool conj, cf*) {
-  return cf{(float)g.hop_re[d], (float)(conj ? -g.hop_im[d] : g.hop_im[d])};
+__device__ __forceinline__ float hop_value(const StencilGeom& g, int d, bool conj, double phase, float*) {
+  return (float)g.hop_re[d];
+}
+__device__ __forceinline__ zc hop_value(const StencilGeom& g, int d, bool conj, double phase, zc*) {
+  double re = g.hop_re[d], im = g.hop_im[d];
+  if (g.has_phase[d]) {
+    double sn, cs;
+    sincos(phase, &sn, &cs);
+    const double r2 = re * cs - im * sn, i2 = re * sn + im * cs;
+    re = r2;
+    im = i2;
+  }
+  return zc{re, conj ? -im : im};
+}
+__device__ __forceinline__ cf hop_value(const StencilGeom& g, int d, bool conj, double phase, cf*) {
+  const zc h = hop_value(g, d, conj, phase, (zc*)nullptr);
+  return cf{(float)h.re, (float)h.im};
+}
+// phase of the bond whose lower site has the coordinates c
+__device__ __forceinline__ double bond_phase(const StencilGeom& g, int d, const long long (&c)[3]) {
+  return g.grad[d][0] * (double)c[0] + g.grad[d][1] * (double)c[1] + g.grad[d][2] * (double)c[2];
 }
 __device__ __forceinline__ void fma_real(double& acc, double r, double x) { acc = fma(r, x, acc); }
 __device__ __forceinline__ void fma_real(double& acc, double r, float x) { acc = fma(r, (double)x, acc); }
@@ -1063,7 +1084,11 @@ __global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T*
         if (c[d] > 0) off = -g.stride[d];
         else if (g.periodic[d]) off = d == 0 ? -g.stride[0] : (g.dims[d] - 1) * g.stride[d];  // dim 0 wraps on the ring
         else have = false;
-        if (have) fma_acc(acc, hop_value(g, d, true, (T*)nullptr), fetch(li + off));
+        // the bond's lower site is the neighbour: one step down in dimension d (dims[d]-1 steps up across the wrap)
+        if (have) {
+          const double ph = g.has_phase[d] ? bond_phase(g, d, c) - g.grad[d][d] * (c[d] > 0 ? 1.0 : -(double)(g.dims[d] - 1)) : 0.0;
+          fma_acc(acc, hop_value(g, d, true, ph, (T*)nullptr), fetch(li + off));
+        }
       }
     }
     const T xi = xl[li];
@@ -1077,7 +1102,7 @@ __global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T*
         if (c[d] + 1 < g.dims[d]) off = g.stride[d];
         else if (g.periodic[d]) off = d == 0 ? g.stride[0] : -(g.dims[d] - 1) * g.stride[d];
         else have = false;
-        if (have) fma_acc(acc, hop_value(g, d, false, (T*)nullptr), fetch(li + off));
+        if (have) fma_acc(acc, hop_value(g, d, false, g.has_phase[d] ? bond_phase(g, d, c) : 0.0, (T*)nullptr), fetch(li + off));
       }
     }
     const T yi = add(narrow<T>(acc), rmul(offset, xi));
@@ -1124,6 +1149,19 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
     }
     T ctr[V];
     load_chunk<T, V>(xl + li, ctr);
+    // Peierls phase of site e's upward / downward bond in dimension d: the scalar kernel's expressions, site by site
+    auto upper_phase = [&](int d, int e) -> double {
+      if (!g.has_phase[d]) return 0.0;
+      long long ce[3] = {c[0], c[1], c[2]};
+      ce[last] += e;
+      return bond_phase(g, d, ce);
+    };
+    auto lower_phase = [&](int d, int e) -> double {
+      if (!g.has_phase[d]) return 0.0;
+      long long ce[3] = {c[0], c[1], c[2]};
+      ce[last] += e;
+      return bond_phase(g, d, ce) - g.grad[d][d] * (ce[d] > 0 ? 1.0 : -(double)(g.dims[d] - 1));
+    };
     acc_t<T> acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = zero<acc_t<T>>();
@@ -1139,20 +1177,27 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
         if (have) {
           T nb[V];
           load_chunk<T, V>(chunk_ptr(li + off), nb);
-          const T hv = hop_value(g, d, true, (T*)nullptr);
+          // the phase is evaluated per site with the scalar kernel's expression (identical bits); it is the same for
+          // the whole chunk unless it depends on the fastest coordinate
+          const bool varies = g.has_phase[d] && g.grad[d][last] != 0.0;
+          const T hv = hop_value(g, d, true, lower_phase(d, 0), (T*)nullptr);
 #pragma unroll
-          for (int e = 0; e < V; ++e) fma_acc(acc[e], hv, nb[e]);
+          for (int e = 0; e < V; ++e)
+            fma_acc(acc[e], varies && e > 0 ? hop_value(g, d, true, lower_phase(d, e), (T*)nullptr) : hv, nb[e]);
         }
       } else if (d == last) {
-        const T hv = hop_value(g, d, true, (T*)nullptr);
+        // fastest dimension: site e's lower neighbour is site e-1 of the chunk
+        const bool varies = g.has_phase[d] && g.grad[d][d] != 0.0;
         bool have = true;
         T left = zero<T>();
         if (c[last] > 0) left = fetch(li - 1);
         else if (g.periodic[last]) left = fetch(last == 0 ? li - 1 : li + (dl - 1));  // dimension 0 wraps on the ring
         else have = false;
-        if (have) fma_acc(acc[0], hv, left);
+        if (have) fma_acc(acc[0], hop_value(g, d, true, lower_phase(d, 0), (T*)nullptr), left);
+        const T hv = hop_value(g, d, true, lower_phase(d, 1), (T*)nullptr);
 #pragma unroll
-        for (int e = 1; e < V; ++e) fma_acc(acc[e], hv, ctr[e - 1]);
+        for (int e = 1; e < V; ++e)
+          fma_acc(acc[e], varies && e > 1 ? hop_value(g, d, true, lower_phase(d, e), (T*)nullptr) : hv, ctr[e - 1]);
       }
     }
     if (onsite) {
@@ -1166,15 +1211,17 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
     }
     // upper neighbours, fastest dimension first
     {
-      const T hv = hop_value(g, last, false, (T*)nullptr);
+      const bool varies = g.has_phase[last] && g.grad[last][last] != 0.0;
+      const T hv = hop_value(g, last, false, upper_phase(last, 0), (T*)nullptr);
 #pragma unroll
-      for (int e = 0; e + 1 < V; ++e) fma_acc(acc[e], hv, ctr[e + 1]);
+      for (int e = 0; e + 1 < V; ++e)
+        fma_acc(acc[e], varies && e > 0 ? hop_value(g, last, false, upper_phase(last, e), (T*)nullptr) : hv, ctr[e + 1]);
       bool have = true;
       T right = zero<T>();
       if (c[last] + V < dl) right = fetch(li + V);
       else if (g.periodic[last]) right = fetch(last == 0 ? li + V : li + V - dl);
       else have = false;
-      if (have) fma_acc(acc[V - 1], hv, right);
+      if (have) fma_acc(acc[V - 1], varies ? hop_value(g, last, false, upper_phase(last, V - 1), (T*)nullptr) : hv, right);
     }
 #pragma unroll
     for (int d = 2; d >= 0; --d) {
@@ -1187,9 +1234,11 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
         if (have) {
           T nb[V];
           load_chunk<T, V>(chunk_ptr(li + off), nb);
-          const T hv = hop_value(g, d, false, (T*)nullptr);
+          const bool varies = g.has_phase[d] && g.grad[d][last] != 0.0;
+          const T hv = hop_value(g, d, false, upper_phase(d, 0), (T*)nullptr);
 #pragma unroll
-          for (int e = 0; e < V; ++e) fma_acc(acc[e], hv, nb[e]);
+          for (int e = 0; e < V; ++e)
+            fma_acc(acc[e], varies && e > 0 ? hop_value(g, d, false, upper_phase(d, e), (T*)nullptr) : hv, nb[e]);
         }
       }
     }
@@ -1218,6 +1267,11 @@ int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, co
     g.stride[d] = d < g.ndim ? op.st_stride[d] : 0;
     g.hop_re[d] = op.st.hop_re[d];
     g.hop_im[d] = op.st.hop_im[d];
+    g.has_phase[d] = 0;
+    for (int e = 0; e < 3; ++e) {
+      g.grad[d][e] = (d < g.ndim && e < g.ndim) ? op.st.phase_grad[d][e] : 0.0;
+      if (g.grad[d][e] != 0.0) g.has_phase[d] = 1;
+    }
   }
   g.diag = op.st.diag;
   g.halo = op.st_halo;

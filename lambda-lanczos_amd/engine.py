@@ -230,10 +230,11 @@ class DenseOperator(_Operator):
 class StencilOperator(_Operator):
     """Matrix-free lattice operator (sample3_dynamic.cpp:17-22, T1:265-273, T2:113-121):
     (A x)(r) = (diag + onsite[r]) x(r) + sum_d (hop[d] x(r+e_d) + conj(hop[d]) x(r-e_d)) on a row-major lattice
-    `dims` (last index fastest), open or periodic per dimension.  Sharded contexts pass their ll_partition range."""
+    `dims` (last index fastest), open or periodic per dimension; phase_grad (ndim x ndim, complex types) adds Peierls
+    phases exp(i * phase_grad[d] . coords(lower site)) to the hops.  Sharded contexts pass their ll_partition range."""
 
     def __init__(self, ctx, dims, diag=0.0, hop=-1.0, periodic=False, onsite=None, dtype=np.float64, row_begin=0,
-                 n_local=None):
+                 n_local=None, phase_grad=None):
         dims = [int(d) for d in np.atleast_1d(dims)]
         nd = len(dims)
         if not 1 <= nd <= 3:
@@ -246,6 +247,11 @@ class StencilOperator(_Operator):
             d.dims[k], d.periodic[k] = dims[k], int(periodic[k])
             d.hop_re[k], d.hop_im[k] = float(hop[k].real), float(hop[k].imag)
         d.diag = float(diag)
+        if phase_grad is not None:  # Peierls phases: bond r -> r+e_d carries hop[d] * exp(i * phase_grad[d] . coords(r))
+            pg = np.asarray(phase_grad, dtype=np.float64).reshape(nd, nd)
+            for k in range(nd):
+                for e in range(nd):
+                    d.phase_grad[k][e] = float(pg[k, e])
         self.ctx, self.dtype = ctx, np.dtype(dtype)
         self.n = int(np.prod(dims))
         self.n_local = self.n if n_local is None else int(n_local)

@@ -141,7 +141,8 @@ def chain_csr(n, t=-1.0):
     return coo_to_csr(n, rows, cols, np.full(len(rows), t))
 
 
-def lattice_csr(dims, diag=0.0, hop=-1.0, periodic=False, onsite=None, dtype=np.float64, row_begin=0, n_local=None):
+def lattice_csr(dims, diag=0.0, hop=-1.0, periodic=False, onsite=None, dtype=np.float64, row_begin=0, n_local=None,
+                phase_grad=None):
     """CSR image of the matrix-free lattice operator (ll_op_create_stencil_*): rows [row_begin, row_begin+n_local),
     entries in the operator's own order (lower neighbours slowest dimension first, diagonal, upper neighbours fastest
     first); a neighbour reached twice (periodic dimension of length 1 or 2) appears twice."""
@@ -156,13 +157,21 @@ def lattice_csr(dims, diag=0.0, hop=-1.0, periodic=False, onsite=None, dtype=np.
     strides = [int(np.prod(dims[k + 1:])) for k in range(nd)]
     cols, vals, have = [], [], []
 
+    pg = None if phase_grad is None else np.asarray(phase_grad, dtype=np.float64).reshape(nd, nd)
+
     def neighbour(k, sign):
         c = coords[k] + sign
         ok = (c >= 0) & (c < dims[k])
         if periodic[k]:
             c, ok = c % dims[k], np.ones_like(ok)
         cols.append(r + (c - coords[k]) * strides[k])
-        vals.append(np.full(n_local, np.conj(hop[k]) if sign < 0 else hop[k]))
+        t = np.full(n_local, hop[k])
+        if pg is not None and np.any(pg[k] != 0):   # Peierls phase taken at the bond's LOWER site
+            low = [cc.copy() for cc in coords]
+            if sign < 0:
+                low[k] = c
+            t = t * np.exp(1j * sum(pg[k, e] * low[e] for e in range(nd)))
+        vals.append(np.conj(t) if sign < 0 else t)
         have.append(ok)
 
     for k in range(nd):

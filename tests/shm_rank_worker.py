@@ -96,7 +96,8 @@ def main():
     n7 = int(np.prod(dims_v))
     rb7, nl7 = ctx.partition(n7)
     stv = L.StencilOperator(ctx, dims_v, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=[True, False, True],
-                            onsite=0.3 * np.cos(np.arange(rb7, rb7 + nl7)), dtype=np.complex128, row_begin=rb7, n_local=nl7)
+                            onsite=0.3 * np.cos(np.arange(rb7, rb7 + nl7)), dtype=np.complex128, row_begin=rb7, n_local=nl7,
+                            phase_grad=[[0.1, 0.2, 0.3], [0.0, 0.4, -0.2], [0.5, 0.0, 0.7]])
     x7 = G.start_vector(nl7, 5, np.complex128, rb7)
     xd, yd = ctx.to_device(x7), ctx.empty(nl7, np.complex128)
     dot7 = L.spmv(stv, xd, yd, offset=0.25, want_dot=True)

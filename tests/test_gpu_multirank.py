@@ -118,7 +118,8 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, f
     dims_v = [12, 6, 8]
     n7 = int(np.prod(dims_v))
     c7 = G.lattice_csr(dims_v, diag=0.25, hop=[0.5 + 1j, -1.0, 0.75j], periodic=[True, False, True],
-                       onsite=0.3 * np.cos(np.arange(n7)), dtype=np.complex128)
+                       onsite=0.3 * np.cos(np.arange(n7)), dtype=np.complex128,
+                       phase_grad=[[0.1, 0.2, 0.3], [0.0, 0.4, -0.2], [0.5, 0.0, 0.7]])
     x7 = G.start_vector(n7, 5, np.complex128)
     y7 = oracle.spmv(c7, x7) + 0.25 * x7
     got7 = np.concatenate([list2c(r["stencil_vec"]["y"]) for r in ranks])

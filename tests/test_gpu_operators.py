@@ -40,13 +40,25 @@ COMPLEX_HOPS = {"vec_ring_4096": 0.3 - 1j, "vec_torus_48x96": [-1.0 + 0.2j, 0.5j
                 "thin_3d": [1.0 + 1j, -1j, 0.5], "slab_3d": [-1.0, -0.5 + 0.5j, 0.25j]}
 
 
+# Peierls phases (complex storage types only): phase_grad[d][e] = d(phase of the hop along d) / d(coordinate e)
+PHASES = {"vec_torus_48x96": [[0.0, 0.0], [2 * math.pi * 3 / 48, 0.0]],                 # config 5's Landau gauge
+          "torus_300x257": [[0.0, 0.01], [0.02, 0.0]],
+          "mixed_3d": [[0.1, 0.2, 0.3], [0.0, 0.4, -0.2], [0.5, 0.0, 0.7]],             # every kind of dependence
+          "vec_mixed_3d": [[0.1, 0.2, 0.3], [0.0, 0.4, -0.2], [0.5, 0.0, 0.7]],
+          "vec_ring_4096": [[0.003]]}
+
+
 def lattice(name, dtype):
     dims, diag, hop, periodic, with_onsite = LATTICES[name]
-    if np.issubdtype(np.dtype(dtype), np.complexfloating) and name in COMPLEX_HOPS:
+    cplx = np.issubdtype(np.dtype(dtype), np.complexfloating)
+    if cplx and name in COMPLEX_HOPS:
         hop = COMPLEX_HOPS[name]
     n = int(np.prod(dims))
     onsite = 0.3 * np.cos(1.7 * np.arange(n)) if with_onsite else None
-    return dims, dict(diag=diag, hop=hop, periodic=periodic, onsite=onsite, dtype=dtype)
+    kw = dict(diag=diag, hop=hop, periodic=periodic, onsite=onsite, dtype=dtype)
+    if cplx and name in PHASES:
+        kw["phase_grad"] = PHASES[name]
+    return dims, kw
 
 
 def rnd(n, dtype, seed):
@@ -193,9 +205,37 @@ def test_lattice_exponentiate_large_matrix(ctx):
     op.close()
 
 
+def test_config5_torus_as_a_lattice_operator(ctx, oracle):
+    """BASELINE config 5 (complex Hermitian torus, Landau-gauge Peierls phases on the x hops, random on-site terms)
+    expressed matrix-free: the same matrix as generators.torus_np entry by entry, the same exp(-i H dt) v and iteration
+    count as the oracle on the CSR form."""
+    N = 48
+    n = N * N
+    csr = G.torus_np(N)
+    onsite = G.u01(np.arange(n, dtype=np.uint64)) - 0.5
+    kw = dict(diag=0.0, hop=[-1.0, -1.0], periodic=True, onsite=onsite, dtype=np.complex128,
+              phase_grad=[[0.0, 0.0], [2 * math.pi * 3 / N, 0.0]])
+    as_csr = G.lattice_csr([N, N], **kw)
+    import scipy.sparse as sp
+
+    d = sp.csr_matrix((as_csr[2], as_csr[1], as_csr[0]), shape=(n, n)) - sp.csr_matrix((csr[2], csr[1], csr[0]), shape=(n, n))
+    assert abs(d).max() <= 1e-15
+    op = L.StencilOperator(ctx, [N, N], **kw)
+    inp = G.start_vector(n, 1, np.complex128)
+    for dt in (0.1, 1.0):
+        out, it = L.Exponentiator(op, n).run(-1j * dt, inp)
+        o_ref, it_ref, _ = oracle.expo(csr, -1j * dt, inp)
+        assert it == it_ref
+        assert np.max(np.abs(out - o_ref)) <= 1e-11 * np.linalg.norm(inp)
+        assert abs(np.linalg.norm(out) / np.linalg.norm(inp) - 1) <= 1e-12
+    op.close()
+
+
 def test_lattice_rejects_bad_arguments(ctx):
     with pytest.raises(L.LanczosHipError):
         L.StencilOperator(ctx, [4, 4], hop=[1j, 1.0], dtype=np.float64)      # complex hop, real storage
+    with pytest.raises(L.LanczosHipError):
+        L.StencilOperator(ctx, [4, 4], phase_grad=[[0, 0.1], [0, 0]], dtype=np.float32)   # phases, real storage
     with pytest.raises(L.LanczosHipError):
         L.StencilOperator(ctx, [4, 0])
     with pytest.raises((L.LanczosHipError, ValueError)):
