@@ -209,7 +209,7 @@ template <typename T> static int max_vecs_per_launch() { return (1536 - 1) / sca
 
 template <typename T>
 NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
-                         bool first_pass_only) {
+                         bool first_pass_only, Publish* publish) {
   hipStream_t s = ctx->stream;
   const int nb = runs.total();
   const bool sharded = ctx->comm != nullptr;
@@ -224,8 +224,13 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     none.ld = runs.ld;
     ctx->ensure_partials(kMaxGrid);
     const int grid = launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, s);
-    launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
-    all_reduce(c + 1, 1);
+    if (publish && !sharded) {
+      launch_reduce_publish(ctx->d_partials, grid, c + 1, publish->alpha, nullptr, publish->host, s);
+      publish->done = true;
+    } else {
+      launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
+      all_reduce(c + 1, 1);
+    }
     return plain_norm(c + 1);
   }
 
@@ -288,8 +293,13 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, s);
     off += count_of(groups[g]);
   }
-  launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
-  all_reduce(c + 1, 1);
+  if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS) {
+    launch_reduce_publish(ctx->d_partials, grid, c + 1, publish->alpha, c, publish->host, s);
+    publish->done = true;
+  } else {
+    launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
+    all_reduce(c + 1, 1);
+  }
   if (first_pass_only && mode == LL_ORTH_CGS_DGKS) {
     if (h_total) LL_HIP(hipMemcpyAsync(h_total, h1, (size_t)R * nb * sizeof(double), hipMemcpyDeviceToDevice, s));
     return NormRefs{c, c + 1, c + 1, 0};  // final norm = c1; (c0, c1) go to the host through publish
@@ -467,6 +477,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   const int mode = P.orth_mode;
   const double dgks_thr = dgks_threshold();
+  const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
   Engine<T> E(ctx, op, nl);
   constexpr int R = scalar_traits<T>::reals;
 
@@ -553,8 +564,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       runs.ld = ld;
       runs.add(d_locked.p, L);  // P5
       runs.add_basis(U, k);     // P6
-      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true);  // ... P7
-      launch_publish(ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), refs, s);
+      typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
+      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, fuse_publish ? &pub : nullptr);  // ... P7
+      if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
       LL_HIP(hipEventRecord(ring.ev[slot], s));
       launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
       timer.mark();
@@ -836,6 +848,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   Engine<T> E(ctx, op, nl);
   const double dgks_thr = dgks_threshold();
+  const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
   Basis<T> U;
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
   ctx->ensure_pinned(16);
@@ -869,8 +882,9 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     RunList<T> runs;
     runs.ld = ld;
     if (P.full_orthogonalize) runs.add_basis(U, k);  // EX:120-122
-    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true);  // EX:145
-    launch_publish(ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), refs, s);
+    typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
+    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, fuse_publish ? &pub : nullptr);  // EX:145
+    if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
     LL_HIP(hipEventRecord(ring.ev[slot], s));
     launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
     timer.mark();

@@ -72,8 +72,15 @@ template <typename T> struct Engine {
   // first_pass_only (whole-loop drivers, LL_ORTH_CGS_DGKS): enqueue pass 1 only and return refs whose final norm is
   // c1; the driver evaluates the DGKS test on the host from the published (c0, c1) one iteration later and runs the
   // rare second pass itself (second_pass below) — no predicated no-op launches or collectives per iteration.
+  // publish (nullable; single-GPU loops): where the iteration's four scalars go; when the final norm fold of this
+  // call can carry them (first_pass_only, no communicator) it does and sets publish->done.
+  struct Publish {
+    double* host;         // pinned, device-mapped slot of 4 doubles
+    const double* alpha;  // device scalar
+    bool done;
+  };
   NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
-                bool first_pass_only = false);
+                bool first_pass_only = false, Publish* publish = nullptr);
   // The deferred second pass on the already normalised vector u = w1/||w1||: orthogonalise against `runs` once more,
   // renormalise, and return ||u'||^2 (the factor by which beta^2 shrinks).  Synchronises the stream.
   double second_pass(T* u, const RunList<T>& runs);

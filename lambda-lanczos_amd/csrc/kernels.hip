@@ -763,6 +763,29 @@ __global__ __launch_bounds__(256) void reduce_one_kernel(const double* __restric
   double tot = block_sum(acc, red);
   if (threadIdx.x == 0) out[0] = tot;
 }
+// The fold of the post-update norm and the publish step in one launch (single-GPU whole-loop drivers): out[0] = sum of
+// the partials = ||w||^2 after the Gram-Schmidt pass, and the four per-iteration scalars (alpha, that norm, ||w||^2
+// before the pass, the norm again) go straight to the pinned host slot.
+__global__ __launch_bounds__(256) void reduce_publish_kernel(const double* __restrict__ partials, int nparts,
+                                                             double* __restrict__ out, const double* __restrict__ alpha,
+                                                             const double* __restrict__ c0, double* __restrict__ host) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 256) acc += partials[b];
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    out[0] = tot;
+    host[0] = alpha ? *alpha : 0.0;
+    host[1] = tot;
+    host[2] = c0 ? *c0 : 0.0;
+    host[3] = tot;
+  }
+}
+void launch_reduce_publish(const double* partials, int nparts, double* out, const double* alpha, const double* c0,
+                           double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_publish_kernel, dim3(1), dim3(256), 0, s, partials, nparts, out, alpha, c0, host_mapped);
+  LL_HIP(hipGetLastError());
+}
 // last_out (nullable): destination of the LAST column (the ||w||^2 column of mdot) instead of out[ncols-1].
 void launch_reduce_cols(const double* partials, int nparts, int ncols, double* out, double* last_out, hipStream_t s) {
   if (ncols == 1) {

@@ -237,6 +237,9 @@ int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_pa
 // last_out (nullable) redirects the last column.
 void launch_reduce_cols(const double* partials, int nparts, int ncols, double* out, double* last_out, hipStream_t s);
 void launch_copy_scalar(double* dst, const double* src, hipStream_t s);
+// reduce_one + publish in one launch: out[0] = sum(partials); host[0..4) = {*alpha, sum, *c0, sum} (alpha, c0 nullable)
+void launch_reduce_publish(const double* partials, int nparts, double* out, const double* alpha, const double* c0,
+                           double* host_mapped, hipStream_t s);
 void launch_set_scalar(double* dst, double value, hipStream_t s);
 
 // Multi-dot with optional fused three-term update.
