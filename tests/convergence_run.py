@@ -2,8 +2,11 @@
 """Time-to-convergence on the GPU with the reference's DEFAULT settings (nroot = 5, eps = 1e3*eps_machine) on the
 BASELINE configurations, with eigenpair checks (reported number (3)).
 
-    python tools/convergence_demo.py c3 [tridiag_mode]      # random symmetric n=1e7, largest eigenpair
-    python tools/convergence_demo.py c2 [tridiag_mode]      # 5-point Laplacian n=1e6, smallest, offset -8
+    python tests/convergence_run.py c3 [tridiag_mode]      # random symmetric n=1e7, largest eigenpair
+    python tests/convergence_run.py c2 [tridiag_mode]      # 5-point Laplacian n=1e6, smallest, offset -8
+
+Lives under tests/ because its optional second leg (DEMO_ORACLE_THREADS / DEMO_USE_REFERENCE) runs the same problem through
+the CPU checkers (oracle/, oracle/_ref) — test infrastructure that only tests/, smoke() and bench.py's cpu_baseline may use.
 """
 import json
 import os
