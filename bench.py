@@ -48,7 +48,11 @@ def parse_args():
     ap.add_argument("--eps", type=float, default=None,
                     help="override the engine's eps (0 = never converge: every run does exactly --window iterations)")
     ap.add_argument("--orth-mode", type=int, default=0)
-    ap.add_argument("--tridiag-mode", type=int, default=0)
+    ap.add_argument("--tridiag-mode", type=int, default=None,
+                    help="LL_TRIDIAG_*: 0 QR every iteration, 1 bisection, 2 auto (default: the library's default, auto)")
+    ap.add_argument("--watchdog", type=float, default=1500.0,
+                    help="seconds after which a job that has not finished prints a diagnostic and exits with code 3 "
+                         "(a hung collective must not look like a slow run); 0 = off")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="CPU-only check of the multi-process plumbing (rendezvous, id broadcast, partition, shard "
                          "generation, reductions over ranks); no device work, prints one JSON line per job")
@@ -73,11 +77,32 @@ def pmc_traffic(workload, kernels, dtype_tag):
         d = json.load(f)
     total = 0.0
     for k in kernels:
-        e = d["kernels"].get("%s<%s>" % (k, dtype_tag)) or d["kernels"].get("%s<%s, int>" % (k, dtype_tag))
-        if e is None:
+        # template arguments after the scalar type (unroll factors, index width) vary: match on the prefix
+        hits = [v for name, v in d["kernels"].items() if name.startswith("%s<%s" % (k, dtype_tag))]
+        if not hits:
             return None, None
+        e = max(hits, key=lambda v: v.get("launches", 0))
         total += e["fetch_bytes_mean"] + e["write_bytes_mean"]
     return total, os.path.relpath(files[-1], ROOT)
+
+
+STAGE = ["start"]  # where the job is, for the watchdog's diagnostic
+
+
+def start_watchdog(seconds, rank):
+    """A hung RCCL collective (or a rank that never arrives) would otherwise sit silently until the driver's own limit."""
+    if seconds <= 0:
+        return
+    import threading
+
+    def bark():
+        sys.stderr.write("bench.py watchdog: rank %d still in stage '%s' after %.0f s - giving up\n" % (rank, STAGE[0], seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    t = threading.Timer(seconds, bark)
+    t.daemon = True
+    t.start()
 
 
 def main():
@@ -85,6 +110,7 @@ def main():
     world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    start_watchdog(args.watchdog, rank)
     dist = None
     if world > 1:
         # torch.distributed.run pins OMP_NUM_THREADS=1 per worker; the host-side matrix generation and the PB image build
@@ -109,14 +135,17 @@ def main():
             dist.broadcast_object_list(box, src=0)
         uid = box[0]
     else:
-        # LL_BENCH_DEVICE: testing hook — several ranks on one GPU with the host-staged test transport (LL_COMM_BACKEND=shm)
+        # LL_BENCH_DEVICE: testing hook — several ranks on one GPU with the host-staged test transport (LL_COMM_PLUGIN)
         ctx = L.Context(int(os.environ.get("LL_BENCH_DEVICE", local_rank)))
         if world > 1:
+            STAGE[0] = "communicator init + self-check (all-gather of rank tags, all-reduce of ones)"
             box = [L.Context.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            ctx.init_comm(box[0], rank, world)
+            ctx.init_comm(box[0], rank, world)   # fails loudly unless all `world` ranks answer in rank order
+    ranks_seen = 1 if args.dry_run_dist else ctx.ranks_seen()
 
     # ------------------------------------------------------------ synthetic input, resident in HBM
+    STAGE[0] = "matrix generation + upload"
     t_gen = time.time()
     wl = args.workload
     complex_ = wl == "c5"
@@ -168,6 +197,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    t_up = 0.0
     lattice = args.operator == "lattice" and wl in ("c2", "c5")
     if lattice and wl == "c2":
         op = L.StencilOperator(ctx, [side, side], diag=4.0, hop=-1.0, row_begin=rb, n_local=nl)
@@ -181,7 +211,9 @@ def main():
                                phase_grad=[[0.0, 0.0], [2.0 * math.pi * 3.0 / side, 0.0]])
         name += ", matrix-free lattice operator"
     else:
+        t_up = time.time()
         op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
+        t_up = time.time() - t_up
     t_gen = time.time() - t_gen
 
     def barrier():
@@ -199,38 +231,35 @@ def main():
         return float(t.item())
 
     # ------------------------------------------------------------ SpMV kernel: HIP events on its own stream
+    STAGE[0] = "SpMV timing"
     xd = ctx.to_device(init / np.linalg.norm(init))
     yd = ctx.empty(nl, dtype)
     # lattice: x read once, y written once (+ the real on-site array of config 5)
     b_spmv = (2 * (16 if complex_ else 8) * n + (8 * n if complex_ else 0)) if lattice else spmv_bytes(n, nnz, complex_)
     selected = -1 if lattice else op.selected_spmv()
     kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2", -1: "stencil_kernel"}
-    spmv_variants = {}
-    for rnd in range(3):  # interleaved rounds in one process; the median is reported
-        for kind in ((-1,) if lattice else (L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB)):
-            try:
-                if not lattice:
-                    op.select_spmv(kind)
-            except L.LanczosHipError:
-                continue
+    # The operator timed both kernels on the actual matrix when it was created and released the slower image; those
+    # creation-time figures are reported next to the event timing of the kernel that is in use.
+    tune = None if lattice else dict(zip(("spmv_stream", "pb_phase1+pb_phase2"), op.autotune_ms()))
+    rounds = []
+    for rnd in range(3):
+        L.spmv(op, xd, yd)
+        barrier()
+        ctx.timer_start()
+        for _ in range(args.spmv_reps):
             L.spmv(op, xd, yd)
-            barrier()
-            ctx.timer_start()
-            for _ in range(args.spmv_reps):
-                L.spmv(op, xd, yd)
-            ms = max_over_ranks(ctx.timer_stop() / args.spmv_reps)
-            spmv_variants.setdefault(kernel_names[kind], []).append(ms)
-    if not lattice:
-        op.select_spmv(selected)
-    spmv_variants = {k: sorted(v)[len(v) // 2] for k, v in spmv_variants.items()}
-    spmv_ms = spmv_variants[kernel_names[selected]]
+        rounds.append(max_over_ranks(ctx.timer_stop() / args.spmv_reps))
+    spmv_ms = sorted(rounds)[len(rounds) // 2]
+    spmv_variants = {kernel_names[selected]: spmv_ms}
     spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
 
     # ------------------------------------------------------------ timed steps
+    STAGE[0] = "timed Lanczos windows"
     ctx.set_profiling(True)
     itern = []
     stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0, "seconds_host_enqueue": 0.0,
-                 "seconds_host_wait": 0.0, "seconds_setup": 0.0, "seconds_finish": 0.0, "seconds_total": 0.0}
+                 "seconds_host_wait": 0.0, "seconds_setup": 0.0, "seconds_finish": 0.0, "seconds_total": 0.0,
+                 "seconds_comm_gather": 0.0, "seconds_comm_allreduce": 0.0}
 
     if wl == "c5":
         eng = L.Exponentiator(op, n)
@@ -244,7 +273,8 @@ def main():
         eng.max_iteration = args.window
         eng.eigenvalue_offset = offset
         eng.orth_mode = args.orth_mode
-        eng.tridiag_mode = args.tridiag_mode
+        if args.tridiag_mode is not None:
+            eng.tridiag_mode = args.tridiag_mode
         if args.eps is not None:
             eng.eps = args.eps
         eng.init_vector = lambda v, *_: np.copyto(v, init)
@@ -274,9 +304,52 @@ def main():
         orth_bytes = sum(s * n * (2 * k + 9) for it in itern for k in range(1, it + 1))
     orth_s = max_over_ranks(stats_acc["seconds_orth"])
     spmv_loop_s = max_over_ranks(stats_acc["seconds_spmv"])
+    comm_gather_s = max_over_ranks(stats_acc["seconds_comm_gather"])
+    comm_allreduce_s = max_over_ranks(stats_acc["seconds_comm_allreduce"])
+    setup_by_rank = [t_gen]
+    upload_by_rank = [t_up]
+    if dist is not None:
+        import torch
+
+        tt = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tt, torch.tensor([t_gen, t_up], dtype=torch.float64))
+        setup_by_rank = [float(t[0]) for t in tt]
+        upload_by_rank = [float(t[1]) for t in tt]
 
     # ------------------------------------------------------------ CPU baseline (rank 0, N = 1 only; bounded sample)
+    STAGE[0] = "CPU baseline"
     cpu = None
+    if world == 1 and args.cpu_window > 0 and wl == "c5":
+        # config 5 runs fully on the CPU in seconds: the real Exponentiator<T>::run (EX:87-173) through
+        # oracle/_ref, same matrix, same input, same a = -5i; the whole run is the sample
+        import oracle_lib
+
+        kind = "reference" if oracle_lib.have_reference() else "port"
+        chk = oracle_lib.reference() if kind == "reference" else oracle_lib.oracle()
+        o_out, o_it, o_t = chk.expo((csr[0], csr[1], csr[2]), -5.0j, init, max_iteration=args.window)
+        barrier()
+        tg = time.perf_counter()
+        g_out, g_it = eng.run(-1j * 5.0, init)
+        barrier()
+        tg = time.perf_counter() - tg
+        err = float(np.max(np.abs(g_out - o_out)) / np.linalg.norm(init))
+        ovl = float(abs(np.vdot(o_out, g_out)) / (np.linalg.norm(o_out) * np.linalg.norm(g_out)))
+        cpu = {
+            "value": o_it / o_t["t_total"],
+            "unit": "Lanczos iterations/s",
+            "cores": 1,
+            "kind": kind,
+            "sample": "the whole run: Exponentiator::run, exp(-5iH)v on the same matrix and input, %d iterations, "
+                      "single thread like the reference" % o_it,
+            "seconds": o_t["t_total"],
+            "spmv_GBps": b_spmv * o_it / max(o_t["t_mv"], 1e-12) / 1e9,
+            "gpu_same_window_value": g_it / tg,
+            "parity_same_window": {"iterations_cpu": int(o_it), "iterations_gpu": int(g_it),
+                                   "max_abs_diff_over_input_norm": err, "one_minus_overlap": 1.0 - ovl,
+                                   "tolerance": "|out_gpu - out_cpu| <= 1e-10 |in|, 1 - overlap <= 10 eps, iterations within 1",
+                                   "ok": bool(err <= 1e-10 and 1.0 - ovl <= 10 * 2.3e-16 + 1e-15 and abs(int(o_it) - int(g_it)) <= 1)},
+            "host_cores_available": os.cpu_count(),
+        }
     if world == 1 and args.cpu_window > 0 and wl != "c5":
         import oracle_lib
 
@@ -317,7 +390,7 @@ def main():
         traffic, traffic_src = pmc_traffic(wl, kernel_names[selected].split("+"), "ll::zc" if complex_ else "double")
 
     cpu_all = None
-    if cpu is not None:
+    if cpu is not None and wl != "c5":
         # courtesy upper bound: the oracle port with OpenMP over all host cores, same sample
         import oracle_lib
 
@@ -368,14 +441,17 @@ def main():
                            total_iters / max(args.steps, 1), (total_iters / max(args.steps, 1) + 1) / 2,
                            "n/a" if wl == "c5" else "5"),
                 "iterations_per_step": total_iters / max(args.steps, 1),
-                "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL %s" % (world, "halo exchange" if lattice else "all-gather of x"),
+                "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL %s" % (
+                    world, "halo exchange" if lattice else "all-gather of x in chunks on a second stream, own-column SpMV under it"),
                 "orth_mode": args.orth_mode,
-                "tridiag_mode": args.tridiag_mode,
+                "tridiag_mode": int(eng.tridiag_mode) if hasattr(eng, "tridiag_mode") else None,
                 "eps": "engine default" if args.eps is None else args.eps,
             },
+            "rccl_ranks_seen": ranks_seen,
             "spmv": {"GBps": spmv_gbs, "ms": spmv_ms, "algorithmic_bytes": b_spmv, "frac_of_8TBps": spmv_gbs / HBM_PEAK_GBS,
-                     "kernel": kernel_names[selected] + " (picked by timing both at upload)",
-                     "ms_by_kernel": spmv_variants},
+                     "kernel": kernel_names[selected] + " (picked by timing both at upload; the other image is released)",
+                     "ms_by_kernel": spmv_variants, "creation_time_autotune_ms": tune,
+                     "includes_exchange": world > 1},
             "roofline": {
                 "kernel": kernel_names[selected],
                 "launch": "one SpMV y = A x (pb: two back-to-back kernels), HIP events on the library stream, "
@@ -409,7 +485,11 @@ def main():
                 "host_s_ritz_finish": stats_acc["seconds_finish"],
                 "library_s_total": stats_acc["seconds_total"],
                 "wall_s": elapsed,
-                "setup_s_generate_upload": t_gen,
+                "device_s_comm_gather": comm_gather_s,
+                "device_s_comm_allreduce": comm_allreduce_s,
+                "setup_s_generate_upload": max(setup_by_rank),
+                "setup_s_generate_upload_by_rank": setup_by_rank,
+                "setup_s_operator_create_by_rank": upload_by_rank,
             },
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,

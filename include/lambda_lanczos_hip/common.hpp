@@ -8,6 +8,7 @@
 #include <functional>
 #include <cstdint>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -221,6 +222,30 @@ template <typename T> struct HostOp {
       return 0;
     } catch (...) {
       return 1;
+    }
+  }
+};
+
+// The default of the public init_vector member (lambda_lanczos.hpp:133 points it at VectorRandomInitializer<T>::init,
+// :70-104): every element — real and imaginary part for complex T — uniform in [-1, 1] from a std::random_device
+// seeded mt19937.  Callable like the reference's, so user code that invokes engine.init_vector(v) keeps working.
+template <typename T> struct RandomInit {
+  static void init(std::vector<T>& v) {
+    std::random_device dev;
+    std::mt19937 mt(dev());
+    std::uniform_real_distribution<T> rand((T)(-1.0), (T)(1.0));
+    for (auto& e : v) e = rand(mt);
+  }
+};
+template <typename R> struct RandomInit<std::complex<R>> {
+  static void init(std::vector<std::complex<R>>& v) {
+    std::random_device dev;
+    std::mt19937 mt(dev());
+    std::uniform_real_distribution<R> rand((R)(-1.0), (R)(1.0));
+    for (auto& e : v) {
+      const R re = rand(mt);  // real part first, like the reference's constructor-argument order in practice
+      const R im = rand(mt);
+      e = std::complex<R>(re, im);
     }
   }
 };

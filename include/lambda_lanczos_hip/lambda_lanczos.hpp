@@ -27,7 +27,7 @@ template <typename T> class LambdaLanczos {
  public:
   // ---- the reference's public data members (lambda_lanczos.hpp:126-181), same names / types / defaults
   std::function<void(const std::vector<T>& in, std::vector<T>& out)> mv_mul;            // :126
-  std::function<void(std::vector<T>& vec)> init_vector;                                   // :133 (empty = random default, :70-104)
+  std::function<void(std::vector<T>& vec)> init_vector = detail::RandomInit<T>::init;     // :133 (callable default, :70-104)
   size_t matrix_size;                                                                     // :136
   size_t max_iteration;                                                                   // :138
   real_t<T> eps = std::numeric_limits<real_t<T>>::epsilon() * 1e3;                        // :150
@@ -36,8 +36,8 @@ template <typename T> class LambdaLanczos {
   real_t<T> eigenvalue_offset = 0.0;                                                      // :165
   size_t num_eigs_per_iteration = 5;                                                      // :173
   size_t initial_vector_size = 200;                                                       // :181
-  // ---- additions (defaults = reference-faithful behaviour)
-  int tridiag_mode = LL_TRIDIAG_QR;   // how the per-iteration Ritz values are obtained (LL_TRIDIAG_*)
+  // ---- additions (the defaults reproduce the reference's decisions and values)
+  int tridiag_mode = LL_TRIDIAG_AUTO;  // how the per-iteration Ritz values are obtained (LL_TRIDIAG_*)
   int orth_mode = LL_ORTH_CGS_DGKS;   // Gram-Schmidt variant (LL_ORTH_*)
 
   // Reference constructor (lambda_lanczos.hpp:200-208): unmodified user code, host callback operator.
@@ -83,7 +83,7 @@ template <typename T> class LambdaLanczos {
   // container of std::vector<T> with cbegin()/cend(), like the reference's Iterable).  Returns the iteration count.
   template <typename Iterable>
   size_t run_iteration(std::vector<real_t<T>>& eigvalues, std::vector<std::vector<T>>& eigvecs, size_t nroot,
-                       Iterable orthogonalizeTo) {
+                       Iterable orthogonalizeTo) const {
     const size_t n_local = csr_ ? (size_t)csr_->local_rows() : matrix_size;
     ll_lanczos_params p = make_params(1);
     detail::InitHook<T> hook{init_vector};
@@ -165,7 +165,7 @@ template <typename T> class LambdaLanczos {
   Context ctx_;
   std::shared_ptr<DeviceOperator<T>> csr_;
   std::vector<size_t> iter_counts_;
-  ll_run_stats last_stats_{};
+  mutable ll_run_stats last_stats_{};  // run_iteration is const like the reference's (lambda_lanczos.hpp:216-220)
 };
 
 }  // namespace lambda_lanczos_hip

@@ -96,6 +96,11 @@ int ll_comm_unique_id(void* id_out_128);
 /* Collective over all ranks. After it, operators created on this context are row shards. */
 int ll_comm_init(ll_context* ctx, const void* id_128, int rank, int n_ranks);
 int ll_comm_rank(ll_context* ctx, int* rank, int* n_ranks);
+/* ll_comm_init ends with a self-check (every rank's tag through an all-gather on the communication stream, a sum of
+ * ones through an all-reduce on the compute stream) and fails with LL_ERR_RCCL when the communicator does not span
+ * n_ranks ranks in rank order.  This returns how many rank tags arrived (== n_ranks after a successful init; 1 without
+ * a communicator) so that a launcher can print it next to its results. */
+int ll_comm_ranks_seen(ll_context* ctx, int* out);
 /* The contiguous row range of `rank`: shards of ceil(n / n_ranks) rows (the last ones may be shorter or empty).
  * Sharded operators and vectors must use exactly these ranges (the all-gather relies on equal shard strides). */
 int ll_partition(int64_t n, int n_ranks, int rank, int64_t* row_begin, int64_t* n_local);
@@ -198,17 +203,21 @@ int ll_op_create_stencil_d(ll_context* ctx, const ll_stencil_desc* desc, int64_t
 int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
                            const double* onsite_host_local, ll_operator** out);
 
-/* Which SpMV kernel a CSR operator uses (results agree to rounding):
- *   LL_SPMV_CSR_STREAM  plain CSR, products staged in LDS, bit-reproducible sums; best when the x gathers hit
- *                       L1/L2 (stencils, narrow bands).
- *   LL_SPMV_PB          propagation blocking: the same matrix re-ordered once at upload so that one SpMV is two
- *                       fully coalesced streaming sweeps with x and y slices in LDS and no global gather; best for
- *                       matrices without column locality (BASELINE config 3).
- * ll_op_create_csr_{d,z} and _csr_dev_ (one copy back to the host) build both images, time them on the device and keep the faster one
- * (override: environment LL_SPMV_KERNEL=csr|pb, or this call). */
+/* Which SpMV kernel a CSR operator uses (results agree to rounding; both are bit-reproducible run to run):
+ *   LL_SPMV_CSR_STREAM  plain CSR, products staged in LDS; best when the x gathers hit L1/L2 (stencils, narrow bands).
+ *   LL_SPMV_PB          propagation blocking: the same matrix re-ordered once at upload (on the device) so that one
+ *                       SpMV is two fully coalesced streaming sweeps with x and y slices in LDS and no global gather;
+ *                       best for matrices without column locality (BASELINE config 3).  On sharded contexts its
+ *                       own-column part runs under the all-gather.
+ * ll_op_create_csr_{d,z} and _csr_dev_ build both images, time them on the device with the actual matrix (sharded
+ * contexts: summed over the ranks, so every rank takes the same decision), keep the faster one and RELEASE the other
+ * (for BASELINE config 3 that returns 1.8 GB of CSR arrays).  Environment: LL_SPMV_KERNEL=csr|pb skips the timing,
+ * LL_SPMV_KEEP_BOTH=1 keeps both images so that ll_op_select_spmv can switch later (A/B timing, tests). */
 enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1 };
 int ll_op_select_spmv(ll_operator* op, int kind);
 int ll_op_selected_spmv(const ll_operator* op, int* kind_out);
+/* Milliseconds the creation-time timing measured per kernel on this rank (-1: that kernel was not timed). */
+int ll_op_autotune_ms(const ll_operator* op, double* csr_stream_ms, double* pb_ms);
 int ll_op_destroy(ll_operator* op);
 /* Global dimension n, local rows, nnz held locally (0 for callbacks). */
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz_local);
@@ -320,6 +329,8 @@ typedef struct ll_run_stats {
   double seconds_setup;        /* start vector, locked vectors (per pass) */
   double seconds_finish;       /* Ritz step: tridiagonal eigenvectors, GEMV over the basis, copy back */
   int64_t second_passes;       /* iterations whose Gram-Schmidt was repeated (DGKS test decided on the host) */
+  double seconds_comm_gather;    /* device time of the all-gathers / halo exchanges (their own stream; 0 unless profiling) */
+  double seconds_comm_allreduce; /* device time of the all-reduces (0 unless profiling) */
 } ll_run_stats;
 int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 

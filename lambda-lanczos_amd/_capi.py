@@ -87,6 +87,8 @@ class RunStats(C.Structure):
         ("seconds_setup", f64),
         ("seconds_finish", f64),
         ("second_passes", i64),
+        ("seconds_comm_gather", f64),
+        ("seconds_comm_allreduce", f64),
     ]
 
     def as_dict(self):
@@ -110,6 +112,8 @@ PROTOTYPES = {
     "ll_comm_unique_id": (C.c_int, [vp]),
     "ll_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "ll_comm_rank": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
+    "ll_comm_ranks_seen": (C.c_int, [vp, P(C.c_int)]),
+    "ll_comm_attach": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "ll_partition": (C.c_int, [i64, C.c_int, C.c_int, P(i64), P(i64)]),
     "ll_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
     "ll_free": (C.c_int, [vp, vp]),
@@ -133,6 +137,7 @@ PROTOTYPES = {
     "ll_op_create_device_z": (C.c_int, [vp, i64, DEV_MV_FN, vp, P(vp)]),
     "ll_op_select_spmv": (C.c_int, [vp, C.c_int]),
     "ll_op_selected_spmv": (C.c_int, [vp, P(C.c_int)]),
+    "ll_op_autotune_ms": (C.c_int, [vp, P(f64), P(f64)]),
     "ll_op_destroy": (C.c_int, [vp]),
     "ll_op_info": (C.c_int, [vp, P(i64), P(i64), P(i64)]),
     "ll_spmv_d": (C.c_int, [vp, vp, vp, vp, f64, P(f64)]),

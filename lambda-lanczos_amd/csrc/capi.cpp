@@ -19,19 +19,34 @@ using namespace ll;
 // ---------------------------------------------------------------- context workspace
 static size_t grow(size_t have, size_t want) { return std::max(want, have + have / 2 + 64); }
 
+void ll_context::dev_malloc(void** out, size_t bytes, const char* what) {
+  hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16));
+  if (e != hipSuccess && !slab_cache.empty()) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream);
+    for (auto& c : slab_cache) (void)hipFree(c.first);
+    slab_cache.clear();
+    e = hipMalloc(out, std::max<size_t>(bytes, 16));
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error(std::string("out of device memory: ") + what + " (" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    throw Failure{LL_ERR_ALLOC};
+  }
+}
 void ll_context::ensure_partials(size_t doubles) {
   if (doubles <= partials_cap) return;
   if (d_partials) LL_HIP(hipFree(d_partials));
   d_partials = nullptr;
   partials_cap = grow(partials_cap, doubles);
-  LL_HIP(hipMalloc((void**)&d_partials, partials_cap * sizeof(double)));
+  dev_malloc((void**)&d_partials, partials_cap * sizeof(double), "partial sums");
 }
 void ll_context::ensure_h(size_t doubles) {
   if (doubles <= h_cap) return;
   if (d_h) LL_HIP(hipFree(d_h));
   d_h = nullptr;
   h_cap = grow(h_cap, doubles);
-  LL_HIP(hipMalloc((void**)&d_h, h_cap * sizeof(double)));
+  dev_malloc((void**)&d_h, h_cap * sizeof(double), "projection coefficients");
 }
 void ll_context::ensure_pinned(size_t doubles) {
   if (doubles <= pinned_cap) return;
@@ -50,21 +65,21 @@ void ll_context::ensure_coeff(size_t bytes) {
   if (d_coeff) LL_HIP(hipFree(d_coeff));
   d_coeff = nullptr;
   coeff_cap = grow(coeff_cap, bytes);
-  LL_HIP(hipMalloc(&d_coeff, coeff_cap));
+  dev_malloc(&d_coeff, coeff_cap, "Ritz coefficients");
 }
 void ll_context::ensure_xfull(size_t bytes) {
   if (bytes <= xfull_cap) return;
   if (d_xfull) LL_HIP(hipFree(d_xfull));
   d_xfull = nullptr;
   xfull_cap = bytes;
-  LL_HIP(hipMalloc(&d_xfull, xfull_cap));
+  dev_malloc(&d_xfull, xfull_cap, "gathered vector");
 }
 void ll_context::ensure_halo(size_t bytes) {
   if (bytes <= halo_cap) return;
   if (d_halo) LL_HIP(hipFree(d_halo));
   d_halo = nullptr;
   halo_cap = bytes;
-  LL_HIP(hipMalloc(&d_halo, halo_cap));
+  dev_malloc(&d_halo, halo_cap, "halo buffer");
 }
 void* ll_context::ensure_stage(size_t bytes) {
   if (bytes <= stage_cap) return h_stage;
@@ -74,13 +89,38 @@ void* ll_context::ensure_stage(size_t bytes) {
   LL_HIP(hipHostMalloc(&h_stage, stage_cap, hipHostMallocDefault));
   return h_stage;
 }
+void* ll_context::ensure_cb_stage(size_t bytes) {
+  if (bytes <= cb_cap) return h_cb;
+  LL_HIP(hipStreamSynchronize(stream));  // an H2D copy out of the old buffer may still be in flight
+  if (h_cb) LL_HIP(hipHostFree(h_cb));
+  h_cb = nullptr;
+  cb_cap = grow(cb_cap, bytes);
+  LL_HIP(hipHostMalloc(&h_cb, cb_cap, hipHostMallocDefault));
+  return h_cb;
+}
 void ll_context::sync() { LL_HIP(hipStreamSynchronize(stream)); }
+void ll_context::drain_comm_events(double* gather_s, double* allreduce_s) {
+  auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* acc) {
+    for (auto& p : v) {
+      float ms = 0.f;
+      if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess && acc)
+        *acc += ms * 1e-3;
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    v.clear();
+  };
+  drain(ev_gather, gather_s);
+  drain(ev_allreduce, allreduce_s);
+  (void)hipGetLastError();
+}
 
 // ---------------------------------------------------------------- operator storage
 ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
-                  (void*)d_pb_rptr, d_pb_val, (void*)d_pb_col, (void*)d_pb_row, d_pb_prod})
+                  (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_val, (void*)d_pb_col, (void*)d_pb_row,
+                  d_pb_prod})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -149,12 +189,20 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    ctx->drain_comm_events(nullptr, nullptr);
     comm_destroy(ctx->comm);
+    if (ctx->ev_x_ready) (void)hipEventDestroy(ctx->ev_x_ready);
+    for (auto e : ctx->ev_chunk)
+      if (e) (void)hipEventDestroy(e);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_h) (void)hipFree(ctx->d_h);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_cb) (void)hipHostFree(ctx->h_cb);
+    if (ctx->ev_cb) (void)hipEventDestroy(ctx->ev_cb);
     if (ctx->d_coeff) (void)hipFree(ctx->d_coeff);
     if (ctx->d_xfull) (void)hipFree(ctx->d_xfull);
     if (ctx->d_halo) (void)hipFree(ctx->d_halo);
@@ -189,6 +237,7 @@ int ll_ctx_set_profiling(ll_context* ctx, int enabled) {
   return guarded([&] {
     LL_REQUIRE(ctx != nullptr, "null context");
     ctx->profiling = enabled != 0;
+    if (!ctx->profiling) ctx->drain_comm_events(nullptr, nullptr);
   });
 }
 
@@ -222,6 +271,49 @@ int ll_comm_unique_id(void* id) {
     comm_unique_id(id);
   });
 }
+extern "C++" {
+namespace {
+// After the communicator exists: the second stream + events of the overlapped exchange, and a SELF-CHECK — every rank
+// contributes (rank + 1) to an all-gather and the constant 1 to an all-reduce; a communicator that silently spans
+// fewer ranks than asked for (or delivers shards in another order) fails here instead of producing a wrong spectrum.
+void finish_comm_setup(ll_context* ctx) {
+  if (const char* e = std::getenv("LL_COMM_OVERLAP")) ctx->overlap = std::atoi(e) != 0;
+  LL_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  LL_HIP(hipEventCreateWithFlags(&ctx->ev_x_ready, hipEventDisableTiming));
+  for (auto& e : ctx->ev_chunk) LL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const int P = ctx->nranks;
+  double* d = nullptr;
+  LL_HIP(hipMalloc((void**)&d, (size_t)(P + 2) * sizeof(double)));
+  struct Free {
+    void* p;
+    ~Free() { (void)hipFree(p); }
+  } guard{d};
+  std::vector<double> h((size_t)P + 2, 0.0);
+  h[(size_t)P] = (double)(ctx->rank + 1);  // send slot
+  h[(size_t)P + 1] = 1.0;                  // all-reduce slot
+  LL_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  // the gather runs on the communication stream, the reduction on the compute stream: the two-stream order of the loop
+  LL_HIP(hipEventRecord(ctx->ev_x_ready, ctx->stream));
+  LL_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_x_ready, 0));
+  comm_allgather(ctx->comm, d + P, d, sizeof(double), ctx->comm_stream);
+  LL_HIP(hipEventRecord(ctx->ev_chunk[0], ctx->comm_stream));
+  LL_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_chunk[0], 0));
+  comm_allreduce_sum(ctx->comm, d + P + 1, 1, ctx->stream);
+  LL_HIP(hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LL_HIP(hipStreamSynchronize(ctx->stream));
+  int seen = 0;
+  for (int r = 0; r < P; ++r)
+    if (h[(size_t)r] == (double)(r + 1)) ++seen;
+  ctx->ranks_seen = seen;
+  if (seen != P || h[(size_t)P + 1] != (double)P) {
+    set_error("communicator self-check failed: all-gather delivered " + std::to_string(seen) + " of " + std::to_string(P) +
+              " rank tags, all-reduce of ones gave " + std::to_string(h[(size_t)P + 1]));
+    throw Failure{LL_ERR_RCCL};
+  }
+}
+}  // namespace
+}  // extern "C++"
+
 int ll_comm_init(ll_context* ctx, const void* id, int rank, int n_ranks) {
   return guarded([&] {
     use(ctx);
@@ -231,6 +323,26 @@ int ll_comm_init(ll_context* ctx, const void* id, int rank, int n_ranks) {
     ctx->comm = comm_create(id, rank, n_ranks, ctx->device);
     ctx->rank = rank;
     ctx->nranks = n_ranks;
+    finish_comm_setup(ctx);
+  });
+}
+int ll_comm_attach(ll_context* ctx, const ll_transport* transport, int rank, int n_ranks) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(transport && transport->all_gather && transport->all_reduce_sum_f64 && transport->halo_exchange,
+               "incomplete transport table");
+    LL_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank out of range");
+    LL_REQUIRE(ctx->comm == nullptr, "communicator already attached");
+    ctx->comm = comm_attach(transport, rank, n_ranks);
+    ctx->rank = rank;
+    ctx->nranks = n_ranks;
+    finish_comm_setup(ctx);
+  });
+}
+int ll_comm_ranks_seen(ll_context* ctx, int* out) {
+  return guarded([&] {
+    LL_REQUIRE(ctx != nullptr && out != nullptr, "null argument");
+    *out = ctx->comm ? ctx->ranks_seen : 1;
   });
 }
 int ll_comm_rank(ll_context* ctx, int* rank, int* n_ranks) {
@@ -319,153 +431,123 @@ void finish_csr(ll_operator* op, const int64_t* rp_host) {
   std::vector<int32_t> tiles;
   build_tiles(rp_host, nr, tiles);
   op->ntiles = (int)tiles.size() - 1;
-  LL_HIP(hipMalloc((void**)&op->d_tile_rows, tiles.size() * sizeof(int32_t)));
+  ctx->dev_malloc((void**)&op->d_tile_rows, tiles.size() * sizeof(int32_t), "SpMV tiles");
   LL_HIP(hipMemcpy(op->d_tile_rows, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   // 64-bit row offsets once nnz exceeds int32 (LL_FORCE_RP64=1: exercise that kernel variant on small test matrices)
   op->rp64 = op->nnz > (int64_t)0x7fffffff || (std::getenv("LL_FORCE_RP64") && std::atoi(std::getenv("LL_FORCE_RP64")) != 0);
   if (op->rp64) {
-    LL_HIP(hipMalloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int64_t)));
+    ctx->dev_malloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int64_t), "row offsets");
     LL_HIP(hipMemcpy(op->d_row_ptr, rp_host, (size_t)(nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   } else {
     std::vector<int32_t> rp32((size_t)nr + 1);
     for (int64_t i = 0; i <= nr; ++i) rp32[i] = (int32_t)rp_host[i];
-    LL_HIP(hipMalloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int32_t)));
+    ctx->dev_malloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int32_t), "row offsets");
     LL_HIP(hipMemcpy(op->d_row_ptr, rp32.data(), (size_t)(nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   (void)ctx;
 }
 
-// Propagation-blocked image (kernels.hip pb_phase1/pb_phase2): the entries in column-block order (values + 16-bit
-// local columns) and the matching row-block order (16-bit local rows), plus the segment tables that connect them.
-// A segment = all entries of one (column block, row block) pair; inside a segment both orders agree (row-major,
-// original order within a row), so destination = segment base + offset.
-template <typename T>
-bool build_pb(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va) {
-  const int64_t nr = op->n_local, nc = op->n;
-  const bool z = scalar_traits<T>::is_complex;
-  // LDS budget per workgroup (160 KiB): phase 1 holds the x slice + two tables of nrb entries, phase 2 only the y slice
-  (void)z;
-  const int64_t col_max = std::min<int64_t>(65536, (104 * 1024) / (int64_t)sizeof(T));          // x slice <= 104 KiB
-  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)sizeof(acc_t<T>));   // y slice <= 152 KiB
-  auto block_len = [&](int64_t len, int64_t slice_max, const char* env) {
-    int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
-    int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
-    if (const char* e = std::getenv("LL_PB_BLOCK")) b = std::max(4, std::atoi(e));
-    if (const char* e = std::getenv(env)) b = std::max(4, std::atoi(e));
-    return std::min<int64_t>(b, slice_max);
-  };
-  const int64_t cb_cols = block_len(nc, col_max, "LL_PB_COL_BLOCK"), rb_rows = block_len(nr, row_max, "LL_PB_ROW_BLOCK");
-  const int64_t ncb = (nc + cb_cols - 1) / cb_cols, nrb = std::max<int64_t>(1, (nr + rb_rows - 1) / rb_rows);
-  if (ncb * nrb > (int64_t)24 << 20) return false;  // segment tables would not pay off (n beyond ~6e7): keep CSR
-  // segment sizes
-  std::vector<int64_t> cnt((size_t)ncb * nrb, 0);
-#pragma omp parallel for schedule(dynamic, 2)
-  for (int64_t r = 0; r < nrb; ++r) {
-    const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
-    for (int64_t p = rp[i0]; p < rp[i1]; ++p) ++cnt[(size_t)(ci[p] / cb_cols) * nrb + r];
+// Row ranges of a sharded operator must be the ll_partition() ones (equal shard strides).
+void set_partition(ll_context* ctx, ll_operator* op, int64_t n, int64_t row_begin, int64_t n_local) {
+  op->n = n;
+  op->n_local = n_local;
+  op->row_begin = row_begin;
+  if (ctx->nranks > 1) {
+    op->n_shard = (n + ctx->nranks - 1) / ctx->nranks;
+    LL_REQUIRE(row_begin == std::min<int64_t>(n, op->n_shard * ctx->rank) &&
+                   n_local == std::min<int64_t>(n, op->n_shard * (ctx->rank + 1)) - row_begin,
+               "sharded operators must use the ll_partition() row ranges");
+  } else {
+    op->n_shard = n;
+    LL_REQUIRE(row_begin == 0 && n_local == n, "a single-GPU context needs the whole operator (row_begin 0, n_local == n)");
   }
-  // every segment is padded to 16 entries: kernels move quads (4 entries per lane, 16-byte accesses) and every run of
-  // products written by phase 1 starts and ends on a 128-byte line (measured 3.5 % faster than quad padding)
-  int64_t pad = 16;
-  if (const char* e = std::getenv("LL_PB_PAD")) pad = std::max(4, std::atoi(e) / 4 * 4);
-  for (auto& v : cnt) v = (v + pad - 1) / pad * pad;
-  // column-block order: segments (c, r) with r fastest; row-block order: (r, c) with c fastest
-  std::vector<int64_t> segq((size_t)ncb * (nrb + 1)), segdest((size_t)ncb * nrb), rptr((size_t)nrb + 1);
-  {
-    int64_t q = 0;
-    for (int64_t c = 0; c < ncb; ++c) {
-      for (int64_t r = 0; r < nrb; ++r) {
-        segq[(size_t)c * (nrb + 1) + r] = q;
-        q += cnt[(size_t)c * nrb + r];
-      }
-      segq[(size_t)c * (nrb + 1) + nrb] = q;
-    }
-    int64_t d = 0;
-    for (int64_t r = 0; r < nrb; ++r) {
-      rptr[(size_t)r] = d;
-      for (int64_t c = 0; c < ncb; ++c) {
-        segdest[(size_t)c * nrb + r] = d;
-        d += cnt[(size_t)c * nrb + r];
-      }
-    }
-    rptr[(size_t)nrb] = d;
-  }
-  const size_t nnz = (size_t)rptr[(size_t)nrb];  // padded entry count
-  std::vector<T> pval(std::max<size_t>(nnz, 4));
-  std::memset((void*)pval.data(), 0, pval.size() * sizeof(T));
-  std::vector<uint16_t> pcol(std::max<size_t>(nnz, 4), 0), prow(std::max<size_t>(nnz, 4), 0);
-#pragma omp parallel
-  {
-    std::vector<int64_t> fill((size_t)ncb);
-#pragma omp for schedule(dynamic, 2)
-    for (int64_t r = 0; r < nrb; ++r) {
-      std::fill(fill.begin(), fill.end(), 0);
-      const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
-      for (int64_t i = i0; i < i1; ++i)
-        for (int64_t p = rp[i]; p < rp[i + 1]; ++p) {
-          const int64_t c = ci[p] / cb_cols;
-          const int64_t off = fill[(size_t)c]++;
-          const int64_t q = segq[(size_t)c * (nrb + 1) + r] + off;
-          pval[(size_t)q] = va[p];
-          pcol[(size_t)q] = (uint16_t)(ci[p] - c * cb_cols);
-          prow[(size_t)(segdest[(size_t)c * nrb + r] + off)] = (uint16_t)(i - i0);
-        }
-    }
-  }
-  op->pb_ncb = (int)ncb;
-  op->pb_nrb = (int)nrb;
-  op->pb_cb_cols = (int)cb_cols;
-  op->pb_rb_rows = (int)rb_rows;
-  auto up = [](void** dst, const void* src, size_t bytes) {
-    LL_HIP(hipMalloc(dst, std::max<size_t>(bytes, 8)));
-    LL_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-  };
-  up((void**)&op->d_pb_segq, segq.data(), segq.size() * sizeof(int64_t));
-  up((void**)&op->d_pb_segdest, segdest.data(), segdest.size() * sizeof(int64_t));
-  up((void**)&op->d_pb_rptr, rptr.data(), rptr.size() * sizeof(int64_t));
-  up(&op->d_pb_val, pval.data(), nnz * sizeof(T));
-  up((void**)&op->d_pb_col, pcol.data(), nnz * sizeof(uint16_t));
-  up((void**)&op->d_pb_row, prow.data(), nnz * sizeof(uint16_t));
-  LL_HIP(hipMalloc(&op->d_pb_prod, std::max<size_t>(nnz, 4) * sizeof(T)));
-  return true;
 }
 
-// Time both SpMV kernels on the device with the actual matrix and keep the faster one.
+// Drop the device arrays of the SpMV image that is NOT selected (LL_SPMV_KEEP_BOTH=1 keeps both for A/B timing).
+void release_unselected_image(ll_operator* op) {
+  if (const char* e = std::getenv("LL_SPMV_KEEP_BOTH"))
+    if (std::atoi(e) != 0) return;
+  auto drop = [](auto*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+  };
+  if (op->spmv_kind == LL_SPMV_PB) {  // CSR-stream needs row_ptr / col / val / tiles; PB needs none of them
+    if (op->owns_arrays) {
+      drop(op->d_col);
+      drop(op->d_val);
+    } else {
+      op->d_col = nullptr;  // the caller's arrays: just forget them
+      op->d_val = nullptr;
+    }
+    drop(op->d_row_ptr);
+    drop(op->d_tile_rows);
+    op->ntiles = 0;
+  } else {
+    drop(op->d_pb_segq);
+    drop(op->d_pb_segdest);
+    drop(op->d_pb_rptr);
+    drop(op->d_pb_xoff);
+    drop(op->d_pb_ncols);
+    drop(op->d_pb_val);
+    drop(op->d_pb_col);
+    drop(op->d_pb_row);
+    drop(op->d_pb_prod);
+    op->pb_ncb = op->pb_nrb = 0;
+  }
+}
+
+// Time both SpMV kernels on the device with the actual matrix and keep the faster one.  Sharded contexts decide on
+// the SUM of the per-rank times, so every rank runs the same kernel (the exchange plan depends on it).  A kernel
+// whose launch fails is simply not a candidate.
 template <typename T> void autotune_spmv(ll_operator* op) {
   ll_context* ctx = op->ctx;
   hipStream_t s = ctx->stream;
   const size_t xn = (size_t)std::max<int64_t>(op->n, op->n_shard * std::max(1, ctx->nranks));
-  T *x = nullptr, *y = nullptr;
-  LL_HIP(hipMalloc((void**)&x, xn * sizeof(T)));
-  LL_HIP(hipMalloc((void**)&y, (size_t)std::max<int64_t>(op->n_local, 1) * sizeof(T)));
-  LL_HIP(hipMemsetAsync(x, 0, xn * sizeof(T), s));
-  hipEvent_t e0, e1;
-  LL_HIP(hipEventCreate(&e0));
-  LL_HIP(hipEventCreate(&e1));
-  float best = 0.f;
-  int best_kind = LL_SPMV_CSR_STREAM;
-  for (int kind : {LL_SPMV_CSR_STREAM, LL_SPMV_PB}) {
-    float t_kind = 1e30f;
-    for (int rep = 0; rep < 3; ++rep) {
-      LL_HIP(hipEventRecord(e0, s));
-      if (kind == LL_SPMV_PB) launch_spmv_pb<T>(*op, x, x + op->row_begin, y, 0.0, nullptr, s);
-      else launch_spmv<T>(*op, x, x + op->row_begin, y, 0.0, nullptr, s);
-      LL_HIP(hipEventRecord(e1, s));
-      LL_HIP(hipEventSynchronize(e1));
-      float ms = 0.f;
-      LL_HIP(hipEventElapsedTime(&ms, e0, e1));
-      if (rep > 0) t_kind = std::min(t_kind, ms);
+  struct Scratch {
+    T *x = nullptr, *y = nullptr;
+    double* t = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (x) (void)hipFree(x);
+      if (y) (void)hipFree(y);
+      if (t) (void)hipFree(t);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
     }
-    if (kind == LL_SPMV_CSR_STREAM || t_kind < best) {
-      best = t_kind;
-      best_kind = kind;
+  } w;
+  ctx->dev_malloc((void**)&w.x, xn * sizeof(T), "autotune x");
+  ctx->dev_malloc((void**)&w.y, (size_t)std::max<int64_t>(op->n_local, 1) * sizeof(T), "autotune y");
+  ctx->dev_malloc((void**)&w.t, 2 * sizeof(double), "autotune scalars");
+  LL_HIP(hipMemsetAsync(w.x, 0, xn * sizeof(T), s));
+  LL_HIP(hipEventCreate(&w.e0));
+  LL_HIP(hipEventCreate(&w.e1));
+  double t_kind[2] = {1e30, 1e30};
+  for (int kind : {LL_SPMV_CSR_STREAM, LL_SPMV_PB}) {
+    try {
+      for (int rep = 0; rep < 3; ++rep) {
+        LL_HIP(hipEventRecord(w.e0, s));
+        if (kind == LL_SPMV_PB) launch_spmv_pb<T>(*op, w.x, w.x + op->row_begin, w.x + op->row_begin, w.y, 0.0, nullptr, s);
+        else launch_spmv<T>(*op, w.x, w.x + op->row_begin, w.y, 0.0, nullptr, s);
+        LL_HIP(hipEventRecord(w.e1, s));
+        LL_HIP(hipEventSynchronize(w.e1));
+        float ms = 0.f;
+        LL_HIP(hipEventElapsedTime(&ms, w.e0, w.e1));
+        if (rep > 0) t_kind[kind] = std::min(t_kind[kind], (double)ms);
+      }
+    } catch (const Failure&) {  // e.g. a launch the device refuses: not a candidate, and not an error of the operator
+      (void)hipGetLastError();
+      t_kind[kind] = 1e30;
     }
   }
-  op->spmv_kind = best_kind;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(x);
-  (void)hipFree(y);
+  op->tune_ms[0] = (float)t_kind[0];
+  op->tune_ms[1] = (float)t_kind[1];
+  if (ctx->comm != nullptr) {
+    LL_HIP(hipMemcpyAsync(w.t, t_kind, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    comm_allreduce_sum(ctx->comm, w.t, 2, s);
+    LL_HIP(hipMemcpyAsync(t_kind, w.t, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    LL_HIP(hipStreamSynchronize(s));
+  }
+  op->spmv_kind = t_kind[LL_SPMV_PB] < t_kind[LL_SPMV_CSR_STREAM] ? LL_SPMV_PB : LL_SPMV_CSR_STREAM;
 }
 
 template <typename T>
@@ -489,93 +571,64 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   op->is_complex = scalar_traits<T>::is_complex;
   op->elem_bytes = (int)sizeof(T);
   op->ctx = ctx;
-  op->n = nc;
-  op->n_local = nr;
-  op->row_begin = row_begin;
+  set_partition(ctx, op.get(), nc, row_begin, nr);
   op->nnz = rp_host[nr];
-  if (ctx->nranks > 1) {
-    op->n_shard = (nc + ctx->nranks - 1) / ctx->nranks;
-    LL_REQUIRE(row_begin == std::min<int64_t>(nc, op->n_shard * ctx->rank) &&
-                   nr == std::min<int64_t>(nc, op->n_shard * (ctx->rank + 1)) - row_begin,
-               "sharded operators must use the ll_partition() row ranges");
-  } else {
-    op->n_shard = nc;
-    LL_REQUIRE(row_begin == 0 && nr == nc, "a single-GPU context needs the whole matrix (row_begin 0, n_rows == n_cols)");
-  }
   const size_t nnz = (size_t)op->nnz;
-  if (!on_device) {  // max absolute row sum, for ll_op_inf_norm (determine_eigenvalue_offset.cpp:12-29)
-    const T* v = (const T*)va;
-    double mx = 0.0;
-#pragma omp parallel for reduction(max : mx) schedule(static)
-    for (int64_t i = 0; i < nr; ++i) {
-      double rs = 0.0;
-      for (int64_t p = rp_host[i]; p < rp_host[i + 1]; ++p) rs += std::sqrt(abs2_host(v[p]));
-      mx = std::max(mx, rs);
-    }
-    op->inf_norm = mx;
-  }
   if (on_device) {
     op->owns_arrays = false;
     op->d_col = const_cast<int32_t*>(ci);
     op->d_val = const_cast<void*>(va);
   } else {
-    if (!on_device && nnz) {
-      for (size_t p = 0; p < nnz; ++p) LL_REQUIRE(ci[p] >= 0 && ci[p] < nc, "column index out of range");
-    }
-    LL_HIP(hipMalloc((void**)&op->d_col, std::max<size_t>(nnz, 1) * sizeof(int32_t)));
-    LL_HIP(hipMalloc(&op->d_val, std::max<size_t>(nnz, 1) * sizeof(T)));
+    ctx->dev_malloc((void**)&op->d_col, std::max<size_t>(nnz, 1) * sizeof(int32_t), "CSR column indices");
+    ctx->dev_malloc(&op->d_val, std::max<size_t>(nnz, 1) * sizeof(T), "CSR values");
     LL_HIP(hipMemcpy(op->d_col, ci, nnz * sizeof(int32_t), hipMemcpyHostToDevice));
     LL_HIP(hipMemcpy(op->d_val, va, nnz * sizeof(T), hipMemcpyHostToDevice));
   }
   finish_csr<T>(op.get(), rp_host);
+  // column range check and max absolute row sum (ll_op_inf_norm; determine_eigenvalue_offset.cpp:12-29), on the device
+  // for host and device inputs alike, whatever kernel gets selected
+  csr_check_device<T>(op.get());
   op->spmv_kind = LL_SPMV_CSR_STREAM;
   const char* fmt = std::getenv("LL_SPMV_KERNEL");
   const std::string want = fmt ? fmt : "auto";
-  if (want != "csr" && nnz > 0) {
-    // the propagation-blocked image is built on the host; arrays that are already in HBM are copied back once for it
-    std::vector<int32_t> ci_copy;
-    std::vector<T> va_copy;
-    const int32_t* ci_host = ci;
-    const T* va_host = (const T*)va;
-    if (on_device) {
-      ci_copy.resize(nnz);
-      va_copy.resize(nnz);
-      LL_HIP(hipMemcpy(ci_copy.data(), ci, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-      LL_HIP(hipMemcpy(va_copy.data(), va, nnz * sizeof(T), hipMemcpyDeviceToHost));
-      ci_host = ci_copy.data();
-      va_host = va_copy.data();
-      for (size_t p = 0; p < nnz; ++p) LL_REQUIRE(ci_host[p] >= 0 && ci_host[p] < nc, "column index out of range");
-      double mx = 0.0;
-#pragma omp parallel for reduction(max : mx) schedule(static)
-      for (int64_t i = 0; i < nr; ++i) {
-        double rs = 0.0;
-        for (int64_t p = rp_host[i]; p < rp_host[i + 1]; ++p) rs += std::sqrt(abs2_host(va_host[p]));
-        mx = std::max(mx, rs);
-      }
-      op->inf_norm = mx;
+  // Sharded contexts take every decision below COLLECTIVELY (an empty shard, or a shard whose shape rules the image
+  // out, must not leave the ranks with different kernels: the exchange plan and the collectives issued depend on it).
+  auto all_ranks_agree = [&](bool mine) {
+    if (ctx->comm == nullptr) return mine;
+    double* d = nullptr;
+    ctx->dev_malloc((void**)&d, sizeof(double), "agreement flag");
+    const double v = mine ? 0.0 : 1.0;
+    double sum = 0.0;
+    try {
+      LL_HIP(hipMemcpyAsync(d, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      comm_allreduce_sum(ctx->comm, d, 1, ctx->stream);
+      LL_HIP(hipMemcpyAsync(&sum, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      LL_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (...) {
+      (void)hipFree(d);
+      throw;
     }
-    if (build_pb<T>(op.get(), rp_host, ci_host, va_host)) {
+    (void)hipFree(d);
+    return sum == 0.0;
+  };
+  if (want != "csr" && (nnz > 0 || ctx->comm != nullptr)) {
+    // the propagation-blocked image is built on the device from the CSR arrays (histogram + scatter kernels)
+    bool built = false;
+    try {
+      built = pb_build_device<T>(op.get());
+    } catch (const Failure& f) {
+      if (ctx->comm == nullptr) throw;
+      built = false;  // the peers are told below; the image is simply not used
+    }
+    if (all_ranks_agree(built)) {
       if (want == "pb") op->spmv_kind = LL_SPMV_PB;
       else autotune_spmv<T>(op.get());
+    } else if (built) {
+      op->spmv_kind = LL_SPMV_CSR_STREAM;  // some rank could not build it: nobody uses it
     }
   }
+  release_unselected_image(op.get());
   *out = op.release();
-}
-
-// Row ranges of a sharded operator must be the ll_partition() ones (equal shard strides).
-void set_partition(ll_context* ctx, ll_operator* op, int64_t n, int64_t row_begin, int64_t n_local) {
-  op->n = n;
-  op->n_local = n_local;
-  op->row_begin = row_begin;
-  if (ctx->nranks > 1) {
-    op->n_shard = (n + ctx->nranks - 1) / ctx->nranks;
-    LL_REQUIRE(row_begin == std::min<int64_t>(n, op->n_shard * ctx->rank) &&
-                   n_local == std::min<int64_t>(n, op->n_shard * (ctx->rank + 1)) - row_begin,
-               "sharded operators must use the ll_partition() row ranges");
-  } else {
-    op->n_shard = n;
-    LL_REQUIRE(row_begin == 0 && n_local == n, "a single-GPU context needs the whole operator (row_begin 0, n_local == n)");
-  }
 }
 
 template <typename T>
@@ -600,7 +653,7 @@ void create_dense(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, co
   }
   op->inf_norm = mx;
   const size_t bytes = (size_t)nr * (size_t)nc * sizeof(T);
-  LL_HIP(hipMalloc(&op->d_dense, std::max<size_t>(bytes, 16)));
+  ctx->dev_malloc(&op->d_dense, std::max<size_t>(bytes, 16), "dense matrix");
   if (bytes) LL_HIP(hipMemcpy(op->d_dense, a, bytes, hipMemcpyHostToDevice));
   *out = op.release();
 }
@@ -650,7 +703,7 @@ void create_stencil(ll_context* ctx, const ll_stencil_desc* d, int64_t row_begin
     typedef typename scalar_traits<T>::real R;
     std::vector<R> tmp((size_t)n_local);
     for (int64_t i = 0; i < n_local; ++i) tmp[(size_t)i] = (R)onsite[i];
-    LL_HIP(hipMalloc(&op->d_onsite, std::max<size_t>((size_t)n_local * sizeof(R), 16)));
+    ctx->dev_malloc(&op->d_onsite, std::max<size_t>((size_t)n_local * sizeof(R), 16), "on-site terms");
     LL_HIP(hipMemcpy(op->d_onsite, tmp.data(), (size_t)n_local * sizeof(R), hipMemcpyHostToDevice));
   }
   op->inf_norm = diag_max + hops;  // an upper bound of the max absolute row sum (equal to it for interior sites)
@@ -784,7 +837,9 @@ int ll_op_select_spmv(ll_operator* op, int kind) {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
     LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB, "unknown SpMV kernel");
     LL_REQUIRE(kind != LL_SPMV_PB || op->d_pb_val != nullptr,
-               "operator has no propagation-blocked image (LL_SPMV_KERNEL=csr or n too large)");
+               "operator has no propagation-blocked image (not selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");
+    LL_REQUIRE(kind != LL_SPMV_CSR_STREAM || op->d_row_ptr != nullptr,
+               "operator has released its CSR image (PB was selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");
     op->spmv_kind = kind;
   });
 }
@@ -792,6 +847,13 @@ int ll_op_selected_spmv(const ll_operator* op, int* kind_out) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && kind_out != nullptr, "null argument");
     *kind_out = op->spmv_kind;
+  });
+}
+int ll_op_autotune_ms(const ll_operator* op, double* csr_stream_ms, double* pb_ms) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr, "null operator");
+    if (csr_stream_ms) *csr_stream_ms = (double)op->tune_ms[LL_SPMV_CSR_STREAM];
+    if (pb_ms) *pb_ms = (double)op->tune_ms[LL_SPMV_PB];
   });
 }
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz) {
@@ -983,7 +1045,7 @@ int ll_lanczos_params_default(ll_lanczos_params* p, int64_t n, int find_maximum,
     p->eigenvalue_offset = 0.0;                                   // LL:165
     p->num_eigs_per_iteration = 5;                                // LL:173
     p->initial_vector_size = 200;                                 // LL:181
-    p->tridiag_mode = LL_TRIDIAG_QR;
+    p->tridiag_mode = LL_TRIDIAG_AUTO;  // decision- and value-identical to the reference's per-iteration QR, O(k) instead of O(k^2)
     p->orth_mode = LL_ORTH_CGS_DGKS;
   });
 }

@@ -10,16 +10,12 @@
 // alpha and the norms.  xGMI is point to point, so the all-gather is the per-link-bound step; everything else is
 // latency sized.
 #include <dlfcn.h>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <unistd.h>
 
-#include <atomic>
 #include <cstdlib>
-#include <random>
 
 #include <rccl/rccl.h>
 
+#include "../../include/lanczos_hip_transport.h"
 #include "ll_internal.hpp"
 
 namespace ll {
@@ -85,62 +81,55 @@ void check(ncclResult_t r, const char* what) {
 }
 }  // namespace
 
-// A second, host-staged backend (LL_COMM_BACKEND=shm) exists for ONE purpose: to run the sharded engine with several
-// ranks on a single GPU, where RCCL refuses duplicate devices.  Same collective semantics through a POSIX shared-memory
-// segment (device -> host slot, barrier, host -> device); slow, deterministic (sums in rank order), never the default.
-// It lets the multi-rank code path (row shards, global column indexing, padded all-gather, replicated decisions) be
-// verified end to end on the 1-GPU test boxes; production multi-GPU runs use RCCL.
-struct ShmSeg {
-  std::atomic<int> arrived;
-  std::atomic<int> generation;
-  int nranks;
-  int pad;
-  size_t slot_bytes;
-};
-
+// The collectives go either to RCCL (production) or to an EXTERNAL transport: a table of function pointers with the
+// same stream-ordered semantics (include/lanczos_hip_transport.h), attached with ll_comm_attach() or loaded from the
+// shared object named by LL_COMM_PLUGIN.  The library itself contains no second transport; the repository's tests
+// keep a host-staged one under tests/transport/ so that several ranks can share the single GPU of a test box (RCCL
+// refuses duplicate devices).
 struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
-  // shm backend
-  bool shm = false;
-  ShmSeg* seg = nullptr;
-  char* slots = nullptr;
-  size_t map_bytes = 0;
-  std::string shm_name;
-  void barrier() {
-    const int gen = seg->generation.load(std::memory_order_acquire);
-    if (seg->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
-      seg->arrived.store(0, std::memory_order_relaxed);
-      seg->generation.fetch_add(1, std::memory_order_release);
-    } else {
-      // bounded wait: a peer that died must not hang the others
-      for (long spins = 0; seg->generation.load(std::memory_order_acquire) == gen; ++spins) {
-        if (spins < 20000) continue;  // busy-wait first (collectives are latency sized), then back off
-        usleep(20);
-        if (spins > 520000) {  // ~30 s
-          set_error("shm backend: barrier timed out (a peer rank is gone?)");
-          throw Failure{LL_ERR_RCCL};
-        }
-      }
-    }
-  }
-  char* slot(int r) { return slots + (size_t)r * seg->slot_bytes; }
+  bool external = false;
+  ll_transport ext = {};
+  void* plugin = nullptr;  // dlopen handle when the transport came from LL_COMM_PLUGIN
 };
 
-static bool want_shm() {
-  const char* e = std::getenv("LL_COMM_BACKEND");
-  return e && std::string(e) == "shm";
+namespace {
+const char* plugin_path() {
+  const char* e = std::getenv("LL_COMM_PLUGIN");
+  return (e && *e) ? e : nullptr;
 }
-static constexpr size_t kShmSlotBytes = (size_t)64 << 20;  // per rank; enough for the test problems
+void* plugin_sym(void* h, const char* name) {
+  void* p = dlsym(h, name);
+  if (!p) {
+    set_error(std::string("LL_COMM_PLUGIN lacks symbol ") + name);
+    throw Failure{LL_ERR_RCCL};
+  }
+  return p;
+}
+void* plugin_open() {
+  void* h = dlopen(plugin_path(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    set_error(std::string("cannot load LL_COMM_PLUGIN: ") + dlerror());
+    throw Failure{LL_ERR_RCCL};
+  }
+  return h;
+}
+void ext_check(int rc, const char* what) {
+  if (rc != 0) {
+    set_error(std::string("external transport: ") + what + " failed with status " + std::to_string(rc));
+    throw Failure{LL_ERR_RCCL};
+  }
+}
+}  // namespace
 
 void comm_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == LL_UNIQUE_ID_BYTES, "unique id size");
-  if (want_shm()) {  // the "id" is the name of the shared-memory segment
-    std::random_device rd;
-    char name[LL_UNIQUE_ID_BYTES] = {0};
-    std::snprintf(name, sizeof(name), "/ll_shm_%d_%08x", (int)getpid(), (unsigned)rd());
-    std::memcpy(id128, name, LL_UNIQUE_ID_BYTES);
-    return;
+  if (plugin_path()) {
+    void* h = plugin_open();
+    auto fn = (int (*)(void*))plugin_sym(h, "ll_transport_unique_id");
+    ext_check(fn(id128), "ll_transport_unique_id");
+    return;  // the handle stays loaded: ll_comm_init will ask for the same object again
   }
   ncclUniqueId id;
   check(api().GetUniqueId(&id), "ncclGetUniqueId");
@@ -149,59 +138,19 @@ void comm_unique_id(void* id128) {
 
 Comm* comm_create(const void* id128, int rank, int nranks, int device) {
   LL_HIP(hipSetDevice(device));
-  ncclUniqueId id;
-  std::memcpy(&id, id128, sizeof(id));
   Comm* c = new Comm;
   c->rank = rank;
   c->nranks = nranks;
-  if (want_shm()) {
-    c->shm = true;
-    c->shm_name.assign((const char*)id128, strnlen((const char*)id128, LL_UNIQUE_ID_BYTES - 1));
-    c->map_bytes = 4096 + kShmSlotBytes * (size_t)nranks;
-    // rank 0 owns the segment: it removes any stale one of the same name (a crashed earlier run) and creates it
-    // afresh (zero-filled); the other ranks wait for it to appear with its final size
-    int fd = -1;
-    if (rank == 0) {
-      shm_unlink(c->shm_name.c_str());
-      fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-      if (fd >= 0 && ftruncate(fd, (off_t)c->map_bytes) != 0) {
-        close(fd);
-        fd = -1;
-      }
-    } else {
-      for (int tries = 0; tries < 3000 && fd < 0; ++tries) {  // ~30 s
-        fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
-        if (fd >= 0) {
-          off_t sz = lseek(fd, 0, SEEK_END);
-          if (sz < (off_t)c->map_bytes) {
-            close(fd);
-            fd = -1;
-          }
-        }
-        if (fd < 0) usleep(10000);
-      }
-    }
-    if (fd < 0) {
-      set_error("shm backend: cannot open " + c->shm_name);
-      delete c;
-      throw Failure{LL_ERR_RCCL};
-    }
-    void* m = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) {
-      set_error("shm backend: mmap failed");
-      delete c;
-      throw Failure{LL_ERR_RCCL};
-    }
-    c->seg = (ShmSeg*)m;  // a fresh segment is zero-filled: arrived = generation = 0
-    c->slots = (char*)m + 4096;
-    c->seg->nranks = nranks;
-    c->seg->slot_bytes = kShmSlotBytes;
-    // rendezvous: everybody has mapped the segment once `arrived` has counted all ranks
-    c->barrier();
-    return c;
-  }
   try {
+    if (plugin_path()) {
+      c->plugin = plugin_open();
+      auto fn = (int (*)(const void*, int, int, int, ll_transport*))plugin_sym(c->plugin, "ll_transport_open");
+      ext_check(fn(id128, rank, nranks, device, &c->ext), "ll_transport_open");
+      c->external = true;
+      return c;
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
     check(api().CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank");
   } catch (...) {
     delete c;
@@ -213,70 +162,30 @@ Comm* comm_create(const void* id128, int rank, int nranks, int device) {
   return c;
 }
 
+Comm* comm_attach(const ll_transport* t, int rank, int nranks) {
+  Comm* c = new Comm;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->external = true;
+  c->ext = *t;
+  return c;
+}
+
 void comm_destroy(Comm* c) {
   if (!c) return;
-  if (c->shm) {
-    if (c->seg) munmap((void*)c->seg, c->map_bytes);
-    if (c->rank == 0) shm_unlink(c->shm_name.c_str());
-    delete c;
-    return;
+  if (c->external) {
+    if (c->ext.destroy) c->ext.destroy(c->ext.self);
+  } else if (c->comm) {
+    api().CommDestroy(c->comm);
   }
-  if (c->comm) api().CommDestroy(c->comm);
-  delete c;
-}
-
-static void shm_allgather(Comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
-  if (bytes > c->seg->slot_bytes) {
-    set_error("shm backend: message larger than the slot (test backend only)");
-    throw Failure{LL_ERR_RCCL};
-  }
-  LL_HIP(hipMemcpyAsync(c->slot(c->rank), send, bytes, hipMemcpyDeviceToHost, s));
-  LL_HIP(hipStreamSynchronize(s));
-  c->barrier();
-  for (int r = 0; r < c->nranks; ++r)
-    LL_HIP(hipMemcpyAsync((char*)recv + (size_t)r * bytes, c->slot(r), bytes, hipMemcpyHostToDevice, s));
-  LL_HIP(hipStreamSynchronize(s));
-  c->barrier();
-}
-static void shm_allreduce(Comm* c, double* buf, size_t n, hipStream_t s) {
-  const size_t bytes = n * sizeof(double);
-  if (bytes > c->seg->slot_bytes) {
-    set_error("shm backend: message larger than the slot (test backend only)");
-    throw Failure{LL_ERR_RCCL};
-  }
-  LL_HIP(hipMemcpyAsync(c->slot(c->rank), buf, bytes, hipMemcpyDeviceToHost, s));
-  LL_HIP(hipStreamSynchronize(s));
-  c->barrier();
-  std::vector<double> sum(n, 0.0);
-  for (int r = 0; r < c->nranks; ++r) {  // rank order on every rank: identical bits everywhere
-    const double* p = (const double*)c->slot(r);
-    for (size_t i = 0; i < n; ++i) sum[i] += p[i];
-  }
-  LL_HIP(hipMemcpyAsync(buf, sum.data(), bytes, hipMemcpyHostToDevice, s));
-  LL_HIP(hipStreamSynchronize(s));
-  c->barrier();
-}
-
-static void shm_halo_exchange(Comm* c, const void* send_prev, void* recv_prev, int prev, const void* send_next,
-                              void* recv_next, int next, size_t bytes, hipStream_t s) {
-  if (2 * bytes > c->seg->slot_bytes) {
-    set_error("shm backend: message larger than the slot (test backend only)");
-    throw Failure{LL_ERR_RCCL};
-  }
-  // own slot = [message for prev | message for next]
-  if (prev >= 0) LL_HIP(hipMemcpyAsync(c->slot(c->rank), send_prev, bytes, hipMemcpyDeviceToHost, s));
-  if (next >= 0) LL_HIP(hipMemcpyAsync(c->slot(c->rank) + bytes, send_next, bytes, hipMemcpyDeviceToHost, s));
-  LL_HIP(hipStreamSynchronize(s));
-  c->barrier();
-  if (prev >= 0) LL_HIP(hipMemcpyAsync(recv_prev, c->slot(prev) + bytes, bytes, hipMemcpyHostToDevice, s));
-  if (next >= 0) LL_HIP(hipMemcpyAsync(recv_next, c->slot(next), bytes, hipMemcpyHostToDevice, s));
-  LL_HIP(hipStreamSynchronize(s));
-  c->barrier();
+  delete c;  // a plug-in object stays mapped: unloading code that may own threads is not worth the risk
 }
 
 void comm_halo_exchange(Comm* c, const void* send_prev, void* recv_prev, int prev, const void* send_next,
                         void* recv_next, int next, size_t bytes, hipStream_t s) {
-  if (c->shm) return shm_halo_exchange(c, send_prev, recv_prev, prev, send_next, recv_next, next, bytes, s);
+  if (c->external)
+    return ext_check(c->ext.halo_exchange(c->ext.self, send_prev, recv_prev, prev, send_next, recv_next, next, bytes, (void*)s),
+                     "halo_exchange");
   // One group = one fused point-to-point step.  Posting order matters when prev == next (two ranks on a ring):
   // messages between one pair of ranks match in posting order, so "to next" is posted before "to prev" and "from
   // prev" before "from next" — the peer's first send (its "to next") then lands in this rank's recv_prev.
@@ -290,12 +199,12 @@ void comm_halo_exchange(Comm* c, const void* send_prev, void* recv_prev, int pre
 }
 
 void comm_allgather(Comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
-  if (c->shm) return shm_allgather(c, send, recv, bytes, s);
+  if (c->external) return ext_check(c->ext.all_gather(c->ext.self, send, recv, bytes, (void*)s), "all_gather");
   check(api().AllGather(send, recv, bytes, ncclChar, c->comm, s), "ncclAllGather");
 }
 
 void comm_allreduce_sum(Comm* c, double* buf, size_t n_doubles, hipStream_t s) {
-  if (c->shm) return shm_allreduce(c, buf, n_doubles, s);
+  if (c->external) return ext_check(c->ext.all_reduce_sum_f64(c->ext.self, buf, n_doubles, (void*)s), "all_reduce_sum_f64");
   check(api().AllReduce(buf, buf, n_doubles, ncclDouble, ncclSum, c->comm, s), "ncclAllReduce");
 }
 

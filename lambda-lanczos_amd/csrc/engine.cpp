@@ -4,6 +4,7 @@
 // the device already executes iteration k+1 (lag-1 speculation: a speculative iteration only writes basis slots
 // the results never read, so stopping one iteration "late" on the device is harmless).
 #include "engine.hpp"
+#include "trace.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -17,6 +18,12 @@ static inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+// DGKS "twice is enough": a second Gram-Schmidt pass is due when the first one removed more than this fraction of
+// ||w||^2.  LL_DGKS_THRESHOLD overrides the 1/2 (testing: a value > 1 forces the second pass in every iteration).
+static double dgks_threshold() {
+  const char* e = std::getenv("LL_DGKS_THRESHOLD");
+  return e ? std::atof(e) : 0.5;
+}
 
 // ================================================================= Basis / RunList
 template <typename T> Basis<T>::~Basis() {
@@ -94,7 +101,30 @@ template <typename T> std::vector<BasisSegs<T>> RunList<T>::groups(int max_vecs)
 
 // ================================================================= Engine
 template <typename T> void Engine<T>::all_reduce(double* d, size_t count) {
-  if (ctx->comm != nullptr) comm_allreduce_sum(ctx->comm, d, count, ctx->stream);
+  if (ctx->comm == nullptr) return;
+  if (ctx->profiling) {
+    hipEvent_t a, b;
+    LL_HIP(hipEventCreate(&a));
+    LL_HIP(hipEventCreate(&b));
+    LL_HIP(hipEventRecord(a, ctx->stream));
+    comm_allreduce_sum(ctx->comm, d, count, ctx->stream);
+    LL_HIP(hipEventRecord(b, ctx->stream));
+    ctx->ev_allreduce.emplace_back(a, b);
+  } else {
+    comm_allreduce_sum(ctx->comm, d, count, ctx->stream);
+  }
+}
+template <typename T> void Engine<T>::comm_timer_begin(hipStream_t cs) {
+  if (!ctx->profiling) return;
+  hipEvent_t a, b;
+  LL_HIP(hipEventCreate(&a));
+  LL_HIP(hipEventCreate(&b));
+  ctx->ev_gather.emplace_back(a, b);
+  LL_HIP(hipEventRecord(a, cs));
+}
+template <typename T> void Engine<T>::comm_timer_end(hipStream_t cs) {
+  if (!ctx->profiling) return;
+  LL_HIP(hipEventRecord(ctx->ev_gather.back().second, cs));
 }
 
 template <typename T> void Engine<T>::fetch(const double* d, double* host, size_t count) {
@@ -104,6 +134,7 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
 
 template <typename T>
 void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded) {
+  TraceRange trace("ll::apply (mv_mul + offset + alpha)");
   hipStream_t s = ctx->stream;
   ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)op->pb_nrb));
   int nparts = 0;
@@ -128,28 +159,65 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     }
     nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
   } else if (op->kind == ll_operator::CSR || op->kind == ll_operator::DENSE) {
+    const bool pb = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB;
     const T* x_full = x_local;
+    const T* x_own = x_local;  // what the own-column blocks of the PB kernels read
+    bool remote_done = false;
     if (ctx->comm != nullptr) {
-      // exchange step: every rank needs the whole x for its row block
-      // The all-gather sends n_shard elements from every rank (equal strides); the last shard can be shorter.  Basis
-      // vectors are padded to the stride (x_padded); a caller-provided shard of exactly n_local elements is copied
-      // into a padded send buffer first (tail of the gathered buffer beyond n is never referenced).
+      // exchange step: every rank needs the whole x for its row block.
+      // Every rank sends n_shard elements (equal strides); the last shard can be shorter.  Basis vectors are padded to
+      // the stride (x_padded); a caller-provided shard of exactly n_local elements is copied into a padded send
+      // buffer first (the tail of the gathered buffer beyond n is never referenced by a matrix entry).
+      const int P = ctx->nranks;
       const size_t shard_bytes = (size_t)op->n_shard * sizeof(T);
-      ctx->ensure_xfull(shard_bytes * (size_t)(ctx->nranks + 1));
+      ctx->ensure_xfull(shard_bytes * (size_t)(P + 1));
+      T* gathered = (T*)ctx->d_xfull;
       const T* send = x_local;
       if (!x_padded && op->n_local < op->n_shard) {
-        T* pad = (T*)((char*)ctx->d_xfull + shard_bytes * (size_t)ctx->nranks);
+        T* pad = (T*)((char*)ctx->d_xfull + shard_bytes * (size_t)P);
         LL_HIP(hipMemsetAsync(pad, 0, shard_bytes, s));
         LL_HIP(hipMemcpyAsync(pad, x_local, (size_t)op->n_local * sizeof(T), hipMemcpyDeviceToDevice, s));
         send = pad;
       }
-      comm_allgather(ctx->comm, send, ctx->d_xfull, shard_bytes, s);
-      x_full = (const T*)ctx->d_xfull;
+      x_own = send;
+      x_full = gathered;
+      // PB: the gather is cut into chunks (op->gather) laid out chunk-major; every other kernel needs global order
+      GatherPlan plan;
+      if (pb) plan = op->gather;
+      else {
+        plan.nchunks = 1;
+        plan.start[0] = 0;
+        plan.len[0] = op->n_shard;
+      }
+      const bool overlap = pb && ctx->overlap && ctx->comm_stream != nullptr;
+      hipStream_t cs = overlap ? ctx->comm_stream : s;
+      comm_timer_begin(cs);
+      if (overlap) {
+        LL_HIP(hipEventRecord(ctx->ev_x_ready, s));  // everything enqueued so far (x final, previous readers of the
+        LL_HIP(hipStreamWaitEvent(cs, ctx->ev_x_ready, 0));  // gathered buffer done) precedes the gather
+      }
+      for (int c = 0; c < plan.nchunks; ++c) {
+        comm_allgather(ctx->comm, send + plan.start[c], gathered + (int64_t)P * plan.start[c],
+                       (size_t)plan.len[c] * sizeof(T), cs);
+        if (overlap) LL_HIP(hipEventRecord(ctx->ev_chunk[c], cs));
+      }
+      comm_timer_end(cs);
+      if (overlap) {
+        // own-column blocks run under the gather; every chunk's remote blocks start when that chunk has arrived
+        launch_pb_phase1<T>(*op, 0, op->pb_own_count, x_own, s);
+        for (int c = 0; c < plan.nchunks; ++c) {
+          LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[c], 0));
+          launch_pb_phase1<T>(*op, op->pb_chunk_first[c], op->pb_chunk_count[c], gathered, s);
+        }
+        nparts = launch_pb_phase2<T>(*op, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+        remote_done = true;
+      }
     }
-    if (op->kind == ll_operator::DENSE)
+    if (remote_done) {
+    } else if (op->kind == ll_operator::DENSE)
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
-    else if (op->spmv_kind == LL_SPMV_PB)
-      nparts = launch_spmv_pb<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    else if (pb)
+      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
   } else {
@@ -157,17 +225,22 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     const size_t bytes = (size_t)n_local * sizeof(T);
     if (op->kind == ll_operator::HOST_CB) {
       // unmodified user code (LL:120-126): one D2H + one H2D of an n-vector per call
-      op->h_in.resize(bytes);
-      op->h_out.assign(bytes, 0);  // "out" is zero-filled on entry (LL:242, EX:107)
-      LL_HIP(hipMemcpyAsync(op->h_in.data(), x_local, bytes, hipMemcpyDeviceToHost, s));
+      // through the context's pinned callback buffers [in | out]: full-rate DMA, no pageable bounce copies
+      char* h_in = (char*)ctx->ensure_cb_stage(2 * bytes);
+      char* h_out = h_in + bytes;
+      if (ctx->ev_cb) LL_HIP(hipEventSynchronize(ctx->ev_cb));  // the previous call's upload out of h_out has finished
+      LL_HIP(hipMemcpyAsync(h_in, x_local, bytes, hipMemcpyDeviceToHost, s));
+      std::memset(h_out, 0, bytes);  // "out" is zero-filled on entry (LL:242, EX:107); overlaps the copy above
       LL_HIP(hipStreamSynchronize(s));
-      int rc = op->host_fn(op->h_in.data(), op->h_out.data(), n_local, op->user);
+      int rc = op->host_fn(h_in, h_out, n_local, op->user);
       if (rc != 0) {
         set_error("mv_mul host callback returned " + std::to_string(rc));
         throw Failure{LL_ERR_CALLBACK};
       }
-      LL_HIP(hipMemcpyAsync(y, op->h_out.data(), bytes, hipMemcpyHostToDevice, s));
-      LL_HIP(hipStreamSynchronize(s));
+      // no second synchronisation: the next callback waits for this upload (ev_cb) before it reuses the buffer
+      LL_HIP(hipMemcpyAsync(y, h_out, bytes, hipMemcpyHostToDevice, s));
+      if (!ctx->ev_cb) LL_HIP(hipEventCreateWithFlags(&ctx->ev_cb, hipEventDisableTiming));
+      LL_HIP(hipEventRecord(ctx->ev_cb, s));
     } else {
       LL_HIP(hipMemsetAsync(y, 0, bytes, s));
       int rc = op->dev_fn(x_local, y, n_local, (void*)s, op->user);
@@ -210,6 +283,7 @@ template <typename T> static int max_vecs_per_launch() { return (1536 - 1) / sca
 template <typename T>
 NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
                          bool first_pass_only, Publish* publish) {
+  TraceRange trace("ll::orth (three-term + Gram-Schmidt + norm)");
   hipStream_t s = ctx->stream;
   const int nb = runs.total();
   const bool sharded = ctx->comm != nullptr;
@@ -263,7 +337,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   }
 
   const std::vector<BasisSegs<T>> groups = runs.groups(max_vecs_per_launch<T>());
-  const NormRefs refs{c, c + 1, c + 2, mode == LL_ORTH_CGS2 ? 1 : 0};
+  const NormRefs refs{c, c + 1, c + 2, mode == LL_ORTH_CGS2 ? 1 : 0, dgks_threshold()};
   const NormRefs* pred = mode == LL_ORTH_CGS2 ? nullptr : &refs;
   auto count_of = [](const BasisSegs<T>& g) {
     int t = 0;
@@ -339,6 +413,7 @@ template <typename T> double Engine<T>::second_pass(T* u, const RunList<T>& runs
 
 template <typename T>
 void Engine<T>::gemv(const RunList<T>& basis, int64_t m, int nout, const T* coeff_host, T* out, int64_t ld_out) {
+  TraceRange trace("ll::gemv_basis (Ritz vectors / exp output)");
   const std::vector<BasisSegs<T>> groups = basis.groups(512);
   ctx->ensure_coeff((size_t)nout * m * sizeof(T));
   LL_HIP(hipMemcpyAsync(ctx->d_coeff, coeff_host, (size_t)nout * m * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
@@ -355,14 +430,10 @@ template <typename T> struct DevBuf {
   ~DevBuf() {
     if (p) (void)hipFree(p);
   }
-  void alloc(size_t count) {
+  void alloc(ll_context* ctx, size_t count) {
     if (p) (void)hipFree(p);
     p = nullptr;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e != hipSuccess) {
-      set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
-      throw Failure{LL_ERR_ALLOC};
-    }
+    ctx->dev_malloc((void**)&p, count * sizeof(T), "work vectors");
   }
 };
 
@@ -439,16 +510,16 @@ inline zc as_real_coeff(double v, zc*) { return zc{v, 0.0}; }
 inline float as_real_coeff(double v, float*) { return (float)v; }
 inline cf as_real_coeff(double v, cf*) { return cf{(float)v, 0.0f}; }
 
-// DGKS "twice is enough": a second Gram-Schmidt pass is due when the first one removed more than this fraction of
-// ||w||^2.  LL_DGKS_THRESHOLD overrides the 1/2 (testing: a value > 1 forces the second pass in every iteration).
-double dgks_threshold() {
-  const char* e = std::getenv("LL_DGKS_THRESHOLD");
-  return e ? std::atof(e) : 0.5;
-}
-
-int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration) {
+// Vectors per basis slab.  The reference's initial_vector_size (LL:181, default 200) only RESERVES the outer
+// std::vector; its Lanczos vectors are allocated one by one.  Here a slab is one hipMalloc, so it is capped by BYTES
+// (4 GiB, LL_SLAB_BYTES overrides): a run that converges after 30 iterations of an n = 1e8 problem must not need
+// 200 vectors of HBM up front.  Slabs are appended on demand and cached in the context between runs.
+int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration, int64_t vec_bytes) {
   int64_t want = initial_vector_size > 0 ? initial_vector_size : 200;
   want = std::min(want, max_iteration + 2);
+  int64_t cap_bytes = (int64_t)4 << 30;
+  if (const char* e = std::getenv("LL_SLAB_BYTES")) cap_bytes = std::max<int64_t>(1, std::atoll(e));
+  want = std::min(want, cap_bytes / std::max<int64_t>(vec_bytes, 1));
   return std::max<int64_t>(want, 4);
 }
 
@@ -456,9 +527,15 @@ int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration) {
 
 // ================================================================= LambdaLanczos<T>::run
 template <typename T>
-void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, double* eigvals, T* eigvecs,
+void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in, double* eigvals, T* eigvecs,
                  int64_t* n_found, int64_t* iter_counts, int64_t iter_cap, double* alpha_out, double* beta_out,
                  ll_run_stats* stats, const IterationSpec<T>* spec) {
+  ll_lanczos_params P = P_in;
+  // ll_lanczos_params_default() fills in the DOUBLE tolerance (LL:150 with real_t<T> = double); the reference scales it
+  // with the epsilon of real_t<T>, so a float run that was left at that default gets 1e3 * FLT_EPSILON instead of a
+  // tolerance float data can never meet (which would run to max_iteration = n).
+  if (sizeof(typename scalar_traits<T>::real) == 4 && P.eps == std::numeric_limits<double>::epsilon() * 1e3)
+    P.eps = (double)std::numeric_limits<float>::epsilon() * 1e3;
   LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
   LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
              "operator scalar type mismatch");
@@ -482,13 +559,13 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
   constexpr int R = scalar_traits<T>::reals;
 
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T)));
   DevBuf<T> d_locked, d_ritz;
   int64_t d_ritz_cap = 0;
   if (spec) {
-    if (spec->n_orth > 0) d_locked.alloc((size_t)spec->n_orth * ld);
+    if (spec->n_orth > 0) d_locked.alloc(ctx, (size_t)spec->n_orth * ld);
   } else if (P.num_eigs > 1) {
-    d_locked.alloc((size_t)P.num_eigs * ld);
+    d_locked.alloc(ctx, (size_t)P.num_eigs * ld);
   }
   const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
   (void)nroot_max;
@@ -547,6 +624,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     alpha.clear();
     beta.clear();
     std::vector<double> evs, pevs, all;
+    bool evs_from_qr = true;  // whether `evs` hold the values of the reference's QR arithmetic (else: bisection values)
     int64_t itern = P.max_iteration;
     bool stopped = false;
     NormRefs refs_prev = refs0;
@@ -606,6 +684,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       }
       alpha.push_back(alpha_j);
       beta.push_back(std::sqrt(beta2_j));
+      TraceRange trace("ll::host_tridiag (Ritz values + stop test)");
       const double t0 = now_s();
       const int64_t m = (int64_t)alpha.size();
       const int64_t ncalc = std::min<int64_t>(nroot, m);
@@ -615,7 +694,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
         all.resize((size_t)m);
         tridiag_qr(m, alpha.data(), beta.data(), all.data(), nullptr);  // H1 LL:267-268
         for (int64_t i = 0; i < ncalc; ++i) evs.push_back(P.find_maximum ? all[m - i - 1] : all[i]);  // H2
+        evs_from_qr = true;
       } else {
+        evs_from_qr = false;
         for (int64_t i = 0; i < ncalc; ++i)
           evs.push_back(tridiag_bisect(m, alpha.data(), beta.data(), P.find_maximum ? m - i - 1 : i));
       }
@@ -649,7 +730,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
             e_before.push_back(P.find_maximum ? prev[m - 2 - i] : prev[i]);
           t_tridiag += now_s() - tq0;
           stop = converged(e_now, e_before, P.eps);
-          if (stop) evs = e_now;
+          if (stop) {
+            evs = e_now;
+            evs_from_qr = true;
+          }
         }
       }
       if (stop) return kStop;
@@ -657,21 +741,42 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       return verdict;
     };
 
-    for (int64_t k = 1; k <= P.max_iteration; ++k) {
-      enqueue(k);
-      if (k > 1) {
-        const int v = process(k - 1);
-        if (v == kStop) { itern = k - 1; stopped = true; break; }
-        if (v == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
+    // Callback operators run WITHOUT the lag-1 speculation: the user's mv_mul must be called exactly as often as the
+    // reference calls it (LL:243: once per executed iteration) and never on the 1/sqrt(~0)-scaled vector that follows a
+    // breakdown; a host callback synchronises the stream anyway, so there is nothing to overlap.
+    const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);
+    if (speculate) {
+      for (int64_t k = 1; k <= P.max_iteration; ++k) {
+        enqueue(k);
+        if (k > 1) {
+          const int v = process(k - 1);
+          if (v == kStop) { itern = k - 1; stopped = true; break; }
+          if (v == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
+        }
+      }
+      if (!stopped) process(P.max_iteration);  // itern stays max_iteration either way (LL:239,312)
+    } else {
+      for (int64_t k = 1; k <= P.max_iteration; ++k) {
+        enqueue(k);
+        if (process(k) == kStop) { itern = k; stopped = true; break; }  // kRedone: u_k was repaired in place, nothing ran ahead
       }
     }
-    if (!stopped) process(P.max_iteration);  // itern stays max_iteration either way (LL:239,312)
     LL_HIP(hipStreamSynchronize(s));
 
     // ---- Ritz pairs (LL:312-319, LL:33-62)
+    TraceRange trace_ritz("ll::ritz (tridiagonal eigenvectors + GEMV + copy back)");
     const double t_fin0 = now_s();
     const int64_t m = (int64_t)alpha.size();  // == itern
     (void)itern;
+    if (P.tridiag_mode == LL_TRIDIAG_AUTO && !evs_from_qr && m > 0) {
+      // the loop ended without a convergence stop (max_iteration or breakdown) while bisection was tracking the
+      // roots: return the values of the reference's QR arithmetic, like every other exit of this mode
+      all.resize((size_t)m);
+      const double t0 = now_s();
+      tridiag_qr(m, alpha.data(), beta.data(), all.data(), nullptr);
+      t_tridiag += now_s() - t0;
+      for (size_t i = 0; i < evs.size(); ++i) evs[i] = P.find_maximum ? all[(size_t)m - i - 1] : all[i];
+    }
     const int64_t nev = (int64_t)evs.size();
     // Eigenvectors of T_m: the reference accumulates all m of them by QR (LL:44, O(m^3)); LL_TRIDIAG_AUTO switches to
     // inverse iteration for the few wanted ones once m is large.
@@ -733,7 +838,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
       basis.ld = ld;
       basis.add_basis(U, m);
       if (!d_ritz.p || d_ritz_cap < nw) {  // only the surviving vectors are formed
-        d_ritz.alloc((size_t)nw * ld);
+        d_ritz.alloc(ctx, (size_t)nw * ld);
         d_ritz_cap = nw;
       }
       E.gemv(basis, m, (int)nw, coeff.data(), d_ritz.p, ld);
@@ -808,8 +913,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, d
     stats->seconds_finish = t_finish;
     stats->second_passes = second_passes;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
+    ctx->drain_comm_events(&stats->seconds_comm_gather, &stats->seconds_comm_allreduce);
     stats->seconds_total = now_s() - t_start;
   }
+  ctx->drain_comm_events(nullptr, nullptr);
   (void)R;
 }
 
@@ -833,9 +940,12 @@ inline std::complex<double> conj_h(std::complex<double> v) { return std::conj(v)
 }  // namespace
 
 template <typename T>
-void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typename host_scalar<T>::type a,
+void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, typename host_scalar<T>::type a,
               const T* input, T* output, int64_t* itern_out, ll_run_stats* stats) {
   typedef typename host_scalar<T>::type H;
+  ll_expo_params P = P_in;
+  if (sizeof(typename scalar_traits<T>::real) == 4 && P.eps == std::numeric_limits<double>::epsilon() * 1e2)
+    P.eps = (double)std::numeric_limits<float>::epsilon() * 1e2;  // EX:58 with real_t<T> = float (see lanczos_run)
   LL_REQUIRE(op && op->ctx == ctx, "operator belongs to another context");
   LL_REQUIRE(op->is_complex == scalar_traits<T>::is_complex && op->elem_bytes == (int)sizeof(T),
              "operator scalar type mismatch");
@@ -850,7 +960,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
   const double dgks_thr = dgks_threshold();
   const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration));
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T)));
   ctx->ensure_pinned(16);
   EventRing ring;
   PhaseTimer timer(ctx->profiling, s);
@@ -915,6 +1025,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     }
     alpha.push_back(alpha_j);
     const double beta_j = std::sqrt(beta2_j);
+    TraceRange trace("ll::host_tridiag (exp(a T_k) e_1 + overlap test)");
     const double t0 = now_s();
     const int64_t m = (int64_t)alpha.size();
     ev.resize((size_t)m);
@@ -936,15 +1047,23 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     return verdict;
   };
 
-  for (int64_t k = 1; k <= P.max_iteration; ++k) {
-    enqueue(k);
-    if (k > 1) {
-      const int v = process(k - 1);
-      if (v == kStop) { itern = k - 1; stopped = true; break; }
-      if (v == kRedone) enqueue(k);
+  const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);  // see lanczos_run
+  if (speculate) {
+    for (int64_t k = 1; k <= P.max_iteration; ++k) {
+      enqueue(k);
+      if (k > 1) {
+        const int v = process(k - 1);
+        if (v == kStop) { itern = k - 1; stopped = true; break; }
+        if (v == kRedone) enqueue(k);
+      }
+    }
+    if (!stopped) process(P.max_iteration);
+  } else {
+    for (int64_t k = 1; k <= P.max_iteration; ++k) {
+      enqueue(k);
+      if (process(k) == kStop) { itern = k; stopped = true; break; }
     }
   }
-  if (!stopped) process(P.max_iteration);
   LL_HIP(hipStreamSynchronize(s));
 
   // output = ||input|| * sum_l coeff_prev[l] u[l]  (EX:163-170)
@@ -952,7 +1071,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
   std::vector<T> c((size_t)m);
   for (int64_t l = 0; l < m; ++l) from_std(H(in_norm) * coeff_prev[l], &c[l]);
   DevBuf<T> d_out;
-  d_out.alloc((size_t)ld);
+  d_out.alloc(ctx, (size_t)ld);
   RunList<T> basis;
   basis.ld = ld;
   basis.add_basis(U, m);
@@ -968,8 +1087,10 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typenam
     stats->last_alpha_len = (int64_t)alpha.size();
     stats->second_passes = second_passes;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
+    ctx->drain_comm_events(&stats->seconds_comm_gather, &stats->seconds_comm_allreduce);
     stats->seconds_total = now_s() - t_start;
   }
+  ctx->drain_comm_events(nullptr, nullptr);
 }
 template void expo_run<double>(ll_context*, ll_operator*, const ll_expo_params&, double, const double*, double*,
                                int64_t*, ll_run_stats*);
@@ -1019,7 +1140,7 @@ void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typen
     factor *= H((double)k) / a;
   }
   DevBuf<T> d_out;
-  d_out.alloc((size_t)ld);
+  d_out.alloc(ctx, (size_t)ld);
   RunList<T> basis;
   basis.ld = ld;
   basis.add_basis(V, terms);

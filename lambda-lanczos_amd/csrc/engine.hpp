@@ -89,6 +89,9 @@ template <typename T> struct Engine {
   // <a,b> -> d_out[0..R) (device, all-reduced)
   void dot_dev(const T* a, const T* b, double* d_out);
   void all_reduce(double* d, size_t count);
+  // device-time stamps around an exchange step on stream cs (no-ops unless ctx->profiling)
+  void comm_timer_begin(hipStream_t cs);
+  void comm_timer_end(hipStream_t cs);
   // read `count` doubles from the device scalar area (synchronises the stream)
   void fetch(const double* d, double* host, size_t count);
   // out_r = sum_k coeff[r*m+k] u_k  (coeff host, type T)

@@ -15,130 +15,11 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "dev_helpers.hpp"
 #include "ll_internal.hpp"
 
 namespace ll {
 
-// ---------------------------------------------------------------- scalar helpers
-// Storage types T: double, zc (complex double), float, cf (complex float).  Products of two stored values stay in T;
-// everything that is SUMMED over many elements (dot products, row sums, norms) is carried in acc_t<T> = double / zc.
-__device__ __forceinline__ double zero_of(double*) { return 0.0; }
-__device__ __forceinline__ zc zero_of(zc*) { return zc{0.0, 0.0}; }
-__device__ __forceinline__ float zero_of(float*) { return 0.0f; }
-__device__ __forceinline__ cf zero_of(cf*) { return cf{0.0f, 0.0f}; }
-template <typename T> __device__ __forceinline__ T zero() { return zero_of((T*)nullptr); }
-
-__device__ __forceinline__ double to_acc(double a) { return a; }
-__device__ __forceinline__ double to_acc(float a) { return (double)a; }
-__device__ __forceinline__ zc to_acc(zc a) { return a; }
-__device__ __forceinline__ zc to_acc(cf a) { return zc{(double)a.re, (double)a.im}; }
-__device__ __forceinline__ void from_acc(double a, double* o) { *o = a; }
-__device__ __forceinline__ void from_acc(double a, float* o) { *o = (float)a; }
-__device__ __forceinline__ void from_acc(zc a, zc* o) { *o = a; }
-__device__ __forceinline__ void from_acc(zc a, cf* o) { *o = cf{(float)a.re, (float)a.im}; }
-template <typename T> __device__ __forceinline__ T narrow(acc_t<T> a) {
-  T o;
-  from_acc(a, &o);
-  return o;
-}
-
-__device__ __forceinline__ double mul(double a, double b) { return a * b; }
-__device__ __forceinline__ float mul(float a, float b) { return a * b; }
-__device__ __forceinline__ zc mul(zc a, zc b) { return zc{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ cf mul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ double add(double a, double b) { return a + b; }
-__device__ __forceinline__ float add(float a, float b) { return a + b; }
-__device__ __forceinline__ zc add(zc a, zc b) { return zc{a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cf add(cf a, cf b) { return cf{a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ double sub(double a, double b) { return a - b; }
-__device__ __forceinline__ float sub(float a, float b) { return a - b; }
-__device__ __forceinline__ zc sub(zc a, zc b) { return zc{a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cf sub(cf a, cf b) { return cf{a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ double rmul(double r, double a) { return r * a; }
-__device__ __forceinline__ float rmul(double r, float a) { return (float)r * a; }
-__device__ __forceinline__ zc rmul(double r, zc a) { return zc{r * a.re, r * a.im}; }
-__device__ __forceinline__ cf rmul(double r, cf a) { return cf{(float)r * a.re, (float)a.im * (float)r}; }
-// acc += a*b
-__device__ __forceinline__ void fma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
-__device__ __forceinline__ void fma_acc(float& acc, float a, float b) { acc = fmaf(a, b, acc); }
-__device__ __forceinline__ void fma_acc(double& acc, float a, float b) { acc = fma((double)a, (double)b, acc); }
-__device__ __forceinline__ void fma_acc(zc& acc, zc a, zc b) {
-  acc.re = fma(a.re, b.re, fma(-a.im, b.im, acc.re));
-  acc.im = fma(a.re, b.im, fma(a.im, b.re, acc.im));
-}
-__device__ __forceinline__ void fma_acc(cf& acc, cf a, cf b) {
-  acc.re = fmaf(a.re, b.re, fmaf(-a.im, b.im, acc.re));
-  acc.im = fmaf(a.re, b.im, fmaf(a.im, b.re, acc.im));
-}
-__device__ __forceinline__ void fma_acc(zc& acc, cf a, cf b) { fma_acc(acc, to_acc(a), to_acc(b)); }
-// acc += conj(a)*b   (inner product is conjugate-linear in its first argument, LA:41,49)
-__device__ __forceinline__ void cfma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
-__device__ __forceinline__ void cfma_acc(double& acc, float a, float b) { acc = fma((double)a, (double)b, acc); }
-__device__ __forceinline__ void cfma_acc(zc& acc, zc a, zc b) {
-  acc.re = fma(a.re, b.re, fma(a.im, b.im, acc.re));
-  acc.im = fma(a.re, b.im, fma(-a.im, b.re, acc.im));
-}
-__device__ __forceinline__ void cfma_acc(zc& acc, cf a, cf b) { cfma_acc(acc, to_acc(a), to_acc(b)); }
-// w -= h*u  (h in the accumulator type, w and u stored values)
-__device__ __forceinline__ void fnma_acc(double& w, double h, double u) { w = fma(-h, u, w); }
-__device__ __forceinline__ void fnma_acc(float& w, double h, float u) { w = (float)fma(-h, (double)u, (double)w); }
-__device__ __forceinline__ void fnma_acc(zc& w, zc h, zc u) {
-  w.re = fma(-h.re, u.re, fma(h.im, u.im, w.re));
-  w.im = fma(-h.re, u.im, fma(-h.im, u.re, w.im));
-}
-__device__ __forceinline__ void fnma_acc(cf& w, zc h, cf u) {
-  zc t = to_acc(w);
-  fnma_acc(t, h, to_acc(u));
-  w = cf{(float)t.re, (float)t.im};
-}
-__device__ __forceinline__ double abs2(double a) { return a * a; }
-__device__ __forceinline__ double abs2(float a) { return (double)a * (double)a; }
-__device__ __forceinline__ double abs2(zc a) { return fma(a.re, a.re, a.im * a.im); }
-__device__ __forceinline__ double abs2(cf a) { return fma((double)a.re, (double)a.re, (double)a.im * (double)a.im); }
-// Re(conj(a)*b)
-__device__ __forceinline__ double re_cmul(double a, double b) { return a * b; }
-__device__ __forceinline__ double re_cmul(float a, float b) { return (double)a * (double)b; }
-__device__ __forceinline__ double re_cmul(zc a, zc b) { return fma(a.re, b.re, a.im * b.im); }
-__device__ __forceinline__ double re_cmul(cf a, cf b) { return fma((double)a.re, (double)b.re, (double)a.im * (double)b.im); }
-
-__device__ __forceinline__ double shfl_down_d(double v, int delta) { return __shfl_down(v, delta, 64); }
-
-// Sum over the 64 lanes of a wavefront; result valid in lane 0.
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += shfl_down_d(v, d);
-  return v;
-}
-__device__ __forceinline__ zc wave_sum(zc v) { return zc{wave_sum(v.re), wave_sum(v.im)}; }
-
-// Sum over the workgroup (kBlock = 4 waves); result valid in thread 0. `scratch` holds >= 4 doubles.
-__device__ __forceinline__ double block_sum(double v, double* scratch) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) v = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-  return v;
-}
-
-// DGKS selection (see NormRefs in ll_internal.hpp).
-__device__ __forceinline__ bool second_pass_due(const NormRefs& r) { return r.force2 || *r.c1 < 0.5 * *r.c0; }
-__device__ __forceinline__ double final_norm2(const NormRefs& r) { return second_pass_due(r) ? *r.c2 : *r.c1; }
-
-// XCD-aware persistent tile walk: workgroups with equal (blockIdx % 8) share an XCD (and its L2), so each such
-// class walks one contiguous eighth of the tile range; neighbouring tiles (which gather neighbouring parts of x
-// for banded / stencil matrices) then hit the same L2 instead of being fetched by all eight.
-struct TileWalk {
-  int first, step, end;
-  __device__ TileWalk(int ntiles) {
-    const int xcd = blockIdx.x % kXcds, local = blockIdx.x / kXcds, nlocal = gridDim.x / kXcds;
-    const int per = (ntiles + kXcds - 1) / kXcds;
-    first = xcd * per + local;
-    step = nlocal;
-    end = min(ntiles, (xcd + 1) * per);
-  }
-};
 
 // ================================================================= a1/a2/a3: CSR SpMV ("CSR-stream")
 // One tile = a run of whole rows holding <= kSpmvTileNnz nonzeros (built at upload time).  The workgroup streams
@@ -247,217 +128,6 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
 #define LL_INST_SPMV(T) template int launch_spmv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
 LL_INST_SPMV(double) LL_INST_SPMV(zc) LL_INST_SPMV(float) LL_INST_SPMV(cf)
 
-// ================================================================= a1/a2/a3: propagation-blocked SpMV
-// Measured on MI355X (profiles/r01_*): a gather that misses the CU's 32 KiB L1 moves a whole 128-byte line for 8
-// useful bytes and the chip sustains only ~70-140 G such lines/s (L2 -> L1 fill path), whether the line comes from
-// L2, Infinity Cache or HBM.  For a matrix without column locality (BASELINE config 3: 1.5e8 gathers into an 80 MB
-// x) that caps ANY gather-based CSR kernel at >= 1.1 ms per SpMV (measured: 2.7 ms CSR-stream, 2.0 ms with L2-sized
-// column blocking) while the matrix itself streams in 0.35 ms.
-//
-// This kernel therefore never gathers from global memory.  The same matrix is stored in two sweeps' order (built
-// once at upload) and one SpMV is two fully coalesced streaming kernels with LDS-resident slices:
-//   phase 1 (one workgroup per COLUMN block): the x slice of the block is loaded into LDS with coalesced 16-byte
-//            loads; the block's entries (value, 16-bit local column) stream in, ordered by destination row block;
-//            product = value * x_lds[col] is written to the product buffer P at its position in row-block order
-//            (contiguous runs of one segment = one (column block, row block) pair);
-//   phase 2 (one workgroup per ROW block): the y slice lives in LDS; the row block's range of P and the 16-bit
-//            local row indices stream in (perfectly sequential) and are added into the slice with ds_add_f64; the
-//            epilogue adds offset*x_i (a2), writes y once and accumulates Re(conj(x_i) y_i) (a3).
-// HBM traffic is 2*sizeof(T) + sizeof(T) + 4 bytes per nonzero (28 B for fp64 against 12 B for CSR) but every byte
-// is streamed at full line efficiency, every x/y element is touched in LDS, and no phase depends on cache
-// residency or workgroup placement.  Main loops carry no barrier; each lane keeps kPbUnroll independent
-// load->LDS chains in flight.  The LDS adds of phase 2 happen in arrival order, so y can differ by O(eps) from run
-// to run; LL_SPMV_CSR_STREAM remains for bit-reproducible sums and wins on matrices whose gathers hit L1/L2
-// (stencils, narrow bands) — ll_op_create_csr_* times both on the actual matrix and keeps the faster one.
-constexpr int kPbThreads = 1024;
-constexpr int kPbUnroll = 2;  // quads per lane per trip (measured: 2 beats 4 and 8 by 1-5 %)
-
-__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
-
-// Entries are handled in QUADS: every segment is padded to a multiple of 16 entries (zero value, local index 0), so
-// a lane always moves four consecutive entries with 16-byte accesses (2 x dwordx4 of values / products, one dwordx2
-// of four 16-bit indices) and all four share one segment, i.e. one destination run.
-template <typename T> struct quad {
-  T e[4];
-};
-template <typename T> __device__ __forceinline__ quad<T> load_quad(const T* __restrict__ p) {
-  constexpr int NCH = (int)(4 * sizeof(T) / 16);  // 16-byte pieces of four entries (float: 1, double / cf: 2, zc: 4)
-  const uint4* src = reinterpret_cast<const uint4*>(p);
-  uint4 c[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) c[i] = src[i];
-  quad<T> q;
-  __builtin_memcpy(&q, c, sizeof(q));
-  return q;
-}
-template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__ p, const quad<T>& q) {
-  constexpr int NCH = (int)(4 * sizeof(T) / 16);
-  uint4 c[NCH];
-  __builtin_memcpy(c, &q, sizeof(q));
-  uint4* dst = reinterpret_cast<uint4*>(p);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) dst[i] = c[i];
-}
-
-template <typename T>
-__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int cb_cols, int64_t n_cols,
-                                                        const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
-                                                        const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
-                                                        const T* __restrict__ val, const ushort4* __restrict__ col,
-                                                        const T* __restrict__ xf, T* __restrict__ P) {
-  extern __shared__ double lds[];
-  T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
-  long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
-                                              (((size_t)cb_cols * sizeof(T) + 7) & ~(size_t)7));  // [nrb + 1]
-  long long* db = qs + (nrb + 1);                                                  // [nrb]
-  const int tid = threadIdx.x;
-  const int c = blockIdx.x;
-  const int64_t col0 = (int64_t)c * cb_cols;
-  const int ncols = (int)min((int64_t)cb_cols, n_cols - col0);
-  for (int i = tid; i < ncols; i += kPbThreads) xs[i] = xf[col0 + i];
-  for (int i = tid; i <= nrb; i += kPbThreads) qs[i] = seg_q[(size_t)c * (nrb + 1) + i];
-  for (int i = tid; i < nrb; i += kPbThreads) db[i] = seg_dest[(size_t)c * nrb + i];
-  __syncthreads();
-  const long long g1 = qs[nrb] >> 2;
-  int r = 0;
-  long long g = (qs[0] >> 2) + tid;
-  for (; g + (long long)(kPbUnroll - 1) * kPbThreads < g1; g += (long long)kPbUnroll * kPbThreads) {
-    quad<T> v[kPbUnroll];
-    ushort4 cl[kPbUnroll];
-#pragma unroll
-    for (int u = 0; u < kPbUnroll; ++u) {
-      const long long gg = g + (long long)u * kPbThreads;
-      v[u] = load_quad<T>(val + 4 * gg);
-      cl[u] = col[gg];
-    }
-#pragma unroll
-    for (int u = 0; u < kPbUnroll; ++u) {
-      const long long qq = 4 * (g + (long long)u * kPbThreads);
-      while (qq >= qs[r + 1]) ++r;
-      quad<T> pr;
-      pr.e[0] = mul(v[u].e[0], xs[cl[u].x]);
-      pr.e[1] = mul(v[u].e[1], xs[cl[u].y]);
-      pr.e[2] = mul(v[u].e[2], xs[cl[u].z]);
-      pr.e[3] = mul(v[u].e[3], xs[cl[u].w]);
-      store_quad<T>(P + db[r] + (qq - qs[r]), pr);
-    }
-  }
-  for (; g < g1; g += kPbThreads) {
-    const long long qq = 4 * g;
-    while (qq >= qs[r + 1]) ++r;
-    const quad<T> v = load_quad<T>(val + qq);
-    const ushort4 cl = col[g];
-    quad<T> pr;
-    pr.e[0] = mul(v.e[0], xs[cl.x]);
-    pr.e[1] = mul(v.e[1], xs[cl.y]);
-    pr.e[2] = mul(v.e[2], xs[cl.z]);
-    pr.e[3] = mul(v.e[3], xs[cl.w]);
-    store_quad<T>(P + db[r] + (qq - qs[r]), pr);
-  }
-}
-
-template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, int rl, const T& v) {
-  if constexpr (scalar_traits<T>::is_complex) {
-    lds_add(&lds[2 * rl], (double)v.re);
-    lds_add(&lds[2 * rl + 1], (double)v.im);
-  } else {
-    lds_add(&lds[rl], (double)v);
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_local,
-                                                        const int64_t* __restrict__ rptr,  // [nrb + 1]
-                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
-                                                        const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                        double* __restrict__ dot_partials) {
-  constexpr int R = scalar_traits<T>::reals;
-  extern __shared__ double lds[];  // [rb_rows * R]
-  __shared__ double red[kPbThreads / 64];
-  const int tid = threadIdx.x;
-  const int rb = blockIdx.x;
-  const int64_t row0 = (int64_t)rb * rb_rows;
-  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
-  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
-  __syncthreads();
-  const long long g1 = rptr[rb + 1] >> 2;
-  long long g = (rptr[rb] >> 2) + tid;
-  for (; g + (long long)(kPbUnroll - 1) * kPbThreads < g1; g += (long long)kPbUnroll * kPbThreads) {
-    quad<T> pr[kPbUnroll];
-    ushort4 rl[kPbUnroll];
-#pragma unroll
-    for (int u = 0; u < kPbUnroll; ++u) {
-      const long long gg = g + (long long)u * kPbThreads;
-      pr[u] = load_quad<T>(P + 4 * gg);
-      rl[u] = row[gg];
-    }
-#pragma unroll
-    for (int u = 0; u < kPbUnroll; ++u) {
-      lds_add_elem<T>(lds, rl[u].x, pr[u].e[0]);
-      lds_add_elem<T>(lds, rl[u].y, pr[u].e[1]);
-      lds_add_elem<T>(lds, rl[u].z, pr[u].e[2]);
-      lds_add_elem<T>(lds, rl[u].w, pr[u].e[3]);
-    }
-  }
-  for (; g < g1; g += kPbThreads) {
-    const quad<T> pr = load_quad<T>(P + 4 * g);
-    const ushort4 rl = row[g];
-    lds_add_elem<T>(lds, rl.x, pr.e[0]);
-    lds_add_elem<T>(lds, rl.y, pr.e[1]);
-    lds_add_elem<T>(lds, rl.z, pr.e[2]);
-    lds_add_elem<T>(lds, rl.w, pr.e[3]);
-  }
-  __syncthreads();
-  double dot_acc = 0.0;
-  for (int i = tid; i < rows; i += kPbThreads) {
-    const T xi = xl[row0 + i];
-    acc_t<T> acc;
-    if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
-    else acc = lds[i];
-    const T yi = add(narrow<T>(acc), rmul(offset, xi));
-    y[row0 + i] = yi;
-    dot_acc += re_cmul(xi, yi);
-  }
-  if (dot_partials) {
-    const double v = wave_sum(dot_acc);
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < kPbThreads / 64; ++w) t += red[w];
-      dot_partials[blockIdx.x] = t;
-    }
-  }
-}
-
-template <typename T>
-int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s) {
-  // the opt-in to > 64 KiB of dynamic LDS is per device: remember which devices have it
-  static std::atomic<unsigned long long> attr_mask{0};
-  int dev = 0;
-  LL_HIP(hipGetDevice(&dev));
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
-    const int cap = 160 * 1024 - 2048;
-#define LL_PB_ATTR(K) LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, cap))
-    LL_PB_ATTR(pb_phase1<double>); LL_PB_ATTR(pb_phase1<zc>); LL_PB_ATTR(pb_phase1<float>); LL_PB_ATTR(pb_phase1<cf>);
-    LL_PB_ATTR(pb_phase2<double>); LL_PB_ATTR(pb_phase2<zc>); LL_PB_ATTR(pb_phase2<float>); LL_PB_ATTR(pb_phase2<cf>);
-#undef LL_PB_ATTR
-    attr_mask.fetch_or(bit, std::memory_order_release);
-  }
-  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 7) & ~(size_t)7) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
-  const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
-  hipLaunchKernelGGL((pb_phase1<T>), dim3(op.pb_ncb), dim3(kPbThreads), lds1, s, op.pb_nrb, op.pb_cb_cols, op.n,
-                     op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, x_full, (T*)op.d_pb_prod);
-  LL_HIP(hipGetLastError());
-  hipLaunchKernelGGL((pb_phase2<T>), dim3(op.pb_nrb), dim3(kPbThreads), lds2, s, op.pb_rb_rows, op.n_local,
-                     op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
-  LL_HIP(hipGetLastError());
-  return op.pb_nrb;
-}
-#define LL_INST_PB(T) template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
-LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)
 
 // ================================================================= strip geometry of the BLAS-1 kernels
 // A workgroup owns strips of kBlock*EPT consecutive elements; every lane keeps EPT elements of w in registers as

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/lanczos_hip.h"
+#include "../../include/lanczos_hip_transport.h"
 
 namespace ll {
 
@@ -106,10 +107,12 @@ struct NormRefs {
   const double* c1;
   const double* c2;
   int force2;
+  double thr = 0.5;  // DGKS threshold of the device-predicated form (LL_DGKS_THRESHOLD overrides it, like on the host)
 };
 
-// ---------------------------------------------------------------- communicator (RCCL, lazily loaded)
+// ---------------------------------------------------------------- communicator (RCCL, lazily loaded; or an external transport)
 struct Comm;
+Comm* comm_attach(const struct ::ll_transport* t, int rank, int nranks);
 Comm* comm_create(const void* id128, int rank, int nranks, int device);
 void comm_destroy(Comm*);
 void comm_unique_id(void* id128);
@@ -123,6 +126,19 @@ void comm_halo_exchange(Comm*, const void* send_prev, void* recv_prev, int prev,
 
 }  // namespace ll
 
+// ---------------------------------------------------------------- exchange plan of a sharded vector
+// The all-gather of a vector whose shards have the stride n_shard is cut into nchunks pieces: piece c = elements
+// [start[c], start[c] + len[c]) of EVERY shard.  Region c of the gathered buffer starts at nranks * start[c] elements
+// and holds rank s's piece at + s * len[c].  One chunk => the buffer is the vector in global order.
+namespace ll {
+constexpr int kMaxGatherChunks = 8;
+struct GatherPlan {
+  int nchunks = 1;
+  int64_t start[kMaxGatherChunks] = {0};
+  int64_t len[kMaxGatherChunks] = {0};
+};
+}  // namespace ll
+
 // ---------------------------------------------------------------- context
 struct ll_context {
   int device = 0;
@@ -130,6 +146,14 @@ struct ll_context {
   bool own_stream = false;
   ll::Comm* comm = nullptr;
   int rank = 0, nranks = 1;
+  int ranks_seen = 0;                 // result of the rank self-check at ll_comm_init (== nranks when healthy)
+  // Exchange overlap: the all-gather of a sharded vector is issued on comm_stream, chunk by chunk, so that
+  // SpMV work on the rank's own columns runs under it and every chunk's remote-column work starts when that chunk
+  // has arrived.  LL_COMM_OVERLAP=0 issues everything on `stream` instead (serial reference path for A/B tests).
+  hipStream_t comm_stream = nullptr;
+  bool overlap = true;
+  hipEvent_t ev_x_ready = nullptr;
+  hipEvent_t ev_chunk[ll::kMaxGatherChunks] = {};
   bool profiling = false;
   hipEvent_t t0 = nullptr, t1 = nullptr;  // ll_timer_*
 
@@ -149,15 +173,25 @@ struct ll_context {
   void* d_halo = nullptr;        // received halos of the lattice operator: [from prev | from next]
   size_t halo_cap = 0;           // bytes
 
+  // hipMalloc that makes room first when the device is full: the cached Krylov slabs of earlier runs are returned to
+  // the device and the allocation is retried; LL_ERR_ALLOC (with the size in the message) if it still fails.
+  void dev_malloc(void** out, size_t bytes, const char* what);
   void ensure_partials(size_t doubles);
   void ensure_h(size_t doubles);
   void ensure_pinned(size_t doubles);
   void ensure_coeff(size_t bytes);
   void ensure_xfull(size_t bytes);
   void ensure_halo(size_t bytes);
+  // device-time stamps of the exchange steps (only with profiling on): (start, end) pairs on the stream they ran on
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_gather, ev_allreduce;
+  void drain_comm_events(double* gather_s, double* allreduce_s);  // adds the elapsed device seconds, frees the events
   void* h_stage = nullptr;       // pinned host staging buffer for n-sized transfers (start vector, Ritz vectors)
   size_t stage_cap = 0;          // bytes
   void* ensure_stage(size_t bytes);
+  void* h_cb = nullptr;          // pinned [in | out] buffers of the host-callback operator
+  size_t cb_cap = 0;
+  hipEvent_t ev_cb = nullptr;    // recorded after the upload of a callback result
+  void* ensure_cb_stage(size_t bytes);
   void sync();
 };
 
@@ -178,16 +212,30 @@ struct ll_operator {
   bool owns_arrays = true;
   int32_t* d_tile_rows = nullptr;  // ntiles+1 row boundaries of the SpMV tiles
   int ntiles = 0;
-  // propagation-blocked image of the same matrix (kernels.hip pb_phase1 / pb_phase2)
+  // propagation-blocked image of the same matrix (spmv_pb.hip pb_phase1 / pb_phase2)
   int spmv_kind = 0;                 // LL_SPMV_*
-  int pb_ncb = 0, pb_nrb = 0, pb_cb_cols = 0, pb_rb_rows = 0;
+  float tune_ms[2] = {-1.f, -1.f};   // what the creation-time autotune measured for LL_SPMV_CSR_STREAM / LL_SPMV_PB (-1: not timed)
+  int pb_ncb = 0, pb_nrb = 0, pb_cb_cols = 0, pb_rb_rows = 0;   // cb_cols = longest column block (LDS sizing)
   int64_t* d_pb_segq = nullptr;      // [ncb][nrb+1] entry offsets of the segments in column-block order
   int64_t* d_pb_segdest = nullptr;   // [ncb][nrb]   position of each segment in row-block order
   int64_t* d_pb_rptr = nullptr;      // [nrb+1]      entry offsets of the row blocks in row-block order
+  int64_t* d_pb_xoff = nullptr;      // [ncb]        element offset of the block's x slice in ITS source buffer
+  int32_t* d_pb_ncols = nullptr;     // [ncb]        columns of the block
   void* d_pb_val = nullptr;          // values, column-block order
   uint16_t* d_pb_col = nullptr;      // local column, column-block order
   uint16_t* d_pb_row = nullptr;      // local row, row-block order
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
+  int64_t pb_entries = 0;            // padded entry count of the image
+  // kernel variants, read from the environment when the image is built (LL_PB_U1 / LL_PB_U2: quads per lane per trip;
+  // LL_PB_PHASE2=atomic: arrival-order LDS adds instead of the wave-ordered, bit-reproducible ones; LL_PB_ROW_GROUPS)
+  int pb_u1 = 2, pb_u2 = 2, pb_ordered = 1, pb_row_groups = 1;
+  // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
+  // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
+  // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
+  int pb_own_count = 0;                        // table range [0, own_count)
+  int pb_chunk_first[ll::kMaxGatherChunks] = {0};  // remote blocks of gather chunk c: [first, first + count)
+  int pb_chunk_count[ll::kMaxGatherChunks] = {0};
+  ll::GatherPlan gather;             // how a sharded vector is all-gathered when the PB kernels are selected
   // dense row-major block (kind DENSE): n_local x n values of T
   void* d_dense = nullptr;
   // lattice operator (kind STENCIL)
@@ -199,7 +247,6 @@ struct ll_operator {
   ll_host_mv_mul_z host_fn = nullptr;  // every host callback is stored under the void* signature
   ll_dev_mv_mul dev_fn = nullptr;
   void* user = nullptr;
-  std::vector<char> h_in, h_out;  // staging for the host callback
   ll_operator() = default;
   ll_operator(const ll_operator&) = delete;
   ll_operator& operator=(const ll_operator&) = delete;
@@ -216,10 +263,21 @@ namespace ll {
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
                 hipStream_t s);
-// Same contract, propagation-blocked kernels (op.spmv_kind == LL_SPMV_PB).
+// Same contract, propagation-blocked kernels (op.spmv_kind == LL_SPMV_PB; spmv_pb.hip): phase 1 over the own-column
+// blocks (x slices from x_own: the local shard readable up to the shard stride), then over every gather chunk's remote blocks (x slices from x_gathered, laid out
+// per op.gather), then phase 2.  The pieces are exposed so that the sharded driver can run the own-column part under
+// the all-gather and each chunk's part as soon as that chunk has arrived.
 template <typename T>
-int launch_spmv_pb(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset,
-                      double* dot_partials, hipStream_t s);
+int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
+                   double* dot_partials, hipStream_t s);
+template <typename T>
+void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s);
+template <typename T>
+int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials, hipStream_t s);
+// Build the propagation-blocked image on the device from the operator's CSR arrays (false: shape not supported).
+template <typename T> bool pb_build_device(ll_operator* op);
+// Column range check + max absolute row sum of the local rows (sets op->inf_norm), on the device.
+template <typename T> void csr_check_device(ll_operator* op);
 // Same contract for the dense row block (op.kind == DENSE).
 template <typename T>
 int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,

@@ -1,0 +1,691 @@
+// Propagation-blocked SpMV for gfx950 (a1/a2/a3: mv_mul LL:243 / EX:108, offset update LL:244-246, alpha dot LL:248)
+// and the device-side construction of its matrix image.
+//
+// Measured on MI355X (profiles/r01_gather_probe.txt): a gather that misses the CU's 32 KiB L1 moves a whole 128-byte
+// line for 8 useful bytes and the chip sustains only 57 G such gathers/s from an 80 MB x (217 G/s from an L2-resident
+// table).  For a matrix without column locality (BASELINE config 3: 1.5e8 gathers) that caps ANY gather-based CSR
+// kernel at >= 0.69 ms per SpMV (measured: 2.7 ms CSR-stream) while the matrix itself streams in 0.35 ms.
+//
+// These kernels therefore never gather from global memory.  The same matrix is stored in two sweeps' order (built
+// once at upload, on the device) and one SpMV is two fully coalesced streaming kernels with LDS-resident slices:
+//   phase 1 (one workgroup per COLUMN block): the x slice of the block is loaded into LDS; the block's entries
+//            (value, 16-bit local column) stream in, ordered by destination row block; product = value * x_lds[col]
+//            is written to the product buffer P at its position in row-block order (contiguous runs of one segment
+//            = one (column block, row block) pair);
+//   phase 2 (one workgroup per ROW block): the y slice lives in LDS; the row block's range of P and the 16-bit
+//            local row indices stream in (perfectly sequential) and are added into the slice with ds_add_f64; the
+//            epilogue adds offset*x_i (a2), writes y once and accumulates Re(conj(x_i) y_i) (a3).
+// HBM traffic is 2*sizeof(T) + sizeof(T) + 4 bytes per nonzero (28 B for fp64 against 12 B for CSR) but every byte
+// is streamed at full line efficiency and every x/y element is touched in LDS.
+//
+// Determinism: the LDS adds of phase 2 are issued WAVE BY WAVE in a fixed order (the 16 waves of the workgroup take
+// turns inside every trip, a barrier between turns), so every y_i is summed in the same order on every launch: the
+// kernel is bit-reproducible like every other reduction of the library (LL_PB_PHASE2=atomic restores the arrival-order
+// adds for A/B timing).  The next trip's loads are in flight while the turns run, so the turns cost no bandwidth.
+//
+// Column blocks carry their own x-slice offset, so one image serves the single-GPU case (x in place), the sharded
+// case (own columns from the local shard, the other ranks' columns from the gathered buffer, launched separately so
+// that own-column work overlaps the all-gather) and a gather that arrives in several chunks.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <string>
+
+#include "dev_helpers.hpp"
+#include "ll_internal.hpp"
+
+namespace ll {
+
+constexpr int kPbThreads = 1024;
+constexpr int kPbWaves = kPbThreads / 64;
+
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// Entries are handled in QUADS: every segment is padded to a multiple of 16 entries (zero value, local index 0), so
+// a lane always moves four consecutive entries with 16-byte accesses (2 x dwordx4 of values / products, one dwordx2
+// of four 16-bit indices), all four share one segment, and every run of products starts and ends on a 128-byte line.
+template <typename T> struct quad {
+  T e[4];
+};
+template <typename T> __device__ __forceinline__ quad<T> load_quad(const T* __restrict__ p) {
+  constexpr int NCH = (int)(4 * sizeof(T) / 16);  // 16-byte pieces of four entries (float: 1, double / cf: 2, zc: 4)
+  const uint4* src = reinterpret_cast<const uint4*>(p);
+  uint4 c[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) c[i] = src[i];
+  quad<T> q;
+  __builtin_memcpy(&q, c, sizeof(q));
+  return q;
+}
+template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__ p, const quad<T>& q) {
+  constexpr int NCH = (int)(4 * sizeof(T) / 16);
+  uint4 c[NCH];
+  __builtin_memcpy(c, &q, sizeof(q));
+  uint4* dst = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) dst[i] = c[i];
+}
+
+// ================================================================= phase 1
+// Workgroup b handles column block blk_first + b, restricted to the destination row blocks [rb_first, rb_first +
+// rb_count) (the whole range in production; a sub-range only for the row-group experiment LL_PB_ROW_GROUPS).
+// The first trip's loads are issued before the x slice is staged, and every trip requests the next one before it
+// consumes its own (U quads per lane per trip, 2U in flight).
+template <typename T, int U>
+__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, int rb_count, int blk_first,
+                                                        const int64_t* __restrict__ xoff,
+                                                        const int32_t* __restrict__ ncols_tab,
+                                                        const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
+                                                        const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
+                                                        const T* __restrict__ val, const ushort4* __restrict__ col,
+                                                        const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols) {
+  extern __shared__ double lds[];
+  T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
+  long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
+                                              (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [rb_count + 1]
+  long long* db = qs + (rb_count + 1);                                             // [rb_count]
+  const int tid = threadIdx.x;
+  const int c = blk_first + blockIdx.x;
+  const int64_t* sq = seg_q + (size_t)c * (nrb + 1) + rb_first;
+  const long long g0 = sq[0] >> 2, g1 = sq[rb_count] >> 2;
+
+  quad<T> v[U];
+  ushort4 cl[U];
+  long long g = g0 + tid;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long gg = g + (long long)u * kPbThreads;
+    if (gg < g1) {
+      v[u] = load_quad<T>(val + 4 * gg);
+      cl[u] = col[gg];
+    }
+  }
+  {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
+    const int ncols = ncols_tab[c];
+    const T* src = xsrc + xoff[c];
+    constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
+    if (V > 1 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const int nv = ncols / V;
+      const uint4* s4 = reinterpret_cast<const uint4*>(src);
+      uint4* d4 = reinterpret_cast<uint4*>(xs);
+      for (int i = tid; i < nv; i += kPbThreads) d4[i] = s4[i];
+      for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = src[i];
+    } else {
+      for (int i = tid; i < ncols; i += kPbThreads) xs[i] = src[i];
+    }
+    for (int i = tid; i <= rb_count; i += kPbThreads) qs[i] = sq[i];
+    const int64_t* sd = seg_dest + (size_t)c * nrb + rb_first;
+    for (int i = tid; i < rb_count; i += kPbThreads) db[i] = sd[i];
+  }
+  __syncthreads();
+  int r = 0;
+  for (; g < g1; g += (long long)U * kPbThreads) {
+    quad<T> vn[U];
+    ushort4 cn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = g + (long long)(U + u) * kPbThreads;
+      if (gg < g1) {
+        vn[u] = load_quad<T>(val + 4 * gg);
+        cn[u] = col[gg];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long qq = 4 * (g + (long long)u * kPbThreads);
+      if (qq < 4 * g1) {
+        while (qq >= qs[r + 1]) ++r;
+        quad<T> pr;
+        pr.e[0] = mul(v[u].e[0], xs[cl[u].x]);
+        pr.e[1] = mul(v[u].e[1], xs[cl[u].y]);
+        pr.e[2] = mul(v[u].e[2], xs[cl[u].z]);
+        pr.e[3] = mul(v[u].e[3], xs[cl[u].w]);
+        store_quad<T>(P + db[r] + (qq - qs[r]), pr);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = vn[u];
+      cl[u] = cn[u];
+    }
+  }
+}
+
+// ================================================================= phase 2
+template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, int rl, const T& v) {
+  if constexpr (scalar_traits<T>::is_complex) {
+    lds_add(&lds[2 * rl], (double)v.re);
+    lds_add(&lds[2 * rl + 1], (double)v.im);
+  } else {
+    lds_add(&lds[rl], (double)v);
+  }
+}
+
+// ORDERED: the waves add in turn (fixed order => bit-reproducible sums); otherwise in arrival order.
+template <typename T, int U, bool ORDERED>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_rows, int64_t n_local,
+                                                        const int64_t* __restrict__ rptr,  // [nrb + 1]
+                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                        const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                        double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];  // [rb_rows * R]
+  __shared__ double red[kPbWaves];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int rb = rb_first + blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+
+  quad<T> pr[U];
+  ushort4 rl[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long gg = g0 + tid + (long long)u * kPbThreads;
+    if (gg < g1) {
+      pr[u] = load_quad<T>(P + 4 * gg);
+      rl[u] = row[gg];
+    }
+  }
+  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
+  __syncthreads();
+  for (long long base = g0; base < g1; base += (long long)U * kPbThreads) {  // trip count is uniform over the workgroup
+    quad<T> pn[U];
+    ushort4 rn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = base + tid + (long long)(U + u) * kPbThreads;
+      if (gg < g1) {
+        pn[u] = load_quad<T>(P + 4 * gg);
+        rn[u] = row[gg];
+      }
+    }
+    auto add_mine = [&]() {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (base + tid + (long long)u * kPbThreads < g1) {
+          lds_add_elem<T>(lds, rl[u].x, pr[u].e[0]);
+          lds_add_elem<T>(lds, rl[u].y, pr[u].e[1]);
+          lds_add_elem<T>(lds, rl[u].z, pr[u].e[2]);
+          lds_add_elem<T>(lds, rl[u].w, pr[u].e[3]);
+        }
+      }
+    };
+    if constexpr (ORDERED) {
+      for (int w = 0; w < kPbWaves; ++w) {
+        if (wave == w) add_mine();
+        __syncthreads();
+      }
+    } else {
+      add_mine();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pr[u] = pn[u];
+      rl[u] = rn[u];
+    }
+  }
+  __syncthreads();
+  double dot_acc = 0.0;
+  for (int i = tid; i < rows; i += kPbThreads) {
+    const T xi = xl[row0 + i];
+    acc_t<T> acc;
+    if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
+    else acc = lds[i];
+    const T yi = add(narrow<T>(acc), rmul(offset, xi));
+    y[row0 + i] = yi;
+    dot_acc += re_cmul(xi, yi);
+  }
+  if (dot_partials) {
+    const double v = wave_sum(dot_acc);
+    if ((tid & 63) == 0) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kPbWaves; ++w) t += red[w];
+      dot_partials[rb] = t;
+    }
+  }
+}
+
+// ================================================================= launchers
+namespace {
+constexpr int kPbLdsCap = 160 * 1024 - 2048;
+
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+// the opt-in to > 64 KiB of dynamic LDS is per device and per kernel symbol
+template <typename T> void pb_opt_in_lds() {
+  static std::atomic<unsigned long long> mask{0};
+  int dev = 0;
+  LL_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return;
+#define LL_PB_ATTR(K) LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, kPbLdsCap))
+  LL_PB_ATTR((pb_phase1<T, 1>)); LL_PB_ATTR((pb_phase1<T, 2>)); LL_PB_ATTR((pb_phase1<T, 4>));
+  LL_PB_ATTR((pb_phase2<T, 1, true>)); LL_PB_ATTR((pb_phase2<T, 2, true>)); LL_PB_ATTR((pb_phase2<T, 4, true>));
+  LL_PB_ATTR((pb_phase2<T, 1, false>)); LL_PB_ATTR((pb_phase2<T, 2, false>)); LL_PB_ATTR((pb_phase2<T, 4, false>));
+#undef LL_PB_ATTR
+  mask.fetch_or(bit, std::memory_order_release);
+}
+
+template <typename T>
+void phase1_range(const ll_operator& op, int blk_first, int blk_count, int rb_first, int rb_count, const T* xsrc,
+                  hipStream_t s) {
+  if (blk_count <= 0 || rb_count <= 0) return;
+  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * rb_count + 1) * sizeof(long long);
+#define LL_P1(U)                                                                                                      \
+  hipLaunchKernelGGL((pb_phase1<T, U>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, rb_first, rb_count,   \
+                     blk_first, op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,   \
+                     (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols)
+  switch (op.pb_u1) {
+    case 1: LL_P1(1); break;
+    case 4: LL_P1(4); break;
+    default: LL_P1(2); break;
+  }
+#undef LL_P1
+  LL_HIP(hipGetLastError());
+}
+
+template <typename T>
+void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_local, T* y, double offset,
+                  double* dot_partials, hipStream_t s) {
+  if (rb_count <= 0) return;
+  const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
+#define LL_P2(U, O)                                                                                                    \
+  hipLaunchKernelGGL((pb_phase2<T, U, O>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,        \
+                     op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, \
+                     dot_partials)
+  const bool ord = op.pb_ordered != 0;
+  switch (op.pb_u2) {
+    case 1: if (ord) LL_P2(1, true); else LL_P2(1, false); break;
+    case 4: if (ord) LL_P2(4, true); else LL_P2(4, false); break;
+    default: if (ord) LL_P2(2, true); else LL_P2(2, false); break;
+  }
+#undef LL_P2
+  LL_HIP(hipGetLastError());
+}
+}  // namespace
+
+template <typename T>
+void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s) {
+  pb_opt_in_lds<T>();
+  phase1_range<T>(op, blk_first, blk_count, 0, op.pb_nrb, xsrc, s);
+}
+
+template <typename T>
+int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials,
+                     hipStream_t s) {
+  pb_opt_in_lds<T>();
+  phase2_range<T>(op, 0, op.pb_nrb, x_local, y, offset, dot_partials, s);
+  return op.pb_nrb;
+}
+
+template <typename T>
+int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
+                   double* dot_partials, hipStream_t s) {
+  pb_opt_in_lds<T>();
+  const int G = std::min(std::max(1, op.pb_row_groups), std::max(1, op.pb_nrb));
+  for (int g = 0; g < G; ++g) {  // G > 1: the row-group experiment (product chunk small enough for the Infinity Cache)
+    const int r0 = (int)((long long)op.pb_nrb * g / G), r1 = (int)((long long)op.pb_nrb * (g + 1) / G);
+    phase1_range<T>(op, 0, op.pb_own_count, r0, r1 - r0, x_own, s);
+    for (int c = 0; c < op.gather.nchunks; ++c)
+      phase1_range<T>(op, op.pb_chunk_first[c], op.pb_chunk_count[c], r0, r1 - r0, x_gathered, s);
+    phase2_range<T>(op, r0, r1 - r0, x_local, y, offset, dot_partials, s);
+  }
+  return op.pb_nrb;
+}
+
+// ================================================================= device-side construction of the image
+// Column -> (table index of its column block, local column).  Blocks never straddle a (rank, gather chunk) region,
+// so the x slice of a block is contiguous both in the local shard and in the gathered buffer.
+struct PbColMap {
+  long long shard;  // shard stride of the vector partition (n when not sharded)
+  int nranks, rank, nchunks;
+  long long cstart[kMaxGatherChunks];  // chunk start within a shard
+  int clen[kMaxGatherChunks];          // chunk length
+  int bl[kMaxGatherChunks];            // block length inside the chunk
+  int nb[kMaxGatherChunks];            // blocks per (rank, chunk)
+  int own_base[kMaxGatherChunks];      // table index of the first own block of chunk c
+  int rem_base[kMaxGatherChunks];      // table index of the first remote block of chunk c
+};
+__host__ __device__ inline int pb_block_of(const PbColMap& m, long long colg, int* local) {
+  const long long s = colg / m.shard;
+  const long long l = colg - s * m.shard;
+  int c = 0;
+  while (c + 1 < m.nchunks && l >= m.cstart[c + 1]) ++c;
+  const int within = (int)(l - m.cstart[c]);
+  const int b = within / m.bl[c];
+  *local = within - b * m.bl[c];
+  if ((int)s == m.rank) return m.own_base[c] + b;
+  const int so = (m.rank >= 0 && (int)s > m.rank) ? (int)s - 1 : (int)s;  // rank < 0: no own blocks at all
+  return m.rem_base[c] + so * m.nb[c] + b;
+}
+
+// Pass 1: entries per (column block, row block).  One workgroup per row block, LDS histogram over the column blocks.
+template <typename RP>
+__global__ __launch_bounds__(256) void pb_count_kernel(PbColMap m, int ncb, int nrb, int rb_rows, long long n_local,
+                                                       const RP* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                       int32_t* __restrict__ cnt /* [ncb][nrb] */) {
+  extern __shared__ int hist[];
+  const int r = blockIdx.x;
+  for (int i = threadIdx.x; i < ncb; i += 256) hist[i] = 0;
+  __syncthreads();
+  const long long i0 = (long long)r * rb_rows, i1 = min(n_local, i0 + rb_rows);
+  const long long p0 = (long long)rp[i0], p1 = (long long)rp[i1];
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+    int local;
+    atomicAdd(&hist[pb_block_of(m, ci[p], &local)], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncb; i += 256) cnt[(size_t)i * nrb + r] = hist[i];
+}
+
+// Pass 2: scatter.  ONE wavefront per row block walks the block's entries in CSR order, 64 at a time; entries of the
+// chunk that fall into the same segment get consecutive slots in lane order (ballot ranking), so the position of
+// every entry is a pure function of the matrix: the image — hence the summation order of phase 2 — is identical
+// from build to build.  Inside a segment both orders agree (row-major, original order within a row).
+template <typename T, typename RP>
+__global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int nrb, int rb_rows, long long n_local,
+                                                        const RP* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                        const T* __restrict__ va, const int64_t* __restrict__ segq,
+                                                        const int64_t* __restrict__ segdest, T* __restrict__ pval,
+                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow) {
+  extern __shared__ int fill[];  // [ncb]
+  const int r = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < ncb; i += 64) fill[i] = 0;
+  __syncthreads();
+  const long long i0 = (long long)r * rb_rows, i1 = min(n_local, i0 + rb_rows);
+  const long long p0 = (long long)rp[i0], p1 = (long long)rp[i1];
+  long long row_hint = i0;  // row of the chunk's first entry (monotone over the chunks)
+  for (long long base = p0; base < p1; base += 64) {
+    const long long p = base + lane;
+    const bool valid = p < p1;
+    // row of entry p: the last row i with rp[i] <= p (binary search from the hint; rows of a chunk are few)
+    long long lo = row_hint, hi = i1 - 1;
+    if (valid) {
+      while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if ((long long)rp[mid] <= p) lo = mid; else hi = mid - 1;
+      }
+    }
+    const long long rowi = lo;
+    row_hint = __shfl(rowi, 0, 64);
+    int local = 0;
+    const int key = valid ? pb_block_of(m, ci[p], &local) : -1;
+    int off = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k = __shfl(key, leader, 64);
+      const unsigned long long same = __ballot(valid && key == k);
+      if (valid && key == k) off = fill[k] + __popcll(same & ((1ull << lane) - 1ull));
+      __syncthreads();  // single wave: orders the LDS read above before the update below
+      if (lane == leader) fill[k] += __popcll(same);
+      __syncthreads();
+      todo &= ~same;
+    }
+    if (valid) {
+      const long long q = segq[(size_t)key * (nrb + 1) + r] + off;
+      pval[q] = va[p];
+      pcol[q] = (uint16_t)local;
+      prow[segdest[(size_t)key * nrb + r] + off] = (uint16_t)(rowi - i0);
+    }
+  }
+}
+
+// max_i sum_j |a_ij| over the local rows and the column range check, on the device (inputs may never have been on
+// the host).  out[0] = max row sum, out[1] = number of out-of-range columns.
+template <typename T, typename RP>
+__global__ __launch_bounds__(256) void csr_check_kernel(long long n_local, long long n_cols, const RP* __restrict__ rp,
+                                                        const int32_t* __restrict__ ci, const T* __restrict__ va,
+                                                        double* __restrict__ part_max, unsigned long long* __restrict__ bad) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  unsigned long long nbad = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_local; i += (long long)gridDim.x * 256) {
+    double rs = 0.0;
+    for (long long p = (long long)rp[i]; p < (long long)rp[i + 1]; ++p) {
+      rs += sqrt(abs2(va[p]));
+      const int c = ci[p];
+      if (c < 0 || c >= n_cols) ++nbad;
+    }
+    mx = fmax(mx, rs);
+  }
+  // fold: max over the workgroup (wave shuffles + LDS), count via one atomic per lane that saw a bad column
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = fmax(mx, __shfl_down(mx, d, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+template <typename T> void csr_check_device(ll_operator* op) {
+  const long long nr = op->n_local;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, (nr + 255) / 256));
+  double* d_part = nullptr;
+  unsigned long long* d_bad = nullptr;
+  op->ctx->dev_malloc((void**)&d_part, (size_t)grid * sizeof(double), "row-sum partials");
+  op->ctx->dev_malloc((void**)&d_bad, sizeof(unsigned long long), "column check");
+  struct Guard {
+    void *a, *b;
+    ~Guard() {
+      (void)hipFree(a);
+      (void)hipFree(b);
+    }
+  } guard{d_part, d_bad};
+  hipStream_t s = op->ctx->stream;
+  LL_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), s));
+  if (op->rp64)
+    hipLaunchKernelGGL((csr_check_kernel<T, int64_t>), dim3(grid), dim3(256), 0, s, nr, (long long)op->n,
+                       (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val, d_part, d_bad);
+  else
+    hipLaunchKernelGGL((csr_check_kernel<T, int32_t>), dim3(grid), dim3(256), 0, s, nr, (long long)op->n,
+                       (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val, d_part, d_bad);
+  LL_HIP(hipGetLastError());
+  std::vector<double> part((size_t)grid);
+  unsigned long long bad = 0;
+  LL_HIP(hipMemcpyAsync(part.data(), d_part, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  LL_REQUIRE(bad == 0, "column index out of range");
+  double mx = 0.0;
+  for (double v : part) mx = std::max(mx, v);
+  op->inf_norm = mx;
+}
+
+// Block geometry + tables on the host (O(ncb * nrb)), entry placement on the device.  Returns false when the image
+// cannot be built for this shape (segment tables too large, or the LDS budget cannot hold a slice and its tables):
+// the operator then keeps CSR-stream.
+template <typename T> bool pb_build_device(ll_operator* op) {
+  ll_context* ctx = op->ctx;
+  hipStream_t s = ctx->stream;
+  const int64_t nr = op->n_local;
+  const int P = std::max(1, ctx->nranks);
+  const int64_t S = P > 1 ? op->n_shard : op->n;
+
+  // ---- row blocks (y slice in LDS, 152 KiB at most)
+  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)sizeof(acc_t<T>));
+  auto block_len = [&](int64_t len, int64_t slice_max, const char* env) {
+    int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
+    int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
+    if (const char* e = std::getenv("LL_PB_BLOCK")) b = std::max(4, std::atoi(e));
+    if (const char* e = std::getenv(env)) b = std::max(4, std::atoi(e));
+    return std::min<int64_t>(b, slice_max);
+  };
+  const int64_t rb_rows = block_len(nr, row_max, "LL_PB_ROW_BLOCK");
+  const int64_t nrb = std::max<int64_t>(1, (nr + rb_rows - 1) / rb_rows);
+  // ---- LDS budget of phase 1: x slice + two tables of nrb entries (the advisor's round-1 finding: check it here)
+  const int64_t table_bytes = (2 * nrb + 1) * (int64_t)sizeof(long long) + 16;
+  if (table_bytes + 1024 > kPbLdsCap) return false;
+  const int64_t col_max = std::min<int64_t>(65536, std::min<int64_t>(104 * 1024, kPbLdsCap - table_bytes) / (int64_t)sizeof(T));
+  if (col_max < 16) return false;
+
+  // ---- gather chunks and column blocks
+  PbColMap m;
+  std::memset(&m, 0, sizeof(m));
+  m.shard = S;
+  m.nranks = P;
+  m.rank = ctx->comm != nullptr ? ctx->rank : 0;
+  // test hook: treat the rank's own columns like everybody else's (every x slice is read from the gathered buffer), so
+  // that a 1-rank RCCL communicator exercises the gather -> remote-block dependency of the overlapped path
+  if (ctx->comm != nullptr && env_int("LL_PB_TEST_ALL_REMOTE", 0) != 0) m.rank = -1;
+  const int nrem = m.rank >= 0 ? P - 1 : P;  // ranks whose columns are remote
+  GatherPlan gp;
+  {
+    int want = P > 1 ? env_int("LL_GATHER_CHUNKS", 4) : 1;
+    want = std::max(1, std::min(want, kMaxGatherChunks));
+    int64_t lc = (S + want - 1) / want;
+    lc = std::max<int64_t>(256, (lc + 255) / 256 * 256);  // chunk starts stay 2 KiB aligned
+    gp.nchunks = (int)std::max<int64_t>(1, (S + lc - 1) / lc);
+    for (int c = 0; c < gp.nchunks; ++c) {
+      gp.start[c] = c * lc;
+      gp.len[c] = std::min<int64_t>(lc, S - c * lc);
+    }
+  }
+  m.nchunks = gp.nchunks;
+  int own_total = 0;
+  for (int c = 0; c < gp.nchunks; ++c) {
+    m.cstart[c] = gp.start[c];
+    m.clen[c] = (int)gp.len[c];
+    int64_t bl;
+    if (P == 1) bl = block_len(gp.len[c], col_max, "LL_PB_COL_BLOCK");
+    else {
+      const int64_t nbw = (gp.len[c] + col_max - 1) / col_max;
+      bl = (gp.len[c] + nbw - 1) / nbw;
+      bl = std::min<int64_t>(col_max, (bl + 3) / 4 * 4);
+      if (const char* e = std::getenv("LL_PB_BLOCK")) bl = std::min<int64_t>(col_max, std::max(4, std::atoi(e)));
+      if (const char* e = std::getenv("LL_PB_COL_BLOCK")) bl = std::min<int64_t>(col_max, std::max(4, std::atoi(e)));
+    }
+    m.bl[c] = (int)bl;
+    m.nb[c] = (int)((gp.len[c] + bl - 1) / bl);
+    m.own_base[c] = own_total;
+    if (m.rank >= 0) own_total += m.nb[c];
+  }
+  int64_t ncb = own_total;
+  for (int c = 0; c < gp.nchunks; ++c) {
+    m.rem_base[c] = (int)ncb;
+    op->pb_chunk_first[c] = (int)ncb;
+    op->pb_chunk_count[c] = nrem * m.nb[c];
+    ncb += (int64_t)nrem * m.nb[c];
+  }
+  if (ncb * nrb > (int64_t)24 << 20) return false;  // segment tables would not pay off (n beyond ~6e7): keep CSR
+  if (ncb * (int64_t)sizeof(int) > 60 * 1024) return false;  // LDS histogram of the build kernels
+  int cb_cols = 0;
+  std::vector<int64_t> xoff((size_t)ncb);
+  std::vector<int32_t> ncols((size_t)ncb);
+  for (int c = 0; c < gp.nchunks; ++c) {
+    cb_cols = std::max(cb_cols, m.bl[c]);
+    for (int sr = 0; sr < P; ++sr)
+      for (int b = 0; b < m.nb[c]; ++b) {
+        const bool own = sr == m.rank;
+        const int idx = own ? m.own_base[c] + b
+                            : m.rem_base[c] + ((m.rank >= 0 && sr > m.rank) ? sr - 1 : sr) * m.nb[c] + b;
+        ncols[(size_t)idx] = (int32_t)std::min<int64_t>(m.bl[c], gp.len[c] - (int64_t)b * m.bl[c]);
+        xoff[(size_t)idx] = own ? gp.start[c] + (int64_t)b * m.bl[c]
+                                : (int64_t)P * gp.start[c] + (int64_t)sr * gp.len[c] + (int64_t)b * m.bl[c];
+      }
+  }
+
+  // ---- pass 1 on the device: segment sizes
+  int32_t* d_cnt = nullptr;
+  ctx->dev_malloc((void**)&d_cnt, (size_t)ncb * nrb * sizeof(int32_t), "segment counts");
+  struct Free1 {
+    void* p;
+    ~Free1() { (void)hipFree(p); }
+  } free_cnt{d_cnt};
+  const size_t hist_bytes = (size_t)ncb * sizeof(int);
+  if (op->rp64)
+    hipLaunchKernelGGL((pb_count_kernel<int64_t>), dim3((int)nrb), dim3(256), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, d_cnt);
+  else
+    hipLaunchKernelGGL((pb_count_kernel<int32_t>), dim3((int)nrb), dim3(256), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, d_cnt);
+  LL_HIP(hipGetLastError());
+  std::vector<int32_t> cnt32((size_t)ncb * nrb);
+  LL_HIP(hipMemcpyAsync(cnt32.data(), d_cnt, cnt32.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  // every segment is padded to 16 entries: kernels move quads (4 entries per lane, 16-byte accesses) and every run of
+  // products written by phase 1 starts and ends on a 128-byte line (measured 3.5 % faster than quad padding)
+  int64_t pad = 16;
+  if (const char* e = std::getenv("LL_PB_PAD")) pad = std::max(4, std::atoi(e) / 4 * 4);
+  // column-block order: segments (c, r) with r fastest; row-block order: (r, c) with c fastest
+  std::vector<int64_t> segq((size_t)ncb * (nrb + 1)), segdest((size_t)ncb * nrb), rptr((size_t)nrb + 1);
+  {
+    int64_t q = 0;
+    for (int64_t c = 0; c < ncb; ++c) {
+      for (int64_t r = 0; r < nrb; ++r) {
+        segq[(size_t)c * (nrb + 1) + r] = q;
+        q += ((int64_t)cnt32[(size_t)c * nrb + r] + pad - 1) / pad * pad;
+      }
+      segq[(size_t)c * (nrb + 1) + nrb] = q;
+    }
+    int64_t d = 0;
+    for (int64_t r = 0; r < nrb; ++r) {
+      rptr[(size_t)r] = d;
+      for (int64_t c = 0; c < ncb; ++c) {
+        segdest[(size_t)c * nrb + r] = d;
+        d += ((int64_t)cnt32[(size_t)c * nrb + r] + pad - 1) / pad * pad;
+      }
+    }
+    rptr[(size_t)nrb] = d;
+  }
+  const size_t entries = (size_t)rptr[(size_t)nrb];
+  op->pb_ncb = (int)ncb;
+  op->pb_nrb = (int)nrb;
+  op->pb_cb_cols = cb_cols;
+  op->pb_rb_rows = (int)rb_rows;
+  op->pb_own_count = own_total;
+  op->pb_entries = (int64_t)entries;
+  op->gather = gp;
+  // kernel variants are fixed per operator at creation (several variants can then be timed in one process)
+  op->pb_u1 = env_int("LL_PB_U1", 2);
+  op->pb_u2 = env_int("LL_PB_U2", 2);
+  {
+    const char* p2 = std::getenv("LL_PB_PHASE2");
+    op->pb_ordered = !(p2 && std::string(p2) == "atomic");
+  }
+  op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
+    LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
+  };
+  up((void**)&op->d_pb_segq, segq.data(), segq.size() * sizeof(int64_t));
+  up((void**)&op->d_pb_segdest, segdest.data(), segdest.size() * sizeof(int64_t));
+  up((void**)&op->d_pb_rptr, rptr.data(), rptr.size() * sizeof(int64_t));
+  up((void**)&op->d_pb_xoff, xoff.data(), xoff.size() * sizeof(int64_t));
+  up((void**)&op->d_pb_ncols, ncols.data(), ncols.size() * sizeof(int32_t));
+  const size_t cap = std::max<size_t>(entries, 16);
+  ctx->dev_malloc(&op->d_pb_val, cap * sizeof(T), "propagation-blocking values");
+  ctx->dev_malloc((void**)&op->d_pb_col, cap * sizeof(uint16_t), "propagation-blocking columns");
+  ctx->dev_malloc((void**)&op->d_pb_row, cap * sizeof(uint16_t), "propagation-blocking rows");
+  ctx->dev_malloc(&op->d_pb_prod, cap * sizeof(T), "product buffer");
+  LL_HIP(hipMemsetAsync(op->d_pb_val, 0, cap * sizeof(T), s));  // padding entries: value 0, local indices 0
+  LL_HIP(hipMemsetAsync(op->d_pb_col, 0, cap * sizeof(uint16_t), s));
+  LL_HIP(hipMemsetAsync(op->d_pb_row, 0, cap * sizeof(uint16_t), s));
+  // ---- pass 2 on the device: place the entries
+  if (op->rp64)
+    hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+  else
+    hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+  LL_HIP(hipGetLastError());
+  LL_HIP(hipStreamSynchronize(s));  // the host tables above go out of scope
+  return true;
+}
+
+#define LL_INST_PB(T)                                                                                              \
+  template void launch_pb_phase1<T>(const ll_operator&, int, int, const T*, hipStream_t);                           \
+  template int launch_pb_phase2<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t);                 \
+  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t); \
+  template bool pb_build_device<T>(ll_operator*);                                                                   \
+  template void csr_check_device<T>(ll_operator*);
+LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)
+
+}  // namespace ll

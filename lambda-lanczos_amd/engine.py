@@ -92,6 +92,12 @@ class Context:
         check(lib().ll_comm_init(self.handle, buf, int(rank), int(n_ranks)))
         self.rank, self.n_ranks = int(rank), int(n_ranks)
 
+    def ranks_seen(self):
+        """Rank tags that arrived in the communicator self-check of init_comm (== n_ranks when healthy; 1 without one)."""
+        out = C.c_int()
+        check(lib().ll_comm_ranks_seen(self.handle, C.byref(out)))
+        return out.value
+
     def partition(self, n):
         return partition(n, self.n_ranks, self.rank)
 
@@ -202,6 +208,12 @@ class CsrOperator(_Operator):
     def select_spmv(self, kind):
         """capi.SPMV_PB or capi.SPMV_CSR_STREAM (default: whichever timed faster at creation)."""
         check(lib().ll_op_select_spmv(self.handle, int(kind)))
+
+    def autotune_ms(self):
+        """(csr_stream_ms, pb_ms) measured when the operator was created (-1: not timed)."""
+        a, b = C.c_double(), C.c_double()
+        check(lib().ll_op_autotune_ms(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def selected_spmv(self):
         k = C.c_int()
@@ -434,7 +446,7 @@ class LambdaLanczos:
         self.num_eigs_per_iteration = 5                          # LL:173
         self.initial_vector_size = 200                           # LL:181
         # additions (0 = reference-faithful)
-        self.tridiag_mode = capi.TRIDIAG_QR
+        self.tridiag_mode = capi.TRIDIAG_AUTO  # decision- and value-identical to the reference's QR, O(k) per iteration
         self.orth_mode = capi.ORTH_CGS_DGKS
         self._iter_counts = []
         self.last_stats = None

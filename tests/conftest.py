@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Tests switch SpMV kernels on live operators (ll_op_select_spmv), so both matrix images are kept; the default
+# (release the image that lost the creation-time timing) has its own test.
+os.environ.setdefault("LL_SPMV_KEEP_BOTH", "1")
+# The host-staged multi-rank TEST transport (tests/transport/, built by __graft_entry__.build()).
+SHM_TRANSPORT = os.path.join(ROOT, "tests", "transport", "_build", "libll_shm_transport.so")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -4,6 +4,7 @@
 // known answers on the GPU.  The PROBLEMS (matrices, expected eigenpairs) are the known-answer data of the reference's
 // test suite (cited per case); the harness is ours: one table of cases, one generic checker.
 // Built and executed by tests/test_cpp_facade.py; exit code 0 = all expectations met.
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -144,6 +145,32 @@ static void run_iteration_direct() {
   }
 }
 
+static void const_and_default_hook() {
+  std::printf("[case] const engine: run_iteration is const and init_vector defaults to a callable (lambda_lanczos.hpp:133,216-220)\n");
+  std::vector<std::vector<double>> m = {{2, 1, 0}, {1, 2, 1}, {0, 1, 2}};
+  const ll::LambdaLanczos<double> engine(dense<double>(m), 3, true, 1);
+  // user code that invokes the public hook itself, like code written against the reference may do
+  std::vector<double> v(1000, 7.0);
+  engine.init_vector(v);
+  double lo = 1e9, hi = -1e9, sum = 0;
+  for (double e : v) lo = std::min(lo, e), hi = std::max(hi, e), sum += e;
+  expect(lo >= -1.0 && hi <= 1.0 && lo < -0.5 && hi > 0.5 && std::abs(sum) < 200.0, "default init_vector fills uniform [-1, 1]");
+  std::vector<std::complex<double>> vz(500);
+  ll::LambdaLanczos<cplx> ez(dense<cplx>({{cplx(1, 0)}}), 1, true, 1);
+  ez.init_vector(vz);
+  bool imag_used = false;
+  for (auto& e : vz) imag_used = imag_used || std::abs(e.imag()) > 0.1;
+  expect(imag_used, "complex default initialiser fills both parts");
+  // run_iteration on a CONST engine with the (random) default start vector
+  std::vector<double> values;
+  std::vector<std::vector<double>> vectors;
+  std::vector<std::vector<double>> none;
+  const size_t itern = engine.run_iteration(values, vectors, 1, none);
+  expect(itern >= 2 && itern <= 3, "run_iteration on a const engine");
+  expect(!values.empty(), "one pair returned");
+  if (!values.empty()) expect_close(2.0 + std::sqrt(2.0), values[0], 1e-10, "largest eigenvalue of tridiag(1,2,1)");
+}
+
 static void device_operator() {
   std::printf("[case] device-resident CsrMatrix operator, 5-point Laplacian 40x40 (analytic spectrum)\n");
   const int64_t N = 40, n = N * N;
@@ -260,6 +287,7 @@ int main() {
     eigen_cases();
     api_shapes();
     run_iteration_direct();
+    const_and_default_hook();
     device_operator();
     operator_zoo();
     exponentiator();

@@ -1,5 +1,5 @@
 """One rank of tests/test_gpu_multirank.py: several of these processes share the single GPU of the test box and talk
-through the library's host-staged test communicator (LL_COMM_BACKEND=shm) — the sharded engine with real HIP kernels
+through the host-staged test transport (LL_COMM_PLUGIN=tests/transport/_build/libll_shm_transport.so) — the sharded engine with real HIP kernels
 and N > 1 ranks.  argv: rank world shm_name out_dir"""
 import json
 import os

