@@ -120,7 +120,7 @@ ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
                   (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_val, (void*)d_pb_col, (void*)d_pb_row,
-                  d_pb_prod})
+                  d_pb_prod, d_l2_val, (void*)d_l2_idx, (void*)d_l2_ptr, (void*)d_l2_sync})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -611,6 +611,24 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     (void)hipFree(d);
     return sum == 0.0;
   };
+  if (want == "l2g") {  // EXPERIMENT: the L2-blocked gather kernel (spmv_l2g.hip), built on the host, single GPU
+    std::vector<int32_t> ci_copy;
+    std::vector<T> va_copy;
+    const int32_t* ci_host = ci;
+    const T* va_host = (const T*)va;
+    if (on_device) {
+      ci_copy.resize(nnz);
+      va_copy.resize(nnz);
+      LL_HIP(hipMemcpy(ci_copy.data(), ci, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+      LL_HIP(hipMemcpy(va_copy.data(), va, nnz * sizeof(T), hipMemcpyDeviceToHost));
+      ci_host = ci_copy.data();
+      va_host = va_copy.data();
+    }
+    LL_REQUIRE(l2g_build_host<T>(op.get(), rp_host, ci_host, va_host), "LL_SPMV_KERNEL=l2g: image not buildable (sharded context or empty matrix)");
+    op->spmv_kind = LL_SPMV_L2G_EXPERIMENT;
+    *out = op.release();
+    return;
+  }
   if (want != "csr" && (nnz > 0 || ctx->comm != nullptr)) {
     // the propagation-blocked image is built on the device from the CSR arrays (histogram + scatter kernels)
     bool built = false;
@@ -835,7 +853,8 @@ int ll_op_destroy(ll_operator* op) {
 int ll_op_select_spmv(ll_operator* op, int kind) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
-    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB, "unknown SpMV kernel");
+    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB || (kind == LL_SPMV_L2G_EXPERIMENT && op->d_l2_val),
+               "unknown SpMV kernel");
     LL_REQUIRE(kind != LL_SPMV_PB || op->d_pb_val != nullptr,
                "operator has no propagation-blocked image (not selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");
     LL_REQUIRE(kind != LL_SPMV_CSR_STREAM || op->d_row_ptr != nullptr,

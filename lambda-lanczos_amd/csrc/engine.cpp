@@ -4,6 +4,7 @@
 // the device already executes iteration k+1 (lag-1 speculation: a speculative iteration only writes basis slots
 // the results never read, so stopping one iteration "late" on the device is harmless).
 #include "engine.hpp"
+#include "ritz_tracker.hpp"
 #include "trace.hpp"
 
 #include <algorithm>
@@ -20,6 +21,10 @@ static inline double now_s() {
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 // DGKS "twice is enough": a second Gram-Schmidt pass is due when the first one removed more than this fraction of
 // ||w||^2.  LL_DGKS_THRESHOLD overrides the 1/2 (testing: a value > 1 forces the second pass in every iteration).
+static bool tridiag_thread_enabled() {
+  const char* e = std::getenv("LL_TRIDIAG_THREAD");
+  return !(e && std::atoi(e) == 0);
+}
 static double dgks_threshold() {
   const char* e = std::getenv("LL_DGKS_THRESHOLD");
   return e ? std::atof(e) : 0.5;
@@ -136,7 +141,7 @@ template <typename T>
 void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded) {
   TraceRange trace("ll::apply (mv_mul + offset + alpha)");
   hipStream_t s = ctx->stream;
-  ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)op->pb_nrb));
+  ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)std::max(op->pb_nrb, op->l2_nrb)));
   int nparts = 0;
   if (op->kind == ll_operator::STENCIL) {
     // exchange step of the lattice operator: one hyperplane from each ring neighbour instead of the all-gather
@@ -218,6 +223,8 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
     else if (pb)
       nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    else if (op->spmv_kind == LL_SPMV_L2G_EXPERIMENT)
+      nparts = launch_spmv_l2g<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
   } else {
@@ -623,7 +630,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     // ---- the Lanczos loop (LL:240-310)
     alpha.clear();
     beta.clear();
-    std::vector<double> evs, pevs, all;
+    std::vector<double> evs, all;
     bool evs_from_qr = true;  // whether `evs` hold the values of the reference's QR arithmetic (else: bisection values)
     int64_t itern = P.max_iteration;
     bool stopped = false;
@@ -651,10 +658,34 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       refs_prev = refs;
       t_enqueue += now_s() - te0;
     };
-    // host half of iteration j (H1-H4): kContinue, kStop (the loop ends after j iterations) or kRedone (a second
-    // Gram-Schmidt pass changed u_j: the speculative iteration j+1 must be enqueued again)
-    enum { kContinue = 0, kStop = 1, kRedone = 2 };
-    auto process = [&](int64_t j) -> int {
+    // Host half of iteration j, part 1 (this thread): wait for the four scalars, take the DGKS decision, append
+    // alpha_j / beta_j and hand T_j to the Ritz tracker.  kRedone: a second Gram-Schmidt pass changed u_j, the
+    // speculative iteration j+1 must be enqueued again.
+    enum { kContinue = 0, kRedone = 2 };
+    RitzTracker tracker_cfg;
+    tracker_cfg.nroot = nroot;
+    tracker_cfg.find_maximum = P.find_maximum != 0;
+    tracker_cfg.mode = P.tridiag_mode;
+    tracker_cfg.eps = P.eps;
+    tracker_cfg.breakdown_tol = (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon() * 1e1;  // H3 LL:279
+    // Callback operators run WITHOUT speculation: the user's mv_mul must be called exactly as often as the reference
+    // calls it (LL:243: once per executed iteration) and never on the 1/sqrt(~0)-scaled vector that follows a
+    // breakdown; a host callback synchronises the stream anyway, so there is nothing to overlap.
+    const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);
+    // Part 2 (H1-H4: Ritz values, breakdown, convergence) runs on a helper thread, in iteration order; this thread
+    // keeps enqueuing and looks at the verdicts as they arrive, at most kMaxLag iterations late.  A verdict that
+    // arrives late only means a few speculative iterations more on the device (they write basis slots the results
+    // never read).  LL_TRIDIAG_THREAD=0 computes the verdicts inline (lag 1, the round-1 behaviour).
+    const bool threaded = speculate && tridiag_thread_enabled();
+    const size_t kMaxLag = threaded ? 3 : 0;
+    TridiagWorker worker(tracker_cfg, threaded);
+    RitzTracker::Out last;
+    auto absorb = [&](RitzTracker::Out& r) {
+      t_tridiag += r.seconds;
+      last = std::move(r);
+      return last.stop;
+    };
+    auto collect = [&](int64_t j) -> int {
       const int slot = (int)(j % 4);
       const double tw0 = now_s();
       LL_HIP(hipEventSynchronize(ring.ev[slot]));
@@ -684,83 +715,34 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       }
       alpha.push_back(alpha_j);
       beta.push_back(std::sqrt(beta2_j));
-      TraceRange trace("ll::host_tridiag (Ritz values + stop test)");
-      const double t0 = now_s();
-      const int64_t m = (int64_t)alpha.size();
-      const int64_t ncalc = std::min<int64_t>(nroot, m);
-      evs.clear();
-      const bool use_qr = P.tridiag_mode == LL_TRIDIAG_QR || (P.tridiag_mode == LL_TRIDIAG_AUTO && m <= 64);
-      if (use_qr) {
-        all.resize((size_t)m);
-        tridiag_qr(m, alpha.data(), beta.data(), all.data(), nullptr);  // H1 LL:267-268
-        for (int64_t i = 0; i < ncalc; ++i) evs.push_back(P.find_maximum ? all[m - i - 1] : all[i]);  // H2
-        evs_from_qr = true;
-      } else {
-        evs_from_qr = false;
-        for (int64_t i = 0; i < ncalc; ++i)
-          evs.push_back(tridiag_bisect(m, alpha.data(), beta.data(), P.find_maximum ? m - i - 1 : i));
-      }
-      t_tridiag += now_s() - t0;
-      // H3 LL:279-283: 10 * machine epsilon of real_t<T> (float storage => the float epsilon, like the reference)
-      if (beta.back() < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon() * 1e1) return kStop;
-      // H4 LL:290-309: every tracked root changed by less than eps (relative)
-      auto converged = [&](const std::vector<double>& now, const std::vector<double>& before, double tol) {
-        if (before.size() != now.size()) return false;
-        for (int64_t r = 0; r < nroot; ++r)
-          if (std::abs(now[r] - before[r]) >= std::min(std::abs(now[r]), std::abs(before[r])) * tol) return false;
-        return true;
-      };
-      bool stop;
-      if (use_qr) {
-        stop = converged(evs, pevs, P.eps);
-      } else {
-        // Bisection values differ from the reference's QR values by a few ulp, far less than eps; the decision can only
-        // differ when a root's change sits within that distance of eps.  So: not even within 4*eps => certainly no
-        // stop; otherwise the reference's own arithmetic (QR of T_m and T_{m-1}) takes the decision, and on a stop
-        // its values are the ones returned — iteration counts and eigenvalues equal LL_TRIDIAG_QR's by construction.
-        const bool guarded = P.tridiag_mode == LL_TRIDIAG_AUTO;  // LL_TRIDIAG_BISECT: bisection values decide alone
-        stop = converged(evs, pevs, guarded ? 4.0 * P.eps : P.eps);
-        if (stop && guarded) {
-          const double tq0 = now_s();
-          std::vector<double> cur((size_t)m), prev((size_t)(m - 1)), e_now, e_before;
-          tridiag_qr(m, alpha.data(), beta.data(), cur.data(), nullptr);
-          tridiag_qr(m - 1, alpha.data(), beta.data(), prev.data(), nullptr);
-          for (int64_t i = 0; i < ncalc; ++i) e_now.push_back(P.find_maximum ? cur[m - i - 1] : cur[i]);
-          for (int64_t i = 0; i < std::min<int64_t>(nroot, m - 1); ++i)
-            e_before.push_back(P.find_maximum ? prev[m - 2 - i] : prev[i]);
-          t_tridiag += now_s() - tq0;
-          stop = converged(e_now, e_before, P.eps);
-          if (stop) {
-            evs = e_now;
-            evs_from_qr = true;
-          }
-        }
-      }
-      if (stop) return kStop;
-      pevs = evs;
+      worker.submit((int64_t)alpha.size(), alpha.data(), beta.data());
       return verdict;
     };
 
-    // Callback operators run WITHOUT the lag-1 speculation: the user's mv_mul must be called exactly as often as the
-    // reference calls it (LL:243: once per executed iteration) and never on the 1/sqrt(~0)-scaled vector that follows a
-    // breakdown; a host callback synchronises the stream anyway, so there is nothing to overlap.
-    const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);
+    RitzTracker::Out r;
     if (speculate) {
-      for (int64_t k = 1; k <= P.max_iteration; ++k) {
+      for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
         enqueue(k);
         if (k > 1) {
-          const int v = process(k - 1);
-          if (v == kStop) { itern = k - 1; stopped = true; break; }
-          if (v == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
+          if (collect(k - 1) == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
+          while (!stopped && worker.try_pop(r)) stopped = absorb(r);
+          while (!stopped && worker.outstanding() > kMaxLag && worker.wait_pop(r)) stopped = absorb(r);
         }
       }
-      if (!stopped) process(P.max_iteration);  // itern stays max_iteration either way (LL:239,312)
+      if (!stopped) collect(P.max_iteration);
     } else {
-      for (int64_t k = 1; k <= P.max_iteration; ++k) {
+      for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
         enqueue(k);
-        if (process(k) == kStop) { itern = k; stopped = true; break; }  // kRedone: u_k was repaired in place, nothing ran ahead
+        collect(k);  // kRedone: u_k was repaired in place, nothing ran ahead
+        while (!stopped && worker.wait_pop(r)) stopped = absorb(r);
       }
     }
+    while (!stopped && worker.wait_pop(r)) stopped = absorb(r);  // the first stop verdict wins; else the last iteration's values
+    itern = last.m;  // == max_iteration without a stop (LL:239,312)
+    evs = last.evs;
+    evs_from_qr = last.evs_from_qr;
+    alpha.resize((size_t)itern);  // iterations the device ran ahead of the verdict are dropped
+    beta.resize((size_t)itern);
     LL_HIP(hipStreamSynchronize(s));
 
     // ---- Ritz pairs (LL:312-319, LL:33-62)

@@ -228,7 +228,7 @@ struct ll_operator {
   int64_t pb_entries = 0;            // padded entry count of the image
   // kernel variants, read from the environment when the image is built (LL_PB_U1 / LL_PB_U2: quads per lane per trip;
   // LL_PB_PHASE2=atomic: arrival-order LDS adds instead of the wave-ordered, bit-reproducible ones; LL_PB_ROW_GROUPS)
-  int pb_u1 = 2, pb_u2 = 2, pb_ordered = 1, pb_row_groups = 1;
+  int pb_u1 = 1, pb_u2 = 2, pb_ordered = 1, pb_row_groups = 1, pb_depth = 2;  // pb_depth: trips of loads in flight (LL_PB_DEPTH)
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
@@ -236,6 +236,12 @@ struct ll_operator {
   int pb_chunk_first[ll::kMaxGatherChunks] = {0};  // remote blocks of gather chunk c: [first, first + count)
   int pb_chunk_count[ll::kMaxGatherChunks] = {0};
   ll::GatherPlan gather;             // how a sharded vector is all-gathered when the PB kernels are selected
+  // EXPERIMENT: L2-blocked gather image (spmv_l2g.hip; only with LL_SPMV_KERNEL=l2g)
+  int l2_nrb = 0, l2_nsl = 0, l2_rb_rows = 0, l2_slice_log2 = 18;
+  void* d_l2_val = nullptr;
+  uint32_t* d_l2_idx = nullptr;
+  int64_t* d_l2_ptr = nullptr;
+  unsigned* d_l2_sync = nullptr;
   // dense row-major block (kind DENSE): n_local x n values of T
   void* d_dense = nullptr;
   // lattice operator (kind STENCIL)
@@ -274,6 +280,12 @@ template <typename T>
 void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s);
 template <typename T>
 int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials, hipStream_t s);
+// EXPERIMENT (LL_SPMV_KERNEL=l2g, single GPU): L2-blocked gather kernel and its host-built image (spmv_l2g.hip).
+template <typename T>
+int launch_spmv_l2g(const ll_operator& op, const T* x, const T* x_local, T* y, double offset, double* dot_partials,
+                    hipStream_t s);
+template <typename T> bool l2g_build_host(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va);
+constexpr int LL_SPMV_L2G_EXPERIMENT = 2;
 // Build the propagation-blocked image on the device from the operator's CSR arrays (false: shape not supported).
 template <typename T> bool pb_build_device(ll_operator* op);
 // Column range check + max absolute row sum of the local rows (sets op->inf_norm), on the device.

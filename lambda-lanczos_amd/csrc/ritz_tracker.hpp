@@ -1,0 +1,202 @@
+// The host scalar step of the eigen-solver loop (LL:264-309): Ritz values of T_m, selection of the
+// nroot extremes, breakdown test, convergence test — and the helper thread that runs it OFF the enqueueing thread
+// (SURVEY section 7 step 5), so that the O(m) .. O(m^2) scalar work of iteration j never delays the launches of
+// iterations j+1, j+2, ...
+#pragma once
+
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "ll_internal.hpp"
+#include "trace.hpp"
+
+namespace ll {
+
+// One call per Lanczos iteration, in order.  Keeps the previous iteration's Ritz values (LL:266 `pevs`).
+struct RitzTracker {
+  // configuration
+  int64_t nroot = 1;
+  bool find_maximum = false;
+  int mode = LL_TRIDIAG_AUTO;
+  double eps = 0.0;
+  double breakdown_tol = 0.0;  // LL:279: 10 * epsilon of real_t<T>
+
+  struct Out {
+    int64_t m = 0;
+    bool stop = false;           // H3 (breakdown) or H4 (converged): the loop ends after m iterations
+    bool evs_from_qr = true;     // the values are those of the reference's QR arithmetic (else: bisection values)
+    std::vector<double> evs;     // the nroot extreme Ritz values of T_m, comparator order
+    double seconds = 0.0;
+  };
+
+  std::vector<double> pevs, all;
+
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+  bool converged(const std::vector<double>& cur, const std::vector<double>& before, double tol) const {
+    if (before.size() != cur.size()) return false;
+    for (int64_t r = 0; r < nroot; ++r)  // LL:296-303: every tracked root changed by less than eps (relative)
+      if (std::abs(cur[(size_t)r] - before[(size_t)r]) >= std::min(std::abs(cur[(size_t)r]), std::abs(before[(size_t)r])) * tol)
+        return false;
+    return true;
+  }
+
+  // alpha[0..m), beta[0..m) (beta[m-1] = ||w_m||)
+  Out step(int64_t m, const double* alpha, const double* beta) {
+    TraceRange trace("ll::host_tridiag (Ritz values + stop test)");
+    Out o;
+    o.m = m;
+    const double t0 = now();
+    const int64_t ncalc = std::min<int64_t>(nroot, m);
+    const bool use_qr = mode == LL_TRIDIAG_QR || (mode == LL_TRIDIAG_AUTO && m <= 64);
+    if (use_qr) {
+      all.resize((size_t)m);
+      tridiag_qr(m, alpha, beta, all.data(), nullptr);  // H1 LL:267-268
+      for (int64_t i = 0; i < ncalc; ++i) o.evs.push_back(find_maximum ? all[(size_t)(m - i - 1)] : all[(size_t)i]);  // H2
+      o.evs_from_qr = true;
+    } else {
+      o.evs_from_qr = false;
+      for (int64_t i = 0; i < ncalc; ++i) o.evs.push_back(tridiag_bisect(m, alpha, beta, find_maximum ? m - i - 1 : i));
+    }
+    // H3 LL:279-283: 10 * machine epsilon of real_t<T> (float storage => the float epsilon, like the reference)
+    if (beta[m - 1] < breakdown_tol) {
+      o.stop = true;
+      o.seconds = now() - t0;
+      return o;
+    }
+    // H4 LL:290-309
+    bool stop;
+    if (use_qr) {
+      stop = converged(o.evs, pevs, eps);
+    } else {
+      // Bisection values differ from the reference's QR values by a few ulp, far less than eps; the decision can only
+      // differ when a root's change sits within that distance of eps.  So: not even within 4*eps => certainly no
+      // stop; otherwise the reference's own arithmetic (QR of T_m and T_{m-1}) takes the decision, and on a stop
+      // its values are the ones returned — iteration counts and eigenvalues equal LL_TRIDIAG_QR's by construction.
+      const bool guarded = mode == LL_TRIDIAG_AUTO;  // LL_TRIDIAG_BISECT: bisection values decide alone
+      stop = converged(o.evs, pevs, guarded ? 4.0 * eps : eps);
+      if (stop && guarded) {
+        std::vector<double> cur((size_t)m), prev((size_t)(m - 1)), e_now, e_before;
+        tridiag_qr(m, alpha, beta, cur.data(), nullptr);
+        tridiag_qr(m - 1, alpha, beta, prev.data(), nullptr);
+        for (int64_t i = 0; i < ncalc; ++i) e_now.push_back(find_maximum ? cur[(size_t)(m - i - 1)] : cur[(size_t)i]);
+        for (int64_t i = 0; i < std::min<int64_t>(nroot, m - 1); ++i)
+          e_before.push_back(find_maximum ? prev[(size_t)(m - 2 - i)] : prev[(size_t)i]);
+        stop = converged(e_now, e_before, eps);
+        if (stop) {
+          o.evs = e_now;
+          o.evs_from_qr = true;
+        }
+      }
+    }
+    o.stop = stop;
+    if (!stop) pevs = o.evs;
+    o.seconds = now() - t0;
+    return o;
+  }
+};
+
+// A single helper thread that feeds the tracker with the iterations in order.  submit() copies the (alpha, beta)
+// prefixes, so the enqueueing thread may keep appending.  Results come back in submission order.
+class TridiagWorker {
+ public:
+  explicit TridiagWorker(const RitzTracker& cfg, bool threaded) : tracker_(cfg), threaded_(threaded) {
+    if (threaded_) thread_ = std::thread([this] { run(); });
+  }
+  ~TridiagWorker() {
+    if (threaded_) {
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        quit_ = true;
+      }
+      cv_job_.notify_all();
+      thread_.join();
+    }
+  }
+  TridiagWorker(const TridiagWorker&) = delete;
+  TridiagWorker& operator=(const TridiagWorker&) = delete;
+
+  void submit(int64_t m, const double* alpha, const double* beta) {
+    if (!threaded_) {
+      done_.push_back(tracker_.step(m, alpha, beta));
+      return;
+    }
+    Job j;
+    j.m = m;
+    j.alpha.assign(alpha, alpha + m);
+    j.beta.assign(beta, beta + m);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      jobs_.push_back(std::move(j));
+      ++outstanding_;
+    }
+    cv_job_.notify_one();
+  }
+  // submitted jobs whose results have not been popped yet
+  size_t outstanding() {
+    if (!threaded_) return done_.size();
+    std::lock_guard<std::mutex> g(mu_);
+    return outstanding_;
+  }
+  bool try_pop(RitzTracker::Out& out) {
+    std::unique_lock<std::mutex> g(mu_, std::defer_lock);
+    if (threaded_) g.lock();
+    if (done_.empty()) return false;
+    out = std::move(done_.front());
+    done_.pop_front();
+    if (threaded_) --outstanding_;
+    return true;
+  }
+  // blocks until the next result is there (false: nothing outstanding)
+  bool wait_pop(RitzTracker::Out& out) {
+    if (!threaded_) return try_pop(out);
+    std::unique_lock<std::mutex> g(mu_);
+    if (outstanding_ == 0) return false;
+    cv_done_.wait(g, [this] { return !done_.empty(); });
+    out = std::move(done_.front());
+    done_.pop_front();
+    --outstanding_;
+    return true;
+  }
+
+ private:
+  struct Job {
+    int64_t m;
+    std::vector<double> alpha, beta;
+  };
+  void run() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_job_.wait(g, [this] { return quit_ || !jobs_.empty(); });
+        if (quit_) return;  // verdicts nobody will read any more (the loop has ended) are not computed
+        j = std::move(jobs_.front());
+        jobs_.pop_front();
+      }
+      RitzTracker::Out o = tracker_.step(j.m, j.alpha.data(), j.beta.data());
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        done_.push_back(std::move(o));
+      }
+      cv_done_.notify_all();
+    }
+  }
+  RitzTracker tracker_;
+  bool threaded_;
+  std::thread thread_;
+  std::mutex mu_;
+  std::condition_variable cv_job_, cv_done_;
+  std::deque<Job> jobs_;
+  std::deque<RitzTracker::Out> done_;
+  size_t outstanding_ = 0;
+  bool quit_ = false;
+};
+
+}  // namespace ll

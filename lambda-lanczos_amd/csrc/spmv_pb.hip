@@ -162,7 +162,9 @@ template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, 
 }
 
 // ORDERED: the waves add in turn (fixed order => bit-reproducible sums); otherwise in arrival order.
-template <typename T, int U, bool ORDERED>
+// D trips of loads are in flight per lane (D - 1 ahead of the one being added): the turns synchronise the whole
+// workgroup 16 times per trip, so without loads issued well ahead the memory pipeline would run in bursts.
+template <typename T, int U, bool ORDERED, int D>
 __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_rows, int64_t n_local,
                                                         const int64_t* __restrict__ rptr,  // [nrb + 1]
                                                         const ushort4* __restrict__ row, const T* __restrict__ P,
@@ -176,38 +178,40 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+  constexpr long long kTrip = (long long)U * kPbThreads;
 
-  quad<T> pr[U];
-  ushort4 rl[U];
+  quad<T> pr[D][U];
+  ushort4 rl[D][U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long long gg = g0 + tid + (long long)u * kPbThreads;
-    if (gg < g1) {
-      pr[u] = load_quad<T>(P + 4 * gg);
-      rl[u] = row[gg];
+  for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[d][u] = load_quad<T>(P + 4 * gg);
+        rl[d][u] = row[gg];
+      }
     }
   }
   for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
   __syncthreads();
-  for (long long base = g0; base < g1; base += (long long)U * kPbThreads) {  // trip count is uniform over the workgroup
-    quad<T> pn[U];
-    ushort4 rn[U];
+  for (long long base = g0; base < g1; base += kTrip) {  // trip count is uniform over the workgroup
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long gg = base + tid + (long long)(U + u) * kPbThreads;
+      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
       if (gg < g1) {
-        pn[u] = load_quad<T>(P + 4 * gg);
-        rn[u] = row[gg];
+        pr[D - 1][u] = load_quad<T>(P + 4 * gg);
+        rl[D - 1][u] = row[gg];
       }
     }
     auto add_mine = [&]() {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (base + tid + (long long)u * kPbThreads < g1) {
-          lds_add_elem<T>(lds, rl[u].x, pr[u].e[0]);
-          lds_add_elem<T>(lds, rl[u].y, pr[u].e[1]);
-          lds_add_elem<T>(lds, rl[u].z, pr[u].e[2]);
-          lds_add_elem<T>(lds, rl[u].w, pr[u].e[3]);
+          lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
+          lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
+          lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
+          lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
         }
       }
     };
@@ -220,9 +224,12 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
       add_mine();
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      pr[u] = pn[u];
-      rl[u] = rn[u];
+    for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pr[d][u] = pr[d + 1][u];
+        rl[d][u] = rl[d + 1][u];
+      }
     }
   }
   __syncthreads();
@@ -265,8 +272,10 @@ template <typename T> void pb_opt_in_lds() {
   if (mask.load(std::memory_order_acquire) & bit) return;
 #define LL_PB_ATTR(K) LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, kPbLdsCap))
   LL_PB_ATTR((pb_phase1<T, 1>)); LL_PB_ATTR((pb_phase1<T, 2>)); LL_PB_ATTR((pb_phase1<T, 4>));
-  LL_PB_ATTR((pb_phase2<T, 1, true>)); LL_PB_ATTR((pb_phase2<T, 2, true>)); LL_PB_ATTR((pb_phase2<T, 4, true>));
-  LL_PB_ATTR((pb_phase2<T, 1, false>)); LL_PB_ATTR((pb_phase2<T, 2, false>)); LL_PB_ATTR((pb_phase2<T, 4, false>));
+  LL_PB_ATTR((pb_phase2<T, 1, true, 2>)); LL_PB_ATTR((pb_phase2<T, 2, true, 2>)); LL_PB_ATTR((pb_phase2<T, 4, true, 2>));
+  LL_PB_ATTR((pb_phase2<T, 1, false, 2>)); LL_PB_ATTR((pb_phase2<T, 2, false, 2>)); LL_PB_ATTR((pb_phase2<T, 4, false, 2>));
+  LL_PB_ATTR((pb_phase2<T, 1, true, 3>)); LL_PB_ATTR((pb_phase2<T, 2, true, 3>)); LL_PB_ATTR((pb_phase2<T, 1, true, 4>));
+  LL_PB_ATTR((pb_phase2<T, 2, true, 4>));
 #undef LL_PB_ATTR
   mask.fetch_or(bit, std::memory_order_release);
 }
@@ -294,15 +303,26 @@ void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_
                   double* dot_partials, hipStream_t s) {
   if (rb_count <= 0) return;
   const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
-#define LL_P2(U, O)                                                                                                    \
-  hipLaunchKernelGGL((pb_phase2<T, U, O>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,        \
+#define LL_P2(U, O, D)                                                                                                 \
+  hipLaunchKernelGGL((pb_phase2<T, U, O, D>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,     \
                      op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, \
                      dot_partials)
   const bool ord = op.pb_ordered != 0;
+  const int depth = ord ? op.pb_depth : 2;
   switch (op.pb_u2) {
-    case 1: if (ord) LL_P2(1, true); else LL_P2(1, false); break;
-    case 4: if (ord) LL_P2(4, true); else LL_P2(4, false); break;
-    default: if (ord) LL_P2(2, true); else LL_P2(2, false); break;
+    case 1:
+      if (!ord) LL_P2(1, false, 2);
+      else if (depth == 4) LL_P2(1, true, 4);
+      else if (depth == 3) LL_P2(1, true, 3);
+      else LL_P2(1, true, 2);
+      break;
+    case 4: if (ord) LL_P2(4, true, 2); else LL_P2(4, false, 2); break;
+    default:
+      if (!ord) LL_P2(2, false, 2);
+      else if (depth == 4) LL_P2(2, true, 4);
+      else if (depth == 3) LL_P2(2, true, 3);
+      else LL_P2(2, true, 2);
+      break;
   }
 #undef LL_P2
   LL_HIP(hipGetLastError());
@@ -642,13 +662,14 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_entries = (int64_t)entries;
   op->gather = gp;
   // kernel variants are fixed per operator at creation (several variants can then be timed in one process)
-  op->pb_u1 = env_int("LL_PB_U1", 2);
+  op->pb_u1 = env_int("LL_PB_U1", 1);  // measured on config 3 (profiles/r02_spmv_variants.jsonl): 1 beats 2 and 4 by 3-5 %
   op->pb_u2 = env_int("LL_PB_U2", 2);
   {
     const char* p2 = std::getenv("LL_PB_PHASE2");
     op->pb_ordered = !(p2 && std::string(p2) == "atomic");
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
+  op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", 2)));
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
     LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));

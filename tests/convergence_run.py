@@ -21,7 +21,7 @@ import lambda_lanczos_amd as L  # noqa: E402
 from lambda_lanczos_amd import generators as G  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
-mode = int(sys.argv[2]) if len(sys.argv) > 2 else L.TRIDIAG_QR
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else None   # None: the library default (LL_TRIDIAG_AUTO)
 ctx = L.Context(0)
 if wl == "c3":
     n = int(os.environ.get("DEMO_N", "10000000"))
@@ -36,7 +36,8 @@ op = L.CsrOperator(ctx, *csr)
 init = G.start_vector_fast(n, 1)
 eng = L.LambdaLanczos(op, n, find_max, 1)
 eng.eigenvalue_offset = offset
-eng.tridiag_mode = mode
+if mode is not None:
+    eng.tridiag_mode = mode
 eng.init_vector = lambda v, *_: np.copyto(v, init)
 ctx.set_profiling(True)
 t0 = time.time()
@@ -46,7 +47,7 @@ v = vecs[0]
 xd, yd = ctx.to_device(v), ctx.empty(n)
 L.spmv(op, xd, yd)
 res = float(np.linalg.norm(yd.get() - vals[0] * v))
-out = {"workload": wl, "n": n, "tridiag_mode": mode, "iterations": eng.getIterationCounts(), "eigenvalue": float(vals[0]),
+out = {"workload": wl, "n": n, "tridiag_mode": int(eng.tridiag_mode), "iterations": eng.getIterationCounts(), "eigenvalue": float(vals[0]),
        "residual_norm": res, "wall_s": wall, "stats": eng.last_stats}
 if wl == "c2":
     out["analytic_lambda_min"] = G.laplace2d_lambda_min(int(round(n ** 0.5)))

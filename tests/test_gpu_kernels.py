@@ -44,7 +44,8 @@ CASES = csr_cases()
 
 # (kernel, LL_PB_BLOCK): the CSR-stream kernel, the propagation-blocked kernels with their default geometry (a few
 # blocks at these sizes) and with tiny blocks (many row and column blocks, ragged last blocks, empty segments)
-KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37")}
+# "l2g" is the EXPERIMENT kernel of csrc/spmv_l2g.hip (L2-blocked gather; only with LL_SPMV_KERNEL=l2g)
+KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37")}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -58,6 +59,11 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     kind, block = KERNELS[kernel]
     if block:
         monkeypatch.setenv("LL_PB_BLOCK", block)
+    if kernel == "l2g":
+        monkeypatch.setenv("LL_SPMV_KERNEL", "l2g")
+        monkeypatch.setenv("LL_L2G_SLICE_LOG2", "8")   # many column slices even on the small test matrices
+    if kernel == "pb_atomic":
+        monkeypatch.setenv("LL_PB_PHASE2", "atomic")   # the arrival-order variant kept for A/B timing
     op = L.CsrOperator(ctx, *csr)
     op.select_spmv(kind)
     assert op.selected_spmv() == kind
@@ -73,9 +79,10 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     assert np.all(np.abs(y - y_ref) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)
     alpha_ref = np.vdot(x, y_ref).real
     assert abs(alpha - alpha_ref) <= 1e-13 * max(1.0, np.sum(np.abs(x) * np.abs(y_ref)))
-    # without the fused dot: same y (bit-identical for the CSR kernel; phase 2 of the PB kernel adds in arrival order)
+    # without the fused dot: same y, bit for bit (CSR-stream folds in a fixed order, phase 2 of the PB kernels adds wave
+    # by wave in a fixed order); only the arrival-order experiment variants may differ by rounding
     L.spmv(op, xd, yd, offset=offset)
-    if kind == 0:
+    if kernel in ("csr_stream", "pb", "pb_small_blocks"):
         assert np.array_equal(yd.get(), y)
     else:
         assert np.all(np.abs(yd.get() - y) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)
