@@ -86,6 +86,21 @@ def pmc_traffic(workload, kernels, dtype_tag):
     return total, os.path.relpath(files[-1], ROOT)
 
 
+def pmc_orth_traffic(workload, window):
+    """Measured HBM bytes of the Gram-Schmidt kernels (mdot + maxpy + scale) per window of `window` iterations, from the
+    committed PMC summary of the same workload and window (None when there is none)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % workload)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    if d.get("window_iterations") != window or "orth_bytes_per_window" not in d:
+        return None, None
+    return d["orth_bytes_per_window"], os.path.relpath(files[-1], ROOT)
+
+
 STAGE = ["start"]  # where the job is, for the watchdog's diagnostic
 
 
@@ -386,8 +401,11 @@ def main():
         }
 
     traffic, traffic_src = (None, None)
+    orth_traffic, orth_traffic_src = (None, None)
     if world == 1 and not args.n and not lattice:
         traffic, traffic_src = pmc_traffic(wl, kernel_names[selected].split("+"), "ll::zc" if complex_ else "double")
+        if args.eps is None and wl != "c5":
+            orth_traffic, orth_traffic_src = pmc_orth_traffic(wl, args.window)
 
     cpu_all = None
     if cpu is not None and wl != "c5":
@@ -472,7 +490,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": orth_bytes / max(orth_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": orth_traffic,
+                "traffic_source": orth_traffic_src,
+                "traffic_note": "measured HBM bytes of mdot + maxpy + scale per step (one window), PMC counters; "
+                                "achieved = algorithmic bytes of the timed steps / their device time",
+                "algorithmic_bytes_per_step": orth_bytes / max(args.steps, 1),
                 "model": "s*n*(2k+9) bytes per iteration (SURVEY 8d minimal-pass model)",
             },
             "phases": {

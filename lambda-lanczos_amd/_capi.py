@@ -158,6 +158,7 @@ PROTOTYPES = {
     "ll_gemv_basis_z": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, vp, i64]),
     "ll_tridiag_eig": (C.c_int, [i64, vp, vp, vp, vp, P(i64)]),
     "ll_tridiag_bisect": (C.c_int, [i64, vp, vp, i64, P(f64)]),
+    "ll_tridiag_bisect_multi": (C.c_int, [i64, vp, vp, i64, vp, vp]),
     "ll_tridiag_eigvecs": (C.c_int, [i64, vp, vp, i64, vp, vp]),
     "ll_lanczos_params_default": (C.c_int, [P(LanczosParams), i64, C.c_int, i64]),
     "ll_expo_params_default": (C.c_int, [P(ExpoParams), i64]),

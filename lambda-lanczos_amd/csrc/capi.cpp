@@ -1037,6 +1037,13 @@ int ll_tridiag_eig(int64_t m, const double* alpha, const double* beta, double* e
     if (unconverged) *unconverged = u;
   });
 }
+int ll_tridiag_bisect_multi(int64_t m, const double* alpha, const double* beta, int64_t nk, const int64_t* ks, double* out) {
+  return guarded([&] {
+    LL_REQUIRE(m >= 1 && alpha && out && ks && nk >= 1 && (beta || m == 1), "bad argument");
+    for (int64_t j = 0; j < nk; ++j) LL_REQUIRE(ks[j] >= 0 && ks[j] < m, "root index out of range");
+    tridiag_bisect_multi(m, alpha, beta, (int)nk, ks, out);
+  });
+}
 int ll_tridiag_eigvecs(int64_t m, const double* alpha, const double* beta, int64_t nw, const double* lambdas,
                        double* out) {
   return guarded([&] {

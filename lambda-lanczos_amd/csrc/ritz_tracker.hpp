@@ -36,6 +36,11 @@ struct RitzTracker {
   };
 
   std::vector<double> pevs, all;
+  // LL_TRIDIAG_AUTO bookkeeping: ||T||_inf so far (noise scale of the two eigenvalue methods), and the extreme QR values
+  // of the last confirmation (T_{m-1} of the next one)
+  double tnorm = 0.0;
+  int64_t qr_m = 0;
+  std::vector<double> qr_ext;
 
   static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -62,7 +67,20 @@ struct RitzTracker {
       o.evs_from_qr = true;
     } else {
       o.evs_from_qr = false;
-      for (int64_t i = 0; i < ncalc; ++i) o.evs.push_back(tridiag_bisect(m, alpha, beta, find_maximum ? m - i - 1 : i));
+      int64_t ks[8];
+      double vals[8];
+      for (int64_t i0 = 0; i0 < ncalc; i0 += 8) {  // all wanted roots in one interleaved bisection (tridiag_host.cpp)
+        const int w = (int)std::min<int64_t>(8, ncalc - i0);
+        for (int j = 0; j < w; ++j) ks[j] = find_maximum ? m - (i0 + j) - 1 : i0 + j;
+        tridiag_bisect_multi(m, alpha, beta, w, ks, vals);
+        for (int j = 0; j < w; ++j) o.evs.push_back(vals[j]);
+      }
+    }
+    // ||T_m||_inf, updated with the new row
+    {
+      const double bl = m >= 2 ? std::abs(beta[m - 2]) : 0.0;
+      tnorm = std::max(tnorm, std::abs(alpha[m - 1]) + bl + std::abs(beta[m - 1]));
+      if (m >= 2) tnorm = std::max(tnorm, std::abs(alpha[m - 2]) + (m >= 3 ? std::abs(beta[m - 3]) : 0.0) + bl);
     }
     // H3 LL:279-283: 10 * machine epsilon of real_t<T> (float storage => the float epsilon, like the reference)
     if (beta[m - 1] < breakdown_tol) {
@@ -74,20 +92,35 @@ struct RitzTracker {
     bool stop;
     if (use_qr) {
       stop = converged(o.evs, pevs, eps);
+    } else if (mode != LL_TRIDIAG_AUTO) {
+      stop = converged(o.evs, pevs, eps);  // LL_TRIDIAG_BISECT: bisection values decide alone
     } else {
-      // Bisection values differ from the reference's QR values by a few ulp, far less than eps; the decision can only
-      // differ when a root's change sits within that distance of eps.  So: not even within 4*eps => certainly no
-      // stop; otherwise the reference's own arithmetic (QR of T_m and T_{m-1}) takes the decision, and on a stop
-      // its values are the ones returned — iteration counts and eigenvalues equal LL_TRIDIAG_QR's by construction.
-      const bool guarded = mode == LL_TRIDIAG_AUTO;  // LL_TRIDIAG_BISECT: bisection values decide alone
-      stop = converged(o.evs, pevs, guarded ? 4.0 * eps : eps);
-      if (stop && guarded) {
-        std::vector<double> cur((size_t)m), prev((size_t)(m - 1)), e_now, e_before;
+      // Every STOP is decided by the reference's own arithmetic (QR of T_m and T_{m-1}), so iteration counts and the
+      // returned eigenvalues equal LL_TRIDIAG_QR's by construction.  Bisection only rules stops OUT: its values and
+      // the QR values differ by rounding noise of the order eps_machine * ||T||, so a root whose change exceeds the
+      // threshold by that noise (with a 25 % margin) cannot pass the reference's test either.  Near the threshold
+      // the QR pair is computed — one QR per iteration while the run lingers there (T_{m-1}'s values are kept).
+      const double noise = 64.0 * std::numeric_limits<double>::epsilon() * tnorm;
+      bool maybe = pevs.size() == o.evs.size();
+      for (int64_t r = 0; maybe && r < nroot; ++r) {
+        const double mn = std::min(std::abs(o.evs[(size_t)r]), std::abs(pevs[(size_t)r]));
+        if (std::abs(o.evs[(size_t)r] - pevs[(size_t)r]) >= 1.25 * (mn * eps + noise)) maybe = false;
+      }
+      stop = false;
+      if (maybe) {
+        std::vector<double> cur((size_t)m), e_now, e_before;
         tridiag_qr(m, alpha, beta, cur.data(), nullptr);
-        tridiag_qr(m - 1, alpha, beta, prev.data(), nullptr);
         for (int64_t i = 0; i < ncalc; ++i) e_now.push_back(find_maximum ? cur[(size_t)(m - i - 1)] : cur[(size_t)i]);
-        for (int64_t i = 0; i < std::min<int64_t>(nroot, m - 1); ++i)
-          e_before.push_back(find_maximum ? prev[(size_t)(m - 2 - i)] : prev[(size_t)i]);
+        if (qr_m == m - 1) {
+          e_before = qr_ext;
+        } else {
+          std::vector<double> prev((size_t)(m - 1));
+          tridiag_qr(m - 1, alpha, beta, prev.data(), nullptr);
+          for (int64_t i = 0; i < std::min<int64_t>(nroot, m - 1); ++i)
+            e_before.push_back(find_maximum ? prev[(size_t)(m - 2 - i)] : prev[(size_t)i]);
+        }
+        qr_m = m;
+        qr_ext = e_now;
         stop = converged(e_now, e_before, eps);
         if (stop) {
           o.evs = e_now;

@@ -556,7 +556,10 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   const int nrem = m.rank >= 0 ? P - 1 : P;  // ranks whose columns are remote
   GatherPlan gp;
   {
-    int want = P > 1 ? env_int("LL_GATHER_CHUNKS", 4) : 1;
+    // Chunks pipeline the remote-column part of phase 1 behind the transfer, but every extra collective costs launch
+    // latency and small messages use xGMI less efficiently: 4 pieces on 2 GPUs (half of the columns are own, long
+    // transfer over one link pair), 2 pieces on more (the own part is 1/P, the transfer uses all links at once).
+    int want = P > 1 ? env_int("LL_GATHER_CHUNKS", P == 2 ? 4 : 2) : 1;
     want = std::max(1, std::min(want, kMaxGatherChunks));
     int64_t lc = (S + want - 1) / want;
     lc = std::max<int64_t>(256, (lc + 255) / 256 * 256);  // chunk starts stay 2 KiB aligned
@@ -669,7 +672,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
     op->pb_ordered = !(p2 && std::string(p2) == "atomic");
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
-  op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", 2)));
+  op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", 3)));  // 3 beats 2 and 4 (profiles/r02_spmv_variants_run3.jsonl)
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
     LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));

