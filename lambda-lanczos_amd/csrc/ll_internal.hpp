@@ -228,7 +228,7 @@ struct ll_operator {
   int64_t pb_entries = 0;            // padded entry count of the image
   // kernel variants, read from the environment when the image is built (LL_PB_U1 / LL_PB_U2: quads per lane per trip;
   // LL_PB_PHASE2=atomic: arrival-order LDS adds instead of the wave-ordered, bit-reproducible ones; LL_PB_ROW_GROUPS)
-  int pb_u1 = 1, pb_u2 = 2, pb_ordered = 1, pb_row_groups = 1, pb_depth = 3;  // pb_depth: trips of loads in flight (LL_PB_DEPTH)
+  int pb_u1 = 1, pb_u2 = 2, pb_ordered = 1, pb_row_groups = 1, pb_depth = 3, pb_xprop = 0;  // pb_xprop: LL_PB_XPROP (x propagation, see spmv_pb.hip)  // pb_depth: trips of loads in flight (LL_PB_DEPTH)
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.

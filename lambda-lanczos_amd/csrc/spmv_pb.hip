@@ -71,7 +71,11 @@ template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__
 // rb_count) (the whole range in production; a sub-range only for the row-group experiment LL_PB_ROW_GROUPS).
 // The first trip's loads are issued before the x slice is staged, and every trip requests the next one before it
 // consumes its own (U quads per lane per trip, 2U in flight).
-template <typename T, int U>
+// XP ("x propagation"): phase 1 writes the gathered x value itself instead of the product, and phase 2 — whose
+// streams are all reads — multiplies by the matrix value (stored in row-block order for that).  Same bytes in total
+// (28 per nonzero), same products, same sums; but 8 of the 18 bytes that phase 1 would read move from the kernel that
+// mixes reads with writes (the slow direction mix for HBM) into the read-only kernel.
+template <typename T, int U, bool XP>
 __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, int rb_count, int blk_first,
                                                         const int64_t* __restrict__ xoff,
                                                         const int32_t* __restrict__ ncols_tab,
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
   for (int u = 0; u < U; ++u) {
     const long long gg = g + (long long)u * kPbThreads;
     if (gg < g1) {
-      v[u] = load_quad<T>(val + 4 * gg);
+      if constexpr (!XP) v[u] = load_quad<T>(val + 4 * gg);
       cl[u] = col[gg];
     }
   }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
     for (int u = 0; u < U; ++u) {
       const long long gg = g + (long long)(U + u) * kPbThreads;
       if (gg < g1) {
-        vn[u] = load_quad<T>(val + 4 * gg);
+        if constexpr (!XP) vn[u] = load_quad<T>(val + 4 * gg);
         cn[u] = col[gg];
       }
     }
@@ -136,16 +140,23 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
       if (qq < 4 * g1) {
         while (qq >= qs[r + 1]) ++r;
         quad<T> pr;
-        pr.e[0] = mul(v[u].e[0], xs[cl[u].x]);
-        pr.e[1] = mul(v[u].e[1], xs[cl[u].y]);
-        pr.e[2] = mul(v[u].e[2], xs[cl[u].z]);
-        pr.e[3] = mul(v[u].e[3], xs[cl[u].w]);
+        if constexpr (XP) {
+          pr.e[0] = xs[cl[u].x];
+          pr.e[1] = xs[cl[u].y];
+          pr.e[2] = xs[cl[u].z];
+          pr.e[3] = xs[cl[u].w];
+        } else {
+          pr.e[0] = mul(v[u].e[0], xs[cl[u].x]);
+          pr.e[1] = mul(v[u].e[1], xs[cl[u].y]);
+          pr.e[2] = mul(v[u].e[2], xs[cl[u].z]);
+          pr.e[3] = mul(v[u].e[3], xs[cl[u].w]);
+        }
         store_quad<T>(P + db[r] + (qq - qs[r]), pr);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      v[u] = vn[u];
+      if constexpr (!XP) v[u] = vn[u];
       cl[u] = cn[u];
     }
   }
@@ -164,10 +175,11 @@ template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, 
 // ORDERED: the waves add in turn (fixed order => bit-reproducible sums); otherwise in arrival order.
 // D trips of loads are in flight per lane (D - 1 ahead of the one being added): the turns synchronise the whole
 // workgroup 16 times per trip, so without loads issued well ahead the memory pipeline would run in bursts.
-template <typename T, int U, bool ORDERED, int D>
+template <typename T, int U, bool ORDERED, int D, bool XP>
 __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_rows, int64_t n_local,
                                                         const int64_t* __restrict__ rptr,  // [nrb + 1]
-                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                        const ushort4* __restrict__ row, const T* __restrict__ val,
+                                                        const T* __restrict__ P,
                                                         const T* __restrict__ xl, T* __restrict__ y, double offset,
                                                         double* __restrict__ dot_partials) {
   constexpr int R = scalar_traits<T>::reals;
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
   constexpr long long kTrip = (long long)U * kPbThreads;
 
   quad<T> pr[D][U];
+  quad<T> vv[XP ? D : 1][XP ? U : 1];  // XP: the matrix values of the same entries (row-block order)
   ushort4 rl[D][U];
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
       const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
       if (gg < g1) {
         pr[d][u] = load_quad<T>(P + 4 * gg);
+        if constexpr (XP) vv[d][u] = load_quad<T>(val + 4 * gg);
         rl[d][u] = row[gg];
       }
     }
@@ -201,6 +215,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
       const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
       if (gg < g1) {
         pr[D - 1][u] = load_quad<T>(P + 4 * gg);
+        if constexpr (XP) vv[D - 1][u] = load_quad<T>(val + 4 * gg);
         rl[D - 1][u] = row[gg];
       }
     }
@@ -208,10 +223,17 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (base + tid + (long long)u * kPbThreads < g1) {
-          lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
-          lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
-          lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
-          lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
+          if constexpr (XP) {
+            lds_add_elem<T>(lds, rl[0][u].x, mul(vv[0][u].e[0], pr[0][u].e[0]));
+            lds_add_elem<T>(lds, rl[0][u].y, mul(vv[0][u].e[1], pr[0][u].e[1]));
+            lds_add_elem<T>(lds, rl[0][u].z, mul(vv[0][u].e[2], pr[0][u].e[2]));
+            lds_add_elem<T>(lds, rl[0][u].w, mul(vv[0][u].e[3], pr[0][u].e[3]));
+          } else {
+            lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
+            lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
+            lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
+            lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
+          }
         }
       }
     };
@@ -228,6 +250,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         pr[d][u] = pr[d + 1][u];
+        if constexpr (XP) vv[d][u] = vv[d + 1][u];
         rl[d][u] = rl[d + 1][u];
       }
     }
@@ -264,19 +287,24 @@ int env_int(const char* name, int dflt) {
   return e ? std::atoi(e) : dflt;
 }
 // the opt-in to > 64 KiB of dynamic LDS is per device and per kernel symbol
+template <typename K> void pb_opt_in(K kernel) {
+  LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbLdsCap));
+}
 template <typename T> void pb_opt_in_lds() {
   static std::atomic<unsigned long long> mask{0};
   int dev = 0;
   LL_HIP(hipGetDevice(&dev));
   const unsigned long long bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
-#define LL_PB_ATTR(K) LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, kPbLdsCap))
-  LL_PB_ATTR((pb_phase1<T, 1>)); LL_PB_ATTR((pb_phase1<T, 2>)); LL_PB_ATTR((pb_phase1<T, 4>));
-  LL_PB_ATTR((pb_phase2<T, 1, true, 2>)); LL_PB_ATTR((pb_phase2<T, 2, true, 2>)); LL_PB_ATTR((pb_phase2<T, 4, true, 2>));
-  LL_PB_ATTR((pb_phase2<T, 1, false, 2>)); LL_PB_ATTR((pb_phase2<T, 2, false, 2>)); LL_PB_ATTR((pb_phase2<T, 4, false, 2>));
-  LL_PB_ATTR((pb_phase2<T, 1, true, 3>)); LL_PB_ATTR((pb_phase2<T, 2, true, 3>)); LL_PB_ATTR((pb_phase2<T, 1, true, 4>));
-  LL_PB_ATTR((pb_phase2<T, 2, true, 4>));
-#undef LL_PB_ATTR
+  pb_opt_in(&pb_phase1<T, 1, false>); pb_opt_in(&pb_phase1<T, 2, false>); pb_opt_in(&pb_phase1<T, 4, false>);
+  pb_opt_in(&pb_phase1<T, 1, true>); pb_opt_in(&pb_phase1<T, 2, true>); pb_opt_in(&pb_phase1<T, 4, true>);
+  pb_opt_in(&pb_phase2<T, 1, false, 2, false>); pb_opt_in(&pb_phase2<T, 2, false, 2, false>); pb_opt_in(&pb_phase2<T, 4, false, 2, false>);
+  pb_opt_in(&pb_phase2<T, 1, true, 2, false>); pb_opt_in(&pb_phase2<T, 2, true, 2, false>); pb_opt_in(&pb_phase2<T, 4, true, 2, false>);
+  pb_opt_in(&pb_phase2<T, 1, true, 3, false>); pb_opt_in(&pb_phase2<T, 2, true, 3, false>);
+  pb_opt_in(&pb_phase2<T, 1, true, 4, false>); pb_opt_in(&pb_phase2<T, 2, true, 4, false>);
+  pb_opt_in(&pb_phase2<T, 1, true, 2, true>); pb_opt_in(&pb_phase2<T, 2, true, 2, true>);
+  pb_opt_in(&pb_phase2<T, 1, true, 3, true>); pb_opt_in(&pb_phase2<T, 2, true, 3, true>);
+  pb_opt_in(&pb_phase2<T, 1, false, 2, true>); pb_opt_in(&pb_phase2<T, 2, false, 2, true>);
   mask.fetch_or(bit, std::memory_order_release);
 }
 
@@ -285,14 +313,15 @@ void phase1_range(const ll_operator& op, int blk_first, int blk_count, int rb_fi
                   hipStream_t s) {
   if (blk_count <= 0 || rb_count <= 0) return;
   const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * rb_count + 1) * sizeof(long long);
-#define LL_P1(U)                                                                                                      \
-  hipLaunchKernelGGL((pb_phase1<T, U>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, rb_first, rb_count,   \
+#define LL_P1(U, XP)                                                                                                  \
+  hipLaunchKernelGGL((pb_phase1<T, U, XP>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, rb_first, rb_count, \
                      blk_first, op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,   \
                      (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols)
+  const bool xp = op.pb_xprop != 0;
   switch (op.pb_u1) {
-    case 1: LL_P1(1); break;
-    case 4: LL_P1(4); break;
-    default: LL_P1(2); break;
+    case 1: if (xp) LL_P1(1, true); else LL_P1(1, false); break;
+    case 4: if (xp) LL_P1(4, true); else LL_P1(4, false); break;
+    default: if (xp) LL_P1(2, true); else LL_P1(2, false); break;
   }
 #undef LL_P1
   LL_HIP(hipGetLastError());
@@ -303,26 +332,27 @@ void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_
                   double* dot_partials, hipStream_t s) {
   if (rb_count <= 0) return;
   const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
-#define LL_P2(U, O, D)                                                                                                 \
-  hipLaunchKernelGGL((pb_phase2<T, U, O, D>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,     \
-                     op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, \
-                     dot_partials)
+#define LL_P2(U, O, D, XP)                                                                                             \
+  hipLaunchKernelGGL((pb_phase2<T, U, O, D, XP>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows, \
+                     op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_val,                    \
+                     (const T*)op.d_pb_prod, x_local, y, offset, dot_partials)
   const bool ord = op.pb_ordered != 0;
   const int depth = ord ? op.pb_depth : 2;
-  switch (op.pb_u2) {
-    case 1:
-      if (!ord) LL_P2(1, false, 2);
-      else if (depth == 4) LL_P2(1, true, 4);
-      else if (depth == 3) LL_P2(1, true, 3);
-      else LL_P2(1, true, 2);
-      break;
-    case 4: if (ord) LL_P2(4, true, 2); else LL_P2(4, false, 2); break;
-    default:
-      if (!ord) LL_P2(2, false, 2);
-      else if (depth == 4) LL_P2(2, true, 4);
-      else if (depth == 3) LL_P2(2, true, 3);
-      else LL_P2(2, true, 2);
-      break;
+  const int u2 = op.pb_u2 == 1 ? 1 : (op.pb_u2 == 4 && !op.pb_xprop ? 4 : 2);
+  if (op.pb_xprop) {
+    if (!ord) { if (u2 == 1) LL_P2(1, false, 2, true); else LL_P2(2, false, 2, true); }
+    else if (depth >= 3) { if (u2 == 1) LL_P2(1, true, 3, true); else LL_P2(2, true, 3, true); }
+    else { if (u2 == 1) LL_P2(1, true, 2, true); else LL_P2(2, true, 2, true); }
+  } else if (!ord) {
+    if (u2 == 1) LL_P2(1, false, 2, false); else if (u2 == 4) LL_P2(4, false, 2, false); else LL_P2(2, false, 2, false);
+  } else if (u2 == 4) {
+    LL_P2(4, true, 2, false);
+  } else if (depth == 4) {
+    if (u2 == 1) LL_P2(1, true, 4, false); else LL_P2(2, true, 4, false);
+  } else if (depth == 3) {
+    if (u2 == 1) LL_P2(1, true, 3, false); else LL_P2(2, true, 3, false);
+  } else {
+    if (u2 == 1) LL_P2(1, true, 2, false); else LL_P2(2, true, 2, false);
   }
 #undef LL_P2
   LL_HIP(hipGetLastError());
@@ -412,7 +442,8 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
                                                         const RP* __restrict__ rp, const int32_t* __restrict__ ci,
                                                         const T* __restrict__ va, const int64_t* __restrict__ segq,
                                                         const int64_t* __restrict__ segdest, T* __restrict__ pval,
-                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow) {
+                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow,
+                                                        int val_in_row_order) {
   extern __shared__ int fill[];  // [ncb]
   const int r = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < ncb; i += 64) fill[i] = 0;
@@ -449,9 +480,10 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
     }
     if (valid) {
       const long long q = segq[(size_t)key * (nrb + 1) + r] + off;
-      pval[q] = va[p];
+      const long long qd = segdest[(size_t)key * nrb + r] + off;
+      pval[val_in_row_order ? qd : q] = va[p];
       pcol[q] = (uint16_t)local;
-      prow[segdest[(size_t)key * nrb + r] + off] = (uint16_t)(rowi - i0);
+      prow[qd] = (uint16_t)(rowi - i0);
     }
   }
 }
@@ -672,6 +704,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
     op->pb_ordered = !(p2 && std::string(p2) == "atomic");
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
+  op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;
   op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", 3)));  // 3 beats 2 and 4 (profiles/r02_spmv_variants_run3.jsonl)
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
@@ -694,11 +727,11 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   if (op->rp64)
     hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
                        (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, op->pb_xprop);
   else
     hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
                        (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, op->pb_xprop);
   LL_HIP(hipGetLastError());
   LL_HIP(hipStreamSynchronize(s));  // the host tables above go out of scope
   return true;

@@ -45,7 +45,8 @@ CASES = csr_cases()
 # (kernel, LL_PB_BLOCK): the CSR-stream kernel, the propagation-blocked kernels with their default geometry (a few
 # blocks at these sizes) and with tiny blocks (many row and column blocks, ragged last blocks, empty segments)
 # "l2g" is the EXPERIMENT kernel of csrc/spmv_l2g.hip (L2-blocked gather; only with LL_SPMV_KERNEL=l2g)
-KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37")}
+KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37"),
+           "pb_xprop": (1, None), "pb_xprop_small_blocks": (1, "37"), "pb_other_unrolls": (1, "53")}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -62,6 +63,12 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     if kernel == "l2g":
         monkeypatch.setenv("LL_SPMV_KERNEL", "l2g")
         monkeypatch.setenv("LL_L2G_SLICE_LOG2", "8")   # many column slices even on the small test matrices
+    if kernel.startswith("pb_xprop"):
+        monkeypatch.setenv("LL_PB_XPROP", "1")        # x propagation: phase 2 multiplies (values in row-block order)
+    if kernel == "pb_other_unrolls":
+        monkeypatch.setenv("LL_PB_U1", "2")
+        monkeypatch.setenv("LL_PB_U2", "1")
+        monkeypatch.setenv("LL_PB_DEPTH", "2")
     if kernel == "pb_atomic":
         monkeypatch.setenv("LL_PB_PHASE2", "atomic")   # the arrival-order variant kept for A/B timing
     op = L.CsrOperator(ctx, *csr)
@@ -82,7 +89,7 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     # without the fused dot: same y, bit for bit (CSR-stream folds in a fixed order, phase 2 of the PB kernels adds wave
     # by wave in a fixed order); only the arrival-order experiment variants may differ by rounding
     L.spmv(op, xd, yd, offset=offset)
-    if kernel in ("csr_stream", "pb", "pb_small_blocks"):
+    if kernel not in ("pb_atomic", "l2g"):
         assert np.array_equal(yd.get(), y)
     else:
         assert np.all(np.abs(yd.get() - y) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)

@@ -41,8 +41,9 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
     """The same 2-rank job with the all-gather on the communication stream (chunked, own-column SpMV under it) and
     with everything on one stream (LL_COMM_OVERLAP=0): every replicated scalar, every Ritz vector shard and the plain
     SpMV results must agree bit for bit — the overlap changes WHEN things run, never what is summed in which order."""
-    a = run_ranks(os.path.join(tmp_path, "overlap"), 2, LL_COMM_OVERLAP="1", LL_GATHER_CHUNKS="3")
-    b = run_ranks(os.path.join(tmp_path, "serial"), 2, LL_COMM_OVERLAP="0", LL_GATHER_CHUNKS="3")
+    # LL_SPMV_KERNEL=pb: no timing-based kernel choice (it may differ from run to run); both images are kept (conftest)
+    a = run_ranks(os.path.join(tmp_path, "overlap"), 2, LL_COMM_OVERLAP="1", LL_GATHER_CHUNKS="3", LL_SPMV_KERNEL="pb")
+    b = run_ranks(os.path.join(tmp_path, "serial"), 2, LL_COMM_OVERLAP="0", LL_GATHER_CHUNKS="3", LL_SPMV_KERNEL="pb")
     for ra, rb in zip(a, b):
         for key in ("randsym_csr", "randsym_pb"):
             assert ra[key]["alpha"] == rb[key]["alpha"] and ra[key]["vals"] == rb[key]["vals"], key

@@ -11,15 +11,15 @@ if has tests; then
 fi
 if has sweep; then
   V="pb_default:LL_SPMV_KERNEL=pb"
-  V="$V;pb_depth3:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3"
-  V="$V;pb_depth4:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=4"
-  V="$V;pb_u21_depth3:LL_SPMV_KERNEL=pb,LL_PB_U2=1,LL_PB_DEPTH=3"
-  V="$V;pb_u21_depth4:LL_SPMV_KERNEL=pb,LL_PB_U2=1,LL_PB_DEPTH=4"
+  V="$V;pb_depth2:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2"
+  V="$V;pb_xprop:LL_SPMV_KERNEL=pb,LL_PB_XPROP=1"
+  V="$V;pb_xprop_u21:LL_SPMV_KERNEL=pb,LL_PB_XPROP=1,LL_PB_U2=1"
+  V="$V;pb_xprop_d2:LL_SPMV_KERNEL=pb,LL_PB_XPROP=1,LL_PB_DEPTH=2"
+  V="$V;pb_xprop_u12:LL_SPMV_KERNEL=pb,LL_PB_XPROP=1,LL_PB_U1=2"
+  V="$V;pb_xprop_atomic:LL_SPMV_KERNEL=pb,LL_PB_XPROP=1,LL_PB_PHASE2=atomic"
   V="$V;pb_atomic_u21:LL_SPMV_KERNEL=pb,LL_PB_U2=1,LL_PB_PHASE2=atomic"
   V="$V;pb_rowgroups2:LL_SPMV_KERNEL=pb,LL_PB_ROW_GROUPS=2"
-  V="$V;pb_rowgroups8:LL_SPMV_KERNEL=pb,LL_PB_ROW_GROUPS=8"
   V="$V;l2g_slice18:LL_SPMV_KERNEL=l2g"
-  V="$V;l2g_slice17:LL_SPMV_KERNEL=l2g,LL_L2G_SLICE_LOG2=17"
   V="$V;csr_stream:LL_SPMV_KERNEL=csr"
   timeout 900 python tools/spmv_sweep.py --variants "$V" --rounds 7 > gpurun_out/r2_sweep.jsonl 2> gpurun_out/r2_sweep.err; echo "sweep rc=$?"
   cut -c1-330 gpurun_out/r2_sweep.jsonl; tail -3 gpurun_out/r2_sweep.err
