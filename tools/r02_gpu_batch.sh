@@ -24,6 +24,18 @@ if has sweep; then
   timeout 900 python tools/spmv_sweep.py --variants "$V" --rounds 7 > gpurun_out/r2_sweep.jsonl 2> gpurun_out/r2_sweep.err; echo "sweep rc=$?"
   cut -c1-330 gpurun_out/r2_sweep.jsonl; tail -3 gpurun_out/r2_sweep.err
 fi
+if has calib; then
+  # the same two variants at several positions of the creation order: separates the kernel effect from the placement
+  # of the operator's buffers (the first operator created in a process has shown 3-5 % slower SpMVs)
+  V="d3_a:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;d2_a:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2;d3_b:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;d2_b:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2"
+  V="$V;atomic_a:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic,LL_PB_U2=1;d3_c:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;d2_c:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2;atomic_b:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic,LL_PB_U2=1"
+  V="$V;u12_d2:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2,LL_PB_U1=2;u11_d2_u21:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2,LL_PB_U2=1;d3_d:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3"
+  timeout 900 python tools/spmv_sweep.py --variants "$V" --rounds 7 > gpurun_out/r2_calib.jsonl 2> gpurun_out/r2_calib.err; echo "calib rc=$?"
+  python -c "
+import json
+for l in open('gpurun_out/r2_calib.jsonl'):
+    d=json.loads(l); print(d['variant'], round(d['ms_median'],4), round(d['ms_min'],4), d['bit_identical_over_4_launches'])"
+fi
 if has small; then
   # host tridiagonal step off the enqueueing thread: window-100 iterations/s, before (inline QR = round 1 default;
   # inline AUTO) and after (AUTO on the helper thread = round 2 default)
