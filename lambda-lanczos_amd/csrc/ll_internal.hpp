@@ -221,6 +221,7 @@ struct ll_operator {
   int64_t* d_pb_rptr = nullptr;      // [nrb+1]      entry offsets of the row blocks in row-block order
   int64_t* d_pb_xoff = nullptr;      // [ncb]        element offset of the block's x slice in ITS source buffer
   int32_t* d_pb_ncols = nullptr;     // [ncb]        columns of the block
+  void* d_pb_arena = nullptr;        // the one allocation that holds the four big streams below (interior pointers)
   void* d_pb_val = nullptr;          // values, column-block order
   uint16_t* d_pb_col = nullptr;      // local column, column-block order
   uint16_t* d_pb_row = nullptr;      // local row, row-block order

@@ -716,10 +716,25 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   up((void**)&op->d_pb_xoff, xoff.data(), xoff.size() * sizeof(int64_t));
   up((void**)&op->d_pb_ncols, ncols.data(), ncols.size() * sizeof(int32_t));
   const size_t cap = std::max<size_t>(entries, 16);
-  ctx->dev_malloc(&op->d_pb_val, cap * sizeof(T), "propagation-blocking values");
-  ctx->dev_malloc((void**)&op->d_pb_col, cap * sizeof(uint16_t), "propagation-blocking columns");
-  ctx->dev_malloc((void**)&op->d_pb_row, cap * sizeof(uint16_t), "propagation-blocking rows");
-  ctx->dev_malloc(&op->d_pb_prod, cap * sizeof(T), "product buffer");
+  // ONE allocation for the four big streams (values, local columns, local rows, product buffer).  Their starts are
+  // 2 MiB aligned plus a per-stream stagger (LL_PB_STAGGER bytes, a multiple of 256): the kernels walk several of
+  // these streams at the same relative position, and starts that are congruent modulo the HBM channel interleave
+  // make them camp on the same channels.
+  {
+    const size_t stagger = (size_t)std::max(0, env_int("LL_PB_STAGGER", 0)) / 256 * 256;
+    auto up2m = [](size_t v) { return (v + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); };
+    const size_t o_val = 0;
+    const size_t o_col = up2m(o_val + cap * sizeof(T)) + 1 * stagger;
+    const size_t o_row = up2m(o_col + cap * sizeof(uint16_t)) + 2 * stagger;
+    const size_t o_prod = up2m(o_row + cap * sizeof(uint16_t)) + 3 * stagger;
+    const size_t total = o_prod + cap * sizeof(T);
+    ctx->dev_malloc(&op->d_pb_arena, total, "propagation-blocked image (values, indices, product buffer)");
+    char* base = (char*)op->d_pb_arena;
+    op->d_pb_val = base + o_val;
+    op->d_pb_col = (uint16_t*)(base + o_col);
+    op->d_pb_row = (uint16_t*)(base + o_row);
+    op->d_pb_prod = base + o_prod;
+  }
   LL_HIP(hipMemsetAsync(op->d_pb_val, 0, cap * sizeof(T), s));  // padding entries: value 0, local indices 0
   LL_HIP(hipMemsetAsync(op->d_pb_col, 0, cap * sizeof(uint16_t), s));
   LL_HIP(hipMemsetAsync(op->d_pb_row, 0, cap * sizeof(uint16_t), s));

@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d DIR -o pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d DIR -o pmc_write -- python3 bench.py ...   (separate pass)
-    python tools/pmc_summary.py DIR OUT.json [n] [windows]
+    python tools/pmc_summary.py DIR OUT.json [n] [windows] [window_iterations]
 
 `windows` = number of LambdaLanczos::run windows the profiled command executed (bench.py: steps + warmup, with
 --cpu-window 0): the per-window traffic of the Gram-Schmidt kernels (sum over their launches / windows) is what
@@ -31,6 +31,7 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
     windows = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    window_iterations = int(sys.argv[5]) if len(sys.argv) > 5 else 100
     fetch, write = load(d + "/pmc_fetch_counter_collection.csv"), load(d + "/pmc_write_counter_collection.csv")
     res = {"units": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count correction), "
                     "write = WRITE_SIZE KiB * 1024",
@@ -44,6 +45,7 @@ def main():
                              "fetch_bytes_sum": sum(f) * 2048, "write_bytes_sum": sum(w) * 1024}
     if windows:
         res["windows"] = windows
+        res["window_iterations"] = window_iterations
         orth = [v for k, v in res["kernels"].items() if k.split("<")[0] in ("mdot_kernel", "maxpy_kernel", "scale_kernel")]
         res["orth_bytes_per_window"] = sum(v["fetch_bytes_sum"] + v["write_bytes_sum"] for v in orth) / windows
     sk = res["kernels"].get("scale_kernel<double>")
