@@ -278,6 +278,96 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
   }
 }
 
+// Phase 2 with a TOKEN instead of barriers (LL_PB_PHASE2=token): the waves still add in the fixed order wave 0, 1, ..,
+// 15 of trip 0, wave 0 .. 15 of trip 1, ... (same sums, bit for bit, as the barrier form), but a wave only waits for
+// its predecessor's ticket in LDS, not for the whole workgroup: the waves drift into a systolic pipeline and their
+// loads are no longer issued in lockstep bursts.
+template <typename T, int U, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2_token(int rb_first, int rb_rows, int64_t n_local,
+                                                              const int64_t* __restrict__ rptr,
+                                                              const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                              const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                              double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];  // [rb_rows * R]
+  __shared__ double red[kPbWaves];
+  __shared__ int turn;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rb = rb_first + blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+  constexpr long long kTrip = (long long)U * kPbThreads;
+
+  quad<T> pr[D][U];
+  ushort4 rl[D][U];
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[d][u] = load_quad<T>(P + 4 * gg);
+        rl[d][u] = row[gg];
+      }
+    }
+  }
+  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
+  if (tid == 0) turn = 0;
+  __syncthreads();
+  int ticket = wave;
+  for (long long base = g0; base < g1; base += kTrip, ticket += kPbWaves) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[D - 1][u] = load_quad<T>(P + 4 * gg);
+        rl[D - 1][u] = row[gg];
+      }
+    }
+    while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + tid + (long long)u * kPbThreads < g1) {
+        lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
+        lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
+        lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
+        lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
+      }
+    }
+    if (lane == 0) __hip_atomic_store(&turn, ticket + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pr[d][u] = pr[d + 1][u];
+        rl[d][u] = rl[d + 1][u];
+      }
+    }
+  }
+  __syncthreads();
+  double dot_acc = 0.0;
+  for (int i = tid; i < rows; i += kPbThreads) {
+    const T xi = xl[row0 + i];
+    acc_t<T> acc;
+    if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
+    else acc = lds[i];
+    const T yi = add(narrow<T>(acc), rmul(offset, xi));
+    y[row0 + i] = yi;
+    dot_acc += re_cmul(xi, yi);
+  }
+  if (dot_partials) {
+    const double v = wave_sum(dot_acc);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kPbWaves; ++w) t += red[w];
+      dot_partials[rb] = t;
+    }
+  }
+}
+
 // ================================================================= launchers
 namespace {
 constexpr int kPbLdsCap = 160 * 1024 - 2048;
@@ -305,6 +395,8 @@ template <typename T> void pb_opt_in_lds() {
   pb_opt_in(&pb_phase2<T, 1, true, 2, true>); pb_opt_in(&pb_phase2<T, 2, true, 2, true>);
   pb_opt_in(&pb_phase2<T, 1, true, 3, true>); pb_opt_in(&pb_phase2<T, 2, true, 3, true>);
   pb_opt_in(&pb_phase2<T, 1, false, 2, true>); pb_opt_in(&pb_phase2<T, 2, false, 2, true>);
+  pb_opt_in(&pb_phase2_token<T, 1, 2>); pb_opt_in(&pb_phase2_token<T, 2, 2>); pb_opt_in(&pb_phase2_token<T, 1, 3>);
+  pb_opt_in(&pb_phase2_token<T, 2, 3>);
   mask.fetch_or(bit, std::memory_order_release);
 }
 
@@ -339,7 +431,15 @@ void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_
   const bool ord = op.pb_ordered != 0;
   const int depth = ord ? op.pb_depth : 2;
   const int u2 = op.pb_u2 == 1 ? 1 : (op.pb_u2 == 4 && !op.pb_xprop ? 4 : 2);
-  if (op.pb_xprop) {
+  if (op.pb_ordered == 2 && !op.pb_xprop) {  // token form of the fixed order
+#define LL_P2T(U, D)                                                                                                   \
+  hipLaunchKernelGGL((pb_phase2_token<T, U, D>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,  \
+                     op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, \
+                     dot_partials)
+    if (u2 == 1) { if (depth >= 3) LL_P2T(1, 3); else LL_P2T(1, 2); }
+    else { if (depth >= 3) LL_P2T(2, 3); else LL_P2T(2, 2); }
+#undef LL_P2T
+  } else if (op.pb_xprop) {
     if (!ord) { if (u2 == 1) LL_P2(1, false, 2, true); else LL_P2(2, false, 2, true); }
     else if (depth >= 3) { if (u2 == 1) LL_P2(1, true, 3, true); else LL_P2(2, true, 3, true); }
     else { if (u2 == 1) LL_P2(1, true, 2, true); else LL_P2(2, true, 2, true); }
@@ -700,8 +800,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_u1 = env_int("LL_PB_U1", 1);  // measured on config 3 (profiles/r02_spmv_variants.jsonl): 1 beats 2 and 4 by 3-5 %
   op->pb_u2 = env_int("LL_PB_U2", 2);
   {
-    const char* p2 = std::getenv("LL_PB_PHASE2");
-    op->pb_ordered = !(p2 && std::string(p2) == "atomic");
+    const char* p2 = std::getenv("LL_PB_PHASE2");  // "atomic": arrival order; "token": fixed order by ticket; else barriers
+    op->pb_ordered = (p2 && std::string(p2) == "atomic") ? 0 : ((p2 && std::string(p2) == "token") ? 2 : 1);
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
   op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;

@@ -46,7 +46,8 @@ CASES = csr_cases()
 # blocks at these sizes) and with tiny blocks (many row and column blocks, ragged last blocks, empty segments)
 # "l2g" is the EXPERIMENT kernel of csrc/spmv_l2g.hip (L2-blocked gather; only with LL_SPMV_KERNEL=l2g)
 KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37"),
-           "pb_xprop": (1, None), "pb_xprop_small_blocks": (1, "37"), "pb_other_unrolls": (1, "53")}
+           "pb_xprop": (1, None), "pb_xprop_small_blocks": (1, "37"), "pb_other_unrolls": (1, "53"),
+           "pb_token": (1, None), "pb_token_small_blocks": (1, "37")}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -69,6 +70,8 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
         monkeypatch.setenv("LL_PB_U1", "2")
         monkeypatch.setenv("LL_PB_U2", "1")
         monkeypatch.setenv("LL_PB_DEPTH", "2")
+    if kernel.startswith("pb_token"):
+        monkeypatch.setenv("LL_PB_PHASE2", "token")   # the fixed order enforced by a ticket in LDS instead of barriers
     if kernel == "pb_atomic":
         monkeypatch.setenv("LL_PB_PHASE2", "atomic")   # the arrival-order variant kept for A/B timing
     op = L.CsrOperator(ctx, *csr)
@@ -94,6 +97,35 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     else:
         assert np.all(np.abs(yd.get() - y) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)
     op.close()
+
+
+@pytest.mark.parametrize("name", ["randsym5000", "ragged", "ragged_z", "torus24"])
+@pytest.mark.parametrize("block", [None, "37"])
+def test_pb_ordered_forms_agree_bit_for_bit(ctx, name, block, monkeypatch):
+    """Barrier turns, ticket turns and the x-propagation layout all add the same products in the same order."""
+    csr = CASES[name]
+    dtype = csr[2].dtype
+    n = csr[0].shape[0] - 1
+    x = rnd(n, dtype, 11)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
+    if block:
+        monkeypatch.setenv("LL_PB_BLOCK", block)
+    ys = {}
+    for label, env in (("barrier", {}), ("token", {"LL_PB_PHASE2": "token"}), ("xprop", {"LL_PB_XPROP": "1"}),
+                       ("token_u1_d2", {"LL_PB_PHASE2": "token", "LL_PB_U2": "1", "LL_PB_DEPTH": "2"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        op = L.CsrOperator(ctx, *csr)
+        L.spmv(op, xd, yd, offset=0.5)
+        ys[label] = yd.get()
+        op.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    # same (trip, wave) order of the adds whenever the trip geometry is the same; across geometries the order changes
+    assert np.array_equal(ys["barrier"], ys["token"])
+    assert np.array_equal(ys["barrier"], ys["xprop"])
+    assert np.max(np.abs(ys["barrier"] - ys["token_u1_d2"])) <= 64 * EPS * np.max(np.abs(ys["barrier"]))
 
 
 @pytest.mark.parametrize("name", ["randsym5000", "torus24", "ragged", "ragged_z"])

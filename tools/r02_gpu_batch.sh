@@ -29,7 +29,7 @@ if has calib; then
   # of the operator's buffers (the first operator created in a process has shown 3-5 % slower SpMVs)
   V="d3_a:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;d2_a:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2;d3_b:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;d2_b:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2"
   V="$V;atomic_a:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic,LL_PB_U2=1;d3_c:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;d2_c:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2;atomic_b:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic,LL_PB_U2=1"
-  V="$V;u12_d2:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2,LL_PB_U1=2;u11_d2_u21:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=2,LL_PB_U2=1;d3_d:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3"
+  V="$V;token_a:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=token;token_d2:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=token,LL_PB_DEPTH=2;token_u1:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=token,LL_PB_U2=1;d3_d:LL_SPMV_KERNEL=pb,LL_PB_DEPTH=3;token_b:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=token;atomic_c:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic,LL_PB_U2=1"
   timeout 900 python tools/spmv_sweep.py --variants "$V" --rounds 7 > gpurun_out/r2_calib.jsonl 2> gpurun_out/r2_calib.err; echo "calib rc=$?"
   python -c "
 import json
