@@ -52,7 +52,7 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
         assert ra["laplace"] == rb["laplace"]
 
 
-@pytest.mark.parametrize("world,forced_second_pass", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,forced_second_pass", [(2, False), (3, False), (4, False), (2, True)])
 def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, forced_second_pass):
     extra = {}
     if forced_second_pass:
