@@ -466,6 +466,24 @@ void launch_reduce_cols(const double* partials, int nparts, int ncols, double* o
   }
   LL_HIP(hipGetLastError());
 }
+// Sharded contexts: ||w - U h||^2 = ||w||^2 - sum |h_j|^2 for an orthonormal U (Pythagoras), from values every rank
+// already holds after the one all-reduce of (h, ||w||^2) — no second all-reduce for the norm.  Fixed summation order,
+// identical inputs on all ranks => identical bits on all ranks.
+__global__ __launch_bounds__(256) void derive_norm_kernel(const double* __restrict__ c0, const double* __restrict__ h,
+                                                          int count, double* __restrict__ c1) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) acc = fma(h[i], h[i], acc);
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    const double v = *c0 - tot;
+    *c1 = v > 0.0 ? v : 0.0;
+  }
+}
+void launch_derive_norm(const double* c0, const double* h, int count, double* c1, hipStream_t s) {
+  hipLaunchKernelGGL(derive_norm_kernel, dim3(1), dim3(256), 0, s, c0, h, count, c1);
+  LL_HIP(hipGetLastError());
+}
 __global__ void set_scalar_kernel(double* dst, double v) { *dst = v; }
 void launch_set_scalar(double* dst, double v, hipStream_t s) {
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, dst, v);

@@ -312,6 +312,8 @@ void launch_copy_scalar(double* dst, const double* src, hipStream_t s);
 void launch_reduce_publish(const double* partials, int nparts, double* out, const double* alpha, const double* c0,
                            double* host_mapped, hipStream_t s);
 void launch_set_scalar(double* dst, double value, hipStream_t s);
+// *c1 = max(0, *c0 - sum_i h[i]^2)  (one workgroup, fixed order)
+void launch_derive_norm(const double* c0, const double* h, int count, double* c1, hipStream_t s);
 
 // Multi-dot with optional fused three-term update.
 //   if (three_term) w = w - beta*u_prev - alpha*u_cur   (u_prev nullable; alpha = *alpha_dev; beta = beta_from(norms_prev))

@@ -52,13 +52,13 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
         assert ra["laplace"] == rb["laplace"]
 
 
-@pytest.mark.parametrize("world,forced_second_pass", [(2, False), (3, False), (4, False), (2, True)])
-def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, forced_second_pass):
-    extra = {}
-    if forced_second_pass:
-        # every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the replicated
-        # decision must keep the ranks' collective sequences aligned, results unchanged up to rounding
-        extra["LL_DGKS_THRESHOLD"] = "2.0"
+# forced second pass: every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the
+# replicated decision must keep the ranks' collective sequences aligned, results unchanged up to rounding.
+# measured norm: the post-pass norm from maxpy's partial sums + an all-reduce instead of ||w||^2 - sum |h_j|^2.
+@pytest.mark.parametrize("world,extra", [(2, {}), (3, {}), (4, {}), (2, {"LL_DGKS_THRESHOLD": "2.0"}),
+                                         (2, {"LL_SHARDED_NORM": "measured"}), (3, {"LL_GATHER_CHUNKS": "1"})],
+                         ids=["2", "3", "4", "2-forced-second-pass", "2-measured-norm", "3-one-chunk"])
+def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, extra):
     ranks = run_ranks(tmp_path, world, **extra)
 
     def stitch(key, field, idx=None):
