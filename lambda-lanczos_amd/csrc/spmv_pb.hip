@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
                                                         const ushort4* __restrict__ row, const T* __restrict__ val,
                                                         const T* __restrict__ P,
                                                         const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                        double* __restrict__ dot_partials) {
+                                                        double* __restrict__ dot_partials, int raw_barrier) {
   constexpr int R = scalar_traits<T>::reals;
   extern __shared__ double lds[];  // [rb_rows * R]
   __shared__ double red[kPbWaves];
@@ -240,7 +240,11 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
     if constexpr (ORDERED) {
       for (int w = 0; w < kPbWaves; ++w) {
         if (wave == w) add_mine();
-        __syncthreads();
+        // EXPERIMENT (LL_PB_PHASE2=issueorder): hand the turn over as soon as the adds are ISSUED (bare s_barrier)
+        // instead of when they have completed (__syncthreads waits for lgkmcnt(0) first) — only valid if the LDS
+        // executes the adds of different waves in issue order
+        if (raw_barrier) __builtin_amdgcn_s_barrier();
+        else __syncthreads();
       }
     } else {
       add_mine();
@@ -427,7 +431,7 @@ void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_
 #define LL_P2(U, O, D, XP)                                                                                             \
   hipLaunchKernelGGL((pb_phase2<T, U, O, D, XP>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows, \
                      op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_val,                    \
-                     (const T*)op.d_pb_prod, x_local, y, offset, dot_partials)
+                     (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, op.pb_ordered == 3 ? 1 : 0)
   const bool ord = op.pb_ordered != 0;
   const int depth = ord ? op.pb_depth : 2;
   const int u2 = op.pb_u2 == 1 ? 1 : (op.pb_u2 == 4 && !op.pb_xprop ? 4 : 2);
@@ -801,7 +805,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_u2 = env_int("LL_PB_U2", 2);
   {
     const char* p2 = std::getenv("LL_PB_PHASE2");  // "atomic": arrival order; "token": fixed order by ticket; else barriers
-    op->pb_ordered = (p2 && std::string(p2) == "atomic") ? 0 : ((p2 && std::string(p2) == "token") ? 2 : 1);
+    const std::string p2s = p2 ? p2 : "";
+    op->pb_ordered = p2s == "atomic" ? 0 : (p2s == "token" ? 2 : (p2s == "issueorder" ? 3 : 1));
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
   op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;
