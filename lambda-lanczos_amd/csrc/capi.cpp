@@ -119,7 +119,8 @@ void ll_context::drain_comm_events(double* gather_s, double* allreduce_s) {
 ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
-                  (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, d_l2_val, (void*)d_l2_idx,
+                  (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp,
+                  (void*)d_pb_blockmax, d_l2_val, (void*)d_l2_idx,
                   (void*)d_l2_ptr, (void*)d_l2_sync})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
@@ -489,6 +490,8 @@ void release_unselected_image(ll_operator* op) {
     drop(op->d_pb_xoff);
     drop(op->d_pb_ncols);
     drop(op->d_pb_arena);
+    drop(op->d_pb_rexp);
+    drop(op->d_pb_blockmax);
     op->d_pb_val = op->d_pb_prod = nullptr;  // interior pointers of the arena
     op->d_pb_col = op->d_pb_row = nullptr;
     op->pb_ncb = op->pb_nrb = 0;

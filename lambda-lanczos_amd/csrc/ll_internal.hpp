@@ -226,6 +226,8 @@ struct ll_operator {
   uint16_t* d_pb_col = nullptr;      // local column, column-block order
   uint16_t* d_pb_row = nullptr;      // local row, row-block order
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
+  int16_t* d_pb_rexp = nullptr;      // LL_PB_PHASE2=fixed: exponent of every local row's absolute sum
+  double* d_pb_blockmax = nullptr;   // LL_PB_PHASE2=fixed: max |x| per column block, left by phase 1
   int64_t pb_entries = 0;            // padded entry count of the image
   // kernel variants, read from the environment when the image is built (LL_PB_U1 / LL_PB_U2: quads per lane per trip;
   // LL_PB_PHASE2=atomic: arrival-order LDS adds instead of the wave-ordered, bit-reproducible ones; LL_PB_ROW_GROUPS)

@@ -40,6 +40,11 @@ constexpr int kPbThreads = 1024;
 constexpr int kPbWaves = kPbThreads / 64;
 
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+// |re| + |im| (>= the modulus): the magnitude the fixed-point scales are built from
+__device__ __forceinline__ double abs1(double a) { return fabs(a); }
+__device__ __forceinline__ double abs1(float a) { return fabs((double)a); }
+__device__ __forceinline__ double abs1(zc a) { return fabs(a.re) + fabs(a.im); }
+__device__ __forceinline__ double abs1(cf a) { return fabs((double)a.re) + fabs((double)a.im); }
 
 // Entries are handled in QUADS: every segment is padded to a multiple of 16 entries (zero value, local index 0), so
 // a lane always moves four consecutive entries with 16-byte accesses (2 x dwordx4 of values / products, one dwordx2
@@ -82,8 +87,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
                                                         const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
                                                         const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
                                                         const T* __restrict__ val, const ushort4* __restrict__ col,
-                                                        const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols) {
+                                                        const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols,
+                                                        double* __restrict__ blockmax) {
   extern __shared__ double lds[];
+  __shared__ double bm_red[kPbWaves];
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
   long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
                                               (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [rb_count + 1]
@@ -122,6 +129,20 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
     for (int i = tid; i < rb_count; i += kPbThreads) db[i] = sd[i];
   }
   __syncthreads();
+  if (blockmax != nullptr) {  // fixed-point phase 2: the largest |x| of the slice (its scale needs max |x| over all columns)
+    double m = 0.0;
+    const int ncols = ncols_tab[c];
+    for (int i = tid; i < ncols; i += kPbThreads) m = fmax(m, abs1(xs[i]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+    if ((tid & 63) == 0) bm_red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      double t = bm_red[0];
+      for (int w = 1; w < kPbWaves; ++w) t = fmax(t, bm_red[w]);
+      blockmax[c] = t;  // NaN in the slice: fmax drops it; the products carry it into P and phase 2 reports it
+    }
+  }
   int r = 0;
   for (; g < g1; g += (long long)U * kPbThreads) {
     quad<T> vn[U];
@@ -372,6 +393,171 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_token(int rb_first, int 
   }
 }
 
+// ================================================================= phase 2 with order-independent (fixed-point) sums
+// LL_PB_PHASE2=fixed.  Integer addition is associative, so if every product is first rounded to a fixed-point grid the
+// LDS adds may arrive in ANY order — all waves add concurrently like in the arrival-order form — and the result is
+// still the same bits on every launch, for every kernel geometry and every partition of the matrix.
+//   grid of row i:  q_i = 2^(E_i - 62),  E_i >= exponent of  (sum_j |a_ij|) * max_j |x_j|,  so that the exact sum of the
+//   row, scaled by 1/q_i, fits a 64-bit integer with room to spare.  E_i = rexp[i] (exponent of the row's absolute
+//   sum, computed when the image is built) + exponent of max |x| (phase 1 leaves the maximum of every x slice) + 1.
+// Error per row: each product is rounded to q_i once (<= q_i / 2), the sum itself is exact:
+//   |y_i - exact| <= nnz_i * 2^-63 * 2^E_i  ~  nnz_i * 2^-62 * (sum_j |a_ij|) max|x|,
+// i.e. 2^9 times finer than the unit roundoff of a double-precision sum of terms of that size: at least as accurate as
+// floating-point summation unless the row's terms are all 500 times smaller than sum_j |a_ij| max|x| — and always
+// far below eps * ||A|| ||x||, the scale that matters to the Lanczos recurrence.
+__device__ __forceinline__ double pow2(int k) {  // 2^k for |k| <= 1022
+  return __longlong_as_double((long long)(1023 + k) << 52);
+}
+// false: the scaled product is not a finite number below 2^63 (NaN / Inf in x or in the matrix): the row is unusable
+__device__ __forceinline__ bool lds_add_i64(long long* p, double scaled) {
+  if (!(fabs(scaled) < 9.0e18)) return false;
+  const long long v = (long long)rint(scaled);
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+  return true;
+}
+
+template <typename T, int U, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_first, int rb_rows, int64_t n_local, int ncb,
+                                                              const int64_t* __restrict__ rptr,
+                                                              const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                              const int16_t* __restrict__ rexp,
+                                                              const double* __restrict__ blockmax,
+                                                              const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                              double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds_raw[];
+  long long* acc = reinterpret_cast<long long*>(lds_raw);                   // [rb_rows * R]
+  int16_t* ex = reinterpret_cast<int16_t*>(acc + (size_t)rb_rows * R);      // [rb_rows]: 62 - E_i, or kBadRow
+  __shared__ double red[kPbWaves];
+  __shared__ int ex_x;
+  constexpr int kBadRow = 32767;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rb = rb_first + blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+  constexpr long long kTrip = (long long)U * kPbThreads;
+
+  quad<T> pr[D][U];
+  ushort4 rl[D][U];
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[d][u] = load_quad<T>(P + 4 * gg);
+        rl[d][u] = row[gg];
+      }
+    }
+  }
+  {  // exponent of max |x| over ALL columns (every column block left its slice maximum)
+    double m = 0.0;
+    for (int i = tid; i < ncb; i += kPbThreads) m = fmax(m, blockmax[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+    if (lane == 0) red[wave] = m;
+    for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+      double t = red[0];
+      for (int w = 1; w < kPbWaves; ++w) t = fmax(t, red[w]);
+      int e = 0;
+      if (t > 0.0 && isfinite(t)) (void)frexp(t, &e);  // t < 2^e
+      else if (!(t == 0.0)) e = 20000;                  // Inf: every row of the block is reported as NaN
+      else e = -2000;                                   // x == 0: any scale does
+      ex_x = e;
+    }
+    __syncthreads();
+    const int e_x = ex_x;
+    for (int i = tid; i < rb_rows; i += kPbThreads) {
+      int k = kBadRow;
+      if (i < rows) {
+        const int er = rexp[row0 + i];
+        if (er != 32767 && e_x != 20000) k = max(-1000, min(1000, 62 - (er + e_x + 1)));
+      } else {
+        k = 0;
+      }
+      ex[i] = (int16_t)k;
+    }
+    __syncthreads();
+  }
+  for (long long base = g0; base < g1; base += kTrip) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[D - 1][u] = load_quad<T>(P + 4 * gg);
+        rl[D - 1][u] = row[gg];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + tid + (long long)u * kPbThreads < g1) {
+        const unsigned short rr[4] = {rl[0][u].x, rl[0][u].y, rl[0][u].z, rl[0][u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = ex[rr[e]];
+          const double sc = pow2(k == kBadRow ? 0 : k);
+          bool ok;
+          if constexpr (scalar_traits<T>::is_complex) {
+            ok = lds_add_i64(&acc[2 * rr[e]], (double)pr[0][u].e[e].re * sc);
+            ok = lds_add_i64(&acc[2 * rr[e] + 1], (double)pr[0][u].e[e].im * sc) && ok;
+          } else {
+            ok = lds_add_i64(&acc[rr[e]], (double)pr[0][u].e[e] * sc);
+          }
+          if (!ok) ex[rr[e]] = (int16_t)kBadRow;  // the row's result is NaN (same value from every writer)
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pr[d][u] = pr[d + 1][u];
+        rl[d][u] = rl[d + 1][u];
+      }
+    }
+  }
+  __syncthreads();
+  double dot_acc = 0.0;
+  for (int i = tid; i < rows; i += kPbThreads) {
+    const T xi = xl[row0 + i];
+    const int k = ex[i];
+    const double back = k == kBadRow ? __longlong_as_double(0x7ff8000000000000ll) : pow2(-k);  // NaN for unusable rows
+    acc_t<T> a;
+    if constexpr (scalar_traits<T>::is_complex) a = zc{(double)acc[2 * i] * back, (double)acc[2 * i + 1] * back};
+    else a = (double)acc[i] * back;
+    const T yi = add(narrow<T>(a), rmul(offset, xi));
+    y[row0 + i] = yi;
+    dot_acc += re_cmul(xi, yi);
+  }
+  if (dot_partials) {
+    const double v = wave_sum(dot_acc);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kPbWaves; ++w) t += red[w];
+      dot_partials[rb] = t;
+    }
+  }
+}
+
+// exponent of every local row's absolute sum: sum_j |a_ij| < 2^rexp[i]  (32767: the row holds Inf / NaN)
+template <typename T, typename RP>
+__global__ __launch_bounds__(256) void pb_rowexp_kernel(long long n_local, const RP* __restrict__ rp,
+                                                        const T* __restrict__ va, int16_t* __restrict__ rexp) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_local; i += (long long)gridDim.x * 256) {
+    double s = 0.0;
+    for (long long p = (long long)rp[i]; p < (long long)rp[i + 1]; ++p) s += abs1(va[p]);
+    int e = -1100;
+    if (s > 0.0 && isfinite(s)) (void)frexp(s, &e);
+    else if (!(s == 0.0)) e = 32767;
+    rexp[i] = (int16_t)e;
+  }
+}
+
 // ================================================================= launchers
 namespace {
 constexpr int kPbLdsCap = 160 * 1024 - 2048;
@@ -399,6 +585,8 @@ template <typename T> void pb_opt_in_lds() {
   pb_opt_in(&pb_phase2<T, 1, true, 2, true>); pb_opt_in(&pb_phase2<T, 2, true, 2, true>);
   pb_opt_in(&pb_phase2<T, 1, true, 3, true>); pb_opt_in(&pb_phase2<T, 2, true, 3, true>);
   pb_opt_in(&pb_phase2<T, 1, false, 2, true>); pb_opt_in(&pb_phase2<T, 2, false, 2, true>);
+  pb_opt_in(&pb_phase2_fixed<T, 1, 2>); pb_opt_in(&pb_phase2_fixed<T, 2, 2>); pb_opt_in(&pb_phase2_fixed<T, 1, 3>);
+  pb_opt_in(&pb_phase2_fixed<T, 2, 3>);
   pb_opt_in(&pb_phase2_token<T, 1, 2>); pb_opt_in(&pb_phase2_token<T, 2, 2>); pb_opt_in(&pb_phase2_token<T, 1, 3>);
   pb_opt_in(&pb_phase2_token<T, 2, 3>);
   mask.fetch_or(bit, std::memory_order_release);
@@ -412,7 +600,8 @@ void phase1_range(const ll_operator& op, int blk_first, int blk_count, int rb_fi
 #define LL_P1(U, XP)                                                                                                  \
   hipLaunchKernelGGL((pb_phase1<T, U, XP>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, rb_first, rb_count, \
                      blk_first, op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,   \
-                     (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols)
+                     (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols,                              \
+                     op.pb_ordered == 4 ? op.d_pb_blockmax : nullptr)
   const bool xp = op.pb_xprop != 0;
   switch (op.pb_u1) {
     case 1: if (xp) LL_P1(1, true); else LL_P1(1, false); break;
@@ -435,7 +624,16 @@ void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_
   const bool ord = op.pb_ordered != 0;
   const int depth = ord ? op.pb_depth : 2;
   const int u2 = op.pb_u2 == 1 ? 1 : (op.pb_u2 == 4 && !op.pb_xprop ? 4 : 2);
-  if (op.pb_ordered == 2 && !op.pb_xprop) {  // token form of the fixed order
+  if (op.pb_ordered == 4 && !op.pb_xprop) {  // order-independent fixed-point sums
+    const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
+#define LL_P2F(U, D)                                                                                                   \
+  hipLaunchKernelGGL((pb_phase2_fixed<T, U, D>), dim3(rb_count), dim3(kPbThreads), ldsf, s, rb_first, op.pb_rb_rows,  \
+                     op.n_local, op.pb_ncb, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod,        \
+                     op.d_pb_rexp, op.d_pb_blockmax, x_local, y, offset, dot_partials)
+    if (u2 == 1) { if (op.pb_depth >= 3) LL_P2F(1, 3); else LL_P2F(1, 2); }
+    else { if (op.pb_depth >= 3) LL_P2F(2, 3); else LL_P2F(2, 2); }
+#undef LL_P2F
+  } else if (op.pb_ordered == 2 && !op.pb_xprop) {  // token form of the fixed order
 #define LL_P2T(U, D)                                                                                                   \
   hipLaunchKernelGGL((pb_phase2_token<T, U, D>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,  \
                      op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, \
@@ -806,7 +1004,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   {
     const char* p2 = std::getenv("LL_PB_PHASE2");  // "atomic": arrival order; "token": fixed order by ticket; else barriers
     const std::string p2s = p2 ? p2 : "";
-    op->pb_ordered = p2s == "atomic" ? 0 : (p2s == "token" ? 2 : (p2s == "issueorder" ? 3 : 1));
+    op->pb_ordered = p2s == "atomic" ? 0 : (p2s == "token" ? 2 : (p2s == "issueorder" ? 3 : (p2s == "fixed" ? 4 : 1)));
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
   op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;
@@ -853,6 +1051,22 @@ template <typename T> bool pb_build_device(ll_operator* op) {
                        (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
                        op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, op->pb_xprop);
   LL_HIP(hipGetLastError());
+  if (op->pb_ordered == 4) {  // fixed-point sums: per-row exponents of the absolute row sums, per-block maxima of |x|
+    // the y slice holds 64-bit integers + one 16-bit exponent per row: it must still fit the LDS
+    LL_REQUIRE((size_t)rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16 <= (size_t)kPbLdsCap,
+               "LL_PB_PHASE2=fixed: row block too large for the LDS (lower LL_PB_ROW_BLOCK)");
+    ctx->dev_malloc((void**)&op->d_pb_rexp, std::max<size_t>((size_t)nr, 8) * sizeof(int16_t), "row exponents");
+    ctx->dev_malloc((void**)&op->d_pb_blockmax, (size_t)ncb * sizeof(double), "x slice maxima");
+    LL_HIP(hipMemsetAsync(op->d_pb_blockmax, 0, (size_t)ncb * sizeof(double), s));
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (nr + 255) / 256));
+    if (op->rp64)
+      hipLaunchKernelGGL((pb_rowexp_kernel<T, int64_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int64_t*)op->d_row_ptr,
+                         (const T*)op->d_val, op->d_pb_rexp);
+    else
+      hipLaunchKernelGGL((pb_rowexp_kernel<T, int32_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int32_t*)op->d_row_ptr,
+                         (const T*)op->d_val, op->d_pb_rexp);
+    LL_HIP(hipGetLastError());
+  }
   LL_HIP(hipStreamSynchronize(s));  // the host tables above go out of scope
   return true;
 }

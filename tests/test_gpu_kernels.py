@@ -47,7 +47,8 @@ CASES = csr_cases()
 # "l2g" is the EXPERIMENT kernel of csrc/spmv_l2g.hip (L2-blocked gather; only with LL_SPMV_KERNEL=l2g)
 KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37"),
            "pb_xprop": (1, None), "pb_xprop_small_blocks": (1, "37"), "pb_other_unrolls": (1, "53"),
-           "pb_token": (1, None), "pb_token_small_blocks": (1, "37")}
+           "pb_token": (1, None), "pb_token_small_blocks": (1, "37"),
+           "pb_fixed": (1, None), "pb_fixed_small_blocks": (1, "37")}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -70,6 +71,8 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
         monkeypatch.setenv("LL_PB_U1", "2")
         monkeypatch.setenv("LL_PB_U2", "1")
         monkeypatch.setenv("LL_PB_DEPTH", "2")
+    if kernel.startswith("pb_fixed"):
+        monkeypatch.setenv("LL_PB_PHASE2", "fixed")   # order-independent fixed-point sums (integer LDS adds)
     if kernel.startswith("pb_token"):
         monkeypatch.setenv("LL_PB_PHASE2", "token")   # the fixed order enforced by a ticket in LDS instead of barriers
     if kernel == "pb_atomic":
@@ -123,6 +126,21 @@ def test_pb_ordered_forms_agree_bit_for_bit(ctx, name, block, monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
     # same (trip, wave) order of the adds whenever the trip geometry is the same; across geometries the order changes
+    # fixed-point sums: the same bits for every kernel geometry (integer addition is associative)
+    fx = {}
+    for label, env in (("a", {}), ("b", {"LL_PB_U2": "1", "LL_PB_DEPTH": "2", "LL_PB_U1": "2"}), ("c", {"LL_PB_ROW_GROUPS": "3"})):
+        monkeypatch.setenv("LL_PB_PHASE2", "fixed")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        op = L.CsrOperator(ctx, *csr)
+        L.spmv(op, xd, yd, offset=0.5)
+        fx[label] = yd.get()
+        op.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LL_PB_PHASE2")
+    assert np.array_equal(fx["a"], fx["b"]) and np.array_equal(fx["a"], fx["c"])
+    assert np.max(np.abs(fx["a"] - ys["barrier"])) <= 64 * EPS * np.max(np.abs(ys["barrier"]))
     assert np.array_equal(ys["barrier"], ys["token"])
     assert np.array_equal(ys["barrier"], ys["xprop"])
     assert np.max(np.abs(ys["barrier"] - ys["token_u1_d2"])) <= 64 * EPS * np.max(np.abs(ys["barrier"]))
