@@ -318,7 +318,11 @@ typedef struct ll_lanczos_params {
   void* init_user;
 } ll_lanczos_params;
 
-/* Fill *p with the reference defaults for an n x n problem (LL:200-208). */
+/* Fill *p with the reference defaults for an n x n problem (LL:200-208); tridiag_mode = LL_TRIDIAG_AUTO (same stop
+ * decisions and values as the reference's per-iteration QR).  eps is the DOUBLE default 1e3 * DBL_EPSILON (LL:150 with
+ * real_t<T> = double); the reference scales it with the epsilon of real_t<T>, so the _s / _c entry points replace
+ * exactly that value by 1e3 * FLT_EPSILON (likewise ll_expo_params_default's 1e2 * DBL_EPSILON, EX:58) — a float run
+ * left at the defaults converges like the reference's float instantiation instead of iterating to max_iteration. */
 int ll_lanczos_params_default(ll_lanczos_params* p, int64_t n, int find_maximum, int64_t num_eigs);
 
 typedef struct ll_run_stats {

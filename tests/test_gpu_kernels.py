@@ -164,6 +164,56 @@ def test_spmv_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
     op.close()
 
 
+@pytest.mark.parametrize("name", ["randsym5000", "ragged_z"])
+def test_pb_image_build_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
+    """The device-side image build (histogram + scatter + row exponents) reads int64 row offsets once nnz exceeds 2^31;
+    forced here on small matrices, for the default and the fixed-point phase 2."""
+    monkeypatch.setenv("LL_FORCE_RP64", "1")
+    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
+    csr = CASES[name]
+    dtype = csr[2].dtype
+    n = csr[0].shape[0] - 1
+    x = rnd(n, dtype, 5)
+    y_ref = oracle.spmv(csr, x) - 1.5 * x
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    for phase2 in ("", "fixed"):
+        if phase2:
+            monkeypatch.setenv("LL_PB_PHASE2", phase2)
+        op = L.CsrOperator(ctx, *csr)
+        assert op.selected_spmv() == L.capi.SPMV_PB
+        L.spmv(op, xd, yd, offset=-1.5)
+        assert np.max(np.abs(yd.get() - y_ref)) <= 1e-13 * 60
+        op.close()
+
+
+def test_fixed_point_phase2_reports_non_finite_input_as_nan(ctx, monkeypatch):
+    """Order-independent integer sums cannot carry Inf / NaN; rows that meet one are reported as NaN, every other row
+    keeps its value (with a finite max |x| the scale of the clean rows is unaffected by a NaN elsewhere)."""
+    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
+    monkeypatch.setenv("LL_PB_PHASE2", "fixed")
+    csr = CASES["laplace37"]
+    n = csr[0].shape[0] - 1
+    x = rnd(n, np.float64, 2)
+    op = L.CsrOperator(ctx, *csr)
+    xd, yd = ctx.to_device(x), ctx.empty(n)
+    L.spmv(op, xd, yd)
+    clean = yd.get()
+    bad = x.copy()
+    bad[100] = np.nan
+    xd.set(bad)
+    L.spmv(op, xd, yd)
+    got = yd.get()
+    rp, ci, _ = csr
+    touched = np.array([np.any(ci[rp[i]:rp[i + 1]] == 100) for i in range(n)])
+    assert np.all(np.isnan(got[touched])) and touched.sum() == 5
+    assert np.max(np.abs(got[~touched] - clean[~touched])) <= 1e-13 * np.max(np.abs(clean))
+    bad[100] = np.inf                       # max |x| = Inf: no usable scale for any row
+    xd.set(bad)
+    L.spmv(op, xd, yd)
+    assert np.all(np.isnan(yd.get()))
+    op.close()
+
+
 def test_device_memory_helpers(ctx):
     """ll_malloc / ll_memset / ll_memcpy_{h2d,d2h} / ll_free round trip."""
     import ctypes as C
