@@ -391,6 +391,8 @@ def main():
             "sample": "same matrix and start vector, LambdaLanczos::run with max_iteration=%d (mean k=%.1f), "
                       "single thread like the reference" % (args.cpu_window, (args.cpu_window + 1) / 2),
             "seconds": r["t_total"],
+            "note": "the cost of an iteration grows with k: compare `value` (window of %d iterations) with "
+                    "`gpu_same_window_value`, NOT with the headline value (window of %d)" % (args.cpu_window, args.window),
             "spmv_GBps": b_spmv * cpu_its / max(r["t_mv"], 1e-12) / 1e9,
             "gpu_same_window_value": cpu_its / tg,
             "parity_same_window": {"eigenvalue_cpu": float(r["eigenvalues"][0]), "eigenvalue_gpu": float(vals_g[0]),
