@@ -14,7 +14,6 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
-#include <string>
 
 #include "dev_helpers.hpp"
 #include "ll_internal.hpp"
@@ -144,9 +143,7 @@ template <typename T> struct strip {
 // (Measured alternative, round 2: equal CONTIGUOUS shares per workgroup instead of strips dealt out round-robin —
 // perfectly balanced, but 8 % slower on the Gram-Schmidt kernels (5.35 vs 5.83 TB/s at n = 1e7): with the round-robin
 // walk the whole chip sweeps each basis vector front to back, which is what the HBM row buffers like.)
-static void apply_strip_layout();
 static int strip_grid(int64_t n, int elems) {
-  apply_strip_layout();
   static int target = 0;
   if (!target) target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : 1024;
   int64_t strips = (n + elems - 1) / elems;
@@ -155,94 +152,42 @@ static int strip_grid(int64_t n, int elems) {
   return (int)((strips + per - 1) / per);
 }
 
-// A lane holds EPT elements of a strip as four 16-byte pieces.  Piece e of lane t is the 16 bytes at
-//   strip base + (e * kBlock + t) * 16 B,
-// so every wave-instruction moves 64 lanes x 16 B = 1 KiB of CONSECUTIVE memory (8 whole 128-byte lines) and the four
-// pieces of the workgroup cover the strip's 16 KiB.  (Round 1 gave every lane 64 contiguous bytes: the same bytes, but
-// each instruction then touched 32 lines and used a quarter of each; LL_STRIP_LAYOUT=lane keeps that form for A/B.)
-// Which elements a lane holds does not matter to the BLAS-1 kernels — all vectors of a kernel use the same mapping.
-__device__ int g_strip_lane_contiguous = 0;
-
+// A lane's EPT elements are contiguous (64 B = four 16-byte pieces) and lanes are adjacent: the four loads of a wave
+// cover 4 KiB of consecutive memory, each of them touching the same 32 lines (the 2nd to 4th hit in L1 / merge with
+// the outstanding misses).  Measured alternatives, round 2 (A/B in one process through a device flag): 16-byte pieces
+// laid out so that every single instruction is contiguous over the workgroup, or over the wave: 5.67-5.71 vs
+// 5.71-5.80 TB/s at n = 1e7 (no gain) and slower at n = 1e6 — this layout stays.
 template <typename T>
 __device__ __forceinline__ void load_strip(const T* __restrict__ v, int64_t base, int64_t n, T (&r)[strip<T>::EPT]) {
   constexpr int EPT = strip<T>::EPT;
-  constexpr int V = EPT / 4;  // elements per 16-byte piece
-  if (g_strip_lane_contiguous) {
-    const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
-    if (i0 + EPT <= n) {
-      const uint4* p = reinterpret_cast<const uint4*>(v + i0);
-      uint4 c[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) c[e] = p[e];
-      __builtin_memcpy(&r[0], c, sizeof(c));
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) r[e] = (i0 + e < n) ? v[i0 + e] : zero<T>();
-    }
-    return;
-  }
-  if (base + strip<T>::ELEMS <= n) {  // whole strip inside the vector (uniform over the workgroup)
-    const uint4* p = reinterpret_cast<const uint4*>(v + base) + threadIdx.x;
+  const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+  if (i0 + EPT <= n) {
+    const uint4* p = reinterpret_cast<const uint4*>(v + i0);
     uint4 c[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c[e] = p[e * kBlock];
+    for (int e = 0; e < 4; ++e) c[e] = p[e];
     __builtin_memcpy(&r[0], c, sizeof(c));
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t i0 = base + ((int64_t)e * kBlock + threadIdx.x) * V;
-#pragma unroll
-      for (int q = 0; q < V; ++q) r[e * V + q] = (i0 + q < n) ? v[i0 + q] : zero<T>();
-    }
+    for (int e = 0; e < EPT; ++e) r[e] = (i0 + e < n) ? v[i0 + e] : zero<T>();
   }
 }
 template <typename T>
 __device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int64_t n,
                                             const T (&r)[strip<T>::EPT]) {
   constexpr int EPT = strip<T>::EPT;
-  constexpr int V = EPT / 4;
-  if (g_strip_lane_contiguous) {
-    const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
-    if (i0 + EPT <= n) {
-      uint4 c[4];
-      __builtin_memcpy(c, &r[0], sizeof(c));
-      uint4* p = reinterpret_cast<uint4*>(v + i0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) p[e] = c[e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e)
-        if (i0 + e < n) v[i0 + e] = r[e];
-    }
-    return;
-  }
-  if (base + strip<T>::ELEMS <= n) {
+  const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+  if (i0 + EPT <= n) {
     uint4 c[4];
     __builtin_memcpy(c, &r[0], sizeof(c));
-    uint4* p = reinterpret_cast<uint4*>(v + base) + threadIdx.x;
+    uint4* p = reinterpret_cast<uint4*>(v + i0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) p[e * kBlock] = c[e];
+    for (int e = 0; e < 4; ++e) p[e] = c[e];
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t i0 = base + ((int64_t)e * kBlock + threadIdx.x) * V;
-#pragma unroll
-      for (int q = 0; q < V; ++q)
-        if (i0 + q < n) v[i0 + q] = r[e * V + q];
-    }
+    for (int e = 0; e < EPT; ++e)
+      if (i0 + e < n) v[i0 + e] = r[e];
   }
-}
-// LL_STRIP_LAYOUT=lane selects the round-1 layout (read once per process, copied to the device flag per device)
-static void apply_strip_layout() {
-  static std::atomic<unsigned long long> done{0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return;
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (done.load(std::memory_order_acquire) & bit) return;
-  const char* e = std::getenv("LL_STRIP_LAYOUT");
-  const int lane = (e && std::string(e) == "lane") ? 1 : 0;
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_strip_lane_contiguous), &lane, sizeof(int));
-  done.fetch_or(bit, std::memory_order_release);
 }
 
 // ================================================================= a4 + a5/a6 (projection half): multi-dot
