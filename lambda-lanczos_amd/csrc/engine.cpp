@@ -26,6 +26,13 @@ static bool tridiag_thread_enabled() {
   const char* e = std::getenv("LL_TRIDIAG_THREAD");
   return !(e && std::atoi(e) == 0);
 }
+// Sharded contexts consume the helper thread's verdicts a fixed number of iterations late (StepWorker::consume); each
+// stop costs that many speculative iterations, a slow host step is hidden for that many.  LL_TRIDIAG_LAG overrides
+// (negative: the single-process opportunistic policy — unsafe with more than one rank, kept to demonstrate the hang).
+static int64_t tridiag_lockstep_lag() {
+  const char* e = std::getenv("LL_TRIDIAG_LAG");
+  return e ? std::max(-1, std::atoi(e)) : 3;
+}
 static double dgks_threshold() {
   const char* e = std::getenv("LL_DGKS_THRESHOLD");
   return e ? std::atof(e) : 0.5;
@@ -694,6 +701,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     // like before.  LL_TRIDIAG_THREAD=0 computes the verdicts inline (lag 1, the round-1 behaviour).
     const bool threaded = speculate && tridiag_thread_enabled();
     const size_t kMaxLag = threaded ? 24 : 0;
+    const int64_t lockstep_lag = threaded && ctx->comm != nullptr ? tridiag_lockstep_lag() : -1;  // see StepWorker::consume
     TridiagWorker worker(tracker_cfg, threaded);
     RitzTracker::Out last;
     auto absorb = [&](RitzTracker::Out& r) {
@@ -741,8 +749,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
         enqueue(k);
         if (k > 1) {
           if (collect(k - 1) == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
-          while (!stopped && worker.try_pop(r)) stopped = absorb(r);
-          while (!stopped && worker.outstanding() > kMaxLag && worker.wait_pop(r)) stopped = absorb(r);
+          stopped = worker.consume(k - 1, lockstep_lag, kMaxLag, absorb);
         }
       }
       if (!stopped) collect(P.max_iteration);
@@ -933,8 +940,6 @@ inline void from_std(double v, double* o) { *o = v; }
 inline void from_std(std::complex<double> v, zc* o) { o->re = v.real(); o->im = v.imag(); }
 inline void from_std(double v, float* o) { *o = (float)v; }
 inline void from_std(std::complex<double> v, cf* o) { o->re = (float)v.real(); o->im = (float)v.imag(); }
-inline double conj_h(double v) { return v; }
-inline std::complex<double> conj_h(std::complex<double> v) { return std::conj(v); }
 }  // namespace
 
 template <typename T>
@@ -973,8 +978,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   NormRefs refs_prev = E.plain_norm(E.S(kScalScratch) + 1);
   launch_scale<T>(nl, U.vec(0), 0.0, &refs_prev, s);
 
-  std::vector<double> alpha, beta, ev, p;
-  std::vector<H> coeff, coeff_prev, expv;
+  std::vector<double> alpha, beta;
+  std::vector<H> coeff_prev;
   int64_t second_passes = 0;
   int64_t itern = P.max_iteration;
   bool stopped = false;
@@ -998,8 +1003,25 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     timer.mark();
     refs_prev = refs;
   };
-  enum { kContinue = 0, kStop = 1, kRedone = 2 };
-  auto process = [&](int64_t j) -> int {
+  // Host half of iteration j, part 1 (this thread): the four scalars, the DGKS decision, alpha_j / beta_j; part 2 (EX:124-158:
+  // exp(a T_j) e_1 and the overlap test, O(j^3)) runs on the helper thread like the eigen-solver's Ritz step.
+  enum { kContinue = 0, kRedone = 2 };
+  ExpoTracker<H> tracker_cfg;
+  tracker_cfg.a = a;
+  tracker_cfg.eps = P.eps;
+  tracker_cfg.breakdown_tol = (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon();  // EX:154
+  const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);  // see lanczos_run
+  const bool threaded = speculate && tridiag_thread_enabled();
+  const size_t kMaxLag = threaded ? 24 : 0;
+  const int64_t lockstep_lag = threaded && ctx->comm != nullptr ? tridiag_lockstep_lag() : -1;  // see StepWorker::consume
+  StepWorker<ExpoTracker<H>> worker(tracker_cfg, threaded);
+  typename ExpoTracker<H>::Out last, r;
+  auto absorb = [&](typename ExpoTracker<H>::Out& o) {
+    t_tridiag += o.seconds;
+    last = std::move(o);
+    return last.stop;
+  };
+  auto collect = [&](int64_t j) -> int {
     const int slot = (int)(j % 4);
     LL_HIP(hipEventSynchronize(ring.ev[slot]));
     const volatile double* hp = ctx->h_pinned + 4 * slot;
@@ -1022,46 +1044,31 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
       }
     }
     alpha.push_back(alpha_j);
-    const double beta_j = std::sqrt(beta2_j);
-    TraceRange trace("ll::host_tridiag (exp(a T_k) e_1 + overlap test)");
-    const double t0 = now_s();
-    const int64_t m = (int64_t)alpha.size();
-    ev.resize((size_t)m);
-    p.resize((size_t)m * m);
-    tridiag_qr(m, alpha.data(), beta.data(), ev.data(), p.data());  // EX:124-126 (beta has m-1 entries here)
-    coeff.assign((size_t)m, H(0));
-    expv.resize((size_t)m);
-    for (int64_t jj = 0; jj < m; ++jj) expv[(size_t)jj] = std::exp(a * ev[jj]);  // m exponentials instead of m^2
-    for (int64_t i = 0; i < m; ++i)  // EX:128-133: (exp(a T_m) e_1)_i, same product order as the reference
-      for (int64_t jj = 0; jj < m; ++jj) coeff[i] += p[(size_t)jj * m + i] * expv[(size_t)jj] * p[(size_t)jj * m];
-    t_tridiag += now_s() - t0;
-    beta.push_back(beta_j);  // EX:145
-    H overlap = H(0);
-    for (size_t i = 0; i < coeff_prev.size(); ++i) overlap += conj_h(coeff_prev[i]) * coeff[i];  // EX:147-150
-    coeff_prev = coeff;  // EX:152
-    if (std::abs(1.0 - std::abs(overlap)) < P.eps ||
-        beta_j < (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon())  // EX:154-158
-      return kStop;
+    beta.push_back(std::sqrt(beta2_j));  // EX:145
+    worker.submit((int64_t)alpha.size(), alpha.data(), beta.data());
     return verdict;
   };
-
-  const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);  // see lanczos_run
   if (speculate) {
-    for (int64_t k = 1; k <= P.max_iteration; ++k) {
+    for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
       enqueue(k);
       if (k > 1) {
-        const int v = process(k - 1);
-        if (v == kStop) { itern = k - 1; stopped = true; break; }
-        if (v == kRedone) enqueue(k);
+        if (collect(k - 1) == kRedone) enqueue(k);
+        stopped = worker.consume(k - 1, lockstep_lag, kMaxLag, absorb);
       }
     }
-    if (!stopped) process(P.max_iteration);
+    if (!stopped) collect(P.max_iteration);
   } else {
-    for (int64_t k = 1; k <= P.max_iteration; ++k) {
+    for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
       enqueue(k);
-      if (process(k) == kStop) { itern = k; stopped = true; break; }
+      collect(k);
+      while (!stopped && worker.wait_pop(r)) stopped = absorb(r);
     }
   }
+  while (!stopped && worker.wait_pop(r)) stopped = absorb(r);
+  itern = last.m;
+  coeff_prev = last.coeff;
+  alpha.resize((size_t)itern);
+  beta.resize((size_t)itern);
   LL_HIP(hipStreamSynchronize(s));
 
   // output = ||input|| * sum_l coeff_prev[l] u[l]  (EX:163-170)

@@ -5,7 +5,10 @@
 #pragma once
 
 #include <chrono>
+#include <unistd.h>
+
 #include <cmath>
+#include <complex>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -146,14 +149,62 @@ struct RitzTracker {
   }
 };
 
-// A single helper thread that feeds the tracker with the iterations in order.  submit() copies the (alpha, beta)
-// prefixes, so the enqueueing thread may keep appending.  Results come back in submission order.
-class TridiagWorker {
+// The host step of Exponentiator<T>::run (EX:124-158): eigenpairs of T_m, coeff = exp(a T_m) e_1,
+// overlap with the previous iteration's coefficients, stop test.  H = double or std::complex<double>.
+template <typename H> struct ExpoTracker {
+  H a = H(0);
+  double eps = 0.0;
+  double breakdown_tol = 0.0;  // EX:154: epsilon of real_t<T>
+
+  struct Out {
+    int64_t m = 0;
+    bool stop = false;
+    std::vector<H> coeff;  // exp(a T_m) e_1: what the output sum uses when the loop ends at m (EX:163-170)
+    double seconds = 0.0;
+  };
+
+  std::vector<H> coeff_prev, expv;
+  std::vector<double> ev, p;
+
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  static double conj_of(double v) { return v; }
+  static std::complex<double> conj_of(std::complex<double> v) { return std::conj(v); }
+
+  // alpha[0..m), beta[0..m): beta[m-1] = ||w_m|| (EX:145); the QR reads beta[0..m-2]
+  Out step(int64_t m, const double* alpha, const double* beta) {
+    TraceRange trace("ll::host_tridiag (exp(a T_k) e_1 + overlap test)");
+    Out o;
+    o.m = m;
+    const double t0 = now();
+    ev.resize((size_t)m);
+    p.resize((size_t)m * m);
+    tridiag_qr(m, alpha, beta, ev.data(), p.data());  // EX:124-126
+    o.coeff.assign((size_t)m, H(0));
+    expv.resize((size_t)m);
+    for (int64_t j = 0; j < m; ++j) expv[(size_t)j] = std::exp(a * ev[(size_t)j]);  // m exponentials instead of m^2
+    for (int64_t i = 0; i < m; ++i)  // EX:128-133: (exp(a T_m) e_1)_i, same product order as the reference
+      for (int64_t j = 0; j < m; ++j) o.coeff[(size_t)i] += p[(size_t)j * m + i] * expv[(size_t)j] * p[(size_t)j * m];
+    H overlap = H(0);
+    for (size_t i = 0; i < coeff_prev.size(); ++i) overlap += conj_of(coeff_prev[i]) * o.coeff[i];  // EX:147-150
+    coeff_prev = o.coeff;                                                                          // EX:152
+    o.stop = std::abs(1.0 - std::abs(overlap)) < eps || beta[m - 1] < breakdown_tol;               // EX:154-158
+    o.seconds = now() - t0;
+    return o;
+  }
+};
+
+// A single helper thread that feeds a tracker (RitzTracker / ExpoTracker) with the iterations in order.  submit()
+// copies the (alpha, beta) prefixes, so the enqueueing thread may keep appending.  Results come back in order.
+template <typename Tracker> class StepWorker {
  public:
-  explicit TridiagWorker(const RitzTracker& cfg, bool threaded) : tracker_(cfg), threaded_(threaded) {
+  typedef typename Tracker::Out Out;
+  explicit StepWorker(const Tracker& cfg, bool threaded) : tracker_(cfg), threaded_(threaded) {
+    // test hook: every verdict is held back by a pseudo-random time up to this many microseconds, differently in every
+    // process, to show that ranks of a sharded run still enqueue the same iterations (tests/test_gpu_multirank.py)
+    if (const char* e = std::getenv("LL_TRIDIAG_TEST_JITTER_US")) jitter_us_ = std::atoi(e);
     if (threaded_) thread_ = std::thread([this] { run(); });
   }
-  ~TridiagWorker() {
+  ~StepWorker() {
     if (threaded_) {
       {
         std::lock_guard<std::mutex> g(mu_);
@@ -163,8 +214,8 @@ class TridiagWorker {
       thread_.join();
     }
   }
-  TridiagWorker(const TridiagWorker&) = delete;
-  TridiagWorker& operator=(const TridiagWorker&) = delete;
+  StepWorker(const StepWorker&) = delete;
+  StepWorker& operator=(const StepWorker&) = delete;
 
   void submit(int64_t m, const double* alpha, const double* beta) {
     if (!threaded_) {
@@ -188,23 +239,43 @@ class TridiagWorker {
     std::lock_guard<std::mutex> g(mu_);
     return outstanding_;
   }
-  bool try_pop(RitzTracker::Out& out) {
+  bool try_pop(Out& out) {
     std::unique_lock<std::mutex> g(mu_, std::defer_lock);
     if (threaded_) g.lock();
     if (done_.empty()) return false;
     out = std::move(done_.front());
     done_.pop_front();
+    ++popped_;
     if (threaded_) --outstanding_;
     return true;
   }
+  // How the enqueueing thread consumes verdicts once iteration `collected` has been submitted; true = stop.
+  //   lockstep_lag < 0 (one process): whatever has arrived, and wait only when more than max_lag are outstanding.
+  //   lockstep_lag >= 0 (sharded context): exactly the verdicts up to collected - lockstep_lag, waiting for them.  Every
+  //   rank holds the same (all-reduced) alpha/beta and so reaches the same verdicts, but WHEN a helper thread delivers
+  //   one differs from rank to rank; a rank that saw the stop one iteration earlier than its peers would leave them
+  //   alone in the next iteration's collectives.  A fixed lag makes the number of enqueued iterations a function of
+  //   the verdicts only.
+  template <typename Absorb> bool consume(int64_t collected, int64_t lockstep_lag, size_t max_lag, Absorb&& absorb) {
+    Out r;
+    bool stop = false;
+    if (lockstep_lag >= 0) {
+      while (!stop && popped_ < collected - lockstep_lag && wait_pop(r)) stop = absorb(r);
+    } else {
+      while (!stop && try_pop(r)) stop = absorb(r);
+      while (!stop && outstanding() > max_lag && wait_pop(r)) stop = absorb(r);
+    }
+    return stop;
+  }
   // blocks until the next result is there (false: nothing outstanding)
-  bool wait_pop(RitzTracker::Out& out) {
+  bool wait_pop(Out& out) {
     if (!threaded_) return try_pop(out);
     std::unique_lock<std::mutex> g(mu_);
     if (outstanding_ == 0) return false;
     cv_done_.wait(g, [this] { return !done_.empty(); });
     out = std::move(done_.front());
     done_.pop_front();
+    ++popped_;
     --outstanding_;
     return true;
   }
@@ -224,7 +295,11 @@ class TridiagWorker {
         j = std::move(jobs_.front());
         jobs_.pop_front();
       }
-      RitzTracker::Out o = tracker_.step(j.m, j.alpha.data(), j.beta.data());
+      Out o = tracker_.step(j.m, j.alpha.data(), j.beta.data());
+      if (jitter_us_ > 0) {
+        rng_ = rng_ * 6364136223846793005ull + 1442695040888963407ull;
+        std::this_thread::sleep_for(std::chrono::microseconds((long)((rng_ >> 33) % (uint64_t)jitter_us_)));
+      }
       {
         std::lock_guard<std::mutex> g(mu_);
         done_.push_back(std::move(o));
@@ -232,15 +307,19 @@ class TridiagWorker {
       cv_done_.notify_all();
     }
   }
-  RitzTracker tracker_;
+  Tracker tracker_;
   bool threaded_;
   std::thread thread_;
   std::mutex mu_;
   std::condition_variable cv_job_, cv_done_;
   std::deque<Job> jobs_;
-  std::deque<RitzTracker::Out> done_;
+  std::deque<Out> done_;
   size_t outstanding_ = 0;
+  int64_t popped_ = 0;
   bool quit_ = false;
+  int jitter_us_ = 0;
+  uint64_t rng_ = (uint64_t)::getpid() * 0x9E3779B97F4A7C15ull;
 };
+typedef StepWorker<RitzTracker> TridiagWorker;
 
 }  // namespace ll

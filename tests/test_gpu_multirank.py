@@ -55,9 +55,16 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
 # forced second pass: every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the
 # replicated decision must keep the ranks' collective sequences aligned, results unchanged up to rounding.
 # measured norm: the post-pass norm from maxpy's partial sums + an all-reduce instead of ||w||^2 - sum |h_j|^2.
+# verdict jitter: the helper thread of every rank delivers its stop verdicts up to 3 ms late, at times that differ from
+# rank to rank (3 ms >> one iteration here): the ranks must still enqueue the same iterations, i.e. consume verdicts at
+# a fixed lag (StepWorker::consume) — with opportunistic consumption a rank that sees the stop earlier leaves its peers
+# alone in a collective and the job hangs.  lag 0: every verdict awaited before the next iteration is enqueued.
 @pytest.mark.parametrize("world,extra", [(2, {}), (3, {}), (4, {}), (2, {"LL_DGKS_THRESHOLD": "2.0"}),
-                                         (2, {"LL_SHARDED_NORM": "measured"}), (3, {"LL_GATHER_CHUNKS": "1"})],
-                         ids=["2", "3", "4", "2-forced-second-pass", "2-measured-norm", "3-one-chunk"])
+                                         (2, {"LL_SHARDED_NORM": "measured"}), (3, {"LL_GATHER_CHUNKS": "1"}),
+                                         (3, {"LL_TRIDIAG_TEST_JITTER_US": "3000"}),
+                                         (2, {"LL_TRIDIAG_TEST_JITTER_US": "1500", "LL_TRIDIAG_LAG": "0"})],
+                         ids=["2", "3", "4", "2-forced-second-pass", "2-measured-norm", "3-one-chunk",
+                              "3-verdict-jitter", "2-verdict-jitter-lag0"])
 def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, world, extra):
     ranks = run_ranks(tmp_path, world, **extra)
 
