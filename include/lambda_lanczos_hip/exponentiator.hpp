@@ -35,11 +35,18 @@ template <typename T> class Exponentiator {
   size_t taylor_run(const T& a, const std::vector<T>& input, std::vector<T>& output) const {
     return call(a, input, output, true);
   }
+  // Addition: input and output in DEVICE memory (local rows each; may be the same buffer): a time-evolution loop
+  // psi <- exp(a*A) psi never crosses PCIe.  Returns the iteration count.
+  size_t run_device(const T& a, const T* d_input, T* d_output) const {
+    if (!csr_) throw Error(LL_ERR_INVALID, "run_device needs a device operator");
+    ll_expo_params p = make_params();
+    int64_t count = 0;
+    check(dispatch(csr_->get(), &p, a, d_input, d_output, &count, false));
+    return (size_t)count;
+  }
 
  private:
-  size_t call(const T& a, const std::vector<T>& input, std::vector<T>& output, bool taylor) const {
-    const size_t n_local = csr_ ? (size_t)csr_->local_rows() : matrix_size;
-    if (input.size() != n_local) throw Error(LL_ERR_INVALID, "input size differs from matrix_size (exponentiator.hpp:88)");
+  ll_expo_params make_params() const {
     ll_expo_params p;
     check(ll_expo_params_default(&p, (int64_t)matrix_size));
     p.max_iteration = (int64_t)max_iteration;
@@ -47,6 +54,12 @@ template <typename T> class Exponentiator {
     p.full_orthogonalize = full_orthogonalize ? 1 : 0;
     p.orth_mode = orth_mode;
     p.initial_vector_size = (int64_t)initial_vector_size;
+    return p;
+  }
+  size_t call(const T& a, const std::vector<T>& input, std::vector<T>& output, bool taylor) const {
+    const size_t n_local = csr_ ? (size_t)csr_->local_rows() : matrix_size;
+    if (input.size() != n_local) throw Error(LL_ERR_INVALID, "input size differs from matrix_size (exponentiator.hpp:88)");
+    ll_expo_params p = make_params();
     detail::HostOp<T> host{mv_mul, {}, {}};
     ll_operator* op = csr_ ? csr_->get() : detail::make_host_operator<T>(ctx_.get(), (int64_t)matrix_size, &host);
     output.assign(n_local, T());

@@ -39,6 +39,8 @@ template <typename T> class LambdaLanczos {
   // ---- additions (the defaults reproduce the reference's decisions and values)
   int tridiag_mode = LL_TRIDIAG_AUTO;  // how the per-iteration Ritz values are obtained (LL_TRIDIAG_*)
   int orth_mode = LL_ORTH_CGS_DGKS;   // Gram-Schmidt variant (LL_ORTH_*)
+  const T* init_vector_device = nullptr;  // non-null: start vector (local rows) already in device memory, used
+                                          // instead of init_vector (copied, never modified)
 
   // Reference constructor (lambda_lanczos.hpp:200-208): unmodified user code, host callback operator.
   LambdaLanczos(std::function<void(const std::vector<T>&, std::vector<T>&)> mv_mul, size_t matrix_size,
@@ -76,6 +78,28 @@ template <typename T> class LambdaLanczos {
       eigenvectors[(size_t)i].assign(vecs.begin() + (size_t)i * n_local, vecs.begin() + (size_t)(i + 1) * n_local);
     iter_counts_.assign(counts.begin(), counts.begin() + std::min<int64_t>(st.n_passes, (int64_t)counts.size()));
     last_stats_ = st;
+  }
+
+  // Addition: run() with the eigenvectors left in DEVICE memory (d_eigenvectors: capacity num_eigs * local rows,
+  // eigenvector i at d_eigenvectors + i * local rows).  With init_vector_device set, nothing n-sized crosses PCIe.
+  // Returns the number of pairs found.
+  size_t run_device(std::vector<real_t<T>>& eigenvalues, T* d_eigenvectors) {
+    if (!csr_) throw Error(LL_ERR_INVALID, "run_device needs a device operator");
+    ll_lanczos_params p = make_params(num_eigs);
+    detail::InitHook<T> hook{init_vector};
+    if (init_vector) {
+      p.init_vector = &detail::InitHook<T>::call;
+      p.init_user = &hook;
+    }
+    std::vector<double> vals(num_eigs);
+    std::vector<int64_t> counts(4 * num_eigs + 64);
+    int64_t found = 0;
+    ll_run_stats st;
+    check(call_run(csr_->get(), &p, vals.data(), d_eigenvectors, &found, counts.data(), (int64_t)counts.size(), &st));
+    eigenvalues.assign(vals.begin(), vals.begin() + found);
+    iter_counts_.assign(counts.begin(), counts.begin() + std::min<int64_t>(st.n_passes, (int64_t)counts.size()));
+    last_stats_ = st;
+    return (size_t)found;
   }
 
   // run_iteration(eigvalues, eigvecs, nroot, orthogonalizeTo) (lambda_lanczos.hpp:216-322): ONE Lanczos pass that
@@ -156,6 +180,7 @@ template <typename T> class LambdaLanczos {
     p.initial_vector_size = (int64_t)initial_vector_size;
     p.tridiag_mode = tridiag_mode;
     p.orth_mode = orth_mode;
+    p.init_vector_dev = init_vector_device;
     return p;
   }
   int call_run(ll_operator* op, const ll_lanczos_params* p, double* vals, T* vecs, int64_t* found, int64_t* counts,

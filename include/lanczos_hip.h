@@ -316,6 +316,8 @@ typedef struct ll_lanczos_params {
   int32_t orth_mode;              /* LL_ORTH_* */
   ll_init_vector_fn init_vector;  /* LL:133 */
   void* init_user;
+  const void* init_vector_dev;    /* non-NULL: the start vector (n_local elements) is already in DEVICE memory; used
+                                   * instead of the hook in every pass, copied, never modified */
 } ll_lanczos_params;
 
 /* Fill *p with the reference defaults for an n x n problem (LL:200-208); tridiag_mode = LL_TRIDIAG_AUTO (same stop
@@ -345,7 +347,10 @@ int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 
 /* LambdaLanczos<T>::run(eigenvalues, eigenvectors) (LL:330-366): restart loop + EigenPairManager semantics.
  *   eigvals_host   : num_eigs doubles, comparator order (descending for find_maximum, else ascending; LL:362-365)
- *   eigvecs_host   : num_eigs * n_local values of T, row-major, LOCAL shard of each eigenvector (nullable)
+ *   eigvecs_host   : num_eigs * n_local values of T, row-major, LOCAL shard of each eigenvector (nullable).
+ *                    Despite the name the buffer may live in HOST or in DEVICE memory (ll_malloc / hipMalloc); a
+ *                    device buffer receives the Ritz vectors without crossing PCIe (with p->init_vector_dev the whole
+ *                    call then moves nothing n-sized over the bus).  The same holds for ll_lanczos_run_iteration_*.
  *   n_found        : number of pairs returned (<= num_eigs)
  *   iter_counts    : capacity iter_cap entries (getIterationCounts, LL:412); nullable
  *   alpha_out/beta_out : optional traces of the LAST pass (capacity max_iteration each); nullable
@@ -386,7 +391,9 @@ typedef struct ll_expo_params {
 int ll_expo_params_default(ll_expo_params* p, int64_t n);
 
 /* Exponentiator<T>::run(a, input, output) (EX:87-173): output = exp(a*A) input; returns the iteration count
- * through itern_out.  input/output are LOCAL shards in host memory (n_local values of T). */
+ * through itern_out.  input/output are LOCAL shards (n_local values of T) in HOST or in DEVICE memory (decided per
+ * pointer): a time-evolution loop psi <- exp(a*A) psi that keeps psi in device buffers never crosses PCIe.  input and
+ * output may be the same buffer.  The same holds for ll_expo_taylor_run_*. */
 int ll_expo_run_d(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a, const double* input_host,
                   double* output_host, int64_t* itern_out, ll_run_stats* stats);
 int ll_expo_run_z(ll_context* ctx, ll_operator* op, const ll_expo_params* p, double a_re, double a_im,

@@ -45,6 +45,7 @@ class LanczosParams(C.Structure):
         ("orth_mode", i32),
         ("init_vector", INIT_FN),
         ("init_user", vp),
+        ("init_vector_dev", vp),
     ]
 
 

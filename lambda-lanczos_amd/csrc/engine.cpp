@@ -33,6 +33,17 @@ static int64_t tridiag_lockstep_lag() {
   const char* e = std::getenv("LL_TRIDIAG_LAG");
   return e ? std::max(-1, std::atoi(e)) : 3;
 }
+// Whole-loop entry points accept host OR device memory for their n-sized inputs and outputs (start vector, Ritz
+// vectors, Exponentiator input/output): a device pointer keeps the vector in HBM (no PCIe crossing, no staging).
+static bool is_device_ptr(const void* p) {
+  if (p == nullptr) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain (unregistered) host memory
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice;
+}
 static double dgks_threshold() {
   const char* e = std::getenv("LL_DGKS_THRESHOLD");
   return e ? std::atof(e) : 0.5;
@@ -613,19 +624,28 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   // or page-faulted per call.
   T* stage = (T*)ctx->ensure_stage((size_t)std::max<int64_t>(nl, 1) * sizeof(T));
   const bool single_pair = P.num_eigs == 1 && !spec;  // one pass, one survivor: its vector goes stage -> caller directly
-  bool result_in_stage = false;
+  bool result_in_stage = false, result_in_caller = false;
+  const bool out_dev = is_device_ptr(eigvecs);
+  auto to_caller = [&](T* dst, const T* src_host) {  // host -> the caller's buffer, wherever it lives
+    if (out_dev) LL_HIP(hipMemcpy(dst, src_host, (size_t)nl * sizeof(T), hipMemcpyHostToDevice));
+    else std::memcpy(dst, src_host, (size_t)nl * sizeof(T));
+  };
 
   while (true) {  // restart loop LL:334-354
     const int64_t nroot = spec ? spec->nroot : std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
     const double t_pass0 = now_s();
     // ---- start vector (LL:231-234)
-    if (P.init_vector) P.init_vector(stage, nl, op->row_begin, P.init_user);
-    else default_init<T>(stage, nl);
-    LL_HIP(hipMemcpyAsync(U.vec(0), stage, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+    if (P.init_vector_dev) {  // start vector already in HBM (copied: the caller's buffer is left untouched)
+      LL_HIP(hipMemcpyAsync(U.vec(0), P.init_vector_dev, (size_t)nl * sizeof(T), hipMemcpyDeviceToDevice, s));
+    } else {
+      if (P.init_vector) P.init_vector(stage, nl, op->row_begin, P.init_user);
+      else default_init<T>(stage, nl);
+      LL_HIP(hipMemcpyAsync(U.vec(0), stage, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+    }
     const int64_t L = spec ? spec->n_orth : (int64_t)kept.size();
     if (spec) {
       for (int64_t j = 0; j < L; ++j)  // the caller's orthogonalizeTo, in the caller's order
-        LL_HIP(hipMemcpyAsync(d_locked.p + j * ld, spec->orth_host + j * nl, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+        LL_HIP(hipMemcpyAsync(d_locked.p + j * ld, spec->orth_host + j * nl, (size_t)nl * sizeof(T), hipMemcpyDefault, s));  // host or device
     } else {
       int64_t j = 0;
       for (auto& kv : kept) {  // comparator order, like MapValueIterable (CM:58-74)
@@ -851,6 +871,12 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
         E.norm2_dev(d_ritz.p + w * ld, E.S(kScalScratch) + 1);
         const NormRefs nr = E.plain_norm(E.S(kScalScratch) + 1);
         launch_scale<T>(nl, d_ritz.p + w * ld, 0.0, &nr, s);  // LL:58
+        if (single_pair && out_dev) {  // the one survivor goes straight to the caller's device buffer
+          LL_HIP(hipMemcpyAsync(eigvecs, d_ritz.p + w * ld, (size_t)nl * sizeof(T), hipMemcpyDeviceToDevice, s));
+          LL_HIP(hipStreamSynchronize(s));
+          result_in_caller = true;
+          continue;
+        }
         LL_HIP(hipMemcpyAsync(stage, d_ritz.p + w * ld, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
         LL_HIP(hipStreamSynchronize(s));
         if (single_pair) {
@@ -869,7 +895,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     if (spec) {  // LL:312-321: hand the pairs back as they are
       for (int64_t i = 0; i < nev; ++i) {
         eigvals[i] = evs[(size_t)i];
-        if (eigvecs) std::memcpy(eigvecs + (size_t)i * nl, xs[(size_t)i].data(), (size_t)nl * sizeof(T));
+        if (eigvecs) to_caller(eigvecs + (size_t)i * nl, xs[(size_t)i].data());
       }
       *n_found = nev;
       break;
@@ -897,9 +923,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   int64_t cnt = spec ? *n_found : 0;
   for (auto kv = kept.begin(); !spec && kv != kept.end(); ++kv) {  // comparator order (LL:356-365)
     eigvals[cnt] = kv->first;
-    if (eigvecs) {
+    if (eigvecs && !(single_pair && result_in_caller)) {
       const T* src = (single_pair && result_in_stage) ? stage : kv->second.data();
-      std::memcpy(eigvecs + (size_t)cnt * nl, src, (size_t)nl * sizeof(T));
+      to_caller(eigvecs + (size_t)cnt * nl, src);
     }
     ++cnt;
   }
@@ -970,7 +996,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   double t_tridiag = 0.0;
 
   // u[0] = input / ||input||  (EX:100-101); ||input|| is kept for the output scaling (EX:165)
-  LL_HIP(hipMemcpyAsync(U.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+  LL_HIP(hipMemcpyAsync(U.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
   E.norm2_dev(U.vec(0), E.S(kScalScratch) + 1);
   double in_norm2 = 0.0;
   E.fetch(E.S(kScalScratch) + 1, &in_norm2, 1);
@@ -1081,7 +1107,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   basis.ld = ld;
   basis.add_basis(U, m);
   E.gemv(basis, m, 1, c.data(), d_out.p, ld);
-  LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
   LL_HIP(hipStreamSynchronize(s));
   *itern_out = itern;
   if (stats) {
@@ -1127,7 +1153,7 @@ void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typen
   Engine<T> E(ctx, op, nl);
   Basis<T> V;
   V.init(ctx, nl, ld, 32);
-  LL_HIP(hipMemcpyAsync(V.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyHostToDevice, s));
+  LL_HIP(hipMemcpyAsync(V.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
   H factor = 1.0;
   int64_t terms = 1;
   for (int64_t k = 1;; ++k) {  // EX:187-195
@@ -1150,7 +1176,7 @@ void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typen
   basis.ld = ld;
   basis.add_basis(V, terms);
   E.gemv(basis, terms, 1, c.data(), d_out.p, ld);
-  LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
   LL_HIP(hipStreamSynchronize(s));
   *nterms_out = terms;
 }

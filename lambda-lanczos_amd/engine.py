@@ -448,6 +448,9 @@ class LambdaLanczos:
         # additions (0 = reference-faithful)
         self.tridiag_mode = capi.TRIDIAG_AUTO  # decision- and value-identical to the reference's QR, O(k) per iteration
         self.orth_mode = capi.ORTH_CGS_DGKS
+        # device-resident I/O (additions): init_vector may be a DeviceArray (start vector already in HBM), and a
+        # DeviceArray of shape (num_eigs, n_local) here receives the eigenvectors instead of a host array
+        self.eigenvectors_out = None
         self._iter_counts = []
         self.last_stats = None
         self.last_alpha = self.last_beta = None
@@ -482,7 +485,10 @@ class LambdaLanczos:
         sfx = _suffix(self.dtype)
         p = self._params(1 if nroot is not None else k)
         keep = None
-        if self.init_vector is not None:
+        if isinstance(self.init_vector, DeviceArray):  # start vector already in HBM
+            assert self.init_vector.dtype == self.dtype and self.init_vector.nbytes >= op.n_local * self.dtype.itemsize
+            p.init_vector_dev = self.init_vector.ptr
+        elif self.init_vector is not None:
             dt, user_fn = self.dtype, self.init_vector
 
             def tramp(vec_p, n_local, row_begin, _user):
@@ -496,7 +502,13 @@ class LambdaLanczos:
             p.init_vector = keep
         n_local = op.n_local
         vals = np.zeros(k, dtype=np.float64)
-        vecs = np.empty((k, n_local), dtype=self.dtype)
+        dev_out = self.eigenvectors_out
+        if dev_out is not None:  # Ritz vectors stay in HBM: rows of the caller's DeviceArray
+            assert dev_out.dtype == self.dtype and dev_out.nbytes >= k * n_local * self.dtype.itemsize
+            vecs, vecs_p = dev_out, C.c_void_p(dev_out.ptr)
+        else:
+            vecs = np.empty((k, n_local), dtype=self.dtype)
+            vecs_p = ptr(vecs)
         n_found = C.c_int64()
         cap = 4 * k + 64
         counts = np.zeros(cap, dtype=np.int64)
@@ -508,7 +520,7 @@ class LambdaLanczos:
         try:
             if nroot is None:
                 fn = getattr(lib(), "ll_lanczos_run_" + sfx)
-                check(fn(self.context.handle, op.handle, C.byref(p), ptr(vals), ptr(vecs), C.byref(n_found), ptr(counts),
+                check(fn(self.context.handle, op.handle, C.byref(p), ptr(vals), vecs_p, C.byref(n_found), ptr(counts),
                          cap, ptr(alpha), ptr(beta), C.byref(stats)))
             else:
                 lock = None
@@ -517,7 +529,7 @@ class LambdaLanczos:
                     lock = np.ascontiguousarray(orth, dtype=self.dtype).reshape(-1, n_local)
                     n_orth = lock.shape[0]
                 fn = getattr(lib(), "ll_lanczos_run_iteration_" + sfx)
-                check(fn(self.context.handle, op.handle, C.byref(p), nroot, n_orth, ptr(lock), ptr(vals), ptr(vecs),
+                check(fn(self.context.handle, op.handle, C.byref(p), nroot, n_orth, ptr(lock), ptr(vals), vecs_p,
                          C.byref(n_found), C.byref(itern), ptr(alpha), ptr(beta), C.byref(stats)))
                 counts[0] = itern.value
         finally:
@@ -528,7 +540,7 @@ class LambdaLanczos:
         self._iter_counts = [int(c) for c in counts[: min(stats.n_passes, cap)]]
         self.last_stats = stats.as_dict()
         self.last_alpha, self.last_beta = alpha[: stats.last_alpha_len].copy(), beta[: stats.last_alpha_len].copy()
-        return vals[:nf], vecs[:nf], int(itern.value)
+        return vals[:nf], (vecs if dev_out is not None else vecs[:nf]), int(itern.value)
 
     def run_single(self):
         """run(eigenvalue, eigenvector): one pair regardless of num_eigs (LL:394-407)."""
@@ -564,12 +576,18 @@ class Exponentiator:
         p.initial_vector_size = int(self.initial_vector_size)
         return p
 
-    def _call(self, name, a, input, want_stats):
+    def _call(self, name, a, input, want_stats, out=None):
         op, owned = _as_operator(self.mv_mul, self.matrix_size, self.dtype, self.context)
         sfx = _suffix(self.dtype)
-        inp = np.ascontiguousarray(input, dtype=self.dtype)
-        assert inp.shape[0] == op.n_local, "input size differs from the (local) matrix size (EX:88)"
-        out = np.zeros_like(inp)
+        if isinstance(input, DeviceArray):  # psi stays in HBM: device input, device output (out= or a new DeviceArray)
+            assert input.dtype == self.dtype and input.nbytes >= op.n_local * self.dtype.itemsize
+            out = out if out is not None else DeviceArray(self.context, (op.n_local,), self.dtype)
+            in_p, out_p = C.c_void_p(input.ptr), C.c_void_p(out.ptr)
+        else:
+            inp = np.ascontiguousarray(input, dtype=self.dtype)
+            assert inp.shape[0] == op.n_local, "input size differs from the (local) matrix size (EX:88)"
+            out = np.zeros_like(inp)
+            in_p, out_p = ptr(inp), ptr(out)
         it = C.c_int64()
         p = self._params()
         stats = capi.RunStats()
@@ -577,7 +595,7 @@ class Exponentiator:
             fn = getattr(lib(), name + sfx)
             args = [self.context.handle, op.handle, C.byref(p)]
             args += [float(a)] if sfx in "ds" else [float(np.real(a)), float(np.imag(a))]
-            args += [ptr(inp), ptr(out), C.byref(it)]
+            args += [in_p, out_p, C.byref(it)]
             if want_stats:
                 args.append(C.byref(stats))
             check(fn(*args))
@@ -588,10 +606,11 @@ class Exponentiator:
             self.last_stats = stats.as_dict()
         return out, it.value
 
-    def run(self, a, input):
-        """Returns (output, iteration_count) (EX:87-173)."""
-        return self._call("ll_expo_run_", a, input, True)
+    def run(self, a, input, out=None):
+        """Returns (output, iteration_count) (EX:87-173).  A DeviceArray input keeps the vector in HBM (output: `out`,
+        which may be `input` itself, or a new DeviceArray)."""
+        return self._call("ll_expo_run_", a, input, True, out)
 
-    def taylor_run(self, a, input):
+    def taylor_run(self, a, input, out=None):
         """Returns (output, number_of_terms) (EX:175-210)."""
-        return self._call("ll_expo_taylor_run_", a, input, False)
+        return self._call("ll_expo_taylor_run_", a, input, False, out)

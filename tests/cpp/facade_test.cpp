@@ -8,6 +8,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
@@ -282,6 +283,55 @@ static void exponentiator() {
   expect(misfit(exact, tout) <= ex.eps * 10, "taylor_run result");
 }
 
+static void device_resident_io() {
+  std::printf("[case] device-resident I/O: init_vector_device + run_device, Exponentiator::run_device in place\n");
+  {
+    const size_t n = 100;
+    ll::LatticeOperator<cplx> ring({(int64_t)n}, 0.0, {-1.0}, {true});
+    ll::Exponentiator<cplx> ex(ring, n);
+    std::vector<cplx> psi(n, 0.0), host_out, dev_out(n);
+    psi[0] = psi[n - 1] = cplx(1, 2);
+    psi[n / 2] = cplx(8, 2);
+    const size_t it_host = ex.run(cplx(0, 3), psi, host_out);
+    ll_context* c = ring.context().get();
+    void* d = nullptr;
+    expect(ll_malloc(c, n * sizeof(cplx), &d) == LL_OK, "ll_malloc");
+    ll_memcpy_h2d(c, d, psi.data(), n * sizeof(cplx));
+    const size_t it_dev = ex.run_device(cplx(0, 3), (const cplx*)d, (cplx*)d);  // psi <- exp(aA) psi in place
+    ll_memcpy_d2h(c, dev_out.data(), d, n * sizeof(cplx));
+    ll_free(c, d);
+    expect(it_dev == it_host, "same iteration count as the host-buffer call");
+    expect(std::memcmp(dev_out.data(), host_out.data(), n * sizeof(cplx)) == 0, "same bits as the host-buffer call");
+  }
+  {
+    const size_t n = 64;
+    ll::LatticeOperator<double> chain({(int64_t)n}, 0.0, {-1.0}, {false});
+    std::vector<double> start(n);
+    for (size_t i = 0; i < n; ++i) start[i] = std::cos(0.37 * (double)i) + 0.1;
+    ll::LambdaLanczos<double> host_engine(chain, n, false, 2), dev_engine(chain, n, false, 2);
+    host_engine.init_vector = [&start](std::vector<double>& v) { v = start; };
+    std::vector<double> hv, dv;
+    std::vector<std::vector<double>> hx;
+    host_engine.run(hv, hx);
+    ll_context* c = chain.context().get();
+    void *d_start = nullptr, *d_vecs = nullptr;
+    ll_malloc(c, n * sizeof(double), &d_start);
+    ll_malloc(c, 2 * n * sizeof(double), &d_vecs);
+    ll_memcpy_h2d(c, d_start, start.data(), n * sizeof(double));
+    dev_engine.init_vector_device = (const double*)d_start;
+    const size_t found = dev_engine.run_device(dv, (double*)d_vecs);
+    std::vector<double> dx(2 * n);
+    ll_memcpy_d2h(c, dx.data(), d_vecs, 2 * n * sizeof(double));
+    ll_free(c, d_start);
+    ll_free(c, d_vecs);
+    expect(found == hv.size() && dv == hv, "same eigenvalues as the host-buffer call");
+    expect(dev_engine.getIterationCounts() == host_engine.getIterationCounts(), "same iteration counts");
+    bool same = found == 2;
+    for (size_t r = 0; same && r < 2; ++r) same = std::memcmp(&dx[r * n], hx[r].data(), n * sizeof(double)) == 0;
+    expect(same, "same eigenvector bits as the host-buffer call");
+  }
+}
+
 int main() {
   try {
     eigen_cases();
@@ -291,6 +341,7 @@ int main() {
     device_operator();
     operator_zoo();
     exponentiator();
+    device_resident_io();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());
     return 2;

@@ -259,3 +259,63 @@ def test_host_callback_is_called_once_per_executed_iteration(ctx):
     vals, _ = eng.run()
     assert abs(vals[0] - 6.0) <= 1e-10
     assert len(calls) == sum(eng.getIterationCounts())
+
+
+# ------------------------------------------------------------------ device-resident inputs and outputs
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
+def test_device_resident_start_vector_and_eigenvectors_equal_the_host_path(ctx, dtype):
+    """init_vector = DeviceArray (ll_lanczos_params.init_vector_dev) and eigenvectors_out = DeviceArray: nothing n-sized
+    crosses PCIe, and eigenvalues, eigenvectors, iteration counts and traces equal the host-buffer call bit for bit
+    (one root = the single-survivor fast path, three roots = the restart loop with locked vectors)."""
+    n = 4000
+    csr = G.randsym_np(n)
+    if dtype == np.complex128:
+        csr = (csr[0], csr[1], csr[2].astype(np.complex128) * np.exp(0j))
+    op = L.CsrOperator(ctx, csr[0], csr[1], csr[2].astype(dtype))
+    init = G.start_vector(n, 1, dtype)
+    for k in (1, 3):
+        host = L.LambdaLanczos(op, n, True, k)
+        host.init_vector = fixed_init(init)
+        hv, hx = host.run()
+        dev = L.LambdaLanczos(op, n, True, k)
+        dev.init_vector = ctx.to_device(init)
+        dev.eigenvectors_out = ctx.empty((k, n), dtype)
+        dv, dx = dev.run()
+        assert dx is dev.eigenvectors_out
+        assert np.array_equal(dv, hv) and dev.getIterationCounts() == host.getIterationCounts()
+        assert np.array_equal(dx.get()[: len(dv)], hx)
+        assert np.array_equal(dev.last_alpha, host.last_alpha) and np.array_equal(dev.last_beta, host.last_beta)
+        assert np.array_equal(dev.init_vector.get(), init)  # the caller's start vector is left untouched
+        # run_iteration: device orthogonalizeTo is not part of the Python mirror; device output is
+        ri_h = host.run_iteration(2, hx[:1])
+        dev.eigenvectors_out = ctx.empty((2, n), dtype)
+        ri_d = dev.run_iteration(2, hx[:1])
+        assert np.array_equal(ri_d[0], ri_h[0]) and ri_d[2] == ri_h[2]
+        assert np.array_equal(ri_d[1].get()[: len(ri_h[0])], ri_h[1])
+
+
+def test_device_resident_time_evolution_loop_equals_the_host_loop(ctx):
+    """psi <- exp(-i dt H) psi, five steps, psi kept in ONE device buffer (input = output) against the same loop through
+    host arrays: identical bits, identical iteration counts; taylor_run likewise for one step."""
+    N = 24
+    csr = G.torus_np(N)
+    n = N * N
+    op = L.CsrOperator(ctx, csr[0], csr[1], csr[2])
+    psi0 = G.start_vector(n, 1, np.complex128)
+    eng = L.Exponentiator(op, n)
+    h = psi0.copy()
+    its_h = []
+    for _ in range(5):
+        h, it = eng.run(-0.4j, h)
+        its_h.append(it)
+    d = ctx.to_device(psi0)
+    its_d = []
+    for _ in range(5):
+        out, it = eng.run(-0.4j, d, out=d)
+        assert out is d
+        its_d.append(it)
+    assert its_d == its_h and np.array_equal(d.get(), h)
+    assert abs(np.linalg.norm(h) - np.linalg.norm(psi0)) <= 1e-12 * np.linalg.norm(psi0)  # unitary evolution
+    th, nt_h = eng.taylor_run(-0.4j, psi0)
+    td, nt_d = eng.taylor_run(-0.4j, ctx.to_device(psi0))
+    assert nt_d == nt_h and np.array_equal(td.get(), th)
