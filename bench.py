@@ -21,6 +21,11 @@ import os
 import sys
 import time
 
+# Host thread pools that keep spinning after their last job (OpenMP workers with an active wait policy, numpy's
+# OpenBLAS pool after np.linalg.norm) hit launch-bound timed steps with one ~80 ms stall per process
+# (tools/stall_probe.py, profiles/r02_host_thread_stalls.txt): they sleep between jobs / stay single-threaded here.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
@@ -54,6 +59,8 @@ def parse_args():
                     help="hand the start vector / input over and take the results back in HOST buffers (the reference's "
                          "std::vector boundary: PCIe copies inside the timed region); default: device buffers, i.e. inputs "
                          "resident in HBM when the timed region starts")
+    ap.add_argument("--no-phase-timers", action="store_true",
+                    help="do not record the per-phase HIP events inside the timed steps (roofline_orth is then not available)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a job that has not finished prints a diagnostic and exits with code 3 "
                          "(a hung collective must not look like a slow run); 0 = off")
@@ -274,7 +281,7 @@ def main():
 
     # ------------------------------------------------------------ timed steps
     STAGE[0] = "timed Lanczos windows"
-    ctx.set_profiling(True)
+    ctx.set_profiling(not args.no_phase_timers)
     itern = []
     stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0, "seconds_host_enqueue": 0.0,
                  "seconds_host_wait": 0.0, "seconds_setup": 0.0, "seconds_finish": 0.0, "seconds_total": 0.0,

@@ -665,7 +665,6 @@ void create_dense(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, co
   op->nnz = nr * nc;
   const T* v = (const T*)a;
   double mx = 0.0;
-#pragma omp parallel for reduction(max : mx) schedule(static)
   for (int64_t i = 0; i < nr; ++i) {
     double rs = 0.0;
     for (int64_t j = 0; j < nc; ++j) rs += std::sqrt(abs2_host(v[i * nc + j]));

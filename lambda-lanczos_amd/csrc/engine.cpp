@@ -44,6 +44,26 @@ static bool is_device_ptr(const void* p) {
   }
   return a.type == hipMemoryTypeDevice;
 }
+// LL_STALL_TRACE=ms: a whole-loop call that takes longer than that prints where its time went (host timestamps at
+// the phase boundaries) — for hunting one-off runtime stalls in launch-bound runs.
+struct StallTrace {
+  double limit_s = -1.0;
+  const char* what;
+  std::vector<std::pair<const char*, double>> pts;
+  explicit StallTrace(const char* w) : what(w) {
+    if (const char* e = std::getenv("LL_STALL_TRACE")) limit_s = std::atof(e) * 1e-3;
+    if (limit_s >= 0) pts.emplace_back("start", now_s());
+  }
+  void at(const char* label) {
+    if (limit_s >= 0) pts.emplace_back(label, now_s());
+  }
+  ~StallTrace() {
+    if (limit_s < 0 || pts.size() < 2 || pts.back().second - pts.front().second < limit_s) return;
+    std::fprintf(stderr, "[ll stall] %s took %.2f ms:", what, (pts.back().second - pts.front().second) * 1e3);
+    for (size_t i = 1; i < pts.size(); ++i) std::fprintf(stderr, " %s +%.2f", pts[i].first, (pts[i].second - pts[i - 1].second) * 1e3);
+    std::fprintf(stderr, "\n");
+  }
+};
 static double dgks_threshold() {
   const char* e = std::getenv("LL_DGKS_THRESHOLD");
   return e ? std::atof(e) : 0.5;
@@ -983,23 +1003,29 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   LL_HIP(hipSetDevice(ctx->device));
   const double t_start = now_s();
   hipStream_t s = ctx->stream;
+  StallTrace st("expo_run");
   const int64_t nl = op->n_local;
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   Engine<T> E(ctx, op, nl);
+  st.at("engine");
   const double dgks_thr = dgks_threshold();
   const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
   Basis<T> U;
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T)));
+  st.at("basis");
   ctx->ensure_pinned(16);
   EventRing ring;
   PhaseTimer timer(ctx->profiling, s);
   double t_tridiag = 0.0;
+  st.at("events");
 
   // u[0] = input / ||input||  (EX:100-101); ||input|| is kept for the output scaling (EX:165)
   LL_HIP(hipMemcpyAsync(U.vec(0), input, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
+  st.at("input-copy-enqueued");
   E.norm2_dev(U.vec(0), E.S(kScalScratch) + 1);
   double in_norm2 = 0.0;
   E.fetch(E.S(kScalScratch) + 1, &in_norm2, 1);
+  st.at("input-norm-fetched");
   const double in_norm = std::sqrt(in_norm2);
   NormRefs refs_prev = E.plain_norm(E.S(kScalScratch) + 1);
   launch_scale<T>(nl, U.vec(0), 0.0, &refs_prev, s);
@@ -1010,7 +1036,9 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   int64_t itern = P.max_iteration;
   bool stopped = false;
 
+  double t_enqueue = 0.0, t_wait = 0.0;
   auto enqueue = [&](int64_t k) {
+    const double te0 = now_s();
     const int slot = (int)(k % 4);
     T* x = U.vec(k - 1);
     T* y = U.vec(k);
@@ -1028,6 +1056,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
     timer.mark();
     refs_prev = refs;
+    t_enqueue += now_s() - te0;
   };
   // Host half of iteration j, part 1 (this thread): the four scalars, the DGKS decision, alpha_j / beta_j; part 2 (EX:124-158:
   // exp(a T_j) e_1 and the overlap test, O(j^3)) runs on the helper thread like the eigen-solver's Ritz step.
@@ -1049,7 +1078,9 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   };
   auto collect = [&](int64_t j) -> int {
     const int slot = (int)(j % 4);
+    const double tw0 = now_s();
     LL_HIP(hipEventSynchronize(ring.ev[slot]));
+    t_wait += now_s() - tw0;
     const volatile double* hp = ctx->h_pinned + 4 * slot;
     const double alpha_j = hp[0], c0_j = hp[2], c1_j = hp[3];
     double beta2_j = hp[1];
@@ -1095,7 +1126,9 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   coeff_prev = last.coeff;
   alpha.resize((size_t)itern);
   beta.resize((size_t)itern);
+  st.at("loop");
   LL_HIP(hipStreamSynchronize(s));
+  st.at("drained");
 
   // output = ||input|| * sum_l coeff_prev[l] u[l]  (EX:163-170)
   const int64_t m = (int64_t)coeff_prev.size();
@@ -1106,9 +1139,12 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   RunList<T> basis;
   basis.ld = ld;
   basis.add_basis(U, m);
+  st.at("out-alloc");
   E.gemv(basis, m, 1, c.data(), d_out.p, ld);
   LL_HIP(hipMemcpyAsync(output, d_out.p, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
+  st.at("gemv+copy-enqueued");
   LL_HIP(hipStreamSynchronize(s));
+  st.at("output-done");
   *itern_out = itern;
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
@@ -1117,6 +1153,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     stats->seconds_host_tridiag = t_tridiag;
     stats->last_alpha_len = (int64_t)alpha.size();
     stats->second_passes = second_passes;
+    stats->seconds_host_enqueue = t_enqueue;
+    stats->seconds_host_wait = t_wait;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     ctx->drain_comm_events(&stats->seconds_comm_gather, &stats->seconds_comm_allreduce);
     stats->seconds_total = now_s() - t_start;

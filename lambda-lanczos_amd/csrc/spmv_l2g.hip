@@ -18,6 +18,10 @@
 #include <vector>
 
 #include "dev_helpers.hpp"
+#include <atomic>
+#include <functional>
+#include <thread>
+
 #include "ll_internal.hpp"
 
 namespace ll {
@@ -147,12 +151,25 @@ template <typename T> bool l2g_build_host(ll_operator* op, const int64_t* rp, co
   const int64_t nsl = (nc + ((int64_t)1 << slice_log2) - 1) >> slice_log2;
   if (nrb * (nsl + 1) > (int64_t)64 << 20) return false;
   std::vector<int64_t> tptr((size_t)nrb * (nsl + 1), 0);
-#pragma omp parallel for schedule(dynamic, 4)
-  for (int64_t r = 0; r < nrb; ++r) {
+  // host threads that end with the loop (no OpenMP runtime in the product library: its idle workers spin for 200 ms
+  // after a region and disturb launch-bound runs that follow, tools/stall_probe.py)
+  auto for_row_blocks = [](int64_t count, const std::function<void(int64_t)>& body) {
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::thread::hardware_concurrency(), 32), count / 4));
+    std::atomic<int64_t> next{0};
+    auto work = [&] {
+      for (int64_t r0; (r0 = next.fetch_add(4)) < count;)
+        for (int64_t r = r0; r < std::min(count, r0 + 4); ++r) body(r);
+    };
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < nt; ++t) helpers.emplace_back(work);
+    work();
+    for (std::thread& t : helpers) t.join();
+  };
+  for_row_blocks(nrb, [&](int64_t r) {
     const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
     int64_t* t = &tptr[(size_t)r * (nsl + 1)];
     for (int64_t p = rp[i0]; p < rp[i1]; ++p) ++t[(ci[p] >> slice_log2) + 1];
-  }
+  });
   {  // global prefix: tile (r, sl) starts after all earlier tiles
     int64_t run = 0;
     for (int64_t r = 0; r < nrb; ++r) {
@@ -170,23 +187,18 @@ template <typename T> bool l2g_build_host(ll_operator* op, const int64_t* rp, co
   const size_t nnz = (size_t)op->nnz;
   std::vector<T> val(nnz);
   std::vector<uint32_t> idx(nnz);
-#pragma omp parallel
-  {
-    std::vector<int64_t> fill((size_t)nsl);
-#pragma omp for schedule(dynamic, 4)
-    for (int64_t r = 0; r < nrb; ++r) {
-      const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
-      const int64_t* t = &tptr[(size_t)r * (nsl + 1)];
-      for (int64_t sl = 0; sl < nsl; ++sl) fill[(size_t)sl] = t[sl];
-      for (int64_t i = i0; i < i1; ++i)
-        for (int64_t p = rp[i]; p < rp[i + 1]; ++p) {
-          const int64_t sl = ci[p] >> slice_log2;
-          const int64_t q = fill[(size_t)sl]++;
-          val[(size_t)q] = va[p];
-          idx[(size_t)q] = ((uint32_t)(i - i0) << (32 - kL2gRowBits)) | ((uint32_t)ci[p] & (((uint32_t)1 << slice_log2) - 1u));
-        }
-    }
-  }
+  for_row_blocks(nrb, [&](int64_t r) {
+    const int64_t i0 = r * rb_rows, i1 = std::min(nr, i0 + rb_rows);
+    const int64_t* t = &tptr[(size_t)r * (nsl + 1)];
+    std::vector<int64_t> fill(t, t + nsl);
+    for (int64_t i = i0; i < i1; ++i)
+      for (int64_t p = rp[i]; p < rp[i + 1]; ++p) {
+        const int64_t sl = ci[p] >> slice_log2;
+        const int64_t q = fill[(size_t)sl]++;
+        val[(size_t)q] = va[p];
+        idx[(size_t)q] = ((uint32_t)(i - i0) << (32 - kL2gRowBits)) | ((uint32_t)ci[p] & (((uint32_t)1 << slice_log2) - 1u));
+      }
+  });
   op->l2_nrb = (int)nrb;
   op->l2_nsl = (int)nsl;
   op->l2_rb_rows = (int)rb_rows;

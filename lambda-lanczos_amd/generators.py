@@ -8,7 +8,12 @@ import ctypes as C
 import math
 import os
 
-import numpy as np
+# the generator library's OpenMP workers must go to sleep right after a parallel region: workers that keep spinning
+# (libomp: 200 ms) disturb launch-bound GPU runs that follow immediately (tools/stall_probe.py: one ~85 ms stall per
+# process).  Read by the OpenMP runtimes when they start, so it is set before the library is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np  # noqa: E402
 
 from . import _capi as capi
 
