@@ -514,10 +514,10 @@ def main():
             "roofline_orth": {
                 "kernel": "mdot+maxpy+scale (three-term, Gram-Schmidt, norm, normalise)",
                 "bound": "hbm",
-                "achieved": orth_bytes / max(orth_s, 1e-12) / 1e9,
+                "achieved": (orth_bytes / orth_s / 1e9) if orth_s > 0 else None,  # None: --no-phase-timers
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": orth_bytes / max(orth_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "frac": (orth_bytes / orth_s / 1e9 / HBM_PEAK_GBS) if orth_s > 0 else None,
                 "traffic": orth_traffic,
                 "traffic_source": orth_traffic_src,
                 "traffic_note": "measured HBM bytes of mdot + maxpy + scale per step (one window), PMC counters; "

@@ -97,6 +97,27 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ zc wave_sum(zc v) { return zc{wave_sum(v.re), wave_sum(v.im)}; }
 
+// Wave sums of N accumulators at once (N a power of two <= 64), transposing as it reduces: at every step a lane hands
+// half of the accumulators it still holds to its partner and keeps the partner's share of the other half, so N sums
+// cost N - 1 + log2(64 / N) shuffle-adds instead of 6 N.  On return a[0] of lane L is the full sum of accumulator
+// L / (64 / N) (all 64 / N lanes of that group hold it).  Fixed order: bit-reproducible.
+template <int N> __device__ __forceinline__ void wave_sum_transposed(double (&a)[N], int lane) {
+  static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two");
+  int m = 32;
+#pragma unroll
+  for (int half = N / 2; half >= 1; half >>= 1, m >>= 1) {
+    const bool upper = (lane & m) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const double keep = upper ? a[i + half] : a[i];
+      const double send = upper ? a[i] : a[i + half];
+      a[i] = keep + __shfl_xor(send, m, 64);
+    }
+  }
+#pragma unroll
+  for (; m >= 1; m >>= 1) a[0] += __shfl_xor(a[0], m, 64);
+}
+
 // Sum over the workgroup (kBlock = 4 waves); result valid in thread 0. `scratch` holds >= 4 doubles.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);

@@ -132,12 +132,20 @@ LL_INST_SPMV(double) LL_INST_SPMV(zc) LL_INST_SPMV(float) LL_INST_SPMV(cf)
 // ================================================================= strip geometry of the BLAS-1 kernels
 // A workgroup owns strips of kBlock*EPT consecutive elements; every lane keeps EPT elements of w in registers as
 // 16-byte pieces, so one strip of one basis vector is EPT*sizeof(T)/16 dwordx4 loads per lane.
-constexpr int kJB = 4;  // basis vectors per trip of the multi-dot / multi-axpy loops
+constexpr int kJB = 4;  // basis vectors per trip of the streaming multi-dot / multi-axpy loops
 
 template <typename T> struct strip {
   static constexpr int EPT = (int)(64 / sizeof(T));  // 64 B per lane per vector: 16 float, 8 double / cf, 4 zc
   static constexpr int ELEMS = kBlock * EPT;
 };
+// The Gram-Schmidt kernels come in two geometries: STREAMING (below; vectors of >= 4 MiB: enough 16 KiB strips to fill
+// the chip, every load a full line) and SMALL-VECTOR (mdot_small / maxpy_small further down; n <~ 5e5 doubles, the
+// reference's everyday sizes).  LL_BLAS_SMALL_BYTES moves the boundary (0 = always streaming, huge = always small).
+static bool blas_small(int64_t n, size_t elem_bytes) {  // LL_BLAS_SMALL_BYTES: 0 = always streaming, huge = always small
+  const char* e = std::getenv("LL_BLAS_SMALL_BYTES");     // (read per launch: the tests flip it inside one process)
+  const int64_t limit = e ? std::atoll(e) : (int64_t)4 << 20;
+  return n * (int64_t)elem_bytes < limit;
+}
 
 // Balanced persistent grid: every workgroup walks the same number of strips (grid-stride), so no tail round.
 // (Measured alternative, round 2: equal CONTIGUOUS shares per workgroup instead of strips dealt out round-robin —
@@ -160,12 +168,13 @@ static int strip_grid(int64_t n, int elems) {
 template <typename T>
 __device__ __forceinline__ void load_strip(const T* __restrict__ v, int64_t base, int64_t n, T (&r)[strip<T>::EPT]) {
   constexpr int EPT = strip<T>::EPT;
+  constexpr int PIECES = 4;
   const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
   if (i0 + EPT <= n) {
     const uint4* p = reinterpret_cast<const uint4*>(v + i0);
-    uint4 c[4];
+    uint4 c[PIECES];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c[e] = p[e];
+    for (int e = 0; e < PIECES; ++e) c[e] = p[e];
     __builtin_memcpy(&r[0], c, sizeof(c));
   } else {
 #pragma unroll
@@ -176,17 +185,73 @@ template <typename T>
 __device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int64_t n,
                                             const T (&r)[strip<T>::EPT]) {
   constexpr int EPT = strip<T>::EPT;
+  constexpr int PIECES = 4;
   const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
   if (i0 + EPT <= n) {
-    uint4 c[4];
+    uint4 c[PIECES];
     __builtin_memcpy(c, &r[0], sizeof(c));
     uint4* p = reinterpret_cast<uint4*>(v + i0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) p[e] = c[e];
+    for (int e = 0; e < PIECES; ++e) p[e] = c[e];
   } else {
 #pragma unroll
     for (int e = 0; e < EPT; ++e)
       if (i0 + e < n) v[i0 + e] = r[e];
+  }
+}
+
+// One trip of the multi-dot: NV basis strips against the strip of w held in registers; the NV (x2 for complex) wave
+// sums are added to the wave's LDS row `mine_col[0 .. R*NV)`.
+template <typename T, int NV, bool TR>
+__device__ __forceinline__ void mdot_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
+                                          const T (&wr)[strip<T>::EPT], double* mine_col, int lane) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int R = scalar_traits<T>::reals;
+  T ur[NV][EPT];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) load_strip<T>(u0 + (int64_t)b * ld, base, n, ur[b]);
+  double a[NV * R];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) {
+    acc_t<T> acc = zero<acc_t<T>>();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) cfma_acc(acc, ur[b][e], wr[e]);
+    if constexpr (scalar_traits<T>::is_complex) {
+      a[2 * b] = acc.re;
+      a[2 * b + 1] = acc.im;
+    } else {
+      a[b] = acc;
+    }
+  }
+  if constexpr (TR) {
+    wave_sum_transposed<NV * R>(a, lane);
+    constexpr int LPI = 64 / (NV * R);  // lanes that end up holding the same sum
+    if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
+  } else {  // one full wave sum per accumulator (LL_MDOT_REDUCE=plain)
+#pragma unroll
+    for (int i = 0; i < NV * R; ++i) a[i] = wave_sum(a[i]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NV * R; ++i) mine_col[i] += a[i];
+    }
+  }
+}
+
+// One trip of the multi-axpy: w -= sum_b h_b u_b for NV basis strips, coefficients from LDS.
+template <typename T, int NV>
+__device__ __forceinline__ void maxpy_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
+                                           T (&wr)[strip<T>::EPT], const double* hcol) {
+  constexpr int EPT = strip<T>::EPT;
+  T ur[NV][EPT];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) load_strip<T>(u0 + (int64_t)b * ld, base, n, ur[b]);
+#pragma unroll
+  for (int b = 0; b < NV; ++b) {
+    acc_t<T> hj;
+    if constexpr (scalar_traits<T>::is_complex) hj = zc{hcol[2 * b], hcol[2 * b + 1]};
+    else hj = hcol[b];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) fnma_acc(wr[e], hj, ur[b][e]);
   }
 }
 
@@ -196,11 +261,13 @@ __device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int
 // three-term update w = w - beta u_prev - alpha u_cur is applied on the fly (saves 3R 1W of a separate sweep).
 // Per-wave partial sums live in LDS ([4][ncols]) across all strips of the workgroup; each workgroup finally writes
 // one row of ncols partials which reduce_cols folds in a fixed order (deterministic, no atomics).
-template <typename T>
+template <typename T, bool TR>
 __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
                                                       ThreeTerm<T> tt, NormRefs pred, int predicated,
                                                       double* __restrict__ partials, int ncols) {
   constexpr int EPT = strip<T>::EPT;
+  constexpr int ELEMS = strip<T>::ELEMS;
+  constexpr int JB = kJB;
   constexpr int R = scalar_traits<T>::reals;
   extern __shared__ double lds[];  // [4 waves][ncols]
   if (predicated && !second_pass_due(pred)) return;  // predicated second DGKS pass
@@ -216,9 +283,9 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
     if (tt.u_prev) beta = sqrt(final_norm2(tt.prev));
   }
 
-  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
-    const int64_t base = sidx * strip<T>::ELEMS;
+    const int64_t base = sidx * ELEMS;
     T wr[EPT];
     load_strip<T>(w, base, n, wr);
     if (do_tt) {
@@ -239,52 +306,12 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
     for (int sg = 0; sg < segs.nseg; ++sg) {
       const T* ub = segs.base[sg];
       const int cnt = segs.count[sg];
-      // JB basis vectors per trip: all JB strips are requested before the first one is consumed (JB x EPT x 8 B per lane
-      // in flight), and the JB wavefront reductions interleave
+      // JB basis vectors per trip: all JB strips are requested before the first one is consumed, and their JB (x2 for
+      // complex) wave sums are formed together
       int j = 0;
-      for (; j + kJB <= cnt; j += kJB) {
-        T ur[kJB][EPT];
-#pragma unroll
-        for (int b = 0; b < kJB; ++b) load_strip<T>(ub + (int64_t)(j + b) * segs.ld, base, n, ur[b]);
-        acc_t<T> acc[kJB];
-#pragma unroll
-        for (int b = 0; b < kJB; ++b) {
-          acc[b] = zero<acc_t<T>>();
-#pragma unroll
-          for (int e = 0; e < EPT; ++e) cfma_acc(acc[b], ur[b][e], wr[e]);
-        }
-#pragma unroll
-        for (int b = 0; b < kJB; ++b) acc[b] = wave_sum(acc[b]);
-        if (lane == 0) {
-#pragma unroll
-          for (int b = 0; b < kJB; ++b) {
-            if constexpr (scalar_traits<T>::is_complex) {
-              mine[col + 2 * b] += acc[b].re;
-              mine[col + 2 * b + 1] += acc[b].im;
-            } else {
-              mine[col + b] += acc[b];
-            }
-          }
-        }
-        col += R * kJB;
-      }
-      for (; j < cnt; ++j) {
-        T ur[EPT];
-        load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
-        acc_t<T> acc = zero<acc_t<T>>();
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) cfma_acc(acc, ur[e], wr[e]);
-        acc = wave_sum(acc);
-        if (lane == 0) {
-          if constexpr (scalar_traits<T>::is_complex) {
-            mine[col] += acc.re;
-            mine[col + 1] += acc.im;
-          } else {
-            mine[col] += acc;
-          }
-        }
-        col += R;
-      }
+      for (; j + JB <= cnt; j += JB, col += R * JB) mdot_trip<T, JB, TR>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane);
+      if (j + 2 <= cnt) { mdot_trip<T, 2, TR>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane); j += 2; col += R * 2; }
+      if (j < cnt) { mdot_trip<T, 1, TR>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane); j += 1; col += R; }
     }
     double nn = 0.0;
 #pragma unroll
@@ -298,17 +325,265 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
     out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
 }
 
+// ================================================================= small-vector Gram-Schmidt kernels (vectors < 4 MiB)
+// With few strips the streaming kernels above are a latency / instruction chain: ONE wave walks all k basis vectors of
+// its strip (n = 1e4, k = 100: 28 us for 8 MB that the chip reads in under 7 us, tools/small_strip_probe.hip).  Here a
+// workgroup is four waves on the SAME strip of 64 lanes x 16 B (n = 1e4 doubles: 79 workgroups instead of 5); the trips
+// of kSmallJB basis vectors are dealt round-robin to the waves, so each wave walks a quarter of the basis:
+//   multi-dot : every basis vector belongs to exactly one wave -> no cross-wave sums; the kSmallJB (x2) per-lane
+//               partial products of a trip are transposed through a per-wave LDS tile and each column is summed by
+//               four lanes (16 reads + 2 quad shuffles instead of 6 dependent shuffle steps per vector);
+//   multi-axpy: every wave accumulates its share of sum_j h_j u_j, wave 0 adds the four shares in a fixed order,
+//               updates w and accumulates ||w||^2.
+// All sums have a fixed order: bit-reproducible like the streaming kernels (the two geometries differ from each other
+// in the last bits, each is deterministic).
+constexpr int kSmallJB = 8;
+constexpr int kSmallTileRow = 65;  // doubles per row of the transpose tile (64 lanes + 1: conflict-free columns)
+
+template <typename T> struct small_geom {
+  static constexpr int EPT = (int)(16 / sizeof(T));  // 16 B per lane: 2 double / cf, 1 zc, 4 float
+  static constexpr int ELEMS = 64 * EPT;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_small(const T* __restrict__ v, int64_t i0, int64_t n, T (&r)[small_geom<T>::EPT]) {
+  constexpr int EPT = small_geom<T>::EPT;
+  if (i0 + EPT <= n) {
+    const uint4 c = *reinterpret_cast<const uint4*>(v + i0);
+    __builtin_memcpy(&r[0], &c, sizeof(c));
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) r[e] = (i0 + e < n) ? v[i0 + e] : zero<T>();
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_small(T* __restrict__ v, int64_t i0, int64_t n, const T (&r)[small_geom<T>::EPT]) {
+  constexpr int EPT = small_geom<T>::EPT;
+  if (i0 + EPT <= n) {
+    uint4 c;
+    __builtin_memcpy(&c, &r[0], sizeof(c));
+    *reinterpret_cast<uint4*>(v + i0) = c;
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (i0 + e < n) v[i0 + e] = r[e];
+  }
+}
+// LDS traffic between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order; these keep the
+// compiler from moving accesses across the hand-over point.
+__device__ __forceinline__ void wave_lds_handover() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mdot_small_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs, ThreeTerm<T> tt,
+                                                            NormRefs pred, int predicated, double* __restrict__ partials,
+                                                            int ncols) {
+  constexpr int EPT = small_geom<T>::EPT;
+  constexpr int ELEMS = small_geom<T>::ELEMS;
+  constexpr int R = scalar_traits<T>::reals;
+  constexpr int NA = kSmallJB * R;  // accumulators per trip: 8 or 16
+  extern __shared__ double lds[];   // [ncols] column sums of the workgroup, then one [16][65] transpose tile per wave
+  if (predicated && !second_pass_due(pred)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* cols = lds;
+  double* tile = lds + ((ncols + 15) & ~15) + wave * (16 * kSmallTileRow);
+  for (int i = tid; i < ncols; i += kBlock) cols[i] = 0.0;
+  __syncthreads();
+
+  double alpha = 0.0, beta = 0.0;
+  const bool do_tt = tt.u_cur != nullptr;
+  if (do_tt) {
+    alpha = *tt.alpha;
+    if (tt.u_prev) beta = sqrt(final_norm2(tt.prev));
+  }
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {  // same trip count for every wave of the workgroup
+    const int64_t i0 = sidx * ELEMS + (int64_t)lane * EPT;
+    T wr[EPT];
+    load_small<T>(w, i0, n, wr);
+    if (do_tt) {  // every wave forms the same three-term strip; wave 0 stores it once all four have read w
+      T uc[EPT];
+      load_small<T>(tt.u_cur, i0, n, uc);
+      if (tt.u_prev) {
+        T up[EPT];
+        load_small<T>(tt.u_prev, i0, n, up);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) wr[e] = sub(sub(wr[e], rmul(beta, up[e])), rmul(alpha, uc[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) wr[e] = sub(wr[e], rmul(alpha, uc[e]));
+      }
+      __syncthreads();
+      if (wave == 0) store_small<T>(w, i0, n, wr);
+    }
+    int trip = 0, col0 = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+      for (int j = 0; j < cnt; j += kSmallJB, ++trip) {
+        if ((trip & 3) != wave) continue;
+        const int nv = min(kSmallJB, cnt - j);
+        T ur[kSmallJB][EPT];
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b)
+          if (b < nv) load_small<T>(ub + (int64_t)(j + b) * segs.ld, i0, n, ur[b]);
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b) {
+          acc_t<T> acc = zero<acc_t<T>>();
+          if (b < nv) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) cfma_acc(acc, ur[b][e], wr[e]);
+          }
+          if constexpr (scalar_traits<T>::is_complex) {
+            tile[(2 * b) * kSmallTileRow + lane] = acc.re;
+            tile[(2 * b + 1) * kSmallTileRow + lane] = acc.im;
+          } else {
+            tile[b * kSmallTileRow + lane] = acc;
+          }
+        }
+        wave_lds_handover();
+        // column i of the tile (16 slots, NA of them used) is summed by the four lanes 4i .. 4i+3, 16 entries each
+        const int i = lane >> 2, q = lane & 3;
+        double sum = 0.0;
+        if (i < nv * R) {
+          const double* row = tile + i * kSmallTileRow + q * 16;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) sum += row[t];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if (q == 0 && i < nv * R) cols[col0 + R * j + i] += sum;  // this column belongs to this wave alone
+        wave_lds_handover();
+        (void)NA;
+      }
+      col0 += R * cnt;
+    }
+    if (wave == 0) {
+      double nn = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) nn += abs2(wr[e]);
+      nn = wave_sum(nn);
+      if (lane == 0) cols[ncols - 1] += nn;
+    }
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < ncols; i += kBlock) out[i] = cols[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void maxpy_small_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
+                                                             const double* __restrict__ h, int nb, NormRefs pred,
+                                                             int predicated, double* __restrict__ partials) {
+  constexpr int EPT = small_geom<T>::EPT;
+  constexpr int ELEMS = small_geom<T>::ELEMS;
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];  // [R*nb] coefficients, then the four waves' shares [4][64][EPT*R]
+  if (predicated && !second_pass_due(pred)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < R * nb; i += kBlock) lds[i] = h[i];
+  double* share = lds + ((R * nb + 15) & ~15);
+  __syncthreads();
+  double nn = 0.0;
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t i0 = sidx * ELEMS + (int64_t)lane * EPT;
+    acc_t<T> delta[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) delta[e] = zero<acc_t<T>>();
+    int trip = 0, col0 = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+      for (int j = 0; j < cnt; j += kSmallJB, ++trip) {
+        if ((trip & 3) != wave) continue;
+        const int nv = min(kSmallJB, cnt - j);
+        T ur[kSmallJB][EPT];
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b)
+          if (b < nv) load_small<T>(ub + (int64_t)(j + b) * segs.ld, i0, n, ur[b]);
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b)
+          if (b < nv) {
+            const double* hc = lds + col0 + R * (j + b);
+            acc_t<T> hj;
+            if constexpr (scalar_traits<T>::is_complex) hj = zc{hc[0], hc[1]};
+            else hj = hc[0];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) fma_acc(delta[e], hj, to_acc(ur[b][e]));
+          }
+      }
+      col0 += R * cnt;
+    }
+    double* mine = share + ((size_t)wave * 64 + lane) * (EPT * R);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      if constexpr (scalar_traits<T>::is_complex) {
+        mine[2 * e] = delta[e].re;
+        mine[2 * e + 1] = delta[e].im;
+      } else {
+        mine[e] = delta[e];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      T wr[EPT];
+      load_small<T>(w, i0, n, wr);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        acc_t<T> tot;
+        const double* s0 = share + ((size_t)0 * 64 + lane) * (EPT * R);
+        const double* s1 = share + ((size_t)1 * 64 + lane) * (EPT * R);
+        const double* s2 = share + ((size_t)2 * 64 + lane) * (EPT * R);
+        const double* s3 = share + ((size_t)3 * 64 + lane) * (EPT * R);
+        if constexpr (scalar_traits<T>::is_complex)
+          tot = zc{(s0[2 * e] + s1[2 * e]) + (s2[2 * e] + s3[2 * e]), (s0[2 * e + 1] + s1[2 * e + 1]) + (s2[2 * e + 1] + s3[2 * e + 1])};
+        else
+          tot = (s0[e] + s1[e]) + (s2[e] + s3[e]);
+        wr[e] = narrow<T>(sub(to_acc(wr[e]), tot));
+      }
+      store_small<T>(w, i0, n, wr);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) nn += abs2(wr[e]);
+    }
+    __syncthreads();  // the shares are rewritten by the next strip
+  }
+  if (wave == 0) {
+    const double tot = wave_sum(nn);
+    if (lane == 0) partials[blockIdx.x] = tot;
+  }
+}
+
+
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
                 double* partials, hipStream_t s) {
   int nb = 0;
   for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
   const int ncols = scalar_traits<T>::reals * nb + 1;
+  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
+  if (blas_small(n, sizeof(T))) {
+    const int grid = strip_grid(n, small_geom<T>::ELEMS);
+    const size_t lds_bytes = ((size_t)((ncols + 15) & ~15) + 4 * 16 * kSmallTileRow) * sizeof(double);
+    hipLaunchKernelGGL((mdot_small_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr, pred ? 1 : 0,
+                       partials, ncols);
+    LL_HIP(hipGetLastError());
+    return grid;
+  }
   const int grid = strip_grid(n, strip<T>::ELEMS);
   const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
-  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
-  hipLaunchKernelGGL((mdot_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr, pred ? 1 : 0,
-                     partials, ncols);
+  // wave sums of the streaming geometry: the 4 (8) sums of a trip are formed with the transposing reduction (+0.5-1.3 %
+  // at n >= 1e6 against one full wave sum per vector); LL_MDOT_REDUCE=plain restores the latter (A/B)
+  const char* rmode = std::getenv("LL_MDOT_REDUCE");
+  if (rmode && rmode[0] == 'p')
+    hipLaunchKernelGGL((mdot_kernel<T, false>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr,
+                       pred ? 1 : 0, partials, ncols);
+  else
+    hipLaunchKernelGGL((mdot_kernel<T, true>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr,
+                       pred ? 1 : 0, partials, ncols);
   LL_HIP(hipGetLastError());
   return grid;
 }
@@ -325,6 +600,8 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
                                                        const double* __restrict__ h, int nb, NormRefs pred,
                                                        int predicated, int reverse, double* __restrict__ partials) {
   constexpr int EPT = strip<T>::EPT;
+  constexpr int ELEMS = strip<T>::ELEMS;
+  constexpr int JB = kJB;
   constexpr int R = scalar_traits<T>::reals;
   extern __shared__ double lds[];  // [R*nb] coefficients, then 4 doubles of reduction scratch
   if (predicated && !second_pass_due(pred)) return;
@@ -333,12 +610,12 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
   __syncthreads();
   double* red = lds + R * nb;
   double nn = 0.0;
-  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
   // Strips are walked in DESCENDING order: the multi-dot that ran just before walked them ascending, so the basis
   // strips it touched last are the ones most likely still in the Infinity Cache.
   for (int64_t sidx0 = blockIdx.x; sidx0 < nstrips; sidx0 += gridDim.x) {
     const int64_t sidx = reverse ? nstrips - 1 - sidx0 : sidx0;
-    const int64_t base = sidx * strip<T>::ELEMS;
+    const int64_t base = sidx * ELEMS;
     T wr[EPT];
     load_strip<T>(w, base, n, wr);
     int col = 0;
@@ -346,30 +623,9 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
       const T* ub = segs.base[sg];
       const int cnt = segs.count[sg];
       int j = 0;
-      for (; j + kJB <= cnt; j += kJB) {
-        T ur[kJB][EPT];
-#pragma unroll
-        for (int b = 0; b < kJB; ++b) load_strip<T>(ub + (int64_t)(j + b) * segs.ld, base, n, ur[b]);
-#pragma unroll
-        for (int b = 0; b < kJB; ++b) {
-          acc_t<T> hj;
-          if constexpr (scalar_traits<T>::is_complex) hj = zc{lds[col + 2 * b], lds[col + 2 * b + 1]};
-          else hj = lds[col + b];
-#pragma unroll
-          for (int e = 0; e < EPT; ++e) fnma_acc(wr[e], hj, ur[b][e]);
-        }
-        col += R * kJB;
-      }
-      for (; j < cnt; ++j) {
-        T ur[EPT];
-        load_strip<T>(ub + (int64_t)j * segs.ld, base, n, ur);
-        acc_t<T> hj;
-        if constexpr (scalar_traits<T>::is_complex) hj = zc{lds[col], lds[col + 1]};
-        else hj = lds[col];
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) fnma_acc(wr[e], hj, ur[e]);
-        col += R;
-      }
+      for (; j + JB <= cnt; j += JB, col += R * JB) maxpy_trip<T, JB>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, lds + col);
+      if (j + 2 <= cnt) { maxpy_trip<T, 2>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, lds + col); j += 2; col += R * 2; }
+      if (j < cnt) { maxpy_trip<T, 1>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, lds + col); j += 1; col += R; }
     }
     store_strip<T>(w, base, n, wr);
 #pragma unroll
@@ -384,15 +640,24 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
                  hipStream_t s) {
   int nb = 0;
   for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
+  if (blas_small(n, sizeof(T))) {
+    constexpr int R = scalar_traits<T>::reals;
+    const int grid = strip_grid(n, small_geom<T>::ELEMS);
+    const size_t lds_bytes = ((size_t)((R * nb + 15) & ~15) + (size_t)kBlock * small_geom<T>::EPT * R) * sizeof(double);
+    hipLaunchKernelGGL((maxpy_small_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr, pred ? 1 : 0,
+                       partials);
+    LL_HIP(hipGetLastError());
+    return grid;
+  }
   const int grid = strip_grid(n, strip<T>::ELEMS);
   const size_t lds_bytes = ((size_t)scalar_traits<T>::reals * nb + 4) * sizeof(double);
-  const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
   static const int reverse = [] {
     const char* e = std::getenv("LL_MAXPY_REVERSE");
     return e ? std::atoi(e) : 1;
   }();
-  hipLaunchKernelGGL((maxpy_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr, pred ? 1 : 0,
-                     reverse, partials);
+  hipLaunchKernelGGL((maxpy_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr,
+                     pred ? 1 : 0, reverse, partials);
   LL_HIP(hipGetLastError());
   return grid;
 }

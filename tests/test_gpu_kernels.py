@@ -267,11 +267,15 @@ def _orthonormal_basis(n, nb, dtype, seed):
     return np.ascontiguousarray(q.T)
 
 
+# geometry: the Gram-Schmidt kernels have a streaming geometry (64 B per lane, 4 vectors per trip; vectors >= 4 MiB) and a
+# small-vector one (16 B per lane, 16 vectors per trip); LL_BLAS_SMALL_BYTES forces either on every size
+@pytest.mark.parametrize("geometry", ["0", str(1 << 40)], ids=["streaming", "small"])
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
 @pytest.mark.parametrize("mode", [L.ORTH_CGS_DGKS, L.ORTH_CGS2, L.ORTH_MGS])
 @pytest.mark.parametrize("n,nb", [(10, 5), (4099, 1), (100003, 37), (30011, 700), (4099, 1700)])  # 1700 > one launch
-def test_orth_block_matches_mgs_oracle(ctx, oracle, dtype, mode, n, nb):
+def test_orth_block_matches_mgs_oracle(ctx, oracle, dtype, mode, n, nb, geometry, monkeypatch):
     """a5/a6/a7: block Gram-Schmidt vs the reference's sequential MGS (LA:132-144, test T1:61-91)."""
+    monkeypatch.setenv("LL_BLAS_SMALL_BYTES", geometry)
     basis = _orthonormal_basis(n, nb, dtype, 5)
     w = rnd(n, dtype, 31) + 3.0 * basis[0] - 2.0 * basis[nb - 1]
     ld = ((n + 255) // 256) * 256
