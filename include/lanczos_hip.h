@@ -44,7 +44,7 @@ extern "C" {
 #endif
 
 #define LL_VERSION_MAJOR 0
-#define LL_VERSION_MINOR 1
+#define LL_VERSION_MINOR 2  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers */
 
 enum {
   LL_OK = 0,

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # and the ctypes table binds exactly that set
     assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
-    assert lib.ll_version() == 1
+    assert lib.ll_version() == 2
 
 
 def test_header_cites_the_reference_interface():
