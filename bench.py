@@ -60,7 +60,9 @@ def parse_args():
                          "std::vector boundary: PCIe copies inside the timed region); default: device buffers, i.e. inputs "
                          "resident in HBM when the timed region starts")
     ap.add_argument("--no-phase-timers", action="store_true",
-                    help="do not record the per-phase HIP events inside the timed steps (roofline_orth is then not available)")
+                    help="skip the instrumented steps after the timed region (no per-phase split, no roofline_orth)")
+    ap.add_argument("--phase-timers-inline", action="store_true",
+                    help="record the per-phase HIP events inside the timed steps instead of in separate steps after them")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a job that has not finished prints a diagnostic and exits with code 3 "
                          "(a hung collective must not look like a slow run); 0 = off")
@@ -281,7 +283,6 @@ def main():
 
     # ------------------------------------------------------------ timed steps
     STAGE[0] = "timed Lanczos windows"
-    ctx.set_profiling(not args.no_phase_timers)
     itern = []
     stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0, "seconds_host_enqueue": 0.0,
                  "seconds_host_wait": 0.0, "seconds_setup": 0.0, "seconds_finish": 0.0, "seconds_total": 0.0,
@@ -320,25 +321,41 @@ def main():
             eng.run()
             return eng.getIterationCounts()[0]
 
+    # The timed steps run WITHOUT the library's per-phase HIP events (three event records per iteration cost 5 % at
+    # n = 1e6 and 20 % on the launch-bound config 5); the per-phase split comes from the same number of steps (at most
+    # three) repeated WITH them right after the timed region.  --phase-timers-inline restores the old single pass.
+    inline = args.phase_timers_inline and not args.no_phase_timers
+    ctx.set_profiling(inline)
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         itern.append(step())
-        for key in stats_acc:
-            stats_acc[key] += eng.last_stats[key]
+        if inline:
+            for key in stats_acc:
+                stats_acc[key] += eng.last_stats[key]
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     total_iters = int(sum(itern))
     value = total_iters / elapsed
+    itern_phases = list(itern)
+    if not inline and not args.no_phase_timers:
+        STAGE[0] = "instrumented steps (per-phase timers)"
+        ctx.set_profiling(True)
+        itern_phases = []
+        for _ in range(min(args.steps, 3)):
+            itern_phases.append(step())
+            for key in stats_acc:
+                stats_acc[key] += eng.last_stats[key]
+        barrier()
 
-    # Gram-Schmidt kernels of the timed windows: algorithmic bytes (minimal-pass model minus the SpMV) / device time
+    # Gram-Schmidt kernels of the instrumented windows: algorithmic bytes (minimal-pass model minus the SpMV) / device time
     s = 16 if complex_ else 8
     if wl == "c5":
-        orth_bytes = sum(s * n * 9 for it in itern for _k in range(1, it + 1))
+        orth_bytes = sum(s * n * 9 for it in itern_phases for _k in range(1, it + 1))
     else:
-        orth_bytes = sum(s * n * (2 * k + 9) for it in itern for k in range(1, it + 1))
+        orth_bytes = sum(s * n * (2 * k + 9) for it in itern_phases for k in range(1, it + 1))
     orth_s = max_over_ranks(stats_acc["seconds_orth"])
     spmv_loop_s = max_over_ranks(stats_acc["seconds_spmv"])
     comm_gather_s = max_over_ranks(stats_acc["seconds_comm_gather"])
@@ -522,10 +539,13 @@ def main():
                 "traffic_source": orth_traffic_src,
                 "traffic_note": "measured HBM bytes of mdot + maxpy + scale per step (one window), PMC counters; "
                                 "achieved = algorithmic bytes of the timed steps / their device time",
-                "algorithmic_bytes_per_step": orth_bytes / max(args.steps, 1),
+                "algorithmic_bytes_per_step": orth_bytes / max(len(itern_phases), 1),
                 "model": "s*n*(2k+9) bytes per iteration (SURVEY 8d minimal-pass model)",
             },
             "phases": {
+                "steps": len(itern_phases) if not args.no_phase_timers else 0,
+                "source": ("the timed steps themselves" if inline else
+                           "the same step repeated with per-phase HIP events after the timed region"),
                 "device_s_operator": spmv_loop_s,
                 "device_s_orth": orth_s,
                 "host_s_tridiag": stats_acc["seconds_host_tridiag"],

@@ -34,7 +34,7 @@ if has pmc; then
     for ctr in FETCH_SIZE WRITE_SIZE; do
       tag=$( [ $ctr = FETCH_SIZE ] && echo pmc_fetch || echo pmc_write )
       d=$OUT/raw_${tag}_$name; rm -rf "$d"
-      timeout 900 rocprofv3 --pmc $ctr --output-format csv -d "$d" -o "$tag" -- python3 bench.py $opts --steps 2 --warmup 1 --cpu-window 0 > "$OUT/${name}_${tag}.json" 2> "$OUT/${name}_${tag}.err"
+      timeout 900 rocprofv3 --pmc $ctr --output-format csv -d "$d" -o "$tag" -- python3 bench.py $opts --steps 2 --warmup 1 --cpu-window 0 --no-phase-timers > "$OUT/${name}_${tag}.json" 2> "$OUT/${name}_${tag}.err"
       echo "pmc $name $ctr rc=$?"
       f=$(find "$d" -name "*counter_collection.csv" | head -1)
       [ -n "$f" ] && cp "$f" "$OUT/r02_${name}_${tag}_counter_collection.csv"
