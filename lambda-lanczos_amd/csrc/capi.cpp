@@ -41,6 +41,13 @@ void ll_context::ensure_partials(size_t doubles) {
   partials_cap = grow(partials_cap, doubles);
   dev_malloc((void**)&d_partials, partials_cap * sizeof(double), "partial sums");
 }
+void ll_context::ensure_alpha_partials(size_t doubles) {
+  if (doubles <= alpha_partials_cap) return;
+  if (d_alpha_partials) LL_HIP(hipFree(d_alpha_partials));
+  d_alpha_partials = nullptr;
+  alpha_partials_cap = grow(alpha_partials_cap, doubles);
+  dev_malloc((void**)&d_alpha_partials, alpha_partials_cap * sizeof(double), "alpha partial sums");
+}
 void ll_context::ensure_h(size_t doubles) {
   if (doubles <= h_cap) return;
   if (d_h) LL_HIP(hipFree(d_h));
@@ -198,6 +205,7 @@ int ll_ctx_destroy(ll_context* ctx) {
       if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_alpha_partials) (void)hipFree(ctx->d_alpha_partials);
     if (ctx->d_h) (void)hipFree(ctx->d_h);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

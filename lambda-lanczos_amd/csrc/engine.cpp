@@ -177,10 +177,11 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
 }
 
 template <typename T>
-void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded) {
+void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer) {
   TraceRange trace("ll::apply (mv_mul + offset + alpha)");
   hipStream_t s = ctx->stream;
-  ctx->ensure_partials(std::max<size_t>(kMaxGrid, (size_t)std::max(op->pb_nrb, op->l2_nrb)));
+  ctx->ensure_alpha_partials(std::max<size_t>(kMaxGrid, (size_t)std::max(op->pb_nrb, op->l2_nrb)));
+  double* const dotp = d_alpha ? ctx->d_alpha_partials : nullptr;
   int nparts = 0;
   if (op->kind == ll_operator::STENCIL) {
     // exchange step of the lattice operator: one hyperplane from each ring neighbour instead of the all-gather
@@ -203,7 +204,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       lo = rlo;
       hi = rhi;
     }
-    nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, dotp, s);
   } else if (op->kind == ll_operator::CSR || op->kind == ll_operator::DENSE) {
     const bool pb = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB;
     const T* x_full = x_local;
@@ -255,19 +256,19 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
           LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[c], 0));
           launch_pb_phase1<T>(*op, op->pb_chunk_first[c], op->pb_chunk_count[c], gathered, s);
         }
-        nparts = launch_pb_phase2<T>(*op, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+        nparts = launch_pb_phase2<T>(*op, x_local, y, offset, dotp, s);
         remote_done = true;
       }
     }
     if (remote_done) {
     } else if (op->kind == ll_operator::DENSE)
-      nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+      nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s);
     else if (pb)
-      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s);
     else if (op->spmv_kind == LL_SPMV_L2G_EXPERIMENT)
-      nparts = launch_spmv_l2g<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+      nparts = launch_spmv_l2g<T>(*op, x_full, x_local, y, offset, dotp, s);
     else
-      nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+      nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s);
   } else {
     LL_REQUIRE(!(ctx->comm != nullptr), "callback operators are not supported on sharded contexts");
     const size_t bytes = (size_t)n_local * sizeof(T);
@@ -297,11 +298,16 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         throw Failure{LL_ERR_CALLBACK};
       }
     }
-    nparts = launch_offset_dot<T>(n_local, x_local, y, offset, d_alpha ? ctx->d_partials : nullptr, s);
+    nparts = launch_offset_dot<T>(n_local, x_local, y, offset, dotp, s);
   }
   if (d_alpha) {
-    launch_reduce_cols(ctx->d_partials, nparts, 1, d_alpha, nullptr, s);
-    all_reduce(d_alpha, 1);
+    if (defer && ctx->comm == nullptr) {  // the caller's multi-dot folds them
+      defer->partials = dotp;
+      defer->nparts = nparts;
+    } else {
+      launch_reduce_cols(dotp, nparts, 1, d_alpha, nullptr, s);
+      all_reduce(d_alpha, 1);
+    }
   }
 }
 
@@ -346,7 +352,9 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     none.ld = runs.ld;
     ctx->ensure_partials(kMaxGrid);
     const int grid = launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, s);
-    if (publish && !sharded) {
+    if (publish && !sharded && publish->can_defer) {
+      *publish = Publish{publish->host, publish->alpha, true, true, true, ctx->d_partials, grid, c + 1, nullptr};
+    } else if (publish && !sharded) {
       launch_reduce_publish(ctx->d_partials, grid, c + 1, publish->alpha, nullptr, publish->host, s);
       publish->done = true;
     } else {
@@ -425,6 +433,8 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   }();
   if (sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && derive_norm) {
     launch_derive_norm(c, h1, R * nb, c + 1, s);
+  } else if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && publish->can_defer) {
+    *publish = Publish{publish->host, publish->alpha, true, true, true, ctx->d_partials, grid, c + 1, c};
   } else if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS) {
     launch_reduce_publish(ctx->d_partials, grid, c + 1, publish->alpha, c, publish->host, s);
     publish->done = true;
@@ -613,6 +623,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   const int mode = P.orth_mode;
   const double dgks_thr = dgks_threshold();
   const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
+  // Two launches per iteration less on single-GPU runs: alpha is folded by the multi-dot that needs it, and the fold of
+  // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
+  const bool fuse_launches = fuse_publish && !(std::getenv("LL_FUSE_LAUNCHES") && std::atoi(std::getenv("LL_FUSE_LAUNCHES")) == 0);
   Engine<T> E(ctx, op, nl);
   constexpr int R = scalar_traits<T>::reals;
 
@@ -702,18 +715,30 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       T* x = U.vec(k - 1);
       T* y = U.vec(k);
       timer.mark();
-      E.apply(x, y, P.eigenvalue_offset, E.S(kScalAlpha + slot), true);  // P0-P3
+      typename Engine<T>::DeferredAlpha da;
+      E.apply(x, y, P.eigenvalue_offset, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr);  // P0-P3
       timer.mark();
-      const ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // P4
+      ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // P4
+      if (da.nparts > 0) {  // the multi-dot folds alpha itself
+        tt.alpha_partials = da.partials;
+        tt.alpha_nparts = da.nparts;
+        tt.alpha_out = E.S(kScalAlpha + slot);
+      }
       RunList<T> runs;
       runs.ld = ld;
       runs.add(d_locked.p, L);  // P5
       runs.add_basis(U, k);     // P6
       typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
+      pub.can_defer = fuse_launches;
       const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, fuse_publish ? &pub : nullptr);  // ... P7
-      if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
-      LL_HIP(hipEventRecord(ring.ev[slot], s));
-      launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
+      if (pub.deferred) {  // norm fold + publish + normalisation in one launch (P8)
+        launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, s);
+        LL_HIP(hipEventRecord(ring.ev[slot], s));
+      } else {
+        if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
+        LL_HIP(hipEventRecord(ring.ev[slot], s));
+        launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
+      }
       timer.mark();
       refs_prev = refs;
       t_enqueue += now_s() - te0;
@@ -1010,6 +1035,9 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   st.at("engine");
   const double dgks_thr = dgks_threshold();
   const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
+  // Two launches per iteration less on single-GPU runs: alpha is folded by the multi-dot that needs it, and the fold of
+  // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
+  const bool fuse_launches = fuse_publish && !(std::getenv("LL_FUSE_LAUNCHES") && std::atoi(std::getenv("LL_FUSE_LAUNCHES")) == 0);
   Basis<T> U;
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T)));
   st.at("basis");
@@ -1043,17 +1071,29 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     T* x = U.vec(k - 1);
     T* y = U.vec(k);
     timer.mark();
-    E.apply(x, y, 0.0, E.S(kScalAlpha + slot), true);  // EX:107-110
+    typename Engine<T>::DeferredAlpha da;
+    E.apply(x, y, 0.0, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr);  // EX:107-110
     timer.mark();
-    const ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // EX:112-118
+    ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // EX:112-118
+    if (da.nparts > 0) {  // the multi-dot folds alpha itself (see lanczos_run)
+      tt.alpha_partials = da.partials;
+      tt.alpha_nparts = da.nparts;
+      tt.alpha_out = E.S(kScalAlpha + slot);
+    }
     RunList<T> runs;
     runs.ld = ld;
     if (P.full_orthogonalize) runs.add_basis(U, k);  // EX:120-122
     typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
+    pub.can_defer = fuse_launches;
     const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, fuse_publish ? &pub : nullptr);  // EX:145
-    if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
-    LL_HIP(hipEventRecord(ring.ev[slot], s));
-    launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
+    if (pub.deferred) {  // norm fold + publish + normalisation (EX:160) in one launch
+      launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, s);
+      LL_HIP(hipEventRecord(ring.ev[slot], s));
+    } else {
+      if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
+      LL_HIP(hipEventRecord(ring.ev[slot], s));
+      launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
+    }
     timer.mark();
     refs_prev = refs;
     t_enqueue += now_s() - te0;

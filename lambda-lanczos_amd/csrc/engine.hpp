@@ -66,7 +66,14 @@ template <typename T> struct Engine {
 
   // y = A x + offset x ; Re<x,y> -> *d_alpha (device scalar, all-reduced over ranks); d_alpha nullable.
   // x_padded: x_local is readable up to the padded shard length n_shard (true for basis vectors).
-  void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false);
+  // defer (nullable): the caller's multi-dot will fold alpha itself (ThreeTerm::alpha_partials); apply then only leaves
+  // the partials behind and reports them here.  Honoured on unsharded contexts only (a communicator needs the folded
+  // scalar for its all-reduce): check defer->nparts > 0 afterwards.
+  struct DeferredAlpha {
+    const double* partials = nullptr;
+    int nparts = 0;
+  };
+  void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false, DeferredAlpha* defer = nullptr);
   // Orthogonalise w against the runs with an optional fused three-term update; c = device triple for the norms.
   // Returns the NormRefs every consumer must use for ||w|| afterwards.  h_total (device, nullable): R*nb doubles.
   // first_pass_only (whole-loop drivers, LL_ORTH_CGS_DGKS): enqueue pass 1 only and return refs whose final norm is
@@ -78,6 +85,14 @@ template <typename T> struct Engine {
     double* host;         // pinned, device-mapped slot of 4 doubles
     const double* alpha;  // device scalar
     bool done;
+    // can_defer (set by the caller): the caller scales w right after orth() and can fold + publish in that kernel
+    // (launch_scale_publish); orth then launches no fold of its own and describes it here (deferred = true).
+    bool can_defer = false;
+    bool deferred = false;
+    const double* partials = nullptr;
+    int nparts = 0;
+    double* c1 = nullptr;
+    const double* c0 = nullptr;
   };
   NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
                 bool first_pass_only = false, Publish* publish = nullptr);

@@ -200,6 +200,17 @@ __device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int
   }
 }
 
+// Sum of `nparts` workgroup partials, formed by EVERY workgroup in the same fixed order (the order of
+// reduce_one_kernel), returned to all lanes.  scratch: 5 doubles of LDS.
+__device__ __forceinline__ double fold_partials_all(const double* __restrict__ p, int nparts, double* scratch) {
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += kBlock) acc += p[b];
+  const double tot = block_sum(acc, scratch);
+  if (threadIdx.x == 0) scratch[4] = tot;
+  __syncthreads();
+  return scratch[4];
+}
+
 // One trip of the multi-dot: NV basis strips against the strip of w held in registers; the NV (x2 for complex) wave
 // sums are added to the wave's LDS row `mine_col[0 .. R*NV)`.
 template <typename T, int NV, bool TR>
@@ -279,7 +290,13 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
   double alpha = 0.0, beta = 0.0;
   const bool do_tt = tt.u_cur != nullptr;
   if (do_tt) {
-    alpha = *tt.alpha;
+    if (tt.alpha_partials) {  // deferred alpha: fold the operator kernel's partials here (ThreeTerm)
+      __shared__ double fold_scratch[5];
+      alpha = fold_partials_all(tt.alpha_partials, tt.alpha_nparts, fold_scratch);
+      if (blockIdx.x == 0 && tid == 0) *tt.alpha_out = alpha;
+    } else {
+      alpha = *tt.alpha;
+    }
     if (tt.u_prev) beta = sqrt(final_norm2(tt.prev));
   }
 
@@ -396,7 +413,13 @@ __global__ __launch_bounds__(kBlock) void mdot_small_kernel(int64_t n, T* __rest
   double alpha = 0.0, beta = 0.0;
   const bool do_tt = tt.u_cur != nullptr;
   if (do_tt) {
-    alpha = *tt.alpha;
+    if (tt.alpha_partials) {  // deferred alpha (ThreeTerm)
+      __shared__ double fold_scratch[5];
+      alpha = fold_partials_all(tt.alpha_partials, tt.alpha_nparts, fold_scratch);
+      if (blockIdx.x == 0 && tid == 0) *tt.alpha_out = alpha;
+    } else {
+      alpha = *tt.alpha;
+    }
     if (tt.u_prev) beta = sqrt(final_norm2(tt.prev));
   }
   const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
@@ -792,6 +815,45 @@ template void launch_scale<double>(int64_t, double*, double, const NormRefs*, hi
 template void launch_scale<zc>(int64_t, zc*, double, const NormRefs*, hipStream_t);
 template void launch_scale<float>(int64_t, float*, double, const NormRefs*, hipStream_t);
 template void launch_scale<cf>(int64_t, cf*, double, const NormRefs*, hipStream_t);
+
+// a8 fused with the fold of the post-pass norm and the publish step (see launch_scale_publish in ll_internal.hpp)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __restrict__ v,
+                                                               const double* __restrict__ partials, int nparts,
+                                                               double* __restrict__ out, const double* __restrict__ alpha,
+                                                               const double* __restrict__ c0, double* __restrict__ host) {
+  constexpr int EPT = strip<T>::EPT;
+  __shared__ double fold_scratch[5];
+  const double tot = fold_partials_all(partials, nparts, fold_scratch);  // the order of reduce_publish_kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = tot;
+    host[0] = alpha ? *alpha : 0.0;
+    host[1] = tot;
+    host[2] = c0 ? *c0 : 0.0;
+    host[3] = tot;
+  }
+  const double f = 1.0 / sqrt(tot);  // T(1)/norm, LA:77-80
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T r[EPT];
+    load_strip<T>(v, base, n, r);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) r[e] = rmul(f, r[e]);
+    store_strip<T>(v, base, n, r);
+  }
+}
+template <typename T>
+void launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
+                          const double* c0, double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL((scale_publish_kernel<T>), dim3(strip_grid(n, strip<T>::ELEMS)), dim3(kBlock), 0, s, n, v, partials,
+                     nparts, out, alpha, c0, host_mapped);
+  LL_HIP(hipGetLastError());
+}
+template void launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
+template void launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
+template void launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
+template void launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void three_term_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ up,

@@ -159,6 +159,8 @@ struct ll_context {
 
   // workspace, all sized lazily
   double* d_partials = nullptr;  // [grid][ncols] block partial sums
+  double* d_alpha_partials = nullptr;  // the operator kernels' partial <x, Ax> (kept apart: the multi-dot that follows
+  size_t alpha_partials_cap = 0;       // may fold them itself while it writes its own partials)
   size_t partials_cap = 0;       // doubles
   double* d_h = nullptr;         // reduced projection coefficients / small scalars
   size_t h_cap = 0;              // doubles
@@ -177,6 +179,7 @@ struct ll_context {
   // the device and the allocation is retried; LL_ERR_ALLOC (with the size in the message) if it still fails.
   void dev_malloc(void** out, size_t bytes, const char* what);
   void ensure_partials(size_t doubles);
+  void ensure_alpha_partials(size_t doubles);
   void ensure_h(size_t doubles);
   void ensure_pinned(size_t doubles);
   void ensure_coeff(size_t bytes);
@@ -327,6 +330,12 @@ template <typename T> struct ThreeTerm {
   const T* u_cur;       // nullable => no three-term update
   const double* alpha;  // device scalar
   NormRefs prev;        // norms of the previous iteration: beta = sqrt(final norm^2)
+  // Deferred alpha (single-GPU whole-loop drivers): alpha has NOT been folded yet; every workgroup of the multi-dot
+  // sums the operator kernel's `alpha_nparts` partials itself (same fixed order everywhere) and workgroup 0 stores the
+  // result to alpha_out for the consumers that follow (publish).  One launch per iteration less.
+  const double* alpha_partials = nullptr;
+  int alpha_nparts = 0;
+  double* alpha_out = nullptr;
 };
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
@@ -337,6 +346,12 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
                  hipStream_t s);
 // v *= factor, factor = a (host value) when norms == nullptr, else 1/sqrt(final norm^2).
 template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRefs* norms, hipStream_t s);
+// scale fused with the fold of the post-pass norm and the publish step (single-GPU whole-loop drivers): every workgroup
+// folds the `nparts` norm partials in the same fixed order, v *= 1/sqrt(sum); workgroup 0 stores the sum to *out and the
+// iteration's four scalars (alpha, sum, c0, sum) to the pinned host slot.
+template <typename T>
+void launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
+                          const double* c0, double* host_mapped, hipStream_t s);
 // Plain three-term update with host scalars (primitive API).
 template <typename T>
 void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double beta, double alpha, hipStream_t s);
