@@ -46,7 +46,8 @@ def main():
     if windows:
         res["windows"] = windows
         res["window_iterations"] = window_iterations
-        orth = [v for k, v in res["kernels"].items() if k.split("<")[0] in ("mdot_kernel", "maxpy_kernel", "scale_kernel")]
+        orth = [v for k, v in res["kernels"].items() if k.split("<")[0] in ("mdot_kernel", "maxpy_kernel", "scale_kernel", "scale_publish_kernel",
+                                                                        "mdot_small_kernel", "maxpy_small_kernel")]
         res["orth_bytes_per_window"] = sum(v["fetch_bytes_sum"] + v["write_bytes_sum"] for v in orth) / windows
     sk = res["kernels"].get("scale_kernel<double>")
     if sk:
