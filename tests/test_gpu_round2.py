@@ -319,3 +319,56 @@ def test_device_resident_time_evolution_loop_equals_the_host_loop(ctx):
     th, nt_h = eng.taylor_run(-0.4j, psi0)
     td, nt_d = eng.taylor_run(-0.4j, ctx.to_device(psi0))
     assert nt_d == nt_h and np.array_equal(td.get(), th)
+
+
+# ------------------------------------------------------------------ launch fusion and kernel geometry: same loop, same numbers
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
+def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, monkeypatch):
+    """Single GPU: alpha folded inside the multi-dot and the norm fold + publish inside the normalisation kernel (default)
+    against the separate fold / publish kernels (LL_FUSE_LAUNCHES=0, also what sharded contexts run): both sum the same
+    partials in the same order, so alpha/beta traces, iteration counts, eigenvalues and eigenvectors agree bit for bit —
+    for the eigen-solver with full re-orthogonalisation and for the Exponentiator without it."""
+    n = 20011
+    csr = G.randsym_np(n)
+    op = L.CsrOperator(ctx, csr[0], csr[1], csr[2].astype(dtype))
+    init = G.start_vector(n, 1, dtype)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LL_FUSE_LAUNCHES", fuse)
+        eng = L.LambdaLanczos(op, n, True, 2)
+        eng.init_vector = fixed_init(init)
+        vals, vecs = eng.run()
+        ex = L.Exponentiator(op, n)
+        ex.max_iteration = 30  # a real exponent never meets the overlap test (EX:154): bounded window
+        a = -0.3j if dtype == np.complex128 else -0.3
+        eo, eit = ex.run(a, init)
+        out[fuse] = (vals, vecs, eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eo, eit)
+    a, b = out["1"], out["0"]
+    assert a[2] == b[2] and a[6] == b[6]
+    for i in (0, 1, 3, 4, 5):
+        assert np.array_equal(a[i], b[i]), i
+
+
+def test_small_and_streaming_geometry_agree_in_the_whole_loop(ctx, oracle, monkeypatch):
+    """The same run with the small-vector Gram-Schmidt kernels (default at this size) and with the streaming ones forced
+    (LL_BLAS_SMALL_BYTES=0): different summation orders, same answers to the parity tolerances, same iteration counts,
+    both equal to the oracle's."""
+    n = 30011
+    csr = G.randsym_np(n)
+    op = L.CsrOperator(ctx, *csr)
+    init = G.start_vector(n, 1)
+    ora = oracle.lanczos(csr, init, True, num_eigs=1)
+    got = {}
+    for limit in (str(1 << 40), "0"):
+        monkeypatch.setenv("LL_BLAS_SMALL_BYTES", limit)
+        eng = L.LambdaLanczos(op, n, True, 1)
+        eng.init_vector = fixed_init(init)
+        vals, vecs = eng.run()
+        got[limit] = (vals, vecs, eng.getIterationCounts(), eng.last_alpha)
+        assert eng.getIterationCounts() == ora["iter_counts"]
+        assert abs(vals[0] - ora["eigenvalues"][0]) <= 1e-10 * abs(vals[0])
+        assert 1 - overlap(vecs[0], ora["eigenvectors"][0]) <= 1e-8
+        m = len(ora["alpha"])
+        assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"])) <= 1e-10 * inf_norm(csr)
+    s, b = got[str(1 << 40)], got["0"]
+    assert abs(s[0][0] - b[0][0]) <= 1e-12 * abs(b[0][0]) and 1 - overlap(s[1][0], b[1][0]) <= 1e-10
