@@ -61,11 +61,15 @@ def test_blas1_single_precision(ctx, dtype, n):
     assert np.allclose(wd.get(), w - np.float32(0.3) * up + np.float32(1.7) * uc, rtol=0, atol=8 * F32)
 
 
+# geometry: streaming (64 B per lane) and small-vector (16 B per lane, four waves per strip) Gram-Schmidt kernels, each
+# forced on every size; the sizes leave partial 16-byte pieces at the end (n % 4 = 3, 2, 1)
+@pytest.mark.parametrize("geometry", ["0", str(1 << 40)], ids=["streaming", "small"])
+@pytest.mark.parametrize("n,nb", [(20011, 23), (66, 9), (7, 5), (513, 40)])
 @pytest.mark.parametrize("dtype", [np.float32, np.complex64])
 @pytest.mark.parametrize("mode", [L.ORTH_CGS_DGKS, L.ORTH_MGS])
-def test_orth_and_gemv_single_precision(ctx, dtype, mode):
+def test_orth_and_gemv_single_precision(ctx, dtype, mode, n, nb, geometry, monkeypatch):
+    monkeypatch.setenv("LL_BLAS_SMALL_BYTES", geometry)
     wide = REAL[np.dtype(dtype)]
-    n, nb = 20011, 23
     rng = np.random.default_rng(4)
     m = rng.uniform(-1, 1, (n, nb)) + (1j * rng.uniform(-1, 1, (n, nb)) if wide == np.complex128 else 0)
     q, _ = np.linalg.qr(m)
