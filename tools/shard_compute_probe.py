@@ -56,6 +56,10 @@ print(json.dumps({"ranks": N, "rows_per_rank": nl, "nnz_per_rank": nnz_local, "s
 
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--child":  # in-process (for rocprofv3: export LL_COMM_PLUGIN first)
+        sys.argv = [sys.argv[0], sys.argv[2]]
+        exec(compile(CHILD, "<shard child>", "exec"), {"__name__": "__main__"})
+        return
     ranks = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
     for N in ranks:
         env = dict(os.environ, LL_COMM_PLUGIN=SOLO)
