@@ -413,17 +413,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     launch_reduce_cols(ctx->d_partials, grid, R * nbg + 1, h1 + R * off, (last && !sharded) ? c : nullptr, s);
     off += nbg;
   }
-  if (sharded) {  // one all-reduce for all coefficients and the norm (latency-sized, SURVEY 8e)
-    all_reduce(h1, (size_t)R * nb + 1);
-    launch_copy_scalar(c, h1 + R * nb, s);
-  }
-  off = 0;
-  int grid = 0;
-  for (size_t g = 0; g < groups.size(); ++g) {
-    grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, s);
-    off += count_of(groups[g]);
-  }
-  // Sharded whole-loop passes: the norm after the pass follows from what the one all-reduce above delivered
+  // Sharded whole-loop passes: the norm after the pass follows from what the one all-reduce below delivers
   // (||w'||^2 = ||w||^2 - sum |h_j|^2 for an orthonormal basis) — one all-reduce per iteration less.  Its relative error
   // is eps * ||w||^2 / ||w'||^2, i.e. a few eps whenever the DGKS test (evaluated on these two numbers) does not ask
   // for a second pass anyway.  LL_SHARDED_NORM=measured restores the reduced-and-all-reduced partial norms of maxpy.
@@ -431,8 +421,20 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     const char* e = std::getenv("LL_SHARDED_NORM");
     return !(e && std::string(e) == "measured");
   }();
-  if (sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && derive_norm) {
-    launch_derive_norm(c, h1, R * nb, c + 1, s);
+  const bool derive = sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && derive_norm;
+  if (sharded) {  // one all-reduce for all coefficients and the norm (latency-sized, SURVEY 8e)
+    all_reduce(h1, (size_t)R * nb + 1);
+    if (!derive) launch_copy_scalar(c, h1 + R * nb, s);  // (derive: copied by the derive kernel after the update)
+  }
+  off = 0;
+  int grid = 0;
+  for (size_t g = 0; g < groups.size(); ++g) {
+    grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, s);
+    off += count_of(groups[g]);
+  }
+  if (derive) {  // norm + copy of ||w||^2 + (whole-loop drivers) the publish step in one small launch
+    launch_derive_norm(h1 + R * nb, h1, R * nb, c, c + 1, publish ? publish->alpha : nullptr, publish ? publish->host : nullptr, s);
+    if (publish) publish->done = true;
   } else if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && publish->can_defer) {
     *publish = Publish{publish->host, publish->alpha, true, true, true, ctx->d_partials, grid, c + 1, c};
   } else if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS) {

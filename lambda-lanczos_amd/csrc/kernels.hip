@@ -763,19 +763,30 @@ void launch_reduce_cols(const double* partials, int nparts, int ncols, double* o
 // Sharded contexts: ||w - U h||^2 = ||w||^2 - sum |h_j|^2 for an orthonormal U (Pythagoras), from values every rank
 // already holds after the one all-reduce of (h, ||w||^2) — no second all-reduce for the norm.  Fixed summation order,
 // identical inputs on all ranks => identical bits on all ranks.
-__global__ __launch_bounds__(256) void derive_norm_kernel(const double* __restrict__ c0, const double* __restrict__ h,
-                                                          int count, double* __restrict__ c1) {
+__global__ __launch_bounds__(256) void derive_norm_kernel(const double* __restrict__ c0_src, const double* __restrict__ h,
+                                                          int count, double* __restrict__ c0, double* __restrict__ c1,
+                                                          const double* __restrict__ alpha, double* __restrict__ host) {
   __shared__ double red[4];
   double acc = 0.0;
   for (int i = threadIdx.x; i < count; i += 256) acc = fma(h[i], h[i], acc);
   const double tot = block_sum(acc, red);
   if (threadIdx.x == 0) {
-    const double v = *c0 - tot;
-    *c1 = v > 0.0 ? v : 0.0;
+    const double before = *c0_src;
+    double v = before - tot;
+    v = v > 0.0 ? v : 0.0;
+    *c0 = before;  // the copy of ||w||^2 out of the all-reduced buffer and ...
+    *c1 = v;
+    if (host) {    // ... the publish step ride along (two launches per iteration less on sharded contexts)
+      host[0] = alpha ? *alpha : 0.0;
+      host[1] = v;
+      host[2] = before;
+      host[3] = v;
+    }
   }
 }
-void launch_derive_norm(const double* c0, const double* h, int count, double* c1, hipStream_t s) {
-  hipLaunchKernelGGL(derive_norm_kernel, dim3(1), dim3(256), 0, s, c0, h, count, c1);
+void launch_derive_norm(const double* c0_src, const double* h, int count, double* c0, double* c1, const double* alpha,
+                        double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL(derive_norm_kernel, dim3(1), dim3(256), 0, s, c0_src, h, count, c0, c1, alpha, host_mapped);
   LL_HIP(hipGetLastError());
 }
 __global__ void set_scalar_kernel(double* dst, double v) { *dst = v; }

@@ -318,7 +318,10 @@ void launch_reduce_publish(const double* partials, int nparts, double* out, cons
                            double* host_mapped, hipStream_t s);
 void launch_set_scalar(double* dst, double value, hipStream_t s);
 // *c1 = max(0, *c0 - sum_i h[i]^2)  (one workgroup, fixed order)
-void launch_derive_norm(const double* c0, const double* h, int count, double* c1, hipStream_t s);
+// c0 = *c0_src (||w||^2 before the pass, from the all-reduced buffer), c1 = max(c0 - sum_i h_i^2, 0); host_mapped (nullable):
+// the iteration's four scalars (alpha, c1, c0, c1) go to the pinned host slot in the same launch.
+void launch_derive_norm(const double* c0_src, const double* h, int count, double* c0, double* c1, const double* alpha,
+                        double* host_mapped, hipStream_t s);
 
 // Multi-dot with optional fused three-term update.
 //   if (three_term) w = w - beta*u_prev - alpha*u_cur   (u_prev nullable; alpha = *alpha_dev; beta = beta_from(norms_prev))
