@@ -911,8 +911,27 @@ template <typename T> bool pb_build_device(ll_operator* op) {
     int64_t bl;
     if (P == 1) bl = block_len(gp.len[c], col_max, "LL_PB_COL_BLOCK");
     else {
-      const int64_t nbw = (gp.len[c] + col_max - 1) / col_max;
-      bl = (gp.len[c] + nbw - 1) / nbw;
+      // Sharded: one launch of phase 1 covers the nrem other ranks' blocks of this chunk, one workgroup per block and
+      // per CU at a time.  Its duration is rounds x (fixed + per-column work) with rounds = ceil(blocks / CUs), so the
+      // block count per (rank, chunk) is chosen to fill whole rounds instead of the fewest blocks that fit the LDS:
+      // N = 8, two chunks: 48 blocks of 13 021 columns per rank give launches of 336 blocks = 1.31 -> 2 rounds; 73
+      // blocks of 8 562 columns give 511 blocks = 2 full rounds of 2/3 the length (measured on the shard shapes with
+      // tools/shard_compute_probe.py).  kFixedCols: the per-workgroup fixed cost in units of one column's work.
+      const int64_t nb_min = (gp.len[c] + col_max - 1) / col_max;
+      const double kFixedCols = 1500.0;
+      int64_t best_nb = nb_min;
+      double best_cost = 1e300;
+      for (int64_t nb = nb_min; nb <= 4 * nb_min + 8; ++nb) {
+        const int64_t len_b = (gp.len[c] + nb - 1) / nb;
+        const int64_t launch = (int64_t)std::max(1, nrem) * nb;
+        const double cost = (double)((launch + kCUs - 1) / kCUs) * (kFixedCols + (double)len_b);
+        if (cost < best_cost * 0.999) {
+          best_cost = cost;
+          best_nb = nb;
+        }
+      }
+      if (env_int("LL_PB_FILL_ROUNDS", 1) == 0) best_nb = nb_min;
+      bl = (gp.len[c] + best_nb - 1) / best_nb;
       bl = std::min<int64_t>(col_max, (bl + 3) / 4 * 4);
       if (const char* e = std::getenv("LL_PB_BLOCK")) bl = std::min<int64_t>(col_max, std::max(4, std::atoi(e)));
       if (const char* e = std::getenv("LL_PB_COL_BLOCK")) bl = std::min<int64_t>(col_max, std::max(4, std::atoi(e)));
