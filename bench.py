@@ -91,7 +91,9 @@ def pmc_traffic(workload, kernels, dtype_tag):
     total = 0.0
     for k in kernels:
         # template arguments after the scalar type (unroll factors, index width) vary: match on the prefix
-        hits = [v for name, v in d["kernels"].items() if name.startswith("%s<%s" % (k, dtype_tag))]
+        # (phase 2 of the PB SpMV runs as pb_phase2_fixed<...> by default, pb_phase2<...> with LL_PB_PHASE2=ordered)
+        hits = [v for name, v in d["kernels"].items()
+                if name.startswith("%s<%s" % (k, dtype_tag)) or name.startswith("%s_fixed<%s" % (k, dtype_tag))]
         if not hits:
             return None, None
         e = max(hits, key=lambda v: v.get("launches", 0))

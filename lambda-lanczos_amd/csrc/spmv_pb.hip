@@ -416,6 +416,8 @@ __device__ __forceinline__ bool lds_add_i64(long long* p, double scaled) {
   return true;
 }
 
+// (Measured and dropped: ONE grid per row block instead of one per row, which removes the per-entry look-up of the row's
+// exponent — 0.858 vs 0.862 ms, no gain, and rows much smaller than their block's largest lose accuracy.)
 template <typename T, int U, int D>
 __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_first, int rb_rows, int64_t n_local, int ncb,
                                                               const int64_t* __restrict__ rptr,
@@ -862,7 +864,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   const int64_t S = P > 1 ? op->n_shard : op->n;
 
   // ---- row blocks (y slice in LDS, 152 KiB at most)
-  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)sizeof(acc_t<T>));
+  // (the fixed-point form of phase 2 keeps a 16-bit exponent per row next to the accumulator)
+  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)(sizeof(acc_t<T>) + sizeof(int16_t)));
   auto block_len = [&](int64_t len, int64_t slice_max, const char* env) {
     int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
     int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
@@ -1021,9 +1024,15 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_u1 = env_int("LL_PB_U1", 1);  // measured on config 3 (profiles/r02_spmv_variants.jsonl): 1 beats 2 and 4 by 3-5 %
   op->pb_u2 = env_int("LL_PB_U2", 2);
   {
-    const char* p2 = std::getenv("LL_PB_PHASE2");  // "atomic": arrival order; "token": fixed order by ticket; else barriers
-    const std::string p2s = p2 ? p2 : "";
+    // Phase 2 forms.  Default "fixed": order-independent fixed-point sums (integer LDS adds, all waves at once) — bit-
+    // reproducible for every launch, kernel geometry and partition, and 2-5 % FASTER than the wave-ordered form
+    // (profiles/r02_spmv_variants_run10_fixed_default.jsonl).  "ordered": floating-point adds, the 16 waves in turn
+    // (barriers); "token": the same order by a ticket in LDS; "issueorder": experiment; "atomic":
+    // floating-point adds in arrival order (not reproducible; A/B reference).
+    const char* p2 = std::getenv("LL_PB_PHASE2");
+    const std::string p2s = p2 ? p2 : "fixed";
     op->pb_ordered = p2s == "atomic" ? 0 : (p2s == "token" ? 2 : (p2s == "issueorder" ? 3 : (p2s == "fixed" ? 4 : 1)));
+    if (op->pb_ordered == 4 && env_int("LL_PB_XPROP", 0) != 0) op->pb_ordered = 1;  // x propagation has no fixed-point form
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
   op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;

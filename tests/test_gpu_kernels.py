@@ -48,7 +48,8 @@ CASES = csr_cases()
 KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37"),
            "pb_xprop": (1, None), "pb_xprop_small_blocks": (1, "37"), "pb_other_unrolls": (1, "53"),
            "pb_token": (1, None), "pb_token_small_blocks": (1, "37"),
-           "pb_fixed": (1, None), "pb_fixed_small_blocks": (1, "37")}
+           "pb_fixed": (1, None), "pb_fixed_small_blocks": (1, "37"),
+           "pb_ordered": (1, None), "pb_ordered_small_blocks": (1, "37")}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -73,6 +74,8 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
         monkeypatch.setenv("LL_PB_DEPTH", "2")
     if kernel.startswith("pb_fixed"):
         monkeypatch.setenv("LL_PB_PHASE2", "fixed")   # order-independent fixed-point sums (integer LDS adds)
+    if kernel.startswith("pb_ordered") or kernel == "pb_other_unrolls":
+        monkeypatch.setenv("LL_PB_PHASE2", "ordered")  # floating-point adds, the 16 waves in turn (the default is "fixed")
     if kernel.startswith("pb_token"):
         monkeypatch.setenv("LL_PB_PHASE2", "token")   # the fixed order enforced by a ticket in LDS instead of barriers
     if kernel == "pb_atomic":
@@ -115,7 +118,7 @@ def test_pb_ordered_forms_agree_bit_for_bit(ctx, name, block, monkeypatch):
     if block:
         monkeypatch.setenv("LL_PB_BLOCK", block)
     ys = {}
-    for label, env in (("barrier", {}), ("token", {"LL_PB_PHASE2": "token"}), ("xprop", {"LL_PB_XPROP": "1"}),
+    for label, env in (("barrier", {"LL_PB_PHASE2": "ordered"}), ("token", {"LL_PB_PHASE2": "token"}), ("xprop", {"LL_PB_XPROP": "1"}),
                        ("token_u1_d2", {"LL_PB_PHASE2": "token", "LL_PB_U2": "1", "LL_PB_DEPTH": "2"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -176,9 +179,8 @@ def test_pb_image_build_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
     x = rnd(n, dtype, 5)
     y_ref = oracle.spmv(csr, x) - 1.5 * x
     xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
-    for phase2 in ("", "fixed"):
-        if phase2:
-            monkeypatch.setenv("LL_PB_PHASE2", phase2)
+    for phase2 in ("ordered", "fixed"):
+        monkeypatch.setenv("LL_PB_PHASE2", phase2)
         op = L.CsrOperator(ctx, *csr)
         assert op.selected_spmv() == L.capi.SPMV_PB
         L.spmv(op, xd, yd, offset=-1.5)

@@ -22,10 +22,11 @@ from lambda_lanczos_amd import generators as G  # noqa: E402
 
 DEFAULT = ";".join([
     "csr_stream:LL_SPMV_KERNEL=csr",
-    "pb_ordered_u2:LL_SPMV_KERNEL=pb",
+    "pb_fixed_default:LL_SPMV_KERNEL=pb",
+    "pb_ordered_u2:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered",
     "pb_atomic_u2:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic",
-    "pb_ordered_u4:LL_SPMV_KERNEL=pb,LL_PB_U2=4",
-    "pb_ordered_u1:LL_SPMV_KERNEL=pb,LL_PB_U2=1",
+    "pb_ordered_u4:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered,LL_PB_U2=4",
+    "pb_ordered_u1:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered,LL_PB_U2=1",
     "pb_p1u1:LL_SPMV_KERNEL=pb,LL_PB_U1=1",
     "pb_p1u4:LL_SPMV_KERNEL=pb,LL_PB_U1=4",
 ])
