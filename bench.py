@@ -267,10 +267,12 @@ def main():
     # lattice: x read once, y written once (+ the real on-site array of config 5)
     b_spmv = (2 * (16 if complex_ else 8) * n + (8 * n if complex_ else 0)) if lattice else spmv_bytes(n, nnz, complex_)
     selected = -1 if lattice else op.selected_spmv()
-    kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2", -1: "stencil_kernel"}
+    # phase 2 of the PB SpMV: pb_phase2_fixed (order-independent fixed-point sums, the default) or pb_phase2 (LL_PB_PHASE2=...)
+    p2 = "pb_phase2_fixed" if os.environ.get("LL_PB_PHASE2", "fixed") == "fixed" and not os.environ.get("LL_PB_XPROP") else "pb_phase2"
+    kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+" + p2, -1: "stencil_kernel"}
     # The operator timed both kernels on the actual matrix when it was created and released the slower image; those
     # creation-time figures are reported next to the event timing of the kernel that is in use.
-    tune = None if lattice else dict(zip(("spmv_stream", "pb_phase1+pb_phase2"), op.autotune_ms()))
+    tune = None if lattice else dict(zip(("spmv_stream", "pb_phase1+" + p2), op.autotune_ms()))
     rounds = []
     for rnd in range(3):
         L.spmv(op, xd, yd)
@@ -519,7 +521,8 @@ def main():
                      "includes_exchange": world > 1},
             "roofline": {
                 "kernel": kernel_names[selected],
-                "launch": "one SpMV y = A x (pb: two back-to-back kernels), HIP events on the library stream, "
+                "launch": "one SpMV y = A x (pb: two back-to-back kernels; phase 2 with order-independent fixed-point "
+                          "sums), HIP events on the library stream, "
                           "%d launches averaged" % args.spmv_reps,
                 "bound": "hbm",
                 "achieved": spmv_gbs,
