@@ -1036,7 +1036,9 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   }
   op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
   op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;
-  op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", 3)));  // 3 beats 2 and 4 (profiles/r02_spmv_variants_run3.jsonl)
+  // trips of loads in flight per lane: 3 beats 2 and 4 for the wave-ordered form (profiles/r02_spmv_variants_run3.jsonl);
+  // the fixed-point form, whose waves all add at once, does best with 2 (0.845-0.850 vs 0.856-0.862 ms, run10)
+  op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", op->pb_ordered == 4 ? 2 : 3)));
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
     LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
