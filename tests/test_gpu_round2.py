@@ -1,7 +1,7 @@
 """Round-2 GPU parity and property tests (through the C ABI):
 full-size parity of BASELINE configs 3 and 2 against the real reference / the oracle, bit-reproducibility of the
-propagation-blocked SpMV at n = 1e7 (phase 2 adds wave by wave in a fixed order; the image is built on the device by
-a deterministic ranking), release of the SpMV image that lost the creation-time timing, the overlapped exchange path
+propagation-blocked SpMV at n = 1e7 (phase 2 sums in fixed point, order-independent — or wave by wave in a fixed order
+with LL_PB_PHASE2=ordered; the image is built on the device by a deterministic ranking), release of the SpMV image that lost the creation-time timing, the overlapped exchange path
 against the serial one through a real 1-rank RCCL communicator, LL_TRIDIAG_AUTO (the default) against the
 reference-faithful per-iteration QR on the reference's own golden traces, device-array validation independent of the
 kernel choice, float tolerances from the C defaults, and the host callback's call count."""
@@ -34,7 +34,8 @@ def c3():
 
 def test_c3_pb_spmv_is_bit_reproducible_at_full_size(ctx, c3, monkeypatch):
     """Two launches on one operator AND a second operator built from the same arrays give the same bits (n = 1e7,
-    nnz = 1.5e8): the wave-ordered LDS adds fix the summation order, the device-side image build fixes the layout."""
+    nnz = 1.5e8): the fixed-point sums of phase 2 do not depend on the order of the adds (the wave-ordered form fixes the
+    order instead), the device-side image build fixes the layout."""
     n, csr = c3
     monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
     monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
