@@ -525,11 +525,17 @@ class LambdaLanczos:
             else:
                 lock = None
                 n_orth = 0
-                if orth is not None and len(orth):
+                lock_p = None
+                if isinstance(orth, DeviceArray):  # orthogonalizeTo vectors already in HBM: rows of a (n_orth, n_local) array
+                    assert orth.dtype == self.dtype and orth.shape[-1] == n_local
+                    n_orth = int(np.prod(orth.shape[:-1])) if len(orth.shape) > 1 else 1
+                    lock_p = C.c_void_p(orth.ptr)
+                elif orth is not None and len(orth):
                     lock = np.ascontiguousarray(orth, dtype=self.dtype).reshape(-1, n_local)
                     n_orth = lock.shape[0]
+                    lock_p = ptr(lock)
                 fn = getattr(lib(), "ll_lanczos_run_iteration_" + sfx)
-                check(fn(self.context.handle, op.handle, C.byref(p), nroot, n_orth, ptr(lock), ptr(vals), vecs_p,
+                check(fn(self.context.handle, op.handle, C.byref(p), nroot, n_orth, lock_p, ptr(vals), vecs_p,
                          C.byref(n_found), C.byref(itern), ptr(alpha), ptr(beta), C.byref(stats)))
                 counts[0] = itern.value
         finally:

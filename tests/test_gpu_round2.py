@@ -287,12 +287,16 @@ def test_device_resident_start_vector_and_eigenvectors_equal_the_host_path(ctx, 
         assert np.array_equal(dx.get()[: len(dv)], hx)
         assert np.array_equal(dev.last_alpha, host.last_alpha) and np.array_equal(dev.last_beta, host.last_beta)
         assert np.array_equal(dev.init_vector.get(), init)  # the caller's start vector is left untouched
-        # run_iteration: device orthogonalizeTo is not part of the Python mirror; device output is
+        # run_iteration: device output ...
         ri_h = host.run_iteration(2, hx[:1])
         dev.eigenvectors_out = ctx.empty((2, n), dtype)
         ri_d = dev.run_iteration(2, hx[:1])
         assert np.array_equal(ri_d[0], ri_h[0]) and ri_d[2] == ri_h[2]
         assert np.array_equal(ri_d[1].get()[: len(ri_h[0])], ri_h[1])
+        # ... and with the orthogonalizeTo list itself in device memory
+        ri_dd = dev.run_iteration(2, ctx.to_device(np.ascontiguousarray(hx[:1])))
+        assert np.array_equal(ri_dd[0], ri_h[0]) and ri_dd[2] == ri_h[2]
+        assert np.array_equal(ri_dd[1].get()[: len(ri_h[0])], ri_h[1])
 
 
 def test_device_resident_time_evolution_loop_equals_the_host_loop(ctx):
