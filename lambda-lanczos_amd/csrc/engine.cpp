@@ -180,7 +180,7 @@ template <typename T>
 void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer) {
   TraceRange trace("ll::apply (mv_mul + offset + alpha)");
   hipStream_t s = ctx->stream;
-  ctx->ensure_alpha_partials(std::max<size_t>(kMaxGrid, (size_t)std::max(op->pb_nrb, op->l2_nrb)));
+  ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)std::max(op->pb_nrb, op->l2_nrb)));
   double* const dotp = d_alpha ? ctx->d_alpha_partials : nullptr;
   int nparts = 0;
   if (op->kind == ll_operator::STENCIL) {

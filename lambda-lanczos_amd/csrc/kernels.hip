@@ -105,15 +105,20 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
   }
 }
 
-static int spmv_grid(int ntiles) {
-  int g = ntiles < kMaxGrid ? ((ntiles + kXcds - 1) / kXcds) * kXcds : kMaxGrid;
+// Persistent grid of the CSR-stream kernel: 8 workgroups per CU for 4- and 8-byte values, 16 for complex double (20 KB
+// of matrix per tile: 24.8 us instead of 27.4 us per SpMV on config 5, 68 % instead of 62 % of the roofline; config 2 is
+// best at 8: 17.8 us against 18.2 us).  LL_SPMV_GRID overrides (at most kMaxSpmvGrid: the alpha partials are sized for it).
+static int spmv_grid(int ntiles, size_t elem_bytes) {
+  int cap = elem_bytes >= 16 ? kMaxSpmvGrid : kMaxGrid;
+  if (const char* e = std::getenv("LL_SPMV_GRID")) cap = std::min(kMaxSpmvGrid, std::max(kXcds, std::atoi(e) / kXcds * kXcds));
+  int g = ntiles < cap ? ((ntiles + kXcds - 1) / kXcds) * kXcds : cap;
   return g < kXcds ? kXcds : g;
 }
 
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
                 hipStream_t s) {
-  const int grid = spmv_grid(op.ntiles);
+  const int grid = spmv_grid(op.ntiles, sizeof(T));
   if (op.rp64)
     hipLaunchKernelGGL((spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
                        (const int64_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,

@@ -85,6 +85,7 @@ constexpr int kBlock = 256;          // threads per workgroup (4 waves of 64)
 constexpr int kCUs = 256;            // MI355X
 constexpr int kXcds = 8;
 constexpr int kMaxGrid = kCUs * 8;   // persistent grids: at most 8 workgroups per CU (multiple of 8 XCDs)
+constexpr int kMaxSpmvGrid = kCUs * 16;  // CSR-stream SpMV with 16-byte values (its partial dot products: d_alpha_partials)
 constexpr int kSpmvTileNnz = 1024;   // nonzeros staged through LDS per SpMV tile
 constexpr int kMaxSegs = 8;          // basis segments per multi-dot / multi-axpy launch
 
