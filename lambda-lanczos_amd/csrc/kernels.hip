@@ -156,11 +156,16 @@ static bool blas_small(int64_t n, size_t elem_bytes) {  // LL_BLAS_SMALL_BYTES: 
 // (Measured alternative, round 2: equal CONTIGUOUS shares per workgroup instead of strips dealt out round-robin —
 // perfectly balanced, but 8 % slower on the Gram-Schmidt kernels (5.35 vs 5.83 TB/s at n = 1e7): with the round-robin
 // walk the whole chip sweeps each basis vector front to back, which is what the HBM row buffers like.)
+// Grid target: 1024 workgroups, but ONE per CU once a vector has more than ~2.25 16-KiB strips per CU (> 9 MiB): every
+// workgroup then sweeps several strips back to back — config 3 (80 MB vectors): 6.0 instead of 5.9 TB/s; the 40 / 20 /
+// 10 MB shards of config 4: Gram-Schmidt -13 % / -9 % / -3 % (profiles/r02_strip_grid_sweep.txt).  At 8 MiB (config 2,
+// 489 strips) the small grid is 2 % slower: too few strips to balance.
 static int strip_grid(int64_t n, int elems) {
-  static int target = 0;
-  if (!target) target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : 1024;
+  static const int env_target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : 0;
   int64_t strips = (n + elems - 1) / elems;
   if (strips < 1) strips = 1;
+  const bool streaming = elems >= 1024;  // the small-vector kernels' strips are 64 .. 256 elements
+  const int target = env_target ? env_target : (streaming && strips > 2 * kCUs + kCUs / 4 ? kCUs : 1024);
   const int64_t per = (strips + target - 1) / target;
   return (int)((strips + per - 1) / per);
 }
