@@ -71,6 +71,10 @@ int ll_ctx_create(int device, ll_context** out);
  * null stream.  The stream stays owned by the caller. */
 int ll_ctx_create_on_stream(int device, void* hip_stream, ll_context** out);
 int ll_ctx_destroy(ll_context* ctx);
+/* The library's LL_* environment switches are read ONCE, when a context is created, and
+ * copied into the operators created on it — never on a launch path.  This reads them again into an existing context
+ * (test suites and tuning scripts that flip a switch inside one process); operators that already exist keep theirs. */
+int ll_ctx_reload_env(ll_context* ctx);
 /* hipStream_t of the context (for callers that enqueue their own work in between). */
 int ll_ctx_stream(ll_context* ctx, void** hip_stream_out);
 /* Block until the context's stream is idle. */
@@ -203,7 +207,8 @@ int ll_op_create_stencil_d(ll_context* ctx, const ll_stencil_desc* desc, int64_t
 int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t row_begin, int64_t n_local,
                            const double* onsite_host_local, ll_operator** out);
 
-/* Which SpMV kernel a CSR operator uses (results agree to rounding; both are bit-reproducible run to run):
+/* Which SpMV kernel a CSR operator uses (both are bit-reproducible run to run; their results agree to rounding IN THE
+ * NORM-WISE SENSE stated below):
  *   LL_SPMV_CSR_STREAM  plain CSR, products staged in LDS; best when the x gathers hit L1/L2 (stencils, narrow bands).
  *   LL_SPMV_PB          propagation blocking: the same matrix re-ordered once at upload (on the device) so that one
  *                       SpMV is two fully coalesced streaming sweeps with x and y slices in LDS and no global gather;
@@ -212,7 +217,23 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  * ll_op_create_csr_{d,z} and _csr_dev_ build both images, time them on the device with the actual matrix (sharded
  * contexts: summed over the ranks, so every rank takes the same decision), keep the faster one and RELEASE the other
  * (for BASELINE config 3 that returns 1.8 GB of CSR arrays).  Environment: LL_SPMV_KERNEL=csr|pb skips the timing,
- * LL_SPMV_KEEP_BOTH=1 keeps both images so that ll_op_select_spmv can switch later (A/B timing, tests). */
+ * LL_SPMV_KEEP_BOTH=1 keeps both images so that ll_op_select_spmv can switch later (A/B timing, tests).
+ *
+ * ACCURACY of y = A x (this is what replaces the user's fp64 mv_mul, LL:243 / EX:108):
+ *   LL_SPMV_CSR_STREAM and LL_SPMV_PB with LL_PB_PHASE2=ordered|atomic sum the products in floating point:
+ *     |y_i - (A x)_i| <= ~nnz_i * eps * sum_j |a_ij| |x_j|             (COMPONENT-wise, like a plain fp64 row loop).
+ *   LL_SPMV_PB in its default form (LL_PB_PHASE2=fixed) rounds every product to a per-row fixed-point grid and adds
+ *   64-bit integers (order-independent: same bits for every launch, block geometry and partition of the matrix):
+ *     |y_i - (A x)_i| <= eps * sum_j |a_ij| |x_j|  +  nnz_i * 2^-60 * (sum_j |a_ij|) * max_k |x_k|   (NORM-wise)
+ *   where max_k runs over the WHOLE input vector.  For vectors whose entries are of comparable size (Lanczos vectors of
+ *   extended states, random vectors) the second term is 2^7 or more times below the first.  For a vector with a huge dynamic
+ *   range (x = e_0, a strongly localised state, an entry of 1e20 next to O(1) entries) rows whose terms are all far
+ *   below (sum_j |a_ij|) max|x| lose RELATIVE accuracy: their absolute error stays below nnz_i 2^-60 ||A||_inf ||x||_inf, which
+ *   is what the Lanczos recurrence and the Exponentiator need (tests/test_gpu_round3.py asserts both bounds and whole
+ *   runs from x = e_0 against the real reference), but it is not the component-wise accuracy of an fp64 row loop.
+ *   Callers who need that from ll_spmv_* on such vectors set LL_PB_PHASE2=ordered (3-5 % slower) or LL_SPMV_KERNEL=csr.
+ *   Rows that meet an Inf / NaN are reported as NaN.  float / complex float storage: the product a_ij x_j is rounded to
+ *   the storage type once (exactly what a float multiply gives) before it is summed in fixed point / double. */
 enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1 };
 int ll_op_select_spmv(ll_operator* op, int kind);
 int ll_op_selected_spmv(const ll_operator* op, int* kind_out);

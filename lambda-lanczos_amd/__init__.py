@@ -26,6 +26,7 @@ from .engine import (  # noqa: F401
     StencilOperator,
     LambdaLanczos,
     default_context,
+    live_contexts,
     dot,
     gemv_basis,
     normalize,

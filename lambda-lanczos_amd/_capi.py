@@ -107,6 +107,7 @@ PROTOTYPES = {
     "ll_ctx_stream": (C.c_int, [vp, P(vp)]),
     "ll_ctx_synchronize": (C.c_int, [vp]),
     "ll_ctx_release_cache": (C.c_int, [vp]),
+    "ll_ctx_reload_env": (C.c_int, [vp]),
     "ll_ctx_set_profiling": (C.c_int, [vp, C.c_int]),
     "ll_timer_start": (C.c_int, [vp]),
     "ll_timer_stop": (C.c_int, [vp, P(f64)]),

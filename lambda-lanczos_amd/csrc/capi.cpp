@@ -16,6 +16,54 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 using namespace ll;
 
+// ---------------------------------------------------------------- environment switches (ll_internal.hpp: ll::Tuning)
+namespace ll {
+Tuning read_tuning() {
+  Tuning t;
+  auto str = [](const char* name) -> std::string {
+    const char* e = std::getenv(name);
+    return e ? std::string(e) : std::string();
+  };
+  auto flag = [&](const char* name, bool dflt) {
+    const std::string v = str(name);
+    return v.empty() ? dflt : std::atoi(v.c_str()) != 0;
+  };
+  auto num = [&](const char* name, long long dflt) {
+    const std::string v = str(name);
+    return v.empty() ? dflt : std::atoll(v.c_str());
+  };
+  const std::string k = str("LL_SPMV_KERNEL");
+  t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : 0);
+  t.keep_both = flag("LL_SPMV_KEEP_BOTH", false);
+  const std::string p2 = str("LL_PB_PHASE2");
+  t.pb_phase2 = p2 == "atomic" ? LL_PB_ATOMIC : (p2 == "ordered" ? LL_PB_ORDERED : LL_PB_FIXED);
+  t.pb_block = (int)std::max<long long>(0, num("LL_PB_BLOCK", 0));
+  t.pb_row_block = (int)std::max<long long>(0, num("LL_PB_ROW_BLOCK", 0));
+  t.pb_col_block = (int)std::max<long long>(0, num("LL_PB_COL_BLOCK", 0));
+  t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
+  t.comm_overlap = flag("LL_COMM_OVERLAP", true);
+  t.tridiag_thread = flag("LL_TRIDIAG_THREAD", true);
+  t.tridiag_lag = (int)num("LL_TRIDIAG_LAG", 3);
+  {
+    const std::string v = str("LL_DGKS_THRESHOLD");
+    if (!v.empty()) t.dgks_threshold = std::atof(v.c_str());
+  }
+  t.sharded_norm_measured = str("LL_SHARDED_NORM") == "measured";
+  t.slab_bytes = std::max<long long>(1, num("LL_SLAB_BYTES", (long long)4 << 30));
+  t.blas_small_bytes = num("LL_BLAS_SMALL_BYTES", (long long)4 << 20);
+  t.fuse_launches = flag("LL_FUSE_LAUNCHES", true);
+  t.force_rp64 = flag("LL_FORCE_RP64", false);
+  t.pb_test_all_remote = flag("LL_PB_TEST_ALL_REMOTE", false);
+  t.tridiag_test_jitter_us = (int)num("LL_TRIDIAG_TEST_JITTER_US", 0);
+  t.stencil_vec = flag("LL_STENCIL_VEC", true);
+  {
+    const std::string v = str("LL_STALL_TRACE");
+    if (!v.empty()) t.stall_trace_ms = std::atof(v.c_str());
+  }
+  return t;
+}
+}  // namespace ll
+
 // ---------------------------------------------------------------- context workspace
 static size_t grow(size_t have, size_t want) { return std::max(want, have + have / 2 + 64); }
 
@@ -127,8 +175,7 @@ ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
                   (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp,
-                  (void*)d_pb_blockmax, d_l2_val, (void*)d_l2_idx,
-                  (void*)d_l2_ptr, (void*)d_l2_sync})
+                  (void*)d_pb_blockmax, (void*)d_pb_xmax, (void*)d_pb_ex})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -177,6 +224,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ll_context** out)
     LL_HIP(hipSetDevice(device));
     std::unique_ptr<ll_context> c(new ll_context);
     c->device = device;
+    c->tune = read_tuning();
     if (own) {
       LL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
       c->own_stream = true;
@@ -208,6 +256,7 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->d_alpha_partials) (void)hipFree(ctx->d_alpha_partials);
     if (ctx->d_h) (void)hipFree(ctx->d_h);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
+    if (ctx->d_xmax) (void)hipFree(ctx->d_xmax);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_cb) (void)hipHostFree(ctx->h_cb);
@@ -220,6 +269,12 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+  });
+}
+int ll_ctx_reload_env(ll_context* ctx) {
+  return guarded([&] {
+    LL_REQUIRE(ctx != nullptr, "null context");
+    ctx->tune = read_tuning();
   });
 }
 int ll_ctx_stream(ll_context* ctx, void** out) {
@@ -285,8 +340,7 @@ namespace {
 // After the communicator exists: the second stream + events of the overlapped exchange, and a SELF-CHECK — every rank
 // contributes (rank + 1) to an all-gather and the constant 1 to an all-reduce; a communicator that silently spans
 // fewer ranks than asked for (or delivers shards in another order) fails here instead of producing a wrong spectrum.
-void finish_comm_setup(ll_context* ctx) {
-  if (const char* e = std::getenv("LL_COMM_OVERLAP")) ctx->overlap = std::atoi(e) != 0;
+void finish_comm_setup_impl(ll_context* ctx) {
   LL_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   LL_HIP(hipEventCreateWithFlags(&ctx->ev_x_ready, hipEventDisableTiming));
   for (auto& e : ctx->ev_chunk) LL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -318,6 +372,33 @@ void finish_comm_setup(ll_context* ctx) {
     set_error("communicator self-check failed: all-gather delivered " + std::to_string(seen) + " of " + std::to_string(P) +
               " rank tags, all-reduce of ones gave " + std::to_string(h[(size_t)P + 1]));
     throw Failure{LL_ERR_RCCL};
+  }
+}
+// A communicator whose set-up or self-check failed must not stay attached: the context would look sharded with a
+// transport known to be broken (later operators would be created as shards, their collectives could hang, and a retry
+// of ll_comm_init / ll_comm_attach would be refused).  Everything is undone and the error is passed on.
+void finish_comm_setup(ll_context* ctx) {
+  try {
+    finish_comm_setup_impl(ctx);
+  } catch (...) {
+    (void)hipGetLastError();
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    comm_destroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->rank = 0;
+    ctx->nranks = 1;
+    ctx->ranks_seen = 0;
+    if (ctx->ev_x_ready) (void)hipEventDestroy(ctx->ev_x_ready);
+    ctx->ev_x_ready = nullptr;
+    for (auto& e : ctx->ev_chunk) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr;
+    (void)hipGetLastError();
+    throw;
   }
 }
 }  // namespace
@@ -443,7 +524,7 @@ void finish_csr(ll_operator* op, const int64_t* rp_host) {
   ctx->dev_malloc((void**)&op->d_tile_rows, tiles.size() * sizeof(int32_t), "SpMV tiles");
   LL_HIP(hipMemcpy(op->d_tile_rows, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   // 64-bit row offsets once nnz exceeds int32 (LL_FORCE_RP64=1: exercise that kernel variant on small test matrices)
-  op->rp64 = op->nnz > (int64_t)0x7fffffff || (std::getenv("LL_FORCE_RP64") && std::atoi(std::getenv("LL_FORCE_RP64")) != 0);
+  op->rp64 = op->nnz > (int64_t)0x7fffffff || ctx->tune.force_rp64;
   if (op->rp64) {
     ctx->dev_malloc(&op->d_row_ptr, (size_t)(nr + 1) * sizeof(int64_t), "row offsets");
     LL_HIP(hipMemcpy(op->d_row_ptr, rp_host, (size_t)(nr + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -473,14 +554,17 @@ void set_partition(ll_context* ctx, ll_operator* op, int64_t n, int64_t row_begi
 }
 
 // Drop the device arrays of the SpMV image that is NOT selected (LL_SPMV_KEEP_BOTH=1 keeps both for A/B timing).
+void release_image(ll_operator* op, int keep_kind);
 void release_unselected_image(ll_operator* op) {
-  if (const char* e = std::getenv("LL_SPMV_KEEP_BOTH"))
-    if (std::atoi(e) != 0) return;
+  if (op->ctx->tune.keep_both) return;
+  release_image(op, op->spmv_kind);
+}
+void release_image(ll_operator* op, int keep_kind) {
   auto drop = [](auto*& p) {
     if (p) (void)hipFree((void*)p);
     p = nullptr;
   };
-  if (op->spmv_kind == LL_SPMV_PB) {  // CSR-stream needs row_ptr / col / val / tiles; PB needs none of them
+  if (keep_kind == LL_SPMV_PB) {  // CSR-stream needs row_ptr / col / val / tiles; PB needs none of them
     if (op->owns_arrays) {
       drop(op->d_col);
       drop(op->d_val);
@@ -500,6 +584,8 @@ void release_unselected_image(ll_operator* op) {
     drop(op->d_pb_arena);
     drop(op->d_pb_rexp);
     drop(op->d_pb_blockmax);
+    drop(op->d_pb_xmax);
+    drop(op->d_pb_ex);
     op->d_pb_val = op->d_pb_prod = nullptr;  // interior pointers of the arena
     op->d_pb_col = op->d_pb_row = nullptr;
     op->pb_ncb = op->pb_nrb = 0;
@@ -599,8 +685,7 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   // for host and device inputs alike, whatever kernel gets selected
   csr_check_device<T>(op.get());
   op->spmv_kind = LL_SPMV_CSR_STREAM;
-  const char* fmt = std::getenv("LL_SPMV_KERNEL");
-  const std::string want = fmt ? fmt : "auto";
+  const int want = ctx->tune.spmv_kernel;  // 0 auto, 1 csr, 2 pb (LL_SPMV_KERNEL)
   // Sharded contexts take every decision below COLLECTIVELY (an empty shard, or a shard whose shape rules the image
   // out, must not leave the ranks with different kernels: the exchange plan and the collectives issued depend on it).
   auto all_ranks_agree = [&](bool mine) {
@@ -621,35 +706,23 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     (void)hipFree(d);
     return sum == 0.0;
   };
-  if (want == "l2g") {  // EXPERIMENT: the L2-blocked gather kernel (spmv_l2g.hip), built on the host, single GPU
-    std::vector<int32_t> ci_copy;
-    std::vector<T> va_copy;
-    const int32_t* ci_host = ci;
-    const T* va_host = (const T*)va;
-    if (on_device) {
-      ci_copy.resize(nnz);
-      va_copy.resize(nnz);
-      LL_HIP(hipMemcpy(ci_copy.data(), ci, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-      LL_HIP(hipMemcpy(va_copy.data(), va, nnz * sizeof(T), hipMemcpyDeviceToHost));
-      ci_host = ci_copy.data();
-      va_host = va_copy.data();
-    }
-    LL_REQUIRE(l2g_build_host<T>(op.get(), rp_host, ci_host, va_host), "LL_SPMV_KERNEL=l2g: image not buildable (sharded context or empty matrix)");
-    op->spmv_kind = LL_SPMV_L2G_EXPERIMENT;
-    *out = op.release();
-    return;
-  }
-  if (want != "csr" && (nnz > 0 || ctx->comm != nullptr)) {
+  if (want != 1 && (nnz > 0 || ctx->comm != nullptr)) {
     // the propagation-blocked image is built on the device from the CSR arrays (histogram + scatter kernels)
     bool built = false;
     try {
       built = pb_build_device<T>(op.get());
     } catch (const Failure& f) {
-      if (ctx->comm == nullptr) throw;
-      built = false;  // the peers are told below; the image is simply not used
+      // The image is the matrix again plus a product buffer (peak at creation: CSR + PB + timing scratch, about 2.3 x the
+      // matrix).  When it does not fit, a matrix that fits as CSR alone is still usable: keep CSR-stream (sharded
+      // contexts: the peers are told below) — unless LL_SPMV_KERNEL=pb asked for this image specifically.
+      const bool out_of_memory = f.code == LL_ERR_ALLOC;
+      if (ctx->comm == nullptr && !(out_of_memory && want == 0)) throw;
+      (void)hipGetLastError();
+      built = false;
     }
+    if (!built) release_image(op.get(), LL_SPMV_CSR_STREAM);  // whatever part of the image was allocated
     if (all_ranks_agree(built)) {
-      if (want == "pb") op->spmv_kind = LL_SPMV_PB;
+      if (want == 2) op->spmv_kind = LL_SPMV_PB;
       else autotune_spmv<T>(op.get());
     } else if (built) {
       op->spmv_kind = LL_SPMV_CSR_STREAM;  // some rank could not build it: nobody uses it
@@ -862,7 +935,7 @@ int ll_op_destroy(ll_operator* op) {
 int ll_op_select_spmv(ll_operator* op, int kind) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
-    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB || (kind == LL_SPMV_L2G_EXPERIMENT && op->d_l2_val),
+    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB,
                "unknown SpMV kernel");
     LL_REQUIRE(kind != LL_SPMV_PB || op->d_pb_val != nullptr,
                "operator has no propagation-blocked image (not selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");

@@ -77,6 +77,11 @@ __device__ __forceinline__ void fnma_acc(cf& w, zc h, cf u) {
   fnma_acc(t, h, to_acc(u));
   w = cf{(float)t.re, (float)t.im};
 }
+// |re| + |im| (>= the modulus): the magnitude the fixed-point scales of the PB SpMV are built from
+__device__ __forceinline__ double abs1(double a) { return fabs(a); }
+__device__ __forceinline__ double abs1(float a) { return fabs((double)a); }
+__device__ __forceinline__ double abs1(zc a) { return fabs(a.re) + fabs(a.im); }
+__device__ __forceinline__ double abs1(cf a) { return fabs((double)a.re) + fabs((double)a.im); }
 __device__ __forceinline__ double abs2(double a) { return a * a; }
 __device__ __forceinline__ double abs2(float a) { return (double)a * (double)a; }
 __device__ __forceinline__ double abs2(zc a) { return fma(a.re, a.re, a.im * a.im); }

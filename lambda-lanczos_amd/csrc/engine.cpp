@@ -20,19 +20,13 @@ static inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-// DGKS "twice is enough": a second Gram-Schmidt pass is due when the first one removed more than this fraction of
-// ||w||^2.  LL_DGKS_THRESHOLD overrides the 1/2 (testing: a value > 1 forces the second pass in every iteration).
-static bool tridiag_thread_enabled() {
-  const char* e = std::getenv("LL_TRIDIAG_THREAD");
-  return !(e && std::atoi(e) == 0);
-}
-// Sharded contexts consume the helper thread's verdicts a fixed number of iterations late (StepWorker::consume); each
-// stop costs that many speculative iterations, a slow host step is hidden for that many.  LL_TRIDIAG_LAG overrides
-// (negative: the single-process opportunistic policy — unsafe with more than one rank, kept to demonstrate the hang).
-static int64_t tridiag_lockstep_lag() {
-  const char* e = std::getenv("LL_TRIDIAG_LAG");
-  return e ? std::max(-1, std::atoi(e)) : 3;
-}
+// Environment switches used below come from ctx->tune (read once per context, ll_internal.hpp):
+//   dgks_threshold  DGKS "twice is enough": a second Gram-Schmidt pass is due when the first one removed more than this
+//                   fraction of ||w||^2 (LL_DGKS_THRESHOLD; a value > 1 forces the second pass in every iteration: tests).
+//   tridiag_lag     sharded contexts consume the helper thread's verdicts a fixed number of iterations late
+//                   (StepWorker::consume); each stop costs that many speculative iterations, a slow host step is hidden
+//                   for that many (LL_TRIDIAG_LAG; negative: the single-process opportunistic policy — unsafe with more
+//                   than one rank, kept to demonstrate the hang).
 // Whole-loop entry points accept host OR device memory for their n-sized inputs and outputs (start vector, Ritz
 // vectors, Exponentiator input/output): a device pointer keeps the vector in HBM (no PCIe crossing, no staging).
 static bool is_device_ptr(const void* p) {
@@ -50,8 +44,8 @@ struct StallTrace {
   double limit_s = -1.0;
   const char* what;
   std::vector<std::pair<const char*, double>> pts;
-  explicit StallTrace(const char* w) : what(w) {
-    if (const char* e = std::getenv("LL_STALL_TRACE")) limit_s = std::atof(e) * 1e-3;
+  StallTrace(const char* w, double limit_ms) : what(w) {
+    if (limit_ms >= 0) limit_s = limit_ms * 1e-3;
     if (limit_s >= 0) pts.emplace_back("start", now_s());
   }
   void at(const char* label) {
@@ -64,10 +58,6 @@ struct StallTrace {
     std::fprintf(stderr, "\n");
   }
 };
-static double dgks_threshold() {
-  const char* e = std::getenv("LL_DGKS_THRESHOLD");
-  return e ? std::atof(e) : 0.5;
-}
 
 // ================================================================= Basis / RunList
 template <typename T> Basis<T>::~Basis() {
@@ -176,11 +166,16 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
   LL_HIP(hipStreamSynchronize(ctx->stream));
 }
 
+template <typename T> double* Engine<T>::xmax_buffer() {
+  if (!ctx->d_xmax) ctx->dev_malloc((void**)&ctx->d_xmax, (size_t)kMaxGrid * sizeof(double), "maxima of |u_k|");
+  return ctx->d_xmax;
+}
+
 template <typename T>
 void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer) {
   TraceRange trace("ll::apply (mv_mul + offset + alpha)");
   hipStream_t s = ctx->stream;
-  ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)std::max(op->pb_nrb, op->l2_nrb)));
+  ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)op->pb_nrb));
   double* const dotp = d_alpha ? ctx->d_alpha_partials : nullptr;
   int nparts = 0;
   if (op->kind == ll_operator::STENCIL) {
@@ -236,7 +231,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         plan.start[0] = 0;
         plan.len[0] = op->n_shard;
       }
-      const bool overlap = pb && ctx->overlap && ctx->comm_stream != nullptr;
+      const bool overlap = pb && ctx->tune.comm_overlap && ctx->comm_stream != nullptr;
       hipStream_t cs = overlap ? ctx->comm_stream : s;
       comm_timer_begin(cs);
       if (overlap) {
@@ -263,10 +258,11 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     if (remote_done) {
     } else if (op->kind == ll_operator::DENSE)
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s);
-    else if (pb)
-      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s);
-    else if (op->spmv_kind == LL_SPMV_L2G_EXPERIMENT)
-      nparts = launch_spmv_l2g<T>(*op, x_full, x_local, y, offset, dotp, s);
+    else if (pb) {
+      const bool have_max = xmax_of == (const void*)x_local && xmax_n > 0 && ctx->comm == nullptr;
+      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, have_max ? ctx->d_xmax : nullptr,
+                                 have_max ? xmax_n : 0);
+    }
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s);
   } else {
@@ -351,7 +347,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     none.nseg = 0;
     none.ld = runs.ld;
     ctx->ensure_partials(kMaxGrid);
-    const int grid = launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, s);
+    const int grid = launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     if (publish && !sharded && publish->can_defer) {
       *publish = Publish{publish->host, publish->alpha, true, true, true, ctx->d_partials, grid, c + 1, nullptr};
     } else if (publish && !sharded) {
@@ -371,7 +367,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
       BasisSegs<T> none;
       none.nseg = 0;
       none.ld = runs.ld;
-      launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, s);
+      launch_mdot<T>(n_local, w, none, tt, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     }
     int j = 0, grid = 0;
     for (auto& r : runs.runs)
@@ -381,10 +377,10 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
         one.ld = runs.ld;
         one.base[0] = r.first + (int64_t)i * runs.ld;
         one.count[0] = 1;
-        grid = launch_mdot<T>(n_local, w, one, no_tt, nullptr, ctx->d_partials, s);
+        grid = launch_mdot<T>(n_local, w, one, no_tt, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
         launch_reduce_cols(ctx->d_partials, grid, R + 1, h1 + R * j, S(kScalSpare), s);
         all_reduce(h1 + R * j, R);
-        grid = launch_maxpy<T>(n_local, w, one, h1 + R * j, nullptr, ctx->d_partials, s);
+        grid = launch_maxpy<T>(n_local, w, one, h1 + R * j, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
       }
     launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
     all_reduce(c + 1, 1);
@@ -393,7 +389,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   }
 
   const std::vector<BasisSegs<T>> groups = runs.groups(max_vecs_per_launch<T>());
-  const NormRefs refs{c, c + 1, c + 2, mode == LL_ORTH_CGS2 ? 1 : 0, dgks_threshold()};
+  const NormRefs refs{c, c + 1, c + 2, mode == LL_ORTH_CGS2 ? 1 : 0, ctx->tune.dgks_threshold};
   const NormRefs* pred = mode == LL_ORTH_CGS2 ? nullptr : &refs;
   auto count_of = [](const BasisSegs<T>& g) {
     int t = 0;
@@ -409,7 +405,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   for (size_t g = 0; g < groups.size(); ++g) {
     const int nbg = count_of(groups[g]);
     const bool last = g + 1 == groups.size();
-    const int grid = launch_mdot<T>(n_local, w, groups[g], g == 0 ? tt : no_tt, nullptr, ctx->d_partials, s);
+    const int grid = launch_mdot<T>(n_local, w, groups[g], g == 0 ? tt : no_tt, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     launch_reduce_cols(ctx->d_partials, grid, R * nbg + 1, h1 + R * off, (last && !sharded) ? c : nullptr, s);
     off += nbg;
   }
@@ -417,10 +413,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   // (||w'||^2 = ||w||^2 - sum |h_j|^2 for an orthonormal basis) — one all-reduce per iteration less.  Its relative error
   // is eps * ||w||^2 / ||w'||^2, i.e. a few eps whenever the DGKS test (evaluated on these two numbers) does not ask
   // for a second pass anyway.  LL_SHARDED_NORM=measured restores the reduced-and-all-reduced partial norms of maxpy.
-  static const bool derive_norm = [] {
-    const char* e = std::getenv("LL_SHARDED_NORM");
-    return !(e && std::string(e) == "measured");
-  }();
+  const bool derive_norm = !ctx->tune.sharded_norm_measured;
   const bool derive = sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && derive_norm;
   if (sharded) {  // one all-reduce for all coefficients and the norm (latency-sized)
     all_reduce(h1, (size_t)R * nb + 1);
@@ -429,7 +422,7 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   off = 0;
   int grid = 0;
   for (size_t g = 0; g < groups.size(); ++g) {
-    grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, s);
+    grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     off += count_of(groups[g]);
   }
   if (derive) {  // norm + copy of ||w||^2 + (whole-loop drivers) the publish step in one small launch
@@ -453,14 +446,14 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
   off = 0;
   for (size_t g = 0; g < groups.size(); ++g) {
     const int nbg = count_of(groups[g]);
-    const int g2 = launch_mdot<T>(n_local, w, groups[g], no_tt, pred, ctx->d_partials, s);
+    const int g2 = launch_mdot<T>(n_local, w, groups[g], no_tt, pred, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     launch_reduce_cols(ctx->d_partials, g2, R * nbg + 1, h2 + R * off, S(kScalSpare), s);
     off += nbg;
   }
   if (sharded) all_reduce(h2, (size_t)R * nb);
   off = 0;
   for (size_t g = 0; g < groups.size(); ++g) {
-    grid = launch_maxpy<T>(n_local, w, groups[g], h2 + R * off, pred, ctx->d_partials, s);
+    grid = launch_maxpy<T>(n_local, w, groups[g], h2 + R * off, pred, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     off += count_of(groups[g]);
   }
   launch_reduce_cols(ctx->d_partials, grid, 1, c + 2, nullptr, s);
@@ -476,6 +469,7 @@ template <typename T> double Engine<T>::second_pass(T* u, const RunList<T>& runs
   const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
   const NormRefs r = orth(u, runs, LL_ORTH_CGS_DGKS, no_tt, S(kScalScratch), nullptr, true);
   launch_scale<T>(n_local, u, 0.0, &r, ctx->stream);
+  if (xmax_of == (const void*)u) xmax_of = nullptr;  // u changed: the maxima left by its normalisation are stale
   double shrink = 0.0;
   fetch(r.c1, &shrink, 1);
   return shrink;
@@ -584,11 +578,9 @@ inline cf as_real_coeff(double v, cf*) { return cf{(float)v, 0.0f}; }
 // std::vector; its Lanczos vectors are allocated one by one.  Here a slab is one hipMalloc, so it is capped by BYTES
 // (4 GiB, LL_SLAB_BYTES overrides): a run that converges after 30 iterations of an n = 1e8 problem must not need
 // 200 vectors of HBM up front.  Slabs are appended on demand and cached in the context between runs.
-int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration, int64_t vec_bytes) {
+int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration, int64_t vec_bytes, int64_t cap_bytes) {
   int64_t want = initial_vector_size > 0 ? initial_vector_size : 200;
   want = std::min(want, max_iteration + 2);
-  int64_t cap_bytes = (int64_t)4 << 30;
-  if (const char* e = std::getenv("LL_SLAB_BYTES")) cap_bytes = std::max<int64_t>(1, std::atoll(e));
   want = std::min(want, cap_bytes / std::max<int64_t>(vec_bytes, 1));
   return std::max<int64_t>(want, 4);
 }
@@ -623,16 +615,17 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   const int64_t n = op->n, nl = op->n_local;
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   const int mode = P.orth_mode;
-  const double dgks_thr = dgks_threshold();
-  const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
+  const double dgks_thr = ctx->tune.dgks_threshold;
   // Two launches per iteration less on single-GPU runs: alpha is folded by the multi-dot that needs it, and the fold of
   // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
-  const bool fuse_launches = fuse_publish && !(std::getenv("LL_FUSE_LAUNCHES") && std::atoi(std::getenv("LL_FUSE_LAUNCHES")) == 0);
+  const bool fuse_launches = ctx->tune.fuse_launches;
   Engine<T> E(ctx, op, nl);
+  // the pre-scaled fixed-point SpMV wants max|u_k| before its phase 1 starts: the normalisation kernel leaves it behind
+  const bool want_xmax = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB && op->pb_prescaled;
   constexpr int R = scalar_traits<T>::reals;
 
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T)));
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
   DevBuf<T> d_locked, d_ritz;
   int64_t d_ritz_cap = 0;
   if (spec) {
@@ -668,6 +661,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
 
   while (true) {  // restart loop LL:334-354
     const int64_t nroot = spec ? spec->nroot : std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
+    E.xmax_of = nullptr;
     const double t_pass0 = now_s();
     // ---- start vector (LL:231-234)
     if (P.init_vector_dev) {  // start vector already in HBM (copied: the caller's buffer is left untouched)
@@ -732,9 +726,14 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       runs.add_basis(U, k);     // P6
       typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
       pub.can_defer = fuse_launches;
-      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, fuse_publish ? &pub : nullptr);  // ... P7
+      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, &pub);  // ... P7
       if (pub.deferred) {  // norm fold + publish + normalisation in one launch (P8)
-        launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, s);
+        double* xm = want_xmax ? E.xmax_buffer() : nullptr;
+        const int g = launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, xm, s);
+        if (xm) {  // the next SpMV reads y: it finds the maxima of |y| ready (fixed-point PB kernels)
+          E.xmax_of = y;
+          E.xmax_n = g;
+        }
         LL_HIP(hipEventRecord(ring.ev[slot], s));
       } else {
         if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
@@ -766,10 +765,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     // confirmations of LL_TRIDIAG_AUTO near convergence at large m (190 ms at m = 3300 against 9 ms per device
     // iteration at n = 1e6) — so the bound is generous; while the helper keeps up the verdicts are one iteration late
     // like before.  LL_TRIDIAG_THREAD=0 computes the verdicts inline (lag 1, the round-1 behaviour).
-    const bool threaded = speculate && tridiag_thread_enabled();
+    const bool threaded = speculate && ctx->tune.tridiag_thread;
     const size_t kMaxLag = threaded ? 24 : 0;
-    const int64_t lockstep_lag = threaded && ctx->comm != nullptr ? tridiag_lockstep_lag() : -1;  // see StepWorker::consume
-    TridiagWorker worker(tracker_cfg, threaded);
+    const int64_t lockstep_lag = threaded && ctx->comm != nullptr ? std::max(-1, ctx->tune.tridiag_lag) : -1;  // see StepWorker::consume
+    TridiagWorker worker(tracker_cfg, threaded, ctx->tune.tridiag_test_jitter_us);
     RitzTracker::Out last;
     auto absorb = [&](RitzTracker::Out& r) {
       t_tridiag += r.seconds;
@@ -1030,18 +1029,19 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   LL_HIP(hipSetDevice(ctx->device));
   const double t_start = now_s();
   hipStream_t s = ctx->stream;
-  StallTrace st("expo_run");
+  StallTrace st("expo_run", ctx->tune.stall_trace_ms);
   const int64_t nl = op->n_local;
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   Engine<T> E(ctx, op, nl);
+  // the pre-scaled fixed-point SpMV wants max|u_k| before its phase 1 starts: the normalisation kernel leaves it behind
+  const bool want_xmax = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB && op->pb_prescaled;
   st.at("engine");
-  const double dgks_thr = dgks_threshold();
-  const bool fuse_publish = !(std::getenv("LL_FUSE_PUBLISH") && std::atoi(std::getenv("LL_FUSE_PUBLISH")) == 0);
+  const double dgks_thr = ctx->tune.dgks_threshold;
   // Two launches per iteration less on single-GPU runs: alpha is folded by the multi-dot that needs it, and the fold of
   // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
-  const bool fuse_launches = fuse_publish && !(std::getenv("LL_FUSE_LAUNCHES") && std::atoi(std::getenv("LL_FUSE_LAUNCHES")) == 0);
+  const bool fuse_launches = ctx->tune.fuse_launches;
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T)));
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
   st.at("basis");
   ctx->ensure_pinned(16);
   EventRing ring;
@@ -1087,9 +1087,14 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     if (P.full_orthogonalize) runs.add_basis(U, k);  // EX:120-122
     typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
     pub.can_defer = fuse_launches;
-    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, fuse_publish ? &pub : nullptr);  // EX:145
+    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, &pub);  // EX:145
     if (pub.deferred) {  // norm fold + publish + normalisation (EX:160) in one launch
-      launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, s);
+      double* xm = want_xmax ? E.xmax_buffer() : nullptr;
+      const int g = launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, xm, s);
+      if (xm) {
+        E.xmax_of = y;
+        E.xmax_n = g;
+      }
       LL_HIP(hipEventRecord(ring.ev[slot], s));
     } else {
       if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
@@ -1108,10 +1113,10 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   tracker_cfg.eps = P.eps;
   tracker_cfg.breakdown_tol = (double)std::numeric_limits<typename scalar_traits<T>::real>::epsilon();  // EX:154
   const bool speculate = !(op->kind == ll_operator::HOST_CB || op->kind == ll_operator::DEV_CB);  // see lanczos_run
-  const bool threaded = speculate && tridiag_thread_enabled();
+  const bool threaded = speculate && ctx->tune.tridiag_thread;
   const size_t kMaxLag = threaded ? 24 : 0;
-  const int64_t lockstep_lag = threaded && ctx->comm != nullptr ? tridiag_lockstep_lag() : -1;  // see StepWorker::consume
-  StepWorker<ExpoTracker<H>> worker(tracker_cfg, threaded);
+  const int64_t lockstep_lag = threaded && ctx->comm != nullptr ? std::max(-1, ctx->tune.tridiag_lag) : -1;  // see StepWorker::consume
+  StepWorker<ExpoTracker<H>> worker(tracker_cfg, threaded, ctx->tune.tridiag_test_jitter_us);
   typename ExpoTracker<H>::Out last, r;
   auto absorb = [&](typename ExpoTracker<H>::Out& o) {
     t_tridiag += o.seconds;
@@ -1224,8 +1229,11 @@ void taylor_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P, typen
   LL_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const int64_t nl = op->n_local;
-  if (a == H(0)) {  // EX:179-182
-    std::memcpy(output, input, (size_t)nl * sizeof(T));
+  if (a == H(0)) {  // EX:179-182; input / output may be host or device memory, and may be the same buffer
+    if (output != input) {
+      LL_HIP(hipMemcpyAsync(output, input, (size_t)nl * sizeof(T), hipMemcpyDefault, s));
+      LL_HIP(hipStreamSynchronize(s));
+    }
     *nterms_out = 1;
     return;
   }

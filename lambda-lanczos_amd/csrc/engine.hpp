@@ -73,6 +73,12 @@ template <typename T> struct Engine {
     const double* partials = nullptr;
     int nparts = 0;
   };
+  // xmax_of (single GPU): the vector whose per-workgroup maxima of |.| currently sit in ctx->d_xmax (xmax_n of them), left
+  // by the normalisation kernel that produced it; apply() hands them to the fixed-point SpMV when x is that vector.
+  // Anything that modifies the vector afterwards must reset xmax_of.
+  const void* xmax_of = nullptr;
+  int xmax_n = 0;
+  double* xmax_buffer();  // ctx->d_xmax, allocated on first use
   void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false, DeferredAlpha* defer = nullptr);
   // Orthogonalise w against the runs with an optional fused three-term update; c = device triple for the norms.
   // Returns the NormRefs every consumer must use for ||w|| afterwards.  h_total (device, nullable): R*nb doubles.

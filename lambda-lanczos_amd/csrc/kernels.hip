@@ -107,10 +107,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
 
 // Persistent grid of the CSR-stream kernel: 8 workgroups per CU for 4- and 8-byte values, 16 for complex double (20 KB
 // of matrix per tile: 24.8 us instead of 27.4 us per SpMV on config 5, 68 % instead of 62 % of the roofline; config 2 is
-// best at 8: 17.8 us against 18.2 us).  LL_SPMV_GRID overrides (at most kMaxSpmvGrid: the alpha partials are sized for it).
+// best at 8: 17.8 us against 18.2 us; profiles/r02_csr_stream_grid_sweep.txt).
 static int spmv_grid(int ntiles, size_t elem_bytes) {
-  int cap = elem_bytes >= 16 ? kMaxSpmvGrid : kMaxGrid;
-  if (const char* e = std::getenv("LL_SPMV_GRID")) cap = std::min(kMaxSpmvGrid, std::max(kXcds, std::atoi(e) / kXcds * kXcds));
+  const int cap = elem_bytes >= 16 ? kMaxSpmvGrid : kMaxGrid;
   int g = ntiles < cap ? ((ntiles + kXcds - 1) / kXcds) * kXcds : cap;
   return g < kXcds ? kXcds : g;
 }
@@ -145,12 +144,9 @@ template <typename T> struct strip {
 };
 // The Gram-Schmidt kernels come in two geometries: STREAMING (below; vectors of >= 4 MiB: enough 16 KiB strips to fill
 // the chip, every load a full line) and SMALL-VECTOR (mdot_small / maxpy_small further down; n <~ 5e5 doubles, the
-// reference's everyday sizes).  LL_BLAS_SMALL_BYTES moves the boundary (0 = always streaming, huge = always small).
-static bool blas_small(int64_t n, size_t elem_bytes) {  // LL_BLAS_SMALL_BYTES: 0 = always streaming, huge = always small
-  const char* e = std::getenv("LL_BLAS_SMALL_BYTES");     // (read per launch: the tests flip it inside one process)
-  const int64_t limit = e ? std::atoll(e) : (int64_t)4 << 20;
-  return n * (int64_t)elem_bytes < limit;
-}
+// reference's everyday sizes).  The boundary is Tuning::blas_small_bytes (LL_BLAS_SMALL_BYTES: 0 = always streaming,
+// huge = always small), handed to the launchers by the caller.
+static bool blas_small(int64_t n, size_t elem_bytes, int64_t limit) { return n * (int64_t)elem_bytes < limit; }
 
 // Balanced persistent grid: every workgroup walks the same number of strips (grid-stride), so no tail round.
 // (Measured alternative, round 2: equal CONTIGUOUS shares per workgroup instead of strips dealt out round-robin —
@@ -161,11 +157,10 @@ static bool blas_small(int64_t n, size_t elem_bytes) {  // LL_BLAS_SMALL_BYTES: 
 // 10 MB shards of config 4: Gram-Schmidt -13 % / -9 % / -3 % (profiles/r02_strip_grid_sweep.txt).  At 8 MiB (config 2,
 // 489 strips) the small grid is 2 % slower: too few strips to balance.
 static int strip_grid(int64_t n, int elems) {
-  static const int env_target = std::getenv("LL_BLAS_GRID") ? std::max(64, std::atoi(std::getenv("LL_BLAS_GRID"))) : 0;
   int64_t strips = (n + elems - 1) / elems;
   if (strips < 1) strips = 1;
   const bool streaming = elems >= 1024;  // the small-vector kernels' strips are 64 .. 256 elements
-  const int target = env_target ? env_target : (streaming && strips > 2 * kCUs + kCUs / 4 ? kCUs : 1024);
+  const int target = streaming && strips > 2 * kCUs + kCUs / 4 ? kCUs : 1024;
   const int64_t per = (strips + target - 1) / target;
   return (int)((strips + per - 1) / per);
 }
@@ -223,7 +218,7 @@ __device__ __forceinline__ double fold_partials_all(const double* __restrict__ p
 
 // One trip of the multi-dot: NV basis strips against the strip of w held in registers; the NV (x2 for complex) wave
 // sums are added to the wave's LDS row `mine_col[0 .. R*NV)`.
-template <typename T, int NV, bool TR>
+template <typename T, int NV>
 __device__ __forceinline__ void mdot_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
                                           const T (&wr)[strip<T>::EPT], double* mine_col, int lane) {
   constexpr int EPT = strip<T>::EPT;
@@ -244,18 +239,9 @@ __device__ __forceinline__ void mdot_trip(const T* __restrict__ u0, int64_t ld, 
       a[b] = acc;
     }
   }
-  if constexpr (TR) {
-    wave_sum_transposed<NV * R>(a, lane);
-    constexpr int LPI = 64 / (NV * R);  // lanes that end up holding the same sum
-    if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
-  } else {  // one full wave sum per accumulator (LL_MDOT_REDUCE=plain)
-#pragma unroll
-    for (int i = 0; i < NV * R; ++i) a[i] = wave_sum(a[i]);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NV * R; ++i) mine_col[i] += a[i];
-    }
-  }
+  wave_sum_transposed<NV * R>(a, lane);
+  constexpr int LPI = 64 / (NV * R);  // lanes that end up holding the same sum
+  if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
 }
 
 // One trip of the multi-axpy: w -= sum_b h_b u_b for NV basis strips, coefficients from LDS.
@@ -282,7 +268,7 @@ __device__ __forceinline__ void maxpy_trip(const T* __restrict__ u0, int64_t ld,
 // three-term update w = w - beta u_prev - alpha u_cur is applied on the fly (saves 3R 1W of a separate sweep).
 // Per-wave partial sums live in LDS ([4][ncols]) across all strips of the workgroup; each workgroup finally writes
 // one row of ncols partials which reduce_cols folds in a fixed order (deterministic, no atomics).
-template <typename T, bool TR>
+template <typename T>
 __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
                                                       ThreeTerm<T> tt, NormRefs pred, int predicated,
                                                       double* __restrict__ partials, int ncols) {
@@ -336,9 +322,9 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
       // JB basis vectors per trip: all JB strips are requested before the first one is consumed, and their JB (x2 for
       // complex) wave sums are formed together
       int j = 0;
-      for (; j + JB <= cnt; j += JB, col += R * JB) mdot_trip<T, JB, TR>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane);
-      if (j + 2 <= cnt) { mdot_trip<T, 2, TR>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane); j += 2; col += R * 2; }
-      if (j < cnt) { mdot_trip<T, 1, TR>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane); j += 1; col += R; }
+      for (; j + JB <= cnt; j += JB, col += R * JB) mdot_trip<T, JB>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane);
+      if (j + 2 <= cnt) { mdot_trip<T, 2>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane); j += 2; col += R * 2; }
+      if (j < cnt) { mdot_trip<T, 1>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, mine + col, lane); j += 1; col += R; }
     }
     double nn = 0.0;
 #pragma unroll
@@ -593,12 +579,12 @@ __global__ __launch_bounds__(kBlock) void maxpy_small_kernel(int64_t n, T* __res
 
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
-                double* partials, hipStream_t s) {
+                double* partials, int64_t small_bytes, hipStream_t s) {
   int nb = 0;
   for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
   const int ncols = scalar_traits<T>::reals * nb + 1;
   const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
-  if (blas_small(n, sizeof(T))) {
+  if (blas_small(n, sizeof(T), small_bytes)) {
     const int grid = strip_grid(n, small_geom<T>::ELEMS);
     const size_t lds_bytes = ((size_t)((ncols + 15) & ~15) + 4 * 16 * kSmallTileRow) * sizeof(double);
     hipLaunchKernelGGL((mdot_small_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr, pred ? 1 : 0,
@@ -609,21 +595,16 @@ int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& t
   const int grid = strip_grid(n, strip<T>::ELEMS);
   const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
   // wave sums of the streaming geometry: the 4 (8) sums of a trip are formed with the transposing reduction (+0.5-1.3 %
-  // at n >= 1e6 against one full wave sum per vector); LL_MDOT_REDUCE=plain restores the latter (A/B)
-  const char* rmode = std::getenv("LL_MDOT_REDUCE");
-  if (rmode && rmode[0] == 'p')
-    hipLaunchKernelGGL((mdot_kernel<T, false>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr,
-                       pred ? 1 : 0, partials, ncols);
-  else
-    hipLaunchKernelGGL((mdot_kernel<T, true>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr,
-                       pred ? 1 : 0, partials, ncols);
+  // at n >= 1e6 against one full wave sum per vector, measured in round 2)
+  hipLaunchKernelGGL((mdot_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, tt, pr, pred ? 1 : 0, partials,
+                     ncols);
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_mdot<double>(int64_t, double*, const BasisSegs<double>&, const ThreeTerm<double>&, const NormRefs*, double*, hipStream_t);
-template int launch_mdot<zc>(int64_t, zc*, const BasisSegs<zc>&, const ThreeTerm<zc>&, const NormRefs*, double*, hipStream_t);
-template int launch_mdot<float>(int64_t, float*, const BasisSegs<float>&, const ThreeTerm<float>&, const NormRefs*, double*, hipStream_t);
-template int launch_mdot<cf>(int64_t, cf*, const BasisSegs<cf>&, const ThreeTerm<cf>&, const NormRefs*, double*, hipStream_t);
+template int launch_mdot<double>(int64_t, double*, const BasisSegs<double>&, const ThreeTerm<double>&, const NormRefs*, double*, int64_t, hipStream_t);
+template int launch_mdot<zc>(int64_t, zc*, const BasisSegs<zc>&, const ThreeTerm<zc>&, const NormRefs*, double*, int64_t, hipStream_t);
+template int launch_mdot<float>(int64_t, float*, const BasisSegs<float>&, const ThreeTerm<float>&, const NormRefs*, double*, int64_t, hipStream_t);
+template int launch_mdot<cf>(int64_t, cf*, const BasisSegs<cf>&, const ThreeTerm<cf>&, const NormRefs*, double*, int64_t, hipStream_t);
 
 // ================================================================= a5/a6 (update half) + a7: multi-axpy
 // w -= sum_j h_j u_j in one pass (w strip in registers, coefficients broadcast from LDS), then ||w||^2 of the
@@ -631,7 +612,7 @@ template int launch_mdot<cf>(int64_t, cf*, const BasisSegs<cf>&, const ThreeTerm
 template <typename T>
 __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
                                                        const double* __restrict__ h, int nb, NormRefs pred,
-                                                       int predicated, int reverse, double* __restrict__ partials) {
+                                                       int predicated, double* __restrict__ partials) {
   constexpr int EPT = strip<T>::EPT;
   constexpr int ELEMS = strip<T>::ELEMS;
   constexpr int JB = kJB;
@@ -647,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
   // Strips are walked in DESCENDING order: the multi-dot that ran just before walked them ascending, so the basis
   // strips it touched last are the ones most likely still in the Infinity Cache.
   for (int64_t sidx0 = blockIdx.x; sidx0 < nstrips; sidx0 += gridDim.x) {
-    const int64_t sidx = reverse ? nstrips - 1 - sidx0 : sidx0;
+    const int64_t sidx = nstrips - 1 - sidx0;
     const int64_t base = sidx * ELEMS;
     T wr[EPT];
     load_strip<T>(w, base, n, wr);
@@ -670,11 +651,11 @@ __global__ __launch_bounds__(kBlock) void maxpy_kernel(int64_t n, T* __restrict_
 
 template <typename T>
 int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
-                 hipStream_t s) {
+                 int64_t small_bytes, hipStream_t s) {
   int nb = 0;
   for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
   const NormRefs pr = pred ? *pred : NormRefs{nullptr, nullptr, nullptr, 1};
-  if (blas_small(n, sizeof(T))) {
+  if (blas_small(n, sizeof(T), small_bytes)) {
     constexpr int R = scalar_traits<T>::reals;
     const int grid = strip_grid(n, small_geom<T>::ELEMS);
     const size_t lds_bytes = ((size_t)((R * nb + 15) & ~15) + (size_t)kBlock * small_geom<T>::EPT * R) * sizeof(double);
@@ -685,19 +666,15 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
   }
   const int grid = strip_grid(n, strip<T>::ELEMS);
   const size_t lds_bytes = ((size_t)scalar_traits<T>::reals * nb + 4) * sizeof(double);
-  static const int reverse = [] {
-    const char* e = std::getenv("LL_MAXPY_REVERSE");
-    return e ? std::atoi(e) : 1;
-  }();
-  hipLaunchKernelGGL((maxpy_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr,
-                     pred ? 1 : 0, reverse, partials);
+  hipLaunchKernelGGL((maxpy_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr, pred ? 1 : 0,
+                     partials);
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_maxpy<double>(int64_t, double*, const BasisSegs<double>&, const double*, const NormRefs*, double*, hipStream_t);
-template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*, const NormRefs*, double*, hipStream_t);
-template int launch_maxpy<float>(int64_t, float*, const BasisSegs<float>&, const double*, const NormRefs*, double*, hipStream_t);
-template int launch_maxpy<cf>(int64_t, cf*, const BasisSegs<cf>&, const double*, const NormRefs*, double*, hipStream_t);
+template int launch_maxpy<double>(int64_t, double*, const BasisSegs<double>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
+template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
+template int launch_maxpy<float>(int64_t, float*, const BasisSegs<float>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
+template int launch_maxpy<cf>(int64_t, cf*, const BasisSegs<cf>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
 
 // ================================================================= deterministic fold of workgroup partials
 // out[j] = sum_b partials[b*ncols + j].  32 columns x 8 row-groups per workgroup; every column is folded in a
@@ -842,7 +819,8 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __restrict__ v,
                                                                const double* __restrict__ partials, int nparts,
                                                                double* __restrict__ out, const double* __restrict__ alpha,
-                                                               const double* __restrict__ c0, double* __restrict__ host) {
+                                                               const double* __restrict__ c0, double* __restrict__ host,
+                                                               double* __restrict__ xmax) {
   constexpr int EPT = strip<T>::EPT;
   __shared__ double fold_scratch[5];
   const double tot = fold_partials_all(partials, nparts, fold_scratch);  // the order of reduce_publish_kernel
@@ -855,26 +833,40 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
   }
   const double f = 1.0 / sqrt(tot);  // T(1)/norm, LA:77-80
   const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  double mx = 0.0;
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int64_t base = sidx * strip<T>::ELEMS;
     T r[EPT];
     load_strip<T>(v, base, n, r);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) r[e] = rmul(f, r[e]);
+    for (int e = 0; e < EPT; ++e) {
+      r[e] = rmul(f, r[e]);
+      mx = fmax(mx, abs1(r[e]));  // (elements beyond n are zero-filled by load_strip)
+    }
     store_strip<T>(v, base, n, r);
+  }
+  if (xmax != nullptr) {  // the maxima of |u_k| for the fixed-point SpMV that reads u_k next (spmv_pb.hip, pb_phase1_pre)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmax(mx, __shfl_down(mx, d, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) fold_scratch[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) xmax[blockIdx.x] = fmax(fmax(fold_scratch[0], fold_scratch[1]), fmax(fold_scratch[2], fold_scratch[3]));
   }
 }
 template <typename T>
-void launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
-                          const double* c0, double* host_mapped, hipStream_t s) {
-  hipLaunchKernelGGL((scale_publish_kernel<T>), dim3(strip_grid(n, strip<T>::ELEMS)), dim3(kBlock), 0, s, n, v, partials,
-                     nparts, out, alpha, c0, host_mapped);
+int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
+                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s) {
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  hipLaunchKernelGGL((scale_publish_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, v, partials, nparts, out, alpha, c0,
+                     host_mapped, xmax_out);
   LL_HIP(hipGetLastError());
+  return grid;
 }
-template void launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
-template void launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
-template void launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
-template void launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, hipStream_t);
+template int launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
+template int launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
+template int launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
+template int launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void three_term_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ up,
@@ -1344,10 +1336,7 @@ int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, co
   g.n_local = op.n_local;
   typedef typename scalar_traits<T>::real R;
   constexpr int V = (int)(32 / sizeof(T));
-  static const bool allow_vec = [] {
-    const char* e = std::getenv("LL_STENCIL_VEC");
-    return !e || std::atoi(e) != 0;
-  }();
+  const bool allow_vec = op.ctx == nullptr || op.ctx->tune.stencil_vec;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool ptrs_ok = aligned16(x_local) && aligned16(y) && (g.ndim == 1 || (aligned16(halo_lo) && aligned16(halo_hi)));
   if (allow_vec && ptrs_ok && op.n_local >= V && g.dims[g.ndim - 1] % V == 0 && op.row_begin % V == 0 &&

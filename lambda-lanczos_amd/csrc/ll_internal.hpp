@@ -140,8 +140,43 @@ struct GatherPlan {
 };
 }  // namespace ll
 
+// ---------------------------------------------------------------- environment switches
+// Every LL_* switch of the library (INTEGRATION.md section 8 is the user-facing list).  They are read ONCE, when a
+// context is created (ll_ctx_create*), into the context; operators copy what shapes their image when THEY are created.
+// Nothing on a launch path calls getenv.  ll_ctx_reload_env() reads them again (tests and tuning scripts that flip a
+// switch inside one process).
+namespace ll {
+struct Tuning {
+  // --- operator creation
+  int spmv_kernel = 0;             // LL_SPMV_KERNEL = auto (0, time both and keep the faster) | csr (1) | pb (2)
+  bool keep_both = false;          // LL_SPMV_KEEP_BOTH=1: keep the image that lost the timing (ll_op_select_spmv A/B)
+  int pb_phase2 = 4;               // LL_PB_PHASE2 = fixed (4, default) | ordered (1) | atomic (0); see spmv_pb.hip
+  int pb_block = 0;                // LL_PB_BLOCK: rows AND columns per block (0: automatic); tests force ragged blocks
+  int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
+  int pb_col_block = 0;
+  int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
+  bool comm_overlap = true;        // LL_COMM_OVERLAP=0: exchange and compute on one stream (serial A/B reference)
+  // --- the loops
+  bool tridiag_thread = true;      // LL_TRIDIAG_THREAD=0: host Ritz step inline instead of on the helper thread
+  int tridiag_lag = 3;             // LL_TRIDIAG_LAG: fixed verdict lag of sharded runs (engine.cpp)
+  double dgks_threshold = 0.5;     // LL_DGKS_THRESHOLD: second Gram-Schmidt pass when ||w'||^2 < thr * ||w||^2
+  bool sharded_norm_measured = false;  // LL_SHARDED_NORM=measured: all-reduce the post-pass norm instead of deriving it
+  int64_t slab_bytes = (int64_t)4 << 30;       // LL_SLAB_BYTES: cap of one Krylov-basis slab
+  int64_t blas_small_bytes = (int64_t)4 << 20;  // LL_BLAS_SMALL_BYTES: vectors below this use the small-vector kernels
+  bool fuse_launches = true;       // LL_FUSE_LAUNCHES=0: separate fold / publish kernels (A/B of the launch fusion)
+  // --- test hooks (not for users)
+  bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
+  bool pb_test_all_remote = false; // LL_PB_TEST_ALL_REMOTE=1: own columns are read from the gathered buffer too
+  int tridiag_test_jitter_us = 0;  // LL_TRIDIAG_TEST_JITTER_US: random delay of every helper-thread verdict
+  bool stencil_vec = true;         // LL_STENCIL_VEC=0: scalar lattice kernel on shapes the vector kernel would take
+  double stall_trace_ms = -1.0;    // LL_STALL_TRACE: print where a whole-loop call longer than this spent its time
+};
+Tuning read_tuning();  // capi.cpp
+}  // namespace ll
+
 // ---------------------------------------------------------------- context
 struct ll_context {
+  ll::Tuning tune;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -152,7 +187,6 @@ struct ll_context {
   // SpMV work on the rank's own columns runs under it and every chunk's remote-column work starts when that chunk
   // has arrived.  LL_COMM_OVERLAP=0 issues everything on `stream` instead (serial reference path for A/B tests).
   hipStream_t comm_stream = nullptr;
-  bool overlap = true;
   hipEvent_t ev_x_ready = nullptr;
   hipEvent_t ev_chunk[ll::kMaxGatherChunks] = {};
   bool profiling = false;
@@ -166,6 +200,7 @@ struct ll_context {
   double* d_h = nullptr;         // reduced projection coefficients / small scalars
   size_t h_cap = 0;              // doubles
   double* d_scal = nullptr;      // 64 doubles of device scalars (ring slots, flags)
+  double* d_xmax = nullptr;      // kMaxGrid per-workgroup maxima of |u_k| left by the normalisation kernel (lazily sized)
   double* h_pinned = nullptr;    // pinned host mirror for scalar read-back
   size_t pinned_cap = 0;         // doubles
   void* d_coeff = nullptr;       // coefficient upload area for gemv_basis
@@ -232,10 +267,11 @@ struct ll_operator {
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
   int16_t* d_pb_rexp = nullptr;      // LL_PB_PHASE2=fixed: exponent of every local row's absolute sum
   double* d_pb_blockmax = nullptr;   // LL_PB_PHASE2=fixed: max |x| per column block, left by phase 1
+  bool pb_prescaled = false;         // fixed-point sums with phase 1 writing integers on the row's grid (spmv_pb.hip)
+  double* d_pb_xmax = nullptr;       //   per-workgroup maxima of |x| when nobody else provides them (kMaxGrid doubles)
+  int* d_pb_ex = nullptr;            //   exponent of max |x| of the launch in flight (phase 1 -> phase 2)
   int64_t pb_entries = 0;            // padded entry count of the image
-  // kernel variants, read from the environment when the image is built (LL_PB_U1 / LL_PB_U2: quads per lane per trip;
-  // LL_PB_PHASE2=atomic: arrival-order LDS adds instead of the wave-ordered, bit-reproducible ones; LL_PB_ROW_GROUPS)
-  int pb_u1 = 1, pb_u2 = 2, pb_ordered = 1, pb_row_groups = 1, pb_depth = 3, pb_xprop = 0;  // pb_xprop: LL_PB_XPROP (x propagation, see spmv_pb.hip)  // pb_depth: trips of loads in flight (LL_PB_DEPTH)
+  int pb_phase2 = 4;                 // form of phase 2 (ll::LL_PB_FIXED / _ORDERED / _ATOMIC), fixed when the image is built
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
@@ -243,12 +279,6 @@ struct ll_operator {
   int pb_chunk_first[ll::kMaxGatherChunks] = {0};  // remote blocks of gather chunk c: [first, first + count)
   int pb_chunk_count[ll::kMaxGatherChunks] = {0};
   ll::GatherPlan gather;             // how a sharded vector is all-gathered when the PB kernels are selected
-  // EXPERIMENT: L2-blocked gather image (spmv_l2g.hip; only with LL_SPMV_KERNEL=l2g)
-  int l2_nrb = 0, l2_nsl = 0, l2_rb_rows = 0, l2_slice_log2 = 18;
-  void* d_l2_val = nullptr;
-  uint32_t* d_l2_idx = nullptr;
-  int64_t* d_l2_ptr = nullptr;
-  unsigned* d_l2_sync = nullptr;
   // dense row-major block (kind DENSE): n_local x n values of T
   void* d_dense = nullptr;
   // lattice operator (kind STENCIL)
@@ -280,19 +310,17 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
 // blocks (x slices from x_own: the local shard readable up to the shard stride), then over every gather chunk's remote blocks (x slices from x_gathered, laid out
 // per op.gather), then phase 2.  The pieces are exposed so that the sharded driver can run the own-column part under
 // the all-gather and each chunk's part as soon as that chunk has arrived.
+// xmax / xmax_n (nullable): per-workgroup maxima of |x| left behind by the kernel that produced x (the pre-scaled
+// fixed-point form needs max|x| before phase 1 starts; without them it sweeps x once more).
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s);
+                   double* dot_partials, hipStream_t s, const double* xmax = nullptr, int xmax_n = 0);
 template <typename T>
 void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s);
 template <typename T>
 int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials, hipStream_t s);
-// EXPERIMENT (LL_SPMV_KERNEL=l2g, single GPU): L2-blocked gather kernel and its host-built image (spmv_l2g.hip).
-template <typename T>
-int launch_spmv_l2g(const ll_operator& op, const T* x, const T* x_local, T* y, double offset, double* dot_partials,
-                    hipStream_t s);
-template <typename T> bool l2g_build_host(ll_operator* op, const int64_t* rp, const int32_t* ci, const T* va);
-constexpr int LL_SPMV_L2G_EXPERIMENT = 2;
+// forms of PB phase 2 (Tuning::pb_phase2, ll_operator::pb_phase2)
+constexpr int LL_PB_ATOMIC = 0, LL_PB_ORDERED = 1, LL_PB_FIXED = 4;
 // Build the propagation-blocked image on the device from the operator's CSR arrays (false: shape not supported).
 template <typename T> bool pb_build_device(ll_operator* op);
 // Column range check + max absolute row sum of the local rows (sets op->inf_norm), on the device.
@@ -341,21 +369,24 @@ template <typename T> struct ThreeTerm {
   int alpha_nparts = 0;
   double* alpha_out = nullptr;
 };
+// small_bytes: vectors shorter than this many bytes take the small-vector geometry (Tuning::blas_small_bytes).
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
-                double* partials, hipStream_t s);
+                double* partials, int64_t small_bytes, hipStream_t s);
 // w -= sum_j h_j u_j over the segments; partial ||w||^2 per workgroup. h: reals*nb doubles on the device.
 template <typename T>
 int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
-                 hipStream_t s);
+                 int64_t small_bytes, hipStream_t s);
 // v *= factor, factor = a (host value) when norms == nullptr, else 1/sqrt(final norm^2).
 template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRefs* norms, hipStream_t s);
 // scale fused with the fold of the post-pass norm and the publish step (single-GPU whole-loop drivers): every workgroup
 // folds the `nparts` norm partials in the same fixed order, v *= 1/sqrt(sum); workgroup 0 stores the sum to *out and the
 // iteration's four scalars (alpha, sum, c0, sum) to the pinned host slot.
+// xmax_out (nullable, kMaxGrid doubles): the per-workgroup maxima of |v| after scaling (|re| + |im| for complex), for the
+// fixed-point SpMV that reads v next.  Returns the grid = number of maxima written.
 template <typename T>
-void launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
-                          const double* c0, double* host_mapped, hipStream_t s);
+int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
+                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s);
 // Plain three-term update with host scalars (primitive API).
 template <typename T>
 void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double beta, double alpha, hipStream_t s);

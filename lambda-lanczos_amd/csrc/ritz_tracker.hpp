@@ -198,10 +198,10 @@ template <typename H> struct ExpoTracker {
 template <typename Tracker> class StepWorker {
  public:
   typedef typename Tracker::Out Out;
-  explicit StepWorker(const Tracker& cfg, bool threaded) : tracker_(cfg), threaded_(threaded) {
-    // test hook: every verdict is held back by a pseudo-random time up to this many microseconds, differently in every
-    // process, to show that ranks of a sharded run still enqueue the same iterations (tests/test_gpu_multirank.py)
-    if (const char* e = std::getenv("LL_TRIDIAG_TEST_JITTER_US")) jitter_us_ = std::atoi(e);
+  // jitter_us (test hook, LL_TRIDIAG_TEST_JITTER_US): every verdict is held back by a pseudo-random time up to this many
+  // microseconds, differently in every process, to show that ranks of a sharded run still enqueue the same iterations
+  // (tests/test_gpu_multirank.py)
+  StepWorker(const Tracker& cfg, bool threaded, int jitter_us = 0) : tracker_(cfg), threaded_(threaded), jitter_us_(jitter_us) {
     if (threaded_) thread_ = std::thread([this] { run(); });
   }
   ~StepWorker() {

@@ -40,11 +40,6 @@ constexpr int kPbThreads = 1024;
 constexpr int kPbWaves = kPbThreads / 64;
 
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
-// |re| + |im| (>= the modulus): the magnitude the fixed-point scales are built from
-__device__ __forceinline__ double abs1(double a) { return fabs(a); }
-__device__ __forceinline__ double abs1(float a) { return fabs((double)a); }
-__device__ __forceinline__ double abs1(zc a) { return fabs(a.re) + fabs(a.im); }
-__device__ __forceinline__ double abs1(cf a) { return fabs((double)a.re) + fabs((double)a.im); }
 
 // Entries are handled in QUADS: every segment is padded to a multiple of 16 entries (zero value, local index 0), so
 // a lane always moves four consecutive entries with 16-byte accesses (2 x dwordx4 of values / products, one dwordx2
@@ -72,17 +67,11 @@ template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__
 }
 
 // ================================================================= phase 1
-// Workgroup b handles column block blk_first + b, restricted to the destination row blocks [rb_first, rb_first +
-// rb_count) (the whole range in production; a sub-range only for the row-group experiment LL_PB_ROW_GROUPS).
-// The first trip's loads are issued before the x slice is staged, and every trip requests the next one before it
-// consumes its own (U quads per lane per trip, 2U in flight).
-// XP ("x propagation"): phase 1 writes the gathered x value itself instead of the product, and phase 2 — whose
-// streams are all reads — multiplies by the matrix value (stored in row-block order for that).  Same bytes in total
-// (28 per nonzero), same products, same sums; but 8 of the 18 bytes that phase 1 would read move from the kernel that
-// mixes reads with writes (the slow direction mix for HBM) into the read-only kernel.
-template <typename T, int U, bool XP>
-__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, int rb_count, int blk_first,
-                                                        const int64_t* __restrict__ xoff,
+// Workgroup b handles column block blk_first + b.  The first trip's loads are issued before the x slice is staged, and
+// every trip requests the next one before it consumes its own (one quad per lane per trip, two in flight; two or four
+// quads per trip were measured 3-5 % slower in round 2).
+template <typename T>
+__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, const int64_t* __restrict__ xoff,
                                                         const int32_t* __restrict__ ncols_tab,
                                                         const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
                                                         const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
@@ -93,23 +82,19 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
   __shared__ double bm_red[kPbWaves];
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
   long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
-                                              (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [rb_count + 1]
-  long long* db = qs + (rb_count + 1);                                             // [rb_count]
+                                              (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [nrb + 1]
+  long long* db = qs + (nrb + 1);                                                  // [nrb]
   const int tid = threadIdx.x;
   const int c = blk_first + blockIdx.x;
-  const int64_t* sq = seg_q + (size_t)c * (nrb + 1) + rb_first;
-  const long long g0 = sq[0] >> 2, g1 = sq[rb_count] >> 2;
+  const int64_t* sq = seg_q + (size_t)c * (nrb + 1);
+  const long long g0 = sq[0] >> 2, g1 = sq[nrb] >> 2;
 
-  quad<T> v[U];
-  ushort4 cl[U];
+  quad<T> v;
+  ushort4 cl;
   long long g = g0 + tid;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long long gg = g + (long long)u * kPbThreads;
-    if (gg < g1) {
-      if constexpr (!XP) v[u] = load_quad<T>(val + 4 * gg);
-      cl[u] = col[gg];
-    }
+  if (g < g1) {
+    v = load_quad<T>(val + 4 * g);
+    cl = col[g];
   }
   {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
     const int ncols = ncols_tab[c];
@@ -124,9 +109,9 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
     } else {
       for (int i = tid; i < ncols; i += kPbThreads) xs[i] = src[i];
     }
-    for (int i = tid; i <= rb_count; i += kPbThreads) qs[i] = sq[i];
-    const int64_t* sd = seg_dest + (size_t)c * nrb + rb_first;
-    for (int i = tid; i < rb_count; i += kPbThreads) db[i] = sd[i];
+    for (int i = tid; i <= nrb; i += kPbThreads) qs[i] = sq[i];
+    const int64_t* sd = seg_dest + (size_t)c * nrb;
+    for (int i = tid; i < nrb; i += kPbThreads) db[i] = sd[i];
   }
   __syncthreads();
   if (blockmax != nullptr) {  // fixed-point phase 2: the largest |x| of the slice (its scale needs max |x| over all columns)
@@ -144,42 +129,24 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int rb_first, i
     }
   }
   int r = 0;
-  for (; g < g1; g += (long long)U * kPbThreads) {
-    quad<T> vn[U];
-    ushort4 cn[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long gg = g + (long long)(U + u) * kPbThreads;
-      if (gg < g1) {
-        if constexpr (!XP) vn[u] = load_quad<T>(val + 4 * gg);
-        cn[u] = col[gg];
-      }
+  for (; g < g1; g += kPbThreads) {
+    quad<T> vn;
+    ushort4 cn;
+    const long long gn = g + kPbThreads;
+    if (gn < g1) {
+      vn = load_quad<T>(val + 4 * gn);
+      cn = col[gn];
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long qq = 4 * (g + (long long)u * kPbThreads);
-      if (qq < 4 * g1) {
-        while (qq >= qs[r + 1]) ++r;
-        quad<T> pr;
-        if constexpr (XP) {
-          pr.e[0] = xs[cl[u].x];
-          pr.e[1] = xs[cl[u].y];
-          pr.e[2] = xs[cl[u].z];
-          pr.e[3] = xs[cl[u].w];
-        } else {
-          pr.e[0] = mul(v[u].e[0], xs[cl[u].x]);
-          pr.e[1] = mul(v[u].e[1], xs[cl[u].y]);
-          pr.e[2] = mul(v[u].e[2], xs[cl[u].z]);
-          pr.e[3] = mul(v[u].e[3], xs[cl[u].w]);
-        }
-        store_quad<T>(P + db[r] + (qq - qs[r]), pr);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if constexpr (!XP) v[u] = vn[u];
-      cl[u] = cn[u];
-    }
+    const long long qq = 4 * g;
+    while (qq >= qs[r + 1]) ++r;
+    quad<T> pr;
+    pr.e[0] = mul(v.e[0], xs[cl.x]);
+    pr.e[1] = mul(v.e[1], xs[cl.y]);
+    pr.e[2] = mul(v.e[2], xs[cl.z]);
+    pr.e[3] = mul(v.e[3], xs[cl.w]);
+    store_quad<T>(P + db[r] + (qq - qs[r]), pr);
+    v = vn;
+    cl = cn;
   }
 }
 
@@ -193,28 +160,29 @@ template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, 
   }
 }
 
-// ORDERED: the waves add in turn (fixed order => bit-reproducible sums); otherwise in arrival order.
+// ORDERED: the waves add in turn (fixed order => bit-reproducible floating-point sums, component-wise accurate like the
+// reference's fp64 mv_mul); otherwise in arrival order (LL_PB_PHASE2=atomic: not reproducible, A/B timing reference).
 // D trips of loads are in flight per lane (D - 1 ahead of the one being added): the turns synchronise the whole
-// workgroup 16 times per trip, so without loads issued well ahead the memory pipeline would run in bursts.
-template <typename T, int U, bool ORDERED, int D, bool XP>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_rows, int64_t n_local,
+// workgroup 16 times per trip, so without loads issued well ahead the memory pipeline would run in bursts (3 trips for
+// the ordered form, 2 for arrival order; two quads per lane per trip: profiles/r02_spmv_variants_run3.jsonl).
+template <typename T, bool ORDERED, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_local,
                                                         const int64_t* __restrict__ rptr,  // [nrb + 1]
-                                                        const ushort4* __restrict__ row, const T* __restrict__ val,
-                                                        const T* __restrict__ P,
+                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
                                                         const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                        double* __restrict__ dot_partials, int raw_barrier) {
+                                                        double* __restrict__ dot_partials) {
   constexpr int R = scalar_traits<T>::reals;
+  constexpr int U = 2;
   extern __shared__ double lds[];  // [rb_rows * R]
   __shared__ double red[kPbWaves];
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int rb = rb_first + blockIdx.x;
+  const int rb = blockIdx.x;
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
   constexpr long long kTrip = (long long)U * kPbThreads;
 
   quad<T> pr[D][U];
-  quad<T> vv[XP ? D : 1][XP ? U : 1];  // XP: the matrix values of the same entries (row-block order)
   ushort4 rl[D][U];
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
@@ -223,7 +191,6 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
       const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
       if (gg < g1) {
         pr[d][u] = load_quad<T>(P + 4 * gg);
-        if constexpr (XP) vv[d][u] = load_quad<T>(val + 4 * gg);
         rl[d][u] = row[gg];
       }
     }
@@ -236,7 +203,6 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
       const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
       if (gg < g1) {
         pr[D - 1][u] = load_quad<T>(P + 4 * gg);
-        if constexpr (XP) vv[D - 1][u] = load_quad<T>(val + 4 * gg);
         rl[D - 1][u] = row[gg];
       }
     }
@@ -244,28 +210,17 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (base + tid + (long long)u * kPbThreads < g1) {
-          if constexpr (XP) {
-            lds_add_elem<T>(lds, rl[0][u].x, mul(vv[0][u].e[0], pr[0][u].e[0]));
-            lds_add_elem<T>(lds, rl[0][u].y, mul(vv[0][u].e[1], pr[0][u].e[1]));
-            lds_add_elem<T>(lds, rl[0][u].z, mul(vv[0][u].e[2], pr[0][u].e[2]));
-            lds_add_elem<T>(lds, rl[0][u].w, mul(vv[0][u].e[3], pr[0][u].e[3]));
-          } else {
-            lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
-            lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
-            lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
-            lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
-          }
+          lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
+          lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
+          lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
+          lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
         }
       }
     };
     if constexpr (ORDERED) {
       for (int w = 0; w < kPbWaves; ++w) {
         if (wave == w) add_mine();
-        // EXPERIMENT (LL_PB_PHASE2=issueorder): hand the turn over as soon as the adds are ISSUED (bare s_barrier)
-        // instead of when they have completed (__syncthreads waits for lgkmcnt(0) first) — only valid if the LDS
-        // executes the adds of different waves in issue order
-        if (raw_barrier) __builtin_amdgcn_s_barrier();
-        else __syncthreads();
+        __syncthreads();
       }
     } else {
       add_mine();
@@ -275,7 +230,6 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         pr[d][u] = pr[d + 1][u];
-        if constexpr (XP) vv[d][u] = vv[d + 1][u];
         rl[d][u] = rl[d + 1][u];
       }
     }
@@ -294,96 +248,6 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_first, int rb_row
   if (dot_partials) {
     const double v = wave_sum(dot_acc);
     if ((tid & 63) == 0) red[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < kPbWaves; ++w) t += red[w];
-      dot_partials[rb] = t;
-    }
-  }
-}
-
-// Phase 2 with a TOKEN instead of barriers (LL_PB_PHASE2=token): the waves still add in the fixed order wave 0, 1, ..,
-// 15 of trip 0, wave 0 .. 15 of trip 1, ... (same sums, bit for bit, as the barrier form), but a wave only waits for
-// its predecessor's ticket in LDS, not for the whole workgroup: the waves drift into a systolic pipeline and their
-// loads are no longer issued in lockstep bursts.
-template <typename T, int U, int D>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2_token(int rb_first, int rb_rows, int64_t n_local,
-                                                              const int64_t* __restrict__ rptr,
-                                                              const ushort4* __restrict__ row, const T* __restrict__ P,
-                                                              const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                              double* __restrict__ dot_partials) {
-  constexpr int R = scalar_traits<T>::reals;
-  extern __shared__ double lds[];  // [rb_rows * R]
-  __shared__ double red[kPbWaves];
-  __shared__ int turn;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rb = rb_first + blockIdx.x;
-  const int64_t row0 = (int64_t)rb * rb_rows;
-  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
-  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  constexpr long long kTrip = (long long)U * kPbThreads;
-
-  quad<T> pr[D][U];
-  ushort4 rl[D][U];
-#pragma unroll
-  for (int d = 0; d < D - 1; ++d) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[d][u] = load_quad<T>(P + 4 * gg);
-        rl[d][u] = row[gg];
-      }
-    }
-  }
-  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
-  if (tid == 0) turn = 0;
-  __syncthreads();
-  int ticket = wave;
-  for (long long base = g0; base < g1; base += kTrip, ticket += kPbWaves) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[D - 1][u] = load_quad<T>(P + 4 * gg);
-        rl[D - 1][u] = row[gg];
-      }
-    }
-    while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (base + tid + (long long)u * kPbThreads < g1) {
-        lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
-        lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
-        lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
-        lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
-      }
-    }
-    if (lane == 0) __hip_atomic_store(&turn, ticket + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        pr[d][u] = pr[d + 1][u];
-        rl[d][u] = rl[d + 1][u];
-      }
-    }
-  }
-  __syncthreads();
-  double dot_acc = 0.0;
-  for (int i = tid; i < rows; i += kPbThreads) {
-    const T xi = xl[row0 + i];
-    acc_t<T> acc;
-    if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
-    else acc = lds[i];
-    const T yi = add(narrow<T>(acc), rmul(offset, xi));
-    y[row0 + i] = yi;
-    dot_acc += re_cmul(xi, yi);
-  }
-  if (dot_partials) {
-    const double v = wave_sum(dot_acc);
-    if (lane == 0) red[wave] = v;
     __syncthreads();
     if (tid == 0) {
       double t = 0.0;
@@ -418,8 +282,8 @@ __device__ __forceinline__ bool lds_add_i64(long long* p, double scaled) {
 
 // (Measured and dropped: ONE grid per row block instead of one per row, which removes the per-entry look-up of the row's
 // exponent — 0.858 vs 0.862 ms, no gain, and rows much smaller than their block's largest lose accuracy.)
-template <typename T, int U, int D>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_first, int rb_rows, int64_t n_local, int ncb,
+template <typename T>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64_t n_local, int ncb,
                                                               const int64_t* __restrict__ rptr,
                                                               const ushort4* __restrict__ row, const T* __restrict__ P,
                                                               const int16_t* __restrict__ rexp,
@@ -434,7 +298,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_first, int 
   __shared__ int ex_x;
   constexpr int kBadRow = 32767;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rb = rb_first + blockIdx.x;
+  const int rb = blockIdx.x;
+  constexpr int U = 2, D = 2;  // two quads per lane per trip, two trips in flight (0.845-0.850 vs 0.856-0.862 ms with three)
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
@@ -546,6 +411,264 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_first, int 
   }
 }
 
+// ================================================================= fixed-point sums, PRE-SCALED form (single GPU, double / zc)
+// The same sums as pb_phase2_fixed, bit for bit, with the per-entry work moved out of phase 2: the image stores
+// a~_ij = a_ij * 2^-er_i (er_i = exponent of the row's absolute sum; an exact scaling), phase 1 knows the exponent e_x of
+// max|x| BEFORE it starts (per-workgroup maxima left by the kernel that produced x, or by pb_absmax_kernel) and writes
+// the product ALREADY on the row's grid, as a 64-bit integer:
+//     P = rint( fl(a~_ij x_j) * 2^(61 - e_x) )  =  rint( fl(a_ij x_j) * 2^(62 - E_i) ),   E_i = er_i + e_x + 1.
+// Phase 2 is then a pure stream: one integer LDS atomic per entry — no exponent look-up, no multiply, no conversion —
+// and the y slice needs 8 bytes per row instead of 10, so a row block can be half again as long.  Rows that meet an
+// Inf / NaN carry the sentinel INT64_MIN through P and are reported as NaN.
+constexpr long long kPbBadProduct = (long long)0x8000000000000000ull;
+constexpr int kPbXInf = 20000;   // e_x when max|x| is not finite: every row is reported as NaN
+constexpr int kPbXMinExp = -900; // vectors smaller than 2^-900 everywhere are put on the grid of 2^-900
+
+__device__ __forceinline__ long long pb_to_fixed(double p, int k) {
+  const double sc = ldexp(p, k);  // v_ldexp_f64: one instruction, no range restrictions
+  if (!(fabs(sc) < 9.0e18)) return kPbBadProduct;
+  return (long long)rint(sc);
+}
+__device__ __forceinline__ int pb_exponent_of_max(double t) {
+  int e = kPbXMinExp;
+  if (t > 0.0 && isfinite(t)) {
+    (void)frexp(t, &e);  // t < 2^e
+    e = max(e, kPbXMinExp);
+  } else if (!(t == 0.0)) {
+    e = kPbXInf;
+  }
+  return e;
+}
+
+// Per-workgroup maxima of |x| (|re| + |im| for complex): xmax[b], b < gridDim.x.  NaN entries are skipped (their
+// products carry them); an Inf makes the maximum Inf.
+template <typename T>
+__global__ __launch_bounds__(256) void pb_absmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ xmax) {
+  __shared__ double red[4];
+  constexpr int V = (int)(16 / sizeof(T));  // elements per 16-byte piece (zc: 1)
+  double m = 0.0;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const long long nv = n / V;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+      const uint4 c = x4[i];
+      T e[V];
+      __builtin_memcpy(e, &c, sizeof(c));
+#pragma unroll
+      for (int k = 0; k < V; ++k) m = fmax(m, abs1(e[k]));
+    }
+    if (blockIdx.x == 0)
+      for (long long i = nv * V + threadIdx.x; i < n; i += 256) m = fmax(m, abs1(x[i]));
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmax(m, abs1(x[i]));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) xmax[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kPbThreads) void pb_phase1_pre(int nrb, const int64_t* __restrict__ xoff,
+                                                            const int32_t* __restrict__ ncols_tab,
+                                                            const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
+                                                            const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
+                                                            const T* __restrict__ val, const ushort4* __restrict__ col,
+                                                            const T* __restrict__ xsrc, long long* __restrict__ P,
+                                                            int cb_cols, const double* __restrict__ xmax, int xmax_n,
+                                                            int* __restrict__ ex_out) {
+  constexpr int R = scalar_traits<T>::reals;
+  extern __shared__ double lds[];
+  __shared__ double bm_red[kPbWaves];
+  __shared__ int ex_sh;
+  T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
+  long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
+                                              (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [nrb + 1]
+  long long* db = qs + (nrb + 1);                                                  // [nrb]
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x;
+  const int64_t* sq = seg_q + (size_t)c * (nrb + 1);
+  const long long g0 = sq[0] >> 2, g1 = sq[nrb] >> 2;
+
+  quad<T> v;
+  ushort4 cl;
+  long long g = g0 + tid;
+  if (g < g1) {
+    v = load_quad<T>(val + 4 * g);
+    cl = col[g];
+  }
+  {  // exponent of max |x| over the whole vector, from the per-workgroup maxima
+    double m = 0.0;
+    for (int i = tid; i < xmax_n; i += kPbThreads) m = fmax(m, xmax[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+    if ((tid & 63) == 0) bm_red[tid >> 6] = m;
+  }
+  {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
+    const int ncols = ncols_tab[c];
+    const T* src = xsrc + xoff[c];
+    constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
+    if (V > 1 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const int nv = ncols / V;
+      const uint4* s4 = reinterpret_cast<const uint4*>(src);
+      uint4* d4 = reinterpret_cast<uint4*>(xs);
+      for (int i = tid; i < nv; i += kPbThreads) d4[i] = s4[i];
+      for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = src[i];
+    } else {
+      for (int i = tid; i < ncols; i += kPbThreads) xs[i] = src[i];
+    }
+    for (int i = tid; i <= nrb; i += kPbThreads) qs[i] = sq[i];
+    const int64_t* sd = seg_dest + (size_t)c * nrb;
+    for (int i = tid; i < nrb; i += kPbThreads) db[i] = sd[i];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = bm_red[0];
+    for (int w = 1; w < kPbWaves; ++w) t = fmax(t, bm_red[w]);
+    const int e = pb_exponent_of_max(t);
+    ex_sh = e;
+    if (c == 0) *ex_out = e;  // phase 2 turns the sums back with the same exponent
+  }
+  __syncthreads();
+  const int e_x = ex_sh;
+  const int k = e_x == kPbXInf ? 0 : 61 - e_x;  // (Inf in x: phase 2 reports every row as NaN whatever P holds)
+  int r = 0;
+  for (; g < g1; g += kPbThreads) {
+    quad<T> vn;
+    ushort4 cn;
+    const long long gn = g + kPbThreads;
+    if (gn < g1) {
+      vn = load_quad<T>(val + 4 * gn);
+      cn = col[gn];
+    }
+    const long long qq = 4 * g;
+    while (qq >= qs[r + 1]) ++r;
+    const unsigned short cc[4] = {cl.x, cl.y, cl.z, cl.w};
+    long long out[4 * R];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const T pr = mul(v.e[e], xs[cc[e]]);
+      if constexpr (scalar_traits<T>::is_complex) {
+        out[2 * e] = pb_to_fixed(pr.re, k);
+        out[2 * e + 1] = pb_to_fixed(pr.im, k);
+      } else {
+        out[e] = pb_to_fixed(pr, k);
+      }
+    }
+    quad<T> raw;
+    __builtin_memcpy(&raw, out, sizeof(raw));
+    store_quad<T>(reinterpret_cast<T*>(P) + db[r] + (qq - qs[r]), raw);
+    v = vn;
+    cl = cn;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2_pre(int rb_rows, int64_t n_local,
+                                                            const int64_t* __restrict__ rptr,
+                                                            const ushort4* __restrict__ row,
+                                                            const long long* __restrict__ P,
+                                                            const int16_t* __restrict__ rexp, const int* __restrict__ ex_in,
+                                                            const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                            double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  constexpr int U = 2, D = 2;
+  extern __shared__ double lds_raw[];
+  long long* acc = reinterpret_cast<long long*>(lds_raw);                    // [rb_rows * R]
+  unsigned* bad = reinterpret_cast<unsigned*>(acc + (size_t)rb_rows * R);    // [(rb_rows + 31) / 32] rows that met Inf / NaN
+  __shared__ double red[kPbWaves];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rb = blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+  constexpr long long kTrip = (long long)U * kPbThreads;
+  const T* PT = reinterpret_cast<const T*>(P);
+
+  quad<T> pr[D][U];
+  ushort4 rl[D][U];
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[d][u] = load_quad<T>(PT + 4 * gg);
+        rl[d][u] = row[gg];
+      }
+    }
+  }
+  for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
+  for (int i = tid; i < (rb_rows + 31) / 32; i += kPbThreads) bad[i] = 0u;
+  __syncthreads();
+  for (long long base = g0; base < g1; base += kTrip) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
+      if (gg < g1) {
+        pr[D - 1][u] = load_quad<T>(PT + 4 * gg);
+        rl[D - 1][u] = row[gg];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + tid + (long long)u * kPbThreads < g1) {
+        const unsigned short rr[4] = {rl[0][u].x, rl[0][u].y, rl[0][u].z, rl[0][u].w};
+        long long w[4 * R];
+        __builtin_memcpy(w, &pr[0][u], sizeof(w));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const long long v = w[R * e + q];
+            if (v == kPbBadProduct) atomicOr(&bad[rr[e] >> 5], 1u << (rr[e] & 31));
+            else atomicAdd(reinterpret_cast<unsigned long long*>(&acc[R * rr[e] + q]), (unsigned long long)v);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pr[d][u] = pr[d + 1][u];
+        rl[d][u] = rl[d + 1][u];
+      }
+    }
+  }
+  __syncthreads();
+  const int e_x = *ex_in;
+  double dot_acc = 0.0;
+  for (int i = tid; i < rows; i += kPbThreads) {
+    const T xi = xl[row0 + i];
+    const int er = rexp[row0 + i];
+    const bool unusable = e_x == kPbXInf || er == 32767 || ((bad[i >> 5] >> (i & 31)) & 1u);
+    const int k = er + e_x - 61;
+    acc_t<T> a;
+    if constexpr (scalar_traits<T>::is_complex) a = zc{ldexp((double)acc[2 * i], k), ldexp((double)acc[2 * i + 1], k)};
+    else a = ldexp((double)acc[i], k);
+    if (unusable) {
+      const double nan = __longlong_as_double(0x7ff8000000000000ll);
+      if constexpr (scalar_traits<T>::is_complex) a = zc{nan, nan};
+      else a = nan;
+    }
+    const T yi = add(narrow<T>(a), rmul(offset, xi));
+    y[row0 + i] = yi;
+    dot_acc += re_cmul(xi, yi);
+  }
+  if (dot_partials) {
+    const double v = wave_sum(dot_acc);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kPbWaves; ++w) t += red[w];
+      dot_partials[rb] = t;
+    }
+  }
+}
+
 // exponent of every local row's absolute sum: sum_j |a_ij| < 2^rexp[i]  (32767: the row holds Inf / NaN)
 template <typename T, typename RP>
 __global__ __launch_bounds__(256) void pb_rowexp_kernel(long long n_local, const RP* __restrict__ rp,
@@ -564,10 +687,6 @@ __global__ __launch_bounds__(256) void pb_rowexp_kernel(long long n_local, const
 namespace {
 constexpr int kPbLdsCap = 160 * 1024 - 2048;
 
-int env_int(const char* name, int dflt) {
-  const char* e = std::getenv(name);
-  return e ? std::atoi(e) : dflt;
-}
 // the opt-in to > 64 KiB of dynamic LDS is per device and per kernel symbol
 template <typename K> void pb_opt_in(K kernel) {
   LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbLdsCap));
@@ -578,118 +697,90 @@ template <typename T> void pb_opt_in_lds() {
   LL_HIP(hipGetDevice(&dev));
   const unsigned long long bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
-  pb_opt_in(&pb_phase1<T, 1, false>); pb_opt_in(&pb_phase1<T, 2, false>); pb_opt_in(&pb_phase1<T, 4, false>);
-  pb_opt_in(&pb_phase1<T, 1, true>); pb_opt_in(&pb_phase1<T, 2, true>); pb_opt_in(&pb_phase1<T, 4, true>);
-  pb_opt_in(&pb_phase2<T, 1, false, 2, false>); pb_opt_in(&pb_phase2<T, 2, false, 2, false>); pb_opt_in(&pb_phase2<T, 4, false, 2, false>);
-  pb_opt_in(&pb_phase2<T, 1, true, 2, false>); pb_opt_in(&pb_phase2<T, 2, true, 2, false>); pb_opt_in(&pb_phase2<T, 4, true, 2, false>);
-  pb_opt_in(&pb_phase2<T, 1, true, 3, false>); pb_opt_in(&pb_phase2<T, 2, true, 3, false>);
-  pb_opt_in(&pb_phase2<T, 1, true, 4, false>); pb_opt_in(&pb_phase2<T, 2, true, 4, false>);
-  pb_opt_in(&pb_phase2<T, 1, true, 2, true>); pb_opt_in(&pb_phase2<T, 2, true, 2, true>);
-  pb_opt_in(&pb_phase2<T, 1, true, 3, true>); pb_opt_in(&pb_phase2<T, 2, true, 3, true>);
-  pb_opt_in(&pb_phase2<T, 1, false, 2, true>); pb_opt_in(&pb_phase2<T, 2, false, 2, true>);
-  pb_opt_in(&pb_phase2_fixed<T, 1, 2>); pb_opt_in(&pb_phase2_fixed<T, 2, 2>); pb_opt_in(&pb_phase2_fixed<T, 1, 3>);
-  pb_opt_in(&pb_phase2_fixed<T, 2, 3>);
-  pb_opt_in(&pb_phase2_token<T, 1, 2>); pb_opt_in(&pb_phase2_token<T, 2, 2>); pb_opt_in(&pb_phase2_token<T, 1, 3>);
-  pb_opt_in(&pb_phase2_token<T, 2, 3>);
+  pb_opt_in(&pb_phase1<T>);
+  pb_opt_in(&pb_phase2<T, false, 2>);
+  pb_opt_in(&pb_phase2<T, true, 3>);
+  pb_opt_in(&pb_phase2_fixed<T>);
+  if constexpr (sizeof(typename scalar_traits<T>::real) == 8) {
+    pb_opt_in(&pb_phase1_pre<T>);
+    pb_opt_in(&pb_phase2_pre<T>);
+  }
   mask.fetch_or(bit, std::memory_order_release);
-}
-
-template <typename T>
-void phase1_range(const ll_operator& op, int blk_first, int blk_count, int rb_first, int rb_count, const T* xsrc,
-                  hipStream_t s) {
-  if (blk_count <= 0 || rb_count <= 0) return;
-  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * rb_count + 1) * sizeof(long long);
-#define LL_P1(U, XP)                                                                                                  \
-  hipLaunchKernelGGL((pb_phase1<T, U, XP>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, rb_first, rb_count, \
-                     blk_first, op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,   \
-                     (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols,                              \
-                     op.pb_ordered == 4 ? op.d_pb_blockmax : nullptr)
-  const bool xp = op.pb_xprop != 0;
-  switch (op.pb_u1) {
-    case 1: if (xp) LL_P1(1, true); else LL_P1(1, false); break;
-    case 4: if (xp) LL_P1(4, true); else LL_P1(4, false); break;
-    default: if (xp) LL_P1(2, true); else LL_P1(2, false); break;
-  }
-#undef LL_P1
-  LL_HIP(hipGetLastError());
-}
-
-template <typename T>
-void phase2_range(const ll_operator& op, int rb_first, int rb_count, const T* x_local, T* y, double offset,
-                  double* dot_partials, hipStream_t s) {
-  if (rb_count <= 0) return;
-  const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
-#define LL_P2(U, O, D, XP)                                                                                             \
-  hipLaunchKernelGGL((pb_phase2<T, U, O, D, XP>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows, \
-                     op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_val,                    \
-                     (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, op.pb_ordered == 3 ? 1 : 0)
-  const bool ord = op.pb_ordered != 0;
-  const int depth = ord ? op.pb_depth : 2;
-  const int u2 = op.pb_u2 == 1 ? 1 : (op.pb_u2 == 4 && !op.pb_xprop ? 4 : 2);
-  if (op.pb_ordered == 4 && !op.pb_xprop) {  // order-independent fixed-point sums
-    const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
-#define LL_P2F(U, D)                                                                                                   \
-  hipLaunchKernelGGL((pb_phase2_fixed<T, U, D>), dim3(rb_count), dim3(kPbThreads), ldsf, s, rb_first, op.pb_rb_rows,  \
-                     op.n_local, op.pb_ncb, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod,        \
-                     op.d_pb_rexp, op.d_pb_blockmax, x_local, y, offset, dot_partials)
-    if (u2 == 1) { if (op.pb_depth >= 3) LL_P2F(1, 3); else LL_P2F(1, 2); }
-    else { if (op.pb_depth >= 3) LL_P2F(2, 3); else LL_P2F(2, 2); }
-#undef LL_P2F
-  } else if (op.pb_ordered == 2 && !op.pb_xprop) {  // token form of the fixed order
-#define LL_P2T(U, D)                                                                                                   \
-  hipLaunchKernelGGL((pb_phase2_token<T, U, D>), dim3(rb_count), dim3(kPbThreads), lds2, s, rb_first, op.pb_rb_rows,  \
-                     op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, \
-                     dot_partials)
-    if (u2 == 1) { if (depth >= 3) LL_P2T(1, 3); else LL_P2T(1, 2); }
-    else { if (depth >= 3) LL_P2T(2, 3); else LL_P2T(2, 2); }
-#undef LL_P2T
-  } else if (op.pb_xprop) {
-    if (!ord) { if (u2 == 1) LL_P2(1, false, 2, true); else LL_P2(2, false, 2, true); }
-    else if (depth >= 3) { if (u2 == 1) LL_P2(1, true, 3, true); else LL_P2(2, true, 3, true); }
-    else { if (u2 == 1) LL_P2(1, true, 2, true); else LL_P2(2, true, 2, true); }
-  } else if (!ord) {
-    if (u2 == 1) LL_P2(1, false, 2, false); else if (u2 == 4) LL_P2(4, false, 2, false); else LL_P2(2, false, 2, false);
-  } else if (u2 == 4) {
-    LL_P2(4, true, 2, false);
-  } else if (depth == 4) {
-    if (u2 == 1) LL_P2(1, true, 4, false); else LL_P2(2, true, 4, false);
-  } else if (depth == 3) {
-    if (u2 == 1) LL_P2(1, true, 3, false); else LL_P2(2, true, 3, false);
-  } else {
-    if (u2 == 1) LL_P2(1, true, 2, false); else LL_P2(2, true, 2, false);
-  }
-#undef LL_P2
-  LL_HIP(hipGetLastError());
 }
 }  // namespace
 
 template <typename T>
 void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s) {
+  if (blk_count <= 0 || op.pb_nrb <= 0) return;
+  LL_REQUIRE(!op.pb_prescaled, "internal: the pre-scaled PB image is driven by launch_spmv_pb only");
   pb_opt_in_lds<T>();
-  phase1_range<T>(op, blk_first, blk_count, 0, op.pb_nrb, xsrc, s);
+  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
+  hipLaunchKernelGGL((pb_phase1<T>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
+                     op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col,
+                     xsrc, (T*)op.d_pb_prod, op.pb_cb_cols, op.pb_phase2 == LL_PB_FIXED ? op.d_pb_blockmax : nullptr);
+  LL_HIP(hipGetLastError());
 }
 
 template <typename T>
 int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials,
                      hipStream_t s) {
+  if (op.pb_nrb <= 0) return 0;
+  LL_REQUIRE(!op.pb_prescaled, "internal: the pre-scaled PB image is driven by launch_spmv_pb only");
   pb_opt_in_lds<T>();
-  phase2_range<T>(op, 0, op.pb_nrb, x_local, y, offset, dot_partials, s);
+  const dim3 grid(op.pb_nrb), block(kPbThreads);
+  if (op.pb_phase2 == LL_PB_FIXED) {  // order-independent fixed-point sums
+    const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
+    hipLaunchKernelGGL((pb_phase2_fixed<T>), grid, block, ldsf, s, op.pb_rb_rows, op.n_local, op.pb_ncb, op.d_pb_rptr,
+                       (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp, op.d_pb_blockmax, x_local, y,
+                       offset, dot_partials);
+  } else {
+    const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
+    if (op.pb_phase2 == LL_PB_ORDERED)
+      hipLaunchKernelGGL((pb_phase2<T, true, 3>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
+                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
+    else
+      hipLaunchKernelGGL((pb_phase2<T, false, 2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
+                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
+  }
+  LL_HIP(hipGetLastError());
   return op.pb_nrb;
+}
+
+template <typename T> int launch_pb_absmax(const ll_operator& op, const T* x, hipStream_t s) {
+  const long long n = op.n;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(kCUs * 4, (n * (long long)sizeof(T) / 16 + 255) / 256));
+  hipLaunchKernelGGL((pb_absmax_kernel<T>), dim3(grid), dim3(256), 0, s, n, x, op.d_pb_xmax);
+  LL_HIP(hipGetLastError());
+  return grid;
 }
 
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s) {
-  pb_opt_in_lds<T>();
-  const int G = std::min(std::max(1, op.pb_row_groups), std::max(1, op.pb_nrb));
-  for (int g = 0; g < G; ++g) {  // G > 1: the row-group experiment (product chunk small enough for the Infinity Cache)
-    const int r0 = (int)((long long)op.pb_nrb * g / G), r1 = (int)((long long)op.pb_nrb * (g + 1) / G);
-    phase1_range<T>(op, 0, op.pb_own_count, r0, r1 - r0, x_own, s);
-    for (int c = 0; c < op.gather.nchunks; ++c)
-      phase1_range<T>(op, op.pb_chunk_first[c], op.pb_chunk_count[c], r0, r1 - r0, x_gathered, s);
-    phase2_range<T>(op, r0, r1 - r0, x_local, y, offset, dot_partials, s);
+                   double* dot_partials, hipStream_t s, const double* xmax, int xmax_n) {
+  if constexpr (sizeof(typename scalar_traits<T>::real) == 8) {
+    if (op.pb_prescaled) {  // single GPU, fixed-point sums with the products put on their grid by phase 1
+      if (op.pb_nrb <= 0 || op.pb_ncb <= 0) return 0;
+      pb_opt_in_lds<T>();
+      if (xmax == nullptr) {  // nobody left the maxima of |x| behind: one extra sweep over x
+        xmax_n = launch_pb_absmax<T>(op, x_own, s);
+        xmax = op.d_pb_xmax;
+      }
+      const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
+      hipLaunchKernelGGL((pb_phase1_pre<T>), dim3(op.pb_ncb), dim3(kPbThreads), lds1, s, op.pb_nrb, op.d_pb_xoff,
+                         op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col,
+                         x_own, (long long*)op.d_pb_prod, op.pb_cb_cols, xmax, xmax_n, op.d_pb_ex);
+      const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>) + (size_t)((op.pb_rb_rows + 31) / 32) * sizeof(unsigned);
+      hipLaunchKernelGGL((pb_phase2_pre<T>), dim3(op.pb_nrb), dim3(kPbThreads), lds2, s, op.pb_rb_rows, op.n_local,
+                         op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const long long*)op.d_pb_prod, op.d_pb_rexp,
+                         op.d_pb_ex, x_local, y, offset, dot_partials);
+      LL_HIP(hipGetLastError());
+      return op.pb_nrb;
+    }
   }
-  return op.pb_nrb;
+  launch_pb_phase1<T>(op, 0, op.pb_own_count, x_own, s);
+  for (int c = 0; c < op.gather.nchunks; ++c)
+    launch_pb_phase1<T>(op, op.pb_chunk_first[c], op.pb_chunk_count[c], x_gathered, s);
+  return launch_pb_phase2<T>(op, x_local, y, offset, dot_partials, s);
 }
 
 // ================================================================= device-side construction of the image
@@ -737,6 +828,11 @@ __global__ __launch_bounds__(256) void pb_count_kernel(PbColMap m, int ncb, int 
   for (int i = threadIdx.x; i < ncb; i += 256) cnt[(size_t)i * nrb + r] = hist[i];
 }
 
+__device__ __forceinline__ double pb_scale_value(double v, int k) { return ldexp(v, k); }
+__device__ __forceinline__ float pb_scale_value(float v, int k) { return ldexpf(v, k); }
+__device__ __forceinline__ zc pb_scale_value(zc v, int k) { return zc{ldexp(v.re, k), ldexp(v.im, k)}; }
+__device__ __forceinline__ cf pb_scale_value(cf v, int k) { return cf{ldexpf(v.re, k), ldexpf(v.im, k)}; }
+
 // Pass 2: scatter.  ONE wavefront per row block walks the block's entries in CSR order, 64 at a time; entries of the
 // chunk that fall into the same segment get consecutive slots in lane order (ballot ranking), so the position of
 // every entry is a pure function of the matrix: the image — hence the summation order of phase 2 — is identical
@@ -747,7 +843,7 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
                                                         const T* __restrict__ va, const int64_t* __restrict__ segq,
                                                         const int64_t* __restrict__ segdest, T* __restrict__ pval,
                                                         uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow,
-                                                        int val_in_row_order) {
+                                                        const int16_t* __restrict__ rexp /* nullable: pre-scaled image */) {
   extern __shared__ int fill[];  // [ncb]
   const int r = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < ncb; i += 64) fill[i] = 0;
@@ -785,7 +881,12 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
     if (valid) {
       const long long q = segq[(size_t)key * (nrb + 1) + r] + off;
       const long long qd = segdest[(size_t)key * nrb + r] + off;
-      pval[val_in_row_order ? qd : q] = va[p];
+      T v = va[p];
+      if (rexp != nullptr) {  // pre-scaled fixed-point image: a~_ij = a_ij * 2^-er_i (exact)
+        const int er = rexp[rowi];
+        if (er != 32767) v = pb_scale_value(v, -er);
+      }
+      pval[q] = v;
       pcol[q] = (uint16_t)local;
       prow[qd] = (uint16_t)(rowi - i0);
     }
@@ -865,15 +966,20 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 
   // ---- row blocks (y slice in LDS, 152 KiB at most)
   // (the fixed-point form of phase 2 keeps a 16-bit exponent per row next to the accumulator)
-  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)(sizeof(acc_t<T>) + sizeof(int16_t)));
-  auto block_len = [&](int64_t len, int64_t slice_max, const char* env) {
+  // Pre-scaled fixed-point image (spmv_pb.hip, pb_phase1_pre / pb_phase2_pre): double-precision storage types on a
+  // single GPU (a sharded run would need max|x| over all ranks before its own-column work may start).
+  const bool prescaled = ctx->comm == nullptr && ctx->tune.pb_phase2 == LL_PB_FIXED && sizeof(typename scalar_traits<T>::real) == 8;
+  const int64_t row_max = prescaled ? std::min<int64_t>(65536, (kPbLdsCap - 4096) / (int64_t)sizeof(acc_t<T>))
+                                    : std::min<int64_t>(65536, (152 * 1024) / (int64_t)(sizeof(acc_t<T>) + sizeof(int16_t)));
+  const Tuning& tune = ctx->tune;
+  auto block_len = [&](int64_t len, int64_t slice_max, int forced) {
     int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
     int64_t b = std::max<int64_t>(16, (len + 256 * m - 1) / (256 * m));
-    if (const char* e = std::getenv("LL_PB_BLOCK")) b = std::max(4, std::atoi(e));
-    if (const char* e = std::getenv(env)) b = std::max(4, std::atoi(e));
+    if (tune.pb_block > 0) b = std::max(4, tune.pb_block);
+    if (forced > 0) b = std::max(4, forced);
     return std::min<int64_t>(b, slice_max);
   };
-  const int64_t rb_rows = block_len(nr, row_max, "LL_PB_ROW_BLOCK");
+  const int64_t rb_rows = block_len(nr, row_max, tune.pb_row_block);
   const int64_t nrb = std::max<int64_t>(1, (nr + rb_rows - 1) / rb_rows);
   // ---- LDS budget of phase 1: x slice + two tables of nrb entries (the advisor's round-1 finding: check it here)
   const int64_t table_bytes = (2 * nrb + 1) * (int64_t)sizeof(long long) + 16;
@@ -889,14 +995,14 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   m.rank = ctx->comm != nullptr ? ctx->rank : 0;
   // test hook: treat the rank's own columns like everybody else's (every x slice is read from the gathered buffer), so
   // that a 1-rank RCCL communicator exercises the gather -> remote-block dependency of the overlapped path
-  if (ctx->comm != nullptr && env_int("LL_PB_TEST_ALL_REMOTE", 0) != 0) m.rank = -1;
+  if (ctx->comm != nullptr && tune.pb_test_all_remote) m.rank = -1;
   const int nrem = m.rank >= 0 ? P - 1 : P;  // ranks whose columns are remote
   GatherPlan gp;
   {
     // Chunks pipeline the remote-column part of phase 1 behind the transfer, but every extra collective costs launch
     // latency and small messages use xGMI less efficiently: 4 pieces on 2 GPUs (half of the columns are own, long
     // transfer over one link pair), 2 pieces on more (the own part is 1/P, the transfer uses all links at once).
-    int want = P > 1 ? env_int("LL_GATHER_CHUNKS", P == 2 ? 4 : 2) : 1;
+    int want = P > 1 ? (tune.gather_chunks > 0 ? tune.gather_chunks : (P == 2 ? 4 : 2)) : 1;
     want = std::max(1, std::min(want, kMaxGatherChunks));
     int64_t lc = (S + want - 1) / want;
     lc = std::max<int64_t>(256, (lc + 255) / 256 * 256);  // chunk starts stay 2 KiB aligned
@@ -912,7 +1018,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
     m.cstart[c] = gp.start[c];
     m.clen[c] = (int)gp.len[c];
     int64_t bl;
-    if (P == 1) bl = block_len(gp.len[c], col_max, "LL_PB_COL_BLOCK");
+    if (P == 1) bl = block_len(gp.len[c], col_max, tune.pb_col_block);
     else {
       // Sharded: one launch of phase 1 covers the nrem other ranks' blocks of this chunk, one workgroup per block and
       // per CU at a time.  Its duration is rounds x (fixed + per-column work) with rounds = ceil(blocks / CUs), so the
@@ -933,11 +1039,10 @@ template <typename T> bool pb_build_device(ll_operator* op) {
           best_nb = nb;
         }
       }
-      if (env_int("LL_PB_FILL_ROUNDS", 1) == 0) best_nb = nb_min;
       bl = (gp.len[c] + best_nb - 1) / best_nb;
       bl = std::min<int64_t>(col_max, (bl + 3) / 4 * 4);
-      if (const char* e = std::getenv("LL_PB_BLOCK")) bl = std::min<int64_t>(col_max, std::max(4, std::atoi(e)));
-      if (const char* e = std::getenv("LL_PB_COL_BLOCK")) bl = std::min<int64_t>(col_max, std::max(4, std::atoi(e)));
+      if (tune.pb_block > 0) bl = std::min<int64_t>(col_max, std::max(4, tune.pb_block));
+      if (tune.pb_col_block > 0) bl = std::min<int64_t>(col_max, std::max(4, tune.pb_col_block));
     }
     m.bl[c] = (int)bl;
     m.nb[c] = (int)((gp.len[c] + bl - 1) / bl);
@@ -989,8 +1094,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   LL_HIP(hipStreamSynchronize(s));
   // every segment is padded to 16 entries: kernels move quads (4 entries per lane, 16-byte accesses) and every run of
   // products written by phase 1 starts and ends on a 128-byte line (measured 3.5 % faster than quad padding)
-  int64_t pad = 16;
-  if (const char* e = std::getenv("LL_PB_PAD")) pad = std::max(4, std::atoi(e) / 4 * 4);
+  const int64_t pad = 16;
   // column-block order: segments (c, r) with r fastest; row-block order: (r, c) with c fastest
   std::vector<int64_t> segq((size_t)ncb * (nrb + 1)), segdest((size_t)ncb * nrb), rptr((size_t)nrb + 1);
   {
@@ -1020,25 +1124,12 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_own_count = own_total;
   op->pb_entries = (int64_t)entries;
   op->gather = gp;
-  // kernel variants are fixed per operator at creation (several variants can then be timed in one process)
-  op->pb_u1 = env_int("LL_PB_U1", 1);  // measured on config 3 (profiles/r02_spmv_variants.jsonl): 1 beats 2 and 4 by 3-5 %
-  op->pb_u2 = env_int("LL_PB_U2", 2);
-  {
-    // Phase 2 forms.  Default "fixed": order-independent fixed-point sums (integer LDS adds, all waves at once) — bit-
-    // reproducible for every launch, kernel geometry and partition, and 2-5 % FASTER than the wave-ordered form
-    // (profiles/r02_spmv_variants_run10_fixed_default.jsonl).  "ordered": floating-point adds, the 16 waves in turn
-    // (barriers); "token": the same order by a ticket in LDS; "issueorder": experiment; "atomic":
-    // floating-point adds in arrival order (not reproducible; A/B reference).
-    const char* p2 = std::getenv("LL_PB_PHASE2");
-    const std::string p2s = p2 ? p2 : "fixed";
-    op->pb_ordered = p2s == "atomic" ? 0 : (p2s == "token" ? 2 : (p2s == "issueorder" ? 3 : (p2s == "fixed" ? 4 : 1)));
-    if (op->pb_ordered == 4 && env_int("LL_PB_XPROP", 0) != 0) op->pb_ordered = 1;  // x propagation has no fixed-point form
-  }
-  op->pb_row_groups = std::max(1, env_int("LL_PB_ROW_GROUPS", 1));
-  op->pb_xprop = env_int("LL_PB_XPROP", 0) != 0;
-  // trips of loads in flight per lane: 3 beats 2 and 4 for the wave-ordered form (profiles/r02_spmv_variants_run3.jsonl);
-  // the fixed-point form, whose waves all add at once, does best with 2 (0.845-0.850 vs 0.856-0.862 ms, run10)
-  op->pb_depth = std::max(2, std::min(4, env_int("LL_PB_DEPTH", op->pb_ordered == 4 ? 2 : 3)));
+  // Phase 2 form, fixed per operator at creation (LL_PB_PHASE2).  Default "fixed": order-independent fixed-point sums
+  // (integer LDS adds, all waves at once) — bit-reproducible for every launch, kernel geometry and partition, and 2-5 %
+  // faster than the wave-ordered form (profiles/r02_spmv_variants_run10_fixed_default.jsonl).  "ordered": floating-
+  // point adds, the 16 waves in turn (barriers) — reproducible and component-wise accurate; "atomic": floating-point
+  // adds in arrival order (not reproducible; A/B timing reference).
+  op->pb_phase2 = tune.pb_phase2;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
     LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
@@ -1049,12 +1140,10 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   up((void**)&op->d_pb_xoff, xoff.data(), xoff.size() * sizeof(int64_t));
   up((void**)&op->d_pb_ncols, ncols.data(), ncols.size() * sizeof(int32_t));
   const size_t cap = std::max<size_t>(entries, 16);
-  // ONE allocation for the four big streams (values, local columns, local rows, product buffer).  Their starts are
-  // 2 MiB aligned plus a per-stream stagger (LL_PB_STAGGER bytes, a multiple of 256): the kernels walk several of
-  // these streams at the same relative position, and starts that are congruent modulo the HBM channel interleave
-  // make them camp on the same channels.
+  // ONE allocation for the four big streams (values, local columns, local rows, product buffer), starts 2 MiB aligned
+  // (staggering the starts against the HBM channel interleave was measured in round 2: no effect).
   {
-    const size_t stagger = (size_t)std::max(0, env_int("LL_PB_STAGGER", 0)) / 256 * 256;
+    const size_t stagger = 0;
     auto up2m = [](size_t v) { return (v + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); };
     const size_t o_val = 0;
     const size_t o_col = up2m(o_val + cap * sizeof(T)) + 1 * stagger;
@@ -1071,23 +1160,21 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   LL_HIP(hipMemsetAsync(op->d_pb_val, 0, cap * sizeof(T), s));  // padding entries: value 0, local indices 0
   LL_HIP(hipMemsetAsync(op->d_pb_col, 0, cap * sizeof(uint16_t), s));
   LL_HIP(hipMemsetAsync(op->d_pb_row, 0, cap * sizeof(uint16_t), s));
-  // ---- pass 2 on the device: place the entries
-  if (op->rp64)
-    hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
-                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, op->pb_xprop);
-  else
-    hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
-                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, op->pb_xprop);
-  LL_HIP(hipGetLastError());
-  if (op->pb_ordered == 4) {  // fixed-point sums: per-row exponents of the absolute row sums, per-block maxima of |x|
-    // the y slice holds 64-bit integers + one 16-bit exponent per row: it must still fit the LDS
-    LL_REQUIRE((size_t)rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16 <= (size_t)kPbLdsCap,
+  op->pb_prescaled = prescaled;
+  if (op->pb_phase2 == LL_PB_FIXED) {  // fixed-point sums: per-row exponents of the absolute row sums (before the scatter:
+    // the pre-scaled image stores a_ij * 2^-er_i), per-block maxima of |x| or the maxima the producer of x leaves
+    const size_t per_row = sizeof(acc_t<T>) + (prescaled ? 0 : sizeof(int16_t));
+    LL_REQUIRE((size_t)rb_rows * per_row + (prescaled ? (size_t)(rb_rows + 31) / 32 * 4 : 16) <= (size_t)kPbLdsCap,
                "LL_PB_PHASE2=fixed: row block too large for the LDS (lower LL_PB_ROW_BLOCK)");
     ctx->dev_malloc((void**)&op->d_pb_rexp, std::max<size_t>((size_t)nr, 8) * sizeof(int16_t), "row exponents");
-    ctx->dev_malloc((void**)&op->d_pb_blockmax, (size_t)ncb * sizeof(double), "x slice maxima");
-    LL_HIP(hipMemsetAsync(op->d_pb_blockmax, 0, (size_t)ncb * sizeof(double), s));
+    if (prescaled) {
+      ctx->dev_malloc((void**)&op->d_pb_xmax, (size_t)kMaxGrid * sizeof(double), "maxima of |x|");
+      ctx->dev_malloc((void**)&op->d_pb_ex, 16, "exponent of max |x|");
+      LL_HIP(hipMemsetAsync(op->d_pb_ex, 0, 16, s));
+    } else {
+      ctx->dev_malloc((void**)&op->d_pb_blockmax, (size_t)ncb * sizeof(double), "x slice maxima");
+      LL_HIP(hipMemsetAsync(op->d_pb_blockmax, 0, (size_t)ncb * sizeof(double), s));
+    }
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (nr + 255) / 256));
     if (op->rp64)
       hipLaunchKernelGGL((pb_rowexp_kernel<T, int64_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int64_t*)op->d_row_ptr,
@@ -1097,6 +1184,17 @@ template <typename T> bool pb_build_device(ll_operator* op) {
                          (const T*)op->d_val, op->d_pb_rexp);
     LL_HIP(hipGetLastError());
   }
+  // ---- pass 2 on the device: place the entries
+  const int16_t* scale_by = prescaled ? op->d_pb_rexp : nullptr;
+  if (op->rp64)
+    hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, scale_by);
+  else
+    hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, scale_by);
+  LL_HIP(hipGetLastError());
   LL_HIP(hipStreamSynchronize(s));  // the host tables above go out of scope
   return true;
 }
@@ -1104,7 +1202,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 #define LL_INST_PB(T)                                                                                              \
   template void launch_pb_phase1<T>(const ll_operator&, int, int, const T*, hipStream_t);                           \
   template int launch_pb_phase2<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t);                 \
-  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t); \
+  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t, \
+                                 const double*, int);                                                               \
   template bool pb_build_device<T>(ll_operator*);                                                                   \
   template void csr_check_device<T>(ll_operator*);
 LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)

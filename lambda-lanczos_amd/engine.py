@@ -6,6 +6,7 @@ tests read like the reference's own tests; the C++ twin of this file is include/
 All numerics run in liblanczos_hip.so on the GPU — there is no CPU path in this package.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -67,6 +68,14 @@ class DeviceArray:
             self.ptr = None
 
 
+_LIVE_CONTEXTS = weakref.WeakSet()
+
+
+def live_contexts():
+    """The Context objects that have not been closed (the test suite reloads their LL_* switches after changing one)."""
+    return [c for c in list(_LIVE_CONTEXTS) if c.handle]
+
+
 class Context:
     """Device + HIP stream + workspace (+ RCCL communicator): ll_context."""
 
@@ -79,6 +88,7 @@ class Context:
         self.handle = h
         self.device = int(device)
         self.rank, self.n_ranks = 0, 1
+        _LIVE_CONTEXTS.add(self)
 
     # ---- multi-GPU
     @staticmethod
@@ -128,6 +138,10 @@ class Context:
 
     def release_cache(self):
         check(lib().ll_ctx_release_cache(self.handle))
+
+    def reload_env(self):
+        """Read the LL_* environment switches again (they are read once, when the context is created)."""
+        check(lib().ll_ctx_reload_env(self.handle))
 
     def set_profiling(self, on):
         check(lib().ll_ctx_set_profiling(self.handle, 1 if on else 0))

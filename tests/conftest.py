@@ -9,9 +9,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# Tests switch SpMV kernels on live operators (ll_op_select_spmv), so both matrix images are kept; the default
-# (release the image that lost the creation-time timing) has its own test.
-os.environ.setdefault("LL_SPMV_KEEP_BOTH", "1")
+# The suite runs the PRODUCTION defaults (the SpMV image that loses the creation-time timing is released, ...); a test
+# that needs another setting asks for it through the `llenv` fixture below.
 # The host-staged multi-rank TEST transport (tests/transport/, built by __graft_entry__.build()).
 SHM_TRANSPORT = os.path.join(ROOT, "tests", "transport", "_build", "libll_shm_transport.so")
 
@@ -28,6 +27,52 @@ def _have_gpu():
         return torch.cuda.device_count() > 0
     except Exception:  # noqa: BLE001
         return False
+
+
+class _LLEnv:
+    """Set / delete LL_* environment switches for one test.  The library reads them once per context (ll_ctx_create),
+    so every change is followed by ll_ctx_reload_env on all live contexts; the old values come back (and are reloaded)
+    when the test ends."""
+
+    def __init__(self):
+        self._saved = {}
+
+    @staticmethod
+    def _reload():
+        import lambda_lanczos_amd as L
+
+        for c in L.live_contexts():
+            c.reload_env()
+
+    def setenv(self, name, value):
+        self._saved.setdefault(name, os.environ.get(name))
+        os.environ[name] = str(value)
+        self._reload()
+
+    def delenv(self, name, raising=False):
+        if name not in os.environ:
+            if raising:
+                raise KeyError(name)
+            return
+        self._saved.setdefault(name, os.environ.get(name))
+        del os.environ[name]
+        self._reload()
+
+    def undo(self):
+        for name, old in self._saved.items():
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+        self._saved.clear()
+        self._reload()
+
+
+@pytest.fixture
+def llenv():
+    e = _LLEnv()
+    yield e
+    e.undo()
 
 
 @pytest.fixture(scope="session")

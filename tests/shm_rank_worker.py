@@ -19,6 +19,7 @@ from util import c2list  # noqa: E402
 
 def main():
     rank, world, name, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ["LL_SPMV_KEEP_BOTH"] = "1"   # this worker switches kernels on live operators (select_spmv)
     ctx = L.Context(0)
     ctx.init_comm(name.encode() + b"\0" * (128 - len(name)), rank, world)
     res = {}

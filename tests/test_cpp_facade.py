@@ -20,6 +20,24 @@ def build():
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
+COMPAT_SRC = os.path.join(ROOT, "tests", "cpp", "compat_test.cpp")
+COMPAT_EXE = os.path.join(OUT_DIR, "compat_test")
+
+
+def build_compat():
+    """The literal drop-in: a source file that only knows the reference's include lines (README.md:20-21) is compiled with
+    -I include/compat in place of the reference's include directory."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(COMPAT_SRC) as f:
+        src = f.read()
+    includes = [ln for ln in src.splitlines() if ln.startswith("#include") and "lambda_lanczos" in ln]
+    assert includes == ["#include <lambda_lanczos/exponentiator.hpp>", "#include <lambda_lanczos/lambda_lanczos.hpp>"]
+    assert "lambda_lanczos_hip" not in src and "lanczos_hip.h" not in src
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include", "compat"), COMPAT_SRC,
+           "-o", COMPAT_EXE, "-L" + LIB_DIR, "-llanczos_hip", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
 def _no_gpu():
     import torch
 
@@ -36,6 +54,31 @@ def test_facade_fails_loudly_without_device():
     build()
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 2 and "no CPU fallback" in r.stdout
+
+
+def test_reference_include_paths_compile_against_the_compat_directory():
+    build_compat()
+    assert os.path.exists(COMPAT_EXE)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/lambda_lanczos"), reason="reference checkout not present")
+def test_the_same_source_builds_and_passes_with_the_real_reference_headers():
+    """The other half of "unchanged source": the very same file, compiled against the REAL reference's include directory
+    (CPU, this container only), passes its own checks."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    exe = os.path.join(OUT_DIR, "compat_test_reference")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I/root/reference/include", COMPAT_SRC, "-o", exe], check=True,
+                   capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_unchanged_reference_style_source_runs_through_the_compat_include_path():
+    build_compat()
+    r = subprocess.run([COMPAT_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASSED" in r.stdout and r.stdout.count("[case]") == 4
 
 
 @pytest.mark.gpu

@@ -300,12 +300,12 @@ def test_exhausted_krylov_space_runs_like_the_oracle(ctx, oracle):
 
 
 @pytest.mark.parametrize("what", ["lanczos_two_roots", "expo_full_orth", "lanczos_complex"])
-def test_forced_second_pass_every_iteration(ctx, oracle, what, monkeypatch):
+def test_forced_second_pass_every_iteration(ctx, oracle, what, llenv):
     """LL_DGKS_THRESHOLD > 1 makes the host decide for a second pass in EVERY iteration: the pipeline is drained,
     Gram-Schmidt is repeated on the normalised vector, beta is rescaled and the speculative next iteration is enqueued
     again.  A second pass on an already orthogonal vector changes nothing but rounding, so traces, iteration counts and
     results must still equal the oracle's."""
-    monkeypatch.setenv("LL_DGKS_THRESHOLD", "2.0")
+    llenv.setenv("LL_DGKS_THRESHOLD", "2.0")
     if what == "expo_full_orth":
         csr = G.torus_np(20)
         inp = G.start_vector(400, 1, np.complex128)
@@ -364,10 +364,11 @@ def test_run_iteration_matches_reference_fixture(ctx, oracle, name, orth_mode):
 
 
 # ------------------------------------------------------------------ sharded code path on one GPU
-def test_sharded_path_with_single_rank_communicator(oracle):
+def test_sharded_path_with_single_rank_communicator(oracle, llenv):
     """A 1-rank RCCL communicator drives the whole multi-GPU code path (dlopen of librccl, ncclCommInitRank, the
     all-gather of x before every SpMV and the all-reduces of alpha / Gram-Schmidt coefficients / norms on the
     library stream) on the single GPU of the test box: results must equal the communicator-free run."""
+    llenv.setenv("LL_SPMV_KEEP_BOTH", "1")   # select_spmv below needs both images
     csr = G.randsym_np(30011)
     n = 30011
     init = G.start_vector(n)
@@ -431,7 +432,7 @@ def test_lattice_halo_exchange_with_single_rank_communicator(oracle):
 
 
 # ------------------------------------------------------------------ other operator forms of the mv_mul plugin
-def test_device_array_csr_and_device_callback_operators(ctx, oracle):
+def test_device_array_csr_and_device_callback_operators(ctx, oracle, llenv):
     """ll_op_create_csr_dev_d (matrix already in HBM) and ll_op_create_device_d (a callback that enqueues
     out += A*in on the library stream for device pointers, `out` zero-filled) give the same run as the host-array CSR."""
     import ctypes as C
@@ -439,6 +440,7 @@ def test_device_array_csr_and_device_callback_operators(ctx, oracle):
     from lambda_lanczos_amd import _capi as capi
     from lambda_lanczos_amd.engine import _Operator
 
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
     csr = G.randsym_np(20011)
     n = 20011
     init = G.start_vector(n)

@@ -25,8 +25,9 @@ def widen(csr):
 
 @pytest.mark.parametrize("name,dtype", [("randsym", np.float32), ("laplace", np.float32), ("torus", np.complex64)])
 @pytest.mark.parametrize("kind", [L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB])
-def test_spmv_single_precision(ctx, oracle, name, dtype, kind, monkeypatch):
-    monkeypatch.setenv("LL_PB_BLOCK", "257")
+def test_spmv_single_precision(ctx, oracle, name, dtype, kind, llenv):
+    llenv.setenv("LL_PB_BLOCK", "257")
+    llenv.setenv("LL_SPMV_KEEP_BOTH", "1")   # select_spmv below needs both images
     csr = to_single({"randsym": G.randsym_np(5000), "laplace": G.laplace2d_np(37), "torus": G.torus_np(24)}[name], dtype)
     n = csr[0].shape[0] - 1
     x = G.start_vector(n, 3, REAL[np.dtype(dtype)]).astype(dtype)
@@ -67,8 +68,8 @@ def test_blas1_single_precision(ctx, dtype, n):
 @pytest.mark.parametrize("n,nb", [(20011, 23), (66, 9), (7, 5), (513, 40)])
 @pytest.mark.parametrize("dtype", [np.float32, np.complex64])
 @pytest.mark.parametrize("mode", [L.ORTH_CGS_DGKS, L.ORTH_MGS])
-def test_orth_and_gemv_single_precision(ctx, dtype, mode, n, nb, geometry, monkeypatch):
-    monkeypatch.setenv("LL_BLAS_SMALL_BYTES", geometry)
+def test_orth_and_gemv_single_precision(ctx, dtype, mode, n, nb, geometry, llenv):
+    llenv.setenv("LL_BLAS_SMALL_BYTES", geometry)
     wide = REAL[np.dtype(dtype)]
     rng = np.random.default_rng(4)
     m = rng.uniform(-1, 1, (n, nb)) + (1j * rng.uniform(-1, 1, (n, nb)) if wide == np.complex128 else 0)

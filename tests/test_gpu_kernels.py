@@ -42,47 +42,33 @@ def csr_cases():
 CASES = csr_cases()
 
 
-# (kernel, LL_PB_BLOCK): the CSR-stream kernel, the propagation-blocked kernels with their default geometry (a few
-# blocks at these sizes) and with tiny blocks (many row and column blocks, ragged last blocks, empty segments)
-# "l2g" is the EXPERIMENT kernel of csrc/spmv_l2g.hip (L2-blocked gather; only with LL_SPMV_KERNEL=l2g)
-KERNELS = {"csr_stream": (0, None), "pb": (1, None), "pb_small_blocks": (1, "37"), "pb_atomic": (1, None), "l2g": (2, "37"),
-           "pb_xprop": (1, None), "pb_xprop_small_blocks": (1, "37"), "pb_other_unrolls": (1, "53"),
-           "pb_token": (1, None), "pb_token_small_blocks": (1, "37"),
-           "pb_fixed": (1, None), "pb_fixed_small_blocks": (1, "37"),
-           "pb_ordered": (1, None), "pb_ordered_small_blocks": (1, "37")}
+# kernel -> (LL_SPMV_KERNEL, LL_PB_BLOCK, LL_PB_PHASE2): the CSR-stream kernel and the propagation-blocked kernels in
+# their three phase-2 forms, each with the default geometry (a few blocks at these sizes) and with tiny blocks (many
+# row and column blocks, ragged last blocks, empty segments)
+KERNELS = {"csr_stream": ("csr", None, None),
+           "pb_fixed": ("pb", None, "fixed"), "pb_fixed_small_blocks": ("pb", "37", "fixed"),
+           "pb_fixed_ragged_blocks": ("pb", "53", "fixed"),
+           "pb_ordered": ("pb", None, "ordered"), "pb_ordered_small_blocks": ("pb", "37", "ordered"),
+           "pb_atomic": ("pb", None, "atomic"), "pb_atomic_small_blocks": ("pb", "37", "atomic")}
+KIND = {"csr": 0, "pb": 1}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 @pytest.mark.parametrize("offset", [0.0, -2.5])
 @pytest.mark.parametrize("kernel", sorted(KERNELS))
-def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
+def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, llenv):
     csr = CASES[name]
     dtype = csr[2].dtype
     n = csr[0].shape[0] - 1
     x = rnd(n, dtype, 3)
-    kind, block = KERNELS[kernel]
+    which, block, phase2 = KERNELS[kernel]
+    llenv.setenv("LL_SPMV_KERNEL", which)
     if block:
-        monkeypatch.setenv("LL_PB_BLOCK", block)
-    if kernel == "l2g":
-        monkeypatch.setenv("LL_SPMV_KERNEL", "l2g")
-        monkeypatch.setenv("LL_L2G_SLICE_LOG2", "8")   # many column slices even on the small test matrices
-    if kernel.startswith("pb_xprop"):
-        monkeypatch.setenv("LL_PB_XPROP", "1")        # x propagation: phase 2 multiplies (values in row-block order)
-    if kernel == "pb_other_unrolls":
-        monkeypatch.setenv("LL_PB_U1", "2")
-        monkeypatch.setenv("LL_PB_U2", "1")
-        monkeypatch.setenv("LL_PB_DEPTH", "2")
-    if kernel.startswith("pb_fixed"):
-        monkeypatch.setenv("LL_PB_PHASE2", "fixed")   # order-independent fixed-point sums (integer LDS adds)
-    if kernel.startswith("pb_ordered") or kernel == "pb_other_unrolls":
-        monkeypatch.setenv("LL_PB_PHASE2", "ordered")  # floating-point adds, the 16 waves in turn (the default is "fixed")
-    if kernel.startswith("pb_token"):
-        monkeypatch.setenv("LL_PB_PHASE2", "token")   # the fixed order enforced by a ticket in LDS instead of barriers
-    if kernel == "pb_atomic":
-        monkeypatch.setenv("LL_PB_PHASE2", "atomic")   # the arrival-order variant kept for A/B timing
+        llenv.setenv("LL_PB_BLOCK", block)
+    if phase2:
+        llenv.setenv("LL_PB_PHASE2", phase2)
     op = L.CsrOperator(ctx, *csr)
-    op.select_spmv(kind)
-    assert op.selected_spmv() == kind
+    assert op.selected_spmv() == KIND[which]
     xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
     alpha = L.spmv(op, xd, yd, offset=offset, want_dot=True)
     y = yd.get()
@@ -91,14 +77,15 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
     import scipy.sparse as sp
 
     absrow = sp.csr_matrix((np.abs(csr[2]), csr[1], rp), shape=(n, n)) @ np.abs(x) + abs(offset) * np.abs(x)
-    # |y - y_ref| <= c * nnz_row * eps * sum_j |a_ij||x_j|   (different summation order, fma contraction)
+    # |y - y_ref| <= c * nnz_row * eps * sum_j |a_ij||x_j|   (different summation order, fma contraction); x ~ U[-1, 1]:
+    # the norm-wise bound of the fixed-point form coincides with this one here (test_gpu_round3.py separates them)
     assert np.all(np.abs(y - y_ref) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)
     alpha_ref = np.vdot(x, y_ref).real
     assert abs(alpha - alpha_ref) <= 1e-13 * max(1.0, np.sum(np.abs(x) * np.abs(y_ref)))
-    # without the fused dot: same y, bit for bit (CSR-stream folds in a fixed order, phase 2 of the PB kernels adds wave
-    # by wave in a fixed order); only the arrival-order experiment variants may differ by rounding
+    # without the fused dot: same y, bit for bit (CSR-stream folds in a fixed order, the PB kernels add fixed-point
+    # integers or wave by wave in a fixed order); only the arrival-order A/B variant may differ by rounding
     L.spmv(op, xd, yd, offset=offset)
-    if kernel not in ("pb_atomic", "l2g"):
+    if not kernel.startswith("pb_atomic"):
         assert np.array_equal(yd.get(), y)
     else:
         assert np.all(np.abs(yd.get() - y) <= 8 * EPS * (np.diff(rp) + 2) * absrow + 1e-300)
@@ -106,59 +93,47 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["randsym5000", "ragged", "ragged_z", "torus24"])
-@pytest.mark.parametrize("block", [None, "37"])
-def test_pb_ordered_forms_agree_bit_for_bit(ctx, name, block, monkeypatch):
-    """Barrier turns, ticket turns and the x-propagation layout all add the same products in the same order."""
+def test_pb_fixed_point_sums_do_not_depend_on_the_block_geometry(ctx, name, llenv):
+    """Integer addition is associative: the fixed-point phase 2 gives the same bits for every block geometry (hence for
+    every partition of the matrix); the wave-ordered floating-point form agrees with it to rounding."""
     csr = CASES[name]
     dtype = csr[2].dtype
     n = csr[0].shape[0] - 1
     x = rnd(n, dtype, 11)
     xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
-    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
-    if block:
-        monkeypatch.setenv("LL_PB_BLOCK", block)
-    ys = {}
-    for label, env in (("barrier", {"LL_PB_PHASE2": "ordered"}), ("token", {"LL_PB_PHASE2": "token"}), ("xprop", {"LL_PB_XPROP": "1"}),
-                       ("token_u1_d2", {"LL_PB_PHASE2": "token", "LL_PB_U2": "1", "LL_PB_DEPTH": "2"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        op = L.CsrOperator(ctx, *csr)
-        L.spmv(op, xd, yd, offset=0.5)
-        ys[label] = yd.get()
-        op.close()
-        for k in env:
-            monkeypatch.delenv(k)
-    # same (trip, wave) order of the adds whenever the trip geometry is the same; across geometries the order changes
-    # fixed-point sums: the same bits for every kernel geometry (integer addition is associative)
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
     fx = {}
-    for label, env in (("a", {}), ("b", {"LL_PB_U2": "1", "LL_PB_DEPTH": "2", "LL_PB_U1": "2"}), ("c", {"LL_PB_ROW_GROUPS": "3"})):
-        monkeypatch.setenv("LL_PB_PHASE2", "fixed")
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for block in (None, "37", "53", "1000"):
+        llenv.setenv("LL_PB_PHASE2", "fixed")
+        if block:
+            llenv.setenv("LL_PB_BLOCK", block)
         op = L.CsrOperator(ctx, *csr)
         L.spmv(op, xd, yd, offset=0.5)
-        fx[label] = yd.get()
+        fx[block] = yd.get()
         op.close()
-        for k in env:
-            monkeypatch.delenv(k)
-    monkeypatch.delenv("LL_PB_PHASE2")
-    assert np.array_equal(fx["a"], fx["b"]) and np.array_equal(fx["a"], fx["c"])
-    assert np.max(np.abs(fx["a"] - ys["barrier"])) <= 64 * EPS * np.max(np.abs(ys["barrier"]))
-    assert np.array_equal(ys["barrier"], ys["token"])
-    assert np.array_equal(ys["barrier"], ys["xprop"])
-    assert np.max(np.abs(ys["barrier"] - ys["token_u1_d2"])) <= 64 * EPS * np.max(np.abs(ys["barrier"]))
+        llenv.delenv("LL_PB_BLOCK")
+    for block in ("37", "53", "1000"):
+        assert np.array_equal(fx[None], fx[block]), block
+    llenv.setenv("LL_PB_PHASE2", "ordered")
+    op = L.CsrOperator(ctx, *csr)
+    L.spmv(op, xd, yd, offset=0.5)
+    yo = yd.get()
+    L.spmv(op, xd, yd, offset=0.5)
+    assert np.array_equal(yd.get(), yo)  # the wave-ordered form is reproducible launch to launch
+    op.close()
+    assert np.max(np.abs(fx[None] - yo)) <= 64 * EPS * np.max(np.abs(yo))
 
 
 @pytest.mark.parametrize("name", ["randsym5000", "torus24", "ragged", "ragged_z"])
-def test_spmv_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
+def test_spmv_with_64bit_row_offsets(ctx, oracle, name, llenv):
     """The int64 row_ptr variant of the CSR-stream kernel (used once nnz exceeds 2^31) on small matrices."""
-    monkeypatch.setenv("LL_FORCE_RP64", "1")
+    llenv.setenv("LL_FORCE_RP64", "1")
     csr = CASES[name]
     dtype = csr[2].dtype
     n = csr[0].shape[0] - 1
     x = rnd(n, dtype, 9)
+    llenv.setenv("LL_SPMV_KERNEL", "csr")
     op = L.CsrOperator(ctx, *csr)
-    op.select_spmv(L.capi.SPMV_CSR_STREAM)
     xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
     alpha = L.spmv(op, xd, yd, offset=0.25, want_dot=True)
     y_ref = oracle.spmv(csr, x) + 0.25 * x
@@ -168,11 +143,11 @@ def test_spmv_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["randsym5000", "ragged_z"])
-def test_pb_image_build_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
+def test_pb_image_build_with_64bit_row_offsets(ctx, oracle, name, llenv):
     """The device-side image build (histogram + scatter + row exponents) reads int64 row offsets once nnz exceeds 2^31;
     forced here on small matrices, for the default and the fixed-point phase 2."""
-    monkeypatch.setenv("LL_FORCE_RP64", "1")
-    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
+    llenv.setenv("LL_FORCE_RP64", "1")
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
     csr = CASES[name]
     dtype = csr[2].dtype
     n = csr[0].shape[0] - 1
@@ -180,7 +155,7 @@ def test_pb_image_build_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
     y_ref = oracle.spmv(csr, x) - 1.5 * x
     xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
     for phase2 in ("ordered", "fixed"):
-        monkeypatch.setenv("LL_PB_PHASE2", phase2)
+        llenv.setenv("LL_PB_PHASE2", phase2)
         op = L.CsrOperator(ctx, *csr)
         assert op.selected_spmv() == L.capi.SPMV_PB
         L.spmv(op, xd, yd, offset=-1.5)
@@ -188,11 +163,11 @@ def test_pb_image_build_with_64bit_row_offsets(ctx, oracle, name, monkeypatch):
         op.close()
 
 
-def test_fixed_point_phase2_reports_non_finite_input_as_nan(ctx, monkeypatch):
+def test_fixed_point_phase2_reports_non_finite_input_as_nan(ctx, llenv):
     """Order-independent integer sums cannot carry Inf / NaN; rows that meet one are reported as NaN, every other row
     keeps its value (with a finite max |x| the scale of the clean rows is unaffected by a NaN elsewhere)."""
-    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
-    monkeypatch.setenv("LL_PB_PHASE2", "fixed")
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    llenv.setenv("LL_PB_PHASE2", "fixed")
     csr = CASES["laplace37"]
     n = csr[0].shape[0] - 1
     x = rnd(n, np.float64, 2)
@@ -275,9 +250,9 @@ def _orthonormal_basis(n, nb, dtype, seed):
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
 @pytest.mark.parametrize("mode", [L.ORTH_CGS_DGKS, L.ORTH_CGS2, L.ORTH_MGS])
 @pytest.mark.parametrize("n,nb", [(10, 5), (4099, 1), (100003, 37), (30011, 700), (4099, 1700)])  # 1700 > one launch
-def test_orth_block_matches_mgs_oracle(ctx, oracle, dtype, mode, n, nb, geometry, monkeypatch):
+def test_orth_block_matches_mgs_oracle(ctx, oracle, dtype, mode, n, nb, geometry, llenv):
     """a5/a6/a7: block Gram-Schmidt vs the reference's sequential MGS (LA:132-144, test T1:61-91)."""
-    monkeypatch.setenv("LL_BLAS_SMALL_BYTES", geometry)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", geometry)
     basis = _orthonormal_basis(n, nb, dtype, 5)
     w = rnd(n, dtype, 31) + 3.0 * basis[0] - 2.0 * basis[nb - 1]
     ld = ((n + 255) // 256) * 256

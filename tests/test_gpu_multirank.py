@@ -66,7 +66,7 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
                                          (2, {"LL_TRIDIAG_TEST_JITTER_US": "1500", "LL_TRIDIAG_LAG": "0"})],
                          ids=["2", "3", "4", "2-forced-second-pass", "2-measured-norm", "3-one-chunk",
                               "3-verdict-jitter", "2-verdict-jitter-lag0"])
-def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, world, extra):
+def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, world, extra, llenv):
     ranks = run_ranks(tmp_path, world, **extra)
 
     def stitch(key, field, idx=None):
@@ -101,8 +101,8 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
         if label == "pb" and not os.environ.get("LL_PB_PHASE2"):
             # the fixed-point sums of the PB kernel's phase 2 do not depend on the order of the adds, nor on the block
             # geometry, nor on the partition: the shards of `world` ranks stitch to the BITS of a single-GPU product
+            llenv.setenv("LL_SPMV_KERNEL", "pb")
             op1 = L.CsrOperator(ctx, *csr)
-            op1.select_spmv(L.capi.SPMV_PB)
             x1, y1 = ctx.to_device(init), ctx.empty(n)
             L.spmv(op1, x1, y1, offset=0.5)
             assert np.array_equal(y, y1.get())

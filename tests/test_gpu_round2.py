@@ -32,13 +32,13 @@ def c3():
     return n, csr
 
 
-def test_c3_pb_spmv_is_bit_reproducible_at_full_size(ctx, c3, monkeypatch):
+def test_c3_pb_spmv_is_bit_reproducible_at_full_size(ctx, c3, llenv):
     """Two launches on one operator AND a second operator built from the same arrays give the same bits (n = 1e7,
     nnz = 1.5e8): the fixed-point sums of phase 2 do not depend on the order of the adds (the wave-ordered form fixes the
     order instead), the device-side image build fixes the layout."""
     n, csr = c3
-    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
-    monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    llenv.setenv("LL_SPMV_KEEP_BOTH", "0")
     x = G.start_vector_fast(n, 7)
     xd, yd = ctx.to_device(x / np.linalg.norm(x)), ctx.empty(n)
     ys = []
@@ -100,13 +100,13 @@ def test_c2_full_size_short_window_traces_match_the_oracle(ctx, oracle):
 
 
 # ------------------------------------------------------------------ image release
-def test_the_image_that_lost_the_timing_is_released(ctx, monkeypatch):
-    monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
+def test_the_image_that_lost_the_timing_is_released(ctx, llenv):
+    llenv.setenv("LL_SPMV_KEEP_BOTH", "0")
     csr = G.randsym_np(50000)
     x = G.start_vector(50000)
     xd, yd = ctx.to_device(x), ctx.empty(50000)
     for forced, other in (("pb", capi.SPMV_CSR_STREAM), ("csr", capi.SPMV_PB)):
-        monkeypatch.setenv("LL_SPMV_KERNEL", forced)
+        llenv.setenv("LL_SPMV_KERNEL", forced)
         op = L.CsrOperator(ctx, *csr)
         with pytest.raises(L.LanczosHipError):
             op.select_spmv(other)
@@ -114,14 +114,14 @@ def test_the_image_that_lost_the_timing_is_released(ctx, monkeypatch):
         ref = yd.get()
         op.close()
         if forced == "pb":                       # (LL_SPMV_KERNEL=csr never builds the other image)
-            monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "1")
+            llenv.setenv("LL_SPMV_KEEP_BOTH", "1")
             op2 = L.CsrOperator(ctx, *csr)
             op2.select_spmv(other)               # both kept on request
             L.spmv(op2, xd, yd)
             assert np.max(np.abs(yd.get() - ref)) <= 64 * EPS * np.max(np.abs(ref))
             op2.close()
-            monkeypatch.setenv("LL_SPMV_KEEP_BOTH", "0")
-    monkeypatch.delenv("LL_SPMV_KERNEL")
+            llenv.setenv("LL_SPMV_KEEP_BOTH", "0")
+    llenv.delenv("LL_SPMV_KERNEL")
     op = L.CsrOperator(ctx, *csr)                # autotuned: both were timed, one is kept
     a, b = op.autotune_ms()
     assert a > 0 and b > 0
@@ -129,19 +129,19 @@ def test_the_image_that_lost_the_timing_is_released(ctx, monkeypatch):
 
 
 # ------------------------------------------------------------------ overlapped exchange through RCCL (1 rank)
-def test_overlapped_exchange_equals_the_serial_path_with_a_real_rccl_communicator(oracle, monkeypatch):
+def test_overlapped_exchange_equals_the_serial_path_with_a_real_rccl_communicator(oracle, llenv):
     """LL_PB_TEST_ALL_REMOTE makes every column block read its x slice from the GATHERED buffer, so with a 1-rank RCCL
     communicator the all-gather (asynchronous, on the communication stream, in chunks) really feeds phase 1: a missing
     event dependency would show as stale data.  Overlapped and serial issue orders must give identical bits."""
     n = 200_003
     csr = G.randsym_np(n)
     init = G.start_vector(n)
-    monkeypatch.setenv("LL_SPMV_KERNEL", "pb")
-    monkeypatch.setenv("LL_PB_TEST_ALL_REMOTE", "1")
-    monkeypatch.setenv("LL_GATHER_CHUNKS", "3")
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    llenv.setenv("LL_PB_TEST_ALL_REMOTE", "1")
+    llenv.setenv("LL_GATHER_CHUNKS", "3")
     got = {}
     for overlap_on in ("1", "0"):
-        monkeypatch.setenv("LL_COMM_OVERLAP", overlap_on)
+        llenv.setenv("LL_COMM_OVERLAP", overlap_on)
         c = L.Context(0)
         c.init_comm(L.Context.unique_id(), 0, 1)
         assert c.ranks_seen() == 1
@@ -195,8 +195,8 @@ def test_tridiag_auto_equals_qr_on_the_reference_golden_traces(ctx, name):
 
 # ------------------------------------------------------------------ device arrays: validation whatever the kernel
 @pytest.mark.parametrize("kernel", ["csr", "pb"])
-def test_device_array_operator_is_validated_for_every_kernel_choice(ctx, kernel, monkeypatch):
-    monkeypatch.setenv("LL_SPMV_KERNEL", kernel)
+def test_device_array_operator_is_validated_for_every_kernel_choice(ctx, kernel, llenv):
+    llenv.setenv("LL_SPMV_KERNEL", kernel)
     csr = G.randsym_np(5000)
     rp, ci, va = csr
     d_rp, d_ci, d_va = ctx.to_device(rp.astype(np.int64)), ctx.to_device(ci.astype(np.int32)), ctx.to_device(va)
@@ -328,7 +328,7 @@ def test_device_resident_time_evolution_loop_equals_the_host_loop(ctx):
 
 # ------------------------------------------------------------------ launch fusion and kernel geometry: same loop, same numbers
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
-def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, monkeypatch):
+def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, llenv):
     """Single GPU: alpha folded inside the multi-dot and the norm fold + publish inside the normalisation kernel (default)
     against the separate fold / publish kernels (LL_FUSE_LAUNCHES=0, also what sharded contexts run): both sum the same
     partials in the same order, so alpha/beta traces, iteration counts, eigenvalues and eigenvectors agree bit for bit —
@@ -339,7 +339,7 @@ def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, monkeypatch)
     init = G.start_vector(n, 1, dtype)
     out = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("LL_FUSE_LAUNCHES", fuse)
+        llenv.setenv("LL_FUSE_LAUNCHES", fuse)
         eng = L.LambdaLanczos(op, n, True, 2)
         eng.init_vector = fixed_init(init)
         vals, vecs = eng.run()
@@ -354,7 +354,7 @@ def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, monkeypatch)
         assert np.array_equal(a[i], b[i]), i
 
 
-def test_small_and_streaming_geometry_agree_in_the_whole_loop(ctx, oracle, monkeypatch):
+def test_small_and_streaming_geometry_agree_in_the_whole_loop(ctx, oracle, llenv):
     """The same run with the small-vector Gram-Schmidt kernels (default at this size) and with the streaming ones forced
     (LL_BLAS_SMALL_BYTES=0): different summation orders, same answers to the parity tolerances, same iteration counts,
     both equal to the oracle's."""
@@ -365,7 +365,7 @@ def test_small_and_streaming_geometry_agree_in_the_whole_loop(ctx, oracle, monke
     ora = oracle.lanczos(csr, init, True, num_eigs=1)
     got = {}
     for limit in (str(1 << 40), "0"):
-        monkeypatch.setenv("LL_BLAS_SMALL_BYTES", limit)
+        llenv.setenv("LL_BLAS_SMALL_BYTES", limit)
         eng = L.LambdaLanczos(op, n, True, 1)
         eng.init_vector = fixed_init(init)
         vals, vecs = eng.run()

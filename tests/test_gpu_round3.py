@@ -1,0 +1,291 @@
+"""Round-3 GPU tests: the accuracy class of the fixed-point SpMV pinned on inputs where it differs from the floating-point
+one, whole loops from a localized start vector against the REAL reference, BASELINE config 5 at n = 1e6 against the real
+Exponentiator::run, taylor_run's a == 0 exit with device buffers, and a communicator whose self-check fails."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import _capi as capi
+from lambda_lanczos_amd import generators as G
+from util import overlap
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def fixed_init(v):
+    return lambda out, *_: np.copyto(out, v)
+
+
+# ------------------------------------------------------------------ accuracy class of LL_PB_PHASE2=fixed (lanczos_hip.h)
+def _exact_rows(csr, x):
+    """(A x)_i, sum_j |a_ij||x_j| and sum_j |a_ij| in extended precision (x87 long double: 64-bit mantissa); complex
+    through separate real / imaginary parts."""
+    rp, ci, va = csr
+    ld = np.longdouble
+    n = rp.shape[0] - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+
+    def rowsum(v):
+        out = np.zeros(n, dtype=ld)
+        np.add.at(out, rows, v)
+        return out
+
+    xa = x[ci]
+    if np.iscomplexobj(va) or np.iscomplexobj(x):
+        ar, ai = np.real(va).astype(ld), np.imag(va).astype(ld)
+        xr, xi = np.real(xa).astype(ld), np.imag(xa).astype(ld)
+        y = (rowsum(ar * xr - ai * xi), rowsum(ar * xi + ai * xr))
+        mag_a = np.abs(np.real(va)).astype(ld) + np.abs(np.imag(va)).astype(ld)
+        mag_x = np.abs(xr) + np.abs(xi)
+    else:
+        y = (rowsum(va.astype(ld) * xa.astype(ld)), None)
+        mag_a, mag_x = np.abs(va).astype(ld), np.abs(xa).astype(ld)
+    return y, rowsum(mag_a * mag_x), rowsum(mag_a)
+
+
+def _wide_inputs(kind, csr, dtype):
+    rp, ci, va = csr
+    n = rp.shape[0] - 1
+    va = va.astype(dtype)
+    if kind == "decades":            # x_j = 10^-(j mod 300): 300 decades of dynamic range inside every column block
+        x = (10.0 ** (-(np.arange(n) % 300).astype(np.float64))).astype(dtype)
+        if np.dtype(dtype) == np.complex128:
+            x = x * np.exp(1j * np.arange(n))
+    elif kind == "e0":               # a unit vector: the start vector of many users of this library
+        x = np.zeros(n, dtype=dtype)
+        x[0] = 1.0
+    elif kind == "row_scales":       # D A with D_ii = 10^(+-140): the rows differ by 280 decades in scale
+        rng = np.random.default_rng(3)
+        x = rng.uniform(-1, 1, n).astype(dtype)
+        if np.dtype(dtype) == np.complex128:
+            x = x + 1j * rng.uniform(-1, 1, n)
+        scale = np.where(np.arange(n) % 3 == 0, 1e140, np.where(np.arange(n) % 3 == 1, 1e-140, 1.0))
+        va = va * np.repeat(scale, np.diff(rp))
+    else:
+        raise ValueError(kind)
+    return (rp, ci, va), x
+
+
+@pytest.mark.parametrize("block", [None, "37"], ids=["default_blocks", "small_blocks"])
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
+@pytest.mark.parametrize("kind", ["decades", "e0", "row_scales"])
+def test_fixed_point_spmv_meets_its_stated_normwise_bound(ctx, llenv, kind, dtype, block):
+    """lanczos_hip.h states, for the default PB kernel (LL_PB_PHASE2=fixed),
+         |y_i - (A x)_i| <= eps sum_j |a_ij||x_j| + nnz_i 2^-60 (sum_j |a_ij|) max_k |x_k|,
+    and the component-wise bound c nnz_i eps sum_j |a_ij||x_j| for the floating-point forms (CSR-stream, ordered).  On
+    inputs with a huge dynamic range the two differ: both are asserted, each for the kernels it is stated for, and the
+    `decades` case must actually separate them (some row of the fixed-point result violates the component-wise bound)."""
+    csr, x = _wide_inputs(kind, G.randsym_np(5000), dtype)
+    rp = csr[0]
+    n = rp.shape[0] - 1
+    nnz_i = np.diff(rp).astype(np.longdouble)
+    (yr, yi), absrow, rowsum = _exact_rows(csr, x)
+    xmax = np.longdouble(np.max(np.abs(np.real(x)) + np.abs(np.imag(x))))
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+
+    def err_of(y):
+        e = np.abs(np.real(y).astype(np.longdouble) - yr)
+        if yi is not None:
+            e = np.maximum(e, np.abs(np.imag(y).astype(np.longdouble) - yi))
+        return e
+
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    if block:
+        llenv.setenv("LL_PB_BLOCK", block)
+    got = {}
+    for phase2 in ("fixed", "ordered"):
+        llenv.setenv("LL_PB_PHASE2", phase2)
+        op = L.CsrOperator(ctx, *csr)
+        assert op.selected_spmv() == capi.SPMV_PB
+        L.spmv(op, xd, yd)
+        got[phase2] = yd.get()
+        op.close()
+    llenv.setenv("LL_SPMV_KERNEL", "csr")
+    op = L.CsrOperator(ctx, *csr)
+    L.spmv(op, xd, yd)
+    got["csr"] = yd.get()
+    op.close()
+    assert all(np.all(np.isfinite(v)) for v in got.values())
+    tiny = np.longdouble(1e-320)
+    componentwise = 8 * EPS * (nnz_i + 2) * absrow + tiny
+    normwise = 2 * EPS * absrow + nnz_i * np.longdouble(2.0) ** -60 * rowsum * xmax + tiny
+    assert np.all(err_of(got["ordered"]) <= componentwise)
+    assert np.all(err_of(got["csr"]) <= componentwise)
+    assert np.all(err_of(got["fixed"]) <= normwise), float(np.max(err_of(got["fixed"]) / normwise))
+    if kind == "decades":   # the inputs separate the two classes: fixed point is norm-wise accurate only
+        assert np.any(err_of(got["fixed"]) > componentwise)
+    if kind == "row_scales":  # the grid is per ROW: rows of very different scale each keep full relative accuracy
+        assert np.all(err_of(got["fixed"]) <= componentwise)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.complex64], ids=["s", "c"])
+def test_single_precision_pb_rounds_each_product_once_to_the_storage_type(ctx, llenv, dtype):
+    """float / complex<float> PB: the product a_ij x_j goes to the product buffer in the storage type (one rounding, what a
+    float multiply gives), the sum is fixed point / double: |y_i - exact| <= (eps_f / 2) sum |a_ij||x_j| (1 + small) plus
+    the final rounding of y_i to float."""
+    base = G.randsym_np(5000) if np.dtype(dtype) == np.float32 else G.torus_np(40)
+    rp, ci = base[0], base[1]
+    va = base[2].astype(dtype)
+    n = rp.shape[0] - 1
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    if np.dtype(dtype) == np.complex64:
+        x = (x + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+    wide = np.complex128 if np.dtype(dtype) == np.complex64 else np.float64
+    (yr, yi), absrow, _ = _exact_rows((rp, ci, va.astype(wide)), x.astype(wide))
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    llenv.setenv("LL_PB_BLOCK", "257")
+    op = L.CsrOperator(ctx, rp, ci, va)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    L.spmv(op, xd, yd)
+    y = yd.get()
+    op.close()
+    eps_f = np.finfo(np.float32).eps
+    err = np.abs(np.real(y).astype(np.longdouble) - yr)
+    if yi is not None:
+        err = np.maximum(err, np.abs(np.imag(y).astype(np.longdouble) - yi))
+    # complex: each of the four real products and the two sums of a complex product round in float
+    per_product = (2.0 if yi is not None else 0.5) * eps_f
+    assert np.all(err <= (per_product + 0.5 * eps_f) * absrow * 1.001 + 1e-30)
+
+
+# ------------------------------------------------------------------ whole loops from a localized start vector vs the REAL reference
+@pytest.mark.parametrize("kernel", ["pb", "csr"])
+def test_lanczos_from_a_unit_start_vector_matches_the_real_reference(ctx, reference, llenv, kernel):
+    """Start vector e_0 (max|x| = 1 while most entries of the first Lanczos vectors are exactly 0 or tiny): the
+    norm-wise accuracy of the fixed-point SpMV is all the recurrence needs — same iteration count, eigenvalue and
+    eigenvector as LambdaLanczos::run of the real reference with the same start vector."""
+    n = 20011
+    csr = G.randsym_np(n)
+    init = np.zeros(n)
+    init[0] = 1.0
+    llenv.setenv("LL_SPMV_KERNEL", kernel)
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.init_vector = fixed_init(init)
+    vals, vecs = eng.run()
+    ref = reference.lanczos(csr, init, True)
+    assert abs(eng.getIterationCounts()[0] - ref["iter_counts"][0]) <= 2
+    assert abs(vals[0] - ref["eigenvalues"][0]) <= 1e-10 * abs(vals[0])
+    assert 1 - overlap(vecs[0], ref["eigenvectors"][0]) <= 1e-8
+    op.close()
+
+
+def test_exponentiator_from_a_unit_input_vector_matches_the_real_reference(ctx, reference, llenv):
+    """exp(-iH) e_0 on the complex torus (a wave packet spreading from one site: entries from 1 down to exact zeros)."""
+    N = 48
+    n = N * N
+    csr = G.torus_np(N)
+    psi = np.zeros(n, dtype=np.complex128)
+    psi[0] = 1.0
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    llenv.setenv("LL_PB_BLOCK", "300")
+    op = L.CsrOperator(ctx, *csr)
+    assert op.selected_spmv() == capi.SPMV_PB
+    out, it = L.Exponentiator(op, n).run(-1j, psi)
+    r_out, r_it, _ = reference.expo(csr, -1j, psi)
+    assert it == r_it
+    assert np.max(np.abs(out - r_out)) <= 1e-12
+    assert abs(np.linalg.norm(out) - 1.0) <= 1e-12
+    op.close()
+
+
+# ------------------------------------------------------------------ BASELINE config 5 at full size vs the REAL reference
+@pytest.fixture(scope="module")
+def c5():
+    N = 1000
+    return N * N, G.torus(N), G.start_vector_fast(N * N, 1, np.complex128)
+
+
+@pytest.mark.parametrize("dt,iters", [(0.1, 7), (1.0, 15), (5.0, 38)])
+def test_c5_full_size_output_matches_the_real_exponentiator(ctx, reference, c5, dt, iters):
+    """Config 5 at n = 1e6 (complex Hermitian torus, exp(-i H dt) v): iteration counts equal the reference's (7 / 15 / 38,
+    SURVEY 3.4), max |out - out_ref| <= 1e-10 |in|, 1 - overlap <= 10 eps — against Exponentiator::run of the REAL
+    reference (EX:87-173) through oracle/_ref, about 3 s of host time for the three exponents."""
+    n, csr, init = c5
+    op = L.CsrOperator(ctx, *csr)
+    out, it = L.Exponentiator(op, n).run(-1j * dt, init)
+    r_out, r_it, _ = reference.expo(csr, -1j * dt, init)
+    assert it == r_it == iters
+    assert np.max(np.abs(out - r_out)) <= 1e-10 * np.linalg.norm(init)
+    assert 1 - overlap(out, r_out) <= 10 * EPS
+    assert abs(np.linalg.norm(out) / np.linalg.norm(init) - 1.0) <= 1e-12
+    op.close()
+
+
+# ------------------------------------------------------------------ taylor_run, a == 0 (EX:179-182) with device buffers
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
+def test_taylor_run_zero_exponent_with_device_buffers(ctx, dtype):
+    """The a == 0 early exit copies input to output: both may live in HBM (a host memcpy would fault) and may be the SAME
+    buffer (nothing to copy)."""
+    n = 4099
+    csr = G.randsym_np(n)
+    op = L.CsrOperator(ctx, csr[0], csr[1], csr[2].astype(dtype))
+    x = G.start_vector(n, 2, dtype)
+    ex = L.Exponentiator(op, n)
+    out_h, terms = ex.taylor_run(0.0, x)                      # host in, host out
+    assert terms == 1 and np.array_equal(out_h, x)
+    xd = ctx.to_device(x)
+    out_d, terms = ex.taylor_run(0.0, xd)                     # device in, new device out
+    assert terms == 1 and np.array_equal(out_d.get(), x) and out_d.ptr != xd.ptr
+    same, terms = ex.taylor_run(0.0, xd, out=xd)              # in place
+    assert terms == 1 and same.ptr == xd.ptr and np.array_equal(xd.get(), x)
+    # and the Krylov form agrees (a = 0: identity, itern = 2 in the reference; EX:154 stops on the first overlap test)
+    out_k, _ = ex.run(0.0, xd)
+    assert np.max(np.abs(out_k.get() - x)) <= 1e-14 * np.max(np.abs(x))
+    op.close()
+
+
+# ------------------------------------------------------------------ a communicator whose self-check fails is detached again
+def test_failed_communicator_self_check_leaves_the_context_unsharded():
+    """ll_comm_attach runs the rank self-check; a transport that delivers nothing fails it with LL_ERR_RCCL.  The context
+    must then be what it was before — no communicator, rank 0 of 1 — so that it stays usable and the attach can be retried."""
+    calls = {"gather": 0, "reduce": 0, "destroy": 0}
+    GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t,
+                       C.c_void_p)
+    DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+
+    class Transport(C.Structure):
+        _fields_ = [("self", C.c_void_p), ("all_gather", GATHER), ("all_reduce_sum_f64", REDUCE), ("halo_exchange", HALO),
+                    ("destroy", DESTROY)]
+
+    def gather(_self, _send, _recv, _bytes, _stream):
+        calls["gather"] += 1
+        return 0          # claims success, moves nothing: the rank tags never arrive
+
+    def reduce(_self, _buf, _count, _stream):
+        calls["reduce"] += 1
+        return 0
+
+    def halo(*_a):
+        return 0
+
+    def destroy(_self):
+        calls["destroy"] += 1
+
+    t = Transport(None, GATHER(gather), REDUCE(reduce), HALO(halo), DESTROY(destroy))
+    c = L.Context(0)
+    rc = capi.lib().ll_comm_attach(c.handle, C.byref(t), 0, 2)
+    assert rc == capi.LL_ERR_RCCL and b"self-check" in capi.lib().ll_last_error()
+    assert calls["gather"] == 1 and calls["destroy"] == 1
+    r, w = C.c_int(-1), C.c_int(-1)
+    capi.check(capi.lib().ll_comm_rank(c.handle, C.byref(r), C.byref(w)))
+    assert (r.value, w.value) == (0, 1)
+    # the context works as an ordinary single-GPU context ...
+    n = 3001
+    csr = G.randsym_np(n)
+    op = L.CsrOperator(c, *csr)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.max_iteration = 20
+    vals, _ = eng.run()
+    assert np.isfinite(vals[0])
+    op.close()
+    # ... and a second attach is not refused with "communicator already attached" (it fails its self-check again)
+    rc = capi.lib().ll_comm_attach(c.handle, C.byref(t), 0, 2)
+    assert rc == capi.LL_ERR_RCCL and b"self-check" in capi.lib().ll_last_error()
+    c.close()

@@ -23,12 +23,8 @@ from lambda_lanczos_amd import generators as G  # noqa: E402
 DEFAULT = ";".join([
     "csr_stream:LL_SPMV_KERNEL=csr",
     "pb_fixed_default:LL_SPMV_KERNEL=pb",
-    "pb_ordered_u2:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered",
-    "pb_atomic_u2:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic",
-    "pb_ordered_u4:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered,LL_PB_U2=4",
-    "pb_ordered_u1:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered,LL_PB_U2=1",
-    "pb_p1u1:LL_SPMV_KERNEL=pb,LL_PB_U1=1",
-    "pb_p1u4:LL_SPMV_KERNEL=pb,LL_PB_U1=4",
+    "pb_ordered:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=ordered",
+    "pb_atomic:LL_SPMV_KERNEL=pb,LL_PB_PHASE2=atomic",
 ])
 
 ap = argparse.ArgumentParser()
@@ -62,6 +58,7 @@ for spec in a.variants.split(";"):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
+        ctx.reload_env()   # the switches are read once per context
         variants[name] = L.CsrOperator(ctx, *csr)
     finally:
         for k, v in saved.items():
@@ -69,6 +66,7 @@ for spec in a.variants.split(";"):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        ctx.reload_env()
     envs[name] = env
 
 ref = None
