@@ -55,6 +55,7 @@ Tuning read_tuning() {
   t.force_rp64 = flag("LL_FORCE_RP64", false);
   t.pb_test_all_remote = flag("LL_PB_TEST_ALL_REMOTE", false);
   t.tridiag_test_jitter_us = (int)num("LL_TRIDIAG_TEST_JITTER_US", 0);
+  t.pb_prescale = flag("LL_PB_PRESCALE", true);
   t.stencil_vec = flag("LL_STENCIL_VEC", true);
   {
     const std::string v = str("LL_STALL_TRACE");

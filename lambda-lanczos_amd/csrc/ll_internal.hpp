@@ -168,6 +168,7 @@ struct Tuning {
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
   bool pb_test_all_remote = false; // LL_PB_TEST_ALL_REMOTE=1: own columns are read from the gathered buffer too
   int tridiag_test_jitter_us = 0;  // LL_TRIDIAG_TEST_JITTER_US: random delay of every helper-thread verdict
+  bool pb_prescale = true;         // LL_PB_PRESCALE=0: single-GPU fixed-point sums through the sharded contexts' kernel pair (A/B)
   bool stencil_vec = true;         // LL_STENCIL_VEC=0: scalar lattice kernel on shapes the vector kernel would take
   double stall_trace_ms = -1.0;    // LL_STALL_TRACE: print where a whole-loop call longer than this spent its time
 };

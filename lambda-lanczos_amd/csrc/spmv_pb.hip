@@ -66,360 +66,85 @@ template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__
   for (int i = 0; i < NCH; ++i) dst[i] = c[i];
 }
 
-// ================================================================= phase 1
-// Workgroup b handles column block blk_first + b.  The first trip's loads are issued before the x slice is staged, and
-// every trip requests the next one before it consumes its own (one quad per lane per trip, two in flight; two or four
-// quads per trip were measured 3-5 % slower in round 2).
-template <typename T>
-__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, const int64_t* __restrict__ xoff,
-                                                        const int32_t* __restrict__ ncols_tab,
-                                                        const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
-                                                        const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
-                                                        const T* __restrict__ val, const ushort4* __restrict__ col,
-                                                        const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols,
-                                                        double* __restrict__ blockmax) {
-  extern __shared__ double lds[];
-  __shared__ double bm_red[kPbWaves];
-  T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
-  long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
-                                              (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [nrb + 1]
-  long long* db = qs + (nrb + 1);                                                  // [nrb]
-  const int tid = threadIdx.x;
-  const int c = blk_first + blockIdx.x;
-  const int64_t* sq = seg_q + (size_t)c * (nrb + 1);
-  const long long g0 = sq[0] >> 2, g1 = sq[nrb] >> 2;
-
-  quad<T> v;
-  ushort4 cl;
-  long long g = g0 + tid;
-  if (g < g1) {
-    v = load_quad<T>(val + 4 * g);
-    cl = col[g];
+// ================================================================= software pipelines of the two phases
+// One workgroup owns a CU (its LDS slice is > 100 KB), so nothing but the workgroup's own 16 waves hides memory latency:
+// every lane keeps D trips of loads in flight in a STATIC ring of register slots — the trip loop is unrolled D times and
+// every slot index is a compile-time constant, so a trip is consumed while the D - 1 requested after it are still in
+// flight and the compiler can wait for exactly the oldest one (s_waitcnt vmcnt(N)).  (Rounds 1-2 rotated the slots by
+// register copies at the end of every trip; a copy of slot d+1 needs ITS data, so every trip ended with a full drain of
+// the memory pipeline and the stream and the LDS work ran one after the other.)
+// Every vector-memory instruction of the trip loops is UNCONDITIONAL and sits in uniform straight-line code: a lane
+// beyond the end of its range re-reads the range's last quad (a cache hit) and stores to a dump quad behind the image,
+// only the LDS work is predicated.  With loads under divergent branches the number of outstanding loads is unknown at
+// compile time and every wait degenerates to vmcnt(0) again.
+template <typename T, int D> struct ColStream {  // phase 1: (4 values, 4 local columns) per lane per trip
+  quad<T> v[D];
+  ushort4 c[D];
+  const T* val;
+  const ushort4* col;
+  long long glast;  // last valid quad of the range (>= its first quad; the image is padded behind its end)
+  __device__ __forceinline__ void issue(int slot, long long g) {
+    const long long gc = g < glast ? g : glast;
+    v[slot] = load_quad<T>(val + 4 * gc);
+    c[slot] = col[gc];
   }
-  {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
-    const int ncols = ncols_tab[c];
-    const T* src = xsrc + xoff[c];
-    constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
-    if (V > 1 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-      const int nv = ncols / V;
-      const uint4* s4 = reinterpret_cast<const uint4*>(src);
-      uint4* d4 = reinterpret_cast<uint4*>(xs);
-      for (int i = tid; i < nv; i += kPbThreads) d4[i] = s4[i];
-      for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = src[i];
-    } else {
-      for (int i = tid; i < ncols; i += kPbThreads) xs[i] = src[i];
-    }
-    for (int i = tid; i <= nrb; i += kPbThreads) qs[i] = sq[i];
-    const int64_t* sd = seg_dest + (size_t)c * nrb;
-    for (int i = tid; i < nrb; i += kPbThreads) db[i] = sd[i];
-  }
-  __syncthreads();
-  if (blockmax != nullptr) {  // fixed-point phase 2: the largest |x| of the slice (its scale needs max |x| over all columns)
-    double m = 0.0;
-    const int ncols = ncols_tab[c];
-    for (int i = tid; i < ncols; i += kPbThreads) m = fmax(m, abs1(xs[i]));
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
-    if ((tid & 63) == 0) bm_red[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-      double t = bm_red[0];
-      for (int w = 1; w < kPbWaves; ++w) t = fmax(t, bm_red[w]);
-      blockmax[c] = t;  // NaN in the slice: fmax drops it; the products carry it into P and phase 2 reports it
-    }
-  }
-  int r = 0;
-  for (; g < g1; g += kPbThreads) {
-    quad<T> vn;
-    ushort4 cn;
-    const long long gn = g + kPbThreads;
-    if (gn < g1) {
-      vn = load_quad<T>(val + 4 * gn);
-      cn = col[gn];
-    }
-    const long long qq = 4 * g;
-    while (qq >= qs[r + 1]) ++r;
-    quad<T> pr;
-    pr.e[0] = mul(v.e[0], xs[cl.x]);
-    pr.e[1] = mul(v.e[1], xs[cl.y]);
-    pr.e[2] = mul(v.e[2], xs[cl.z]);
-    pr.e[3] = mul(v.e[3], xs[cl.w]);
-    store_quad<T>(P + db[r] + (qq - qs[r]), pr);
-    v = vn;
-    cl = cn;
-  }
-}
-
-// ================================================================= phase 2
-template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, int rl, const T& v) {
-  if constexpr (scalar_traits<T>::is_complex) {
-    lds_add(&lds[2 * rl], (double)v.re);
-    lds_add(&lds[2 * rl + 1], (double)v.im);
-  } else {
-    lds_add(&lds[rl], (double)v);
-  }
-}
-
-// ORDERED: the waves add in turn (fixed order => bit-reproducible floating-point sums, component-wise accurate like the
-// reference's fp64 mv_mul); otherwise in arrival order (LL_PB_PHASE2=atomic: not reproducible, A/B timing reference).
-// D trips of loads are in flight per lane (D - 1 ahead of the one being added): the turns synchronise the whole
-// workgroup 16 times per trip, so without loads issued well ahead the memory pipeline would run in bursts (3 trips for
-// the ordered form, 2 for arrival order; two quads per lane per trip: profiles/r02_spmv_variants_run3.jsonl).
-template <typename T, bool ORDERED, int D>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_local,
-                                                        const int64_t* __restrict__ rptr,  // [nrb + 1]
-                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
-                                                        const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                        double* __restrict__ dot_partials) {
-  constexpr int R = scalar_traits<T>::reals;
-  constexpr int U = 2;
-  extern __shared__ double lds[];  // [rb_rows * R]
-  __shared__ double red[kPbWaves];
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const int rb = blockIdx.x;
-  const int64_t row0 = (int64_t)rb * rb_rows;
-  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
-  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  constexpr long long kTrip = (long long)U * kPbThreads;
-
-  quad<T> pr[D][U];
-  ushort4 rl[D][U];
-#pragma unroll
-  for (int d = 0; d < D - 1; ++d) {
+};
+template <typename T, int U, int D> struct RowStream {  // phase 2: U x (4 products, 4 local rows) per lane per trip
+  quad<T> p[D][U];
+  ushort4 r[D][U];
+  const T* P;
+  const ushort4* row;
+  long long g1, glast;  // end of the range; last valid quad (>= the first quad: the image is padded behind its end)
+  static constexpr long long kTrip = (long long)U * kPbThreads;
+  __device__ __forceinline__ void issue(int slot, long long tbase) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[d][u] = load_quad<T>(P + 4 * gg);
-        rl[d][u] = row[gg];
+      const long long g = tbase + threadIdx.x + (long long)u * kPbThreads;
+      const long long gc = g < glast ? g : glast;
+      p[slot][u] = load_quad<T>(P + 4 * gc);
+      r[slot][u] = row[gc];
+    }
+  }
+  // consume(slot contents, trip base) for every trip of [g0, g1), D - 1 trips requested ahead; prologue() first
+  __device__ __forceinline__ void prologue(long long g0) {
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(d, g0 + d * kTrip);
+  }
+  template <typename F> __device__ __forceinline__ void run(long long g0, F&& consume) {
+    for (long long base = g0; base < g1; base += D * kTrip) {  // trip counts are uniform over the workgroup
+#pragma unroll
+      for (int ph = 0; ph < D; ++ph) {  // (trips beyond g1 in the last round: cache-hit loads, nothing consumed)
+        const long long cur = base + ph * kTrip;
+        issue((ph + D - 1) % D, cur + (D - 1) * kTrip);
+        consume(p[ph], r[ph], cur);
       }
     }
   }
-  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
-  __syncthreads();
-  for (long long base = g0; base < g1; base += kTrip) {  // trip count is uniform over the workgroup
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[D - 1][u] = load_quad<T>(P + 4 * gg);
-        rl[D - 1][u] = row[gg];
-      }
-    }
-    auto add_mine = [&]() {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (base + tid + (long long)u * kPbThreads < g1) {
-          lds_add_elem<T>(lds, rl[0][u].x, pr[0][u].e[0]);
-          lds_add_elem<T>(lds, rl[0][u].y, pr[0][u].e[1]);
-          lds_add_elem<T>(lds, rl[0][u].z, pr[0][u].e[2]);
-          lds_add_elem<T>(lds, rl[0][u].w, pr[0][u].e[3]);
-        }
-      }
-    };
-    if constexpr (ORDERED) {
-      for (int w = 0; w < kPbWaves; ++w) {
-        if (wave == w) add_mine();
-        __syncthreads();
-      }
-    } else {
-      add_mine();
-    }
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        pr[d][u] = pr[d + 1][u];
-        rl[d][u] = rl[d + 1][u];
-      }
-    }
-  }
-  __syncthreads();
-  double dot_acc = 0.0;
-  for (int i = tid; i < rows; i += kPbThreads) {
-    const T xi = xl[row0 + i];
-    acc_t<T> acc;
-    if constexpr (scalar_traits<T>::is_complex) acc = zc{lds[2 * i], lds[2 * i + 1]};
-    else acc = lds[i];
-    const T yi = add(narrow<T>(acc), rmul(offset, xi));
-    y[row0 + i] = yi;
-    dot_acc += re_cmul(xi, yi);
-  }
-  if (dot_partials) {
-    const double v = wave_sum(dot_acc);
-    if ((tid & 63) == 0) red[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < kPbWaves; ++w) t += red[w];
-      dot_partials[rb] = t;
-    }
-  }
-}
+};
 
-// ================================================================= phase 2 with order-independent (fixed-point) sums
-// LL_PB_PHASE2=fixed.  Integer addition is associative, so if every product is first rounded to a fixed-point grid the
-// LDS adds may arrive in ANY order — all waves add concurrently like in the arrival-order form — and the result is
-// still the same bits on every launch, for every kernel geometry and every partition of the matrix.
-//   grid of row i:  q_i = 2^(E_i - 62),  E_i >= exponent of  (sum_j |a_ij|) * max_j |x_j|,  so that the exact sum of the
-//   row, scaled by 1/q_i, fits a 64-bit integer with room to spare.  E_i = rexp[i] (exponent of the row's absolute
-//   sum, computed when the image is built) + exponent of max |x| (phase 1 leaves the maximum of every x slice) + 1.
-// Error per row: each product is rounded to q_i once (<= q_i / 2), the sum itself is exact:
-//   |y_i - exact| <= nnz_i * 2^-63 * 2^E_i  ~  nnz_i * 2^-62 * (sum_j |a_ij|) max|x|,
-// i.e. 2^9 times finer than the unit roundoff of a double-precision sum of terms of that size: at least as accurate as
-// floating-point summation unless the row's terms are all 500 times smaller than sum_j |a_ij| max|x| — and always
-// far below eps * ||A|| ||x||, the scale that matters to the Lanczos recurrence.
 __device__ __forceinline__ double pow2(int k) {  // 2^k for |k| <= 1022
   return __longlong_as_double((long long)(1023 + k) << 52);
 }
-// false: the scaled product is not a finite number below 2^63 (NaN / Inf in x or in the matrix): the row is unusable
-__device__ __forceinline__ bool lds_add_i64(long long* p, double scaled) {
-  if (!(fabs(scaled) < 9.0e18)) return false;
-  const long long v = (long long)rint(scaled);
-  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
-  return true;
-}
 
-// (Measured and dropped: ONE grid per row block instead of one per row, which removes the per-entry look-up of the row's
-// exponent — 0.858 vs 0.862 ms, no gain, and rows much smaller than their block's largest lose accuracy.)
-template <typename T>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64_t n_local, int ncb,
-                                                              const int64_t* __restrict__ rptr,
-                                                              const ushort4* __restrict__ row, const T* __restrict__ P,
-                                                              const int16_t* __restrict__ rexp,
-                                                              const double* __restrict__ blockmax,
-                                                              const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                              double* __restrict__ dot_partials) {
-  constexpr int R = scalar_traits<T>::reals;
-  extern __shared__ double lds_raw[];
-  long long* acc = reinterpret_cast<long long*>(lds_raw);                   // [rb_rows * R]
-  int16_t* ex = reinterpret_cast<int16_t*>(acc + (size_t)rb_rows * R);      // [rb_rows]: 62 - E_i, or kBadRow
-  __shared__ double red[kPbWaves];
-  __shared__ int ex_x;
-  constexpr int kBadRow = 32767;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rb = blockIdx.x;
-  constexpr int U = 2, D = 2;  // two quads per lane per trip, two trips in flight (0.845-0.850 vs 0.856-0.862 ms with three)
-  const int64_t row0 = (int64_t)rb * rb_rows;
-  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
-  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  constexpr long long kTrip = (long long)U * kPbThreads;
-
-  quad<T> pr[D][U];
-  ushort4 rl[D][U];
-#pragma unroll
-  for (int d = 0; d < D - 1; ++d) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[d][u] = load_quad<T>(P + 4 * gg);
-        rl[d][u] = row[gg];
-      }
-    }
-  }
-  {  // exponent of max |x| over ALL columns (every column block left its slice maximum)
-    double m = 0.0;
-    for (int i = tid; i < ncb; i += kPbThreads) m = fmax(m, blockmax[i]);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
-    if (lane == 0) red[wave] = m;
-    for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
-    __syncthreads();
-    if (tid == 0) {
-      double t = red[0];
-      for (int w = 1; w < kPbWaves; ++w) t = fmax(t, red[w]);
-      int e = 0;
-      if (t > 0.0 && isfinite(t)) (void)frexp(t, &e);  // t < 2^e
-      else if (!(t == 0.0)) e = 20000;                  // Inf: every row of the block is reported as NaN
-      else e = -2000;                                   // x == 0: any scale does
-      ex_x = e;
-    }
-    __syncthreads();
-    const int e_x = ex_x;
-    for (int i = tid; i < rb_rows; i += kPbThreads) {
-      int k = kBadRow;
-      if (i < rows) {
-        const int er = rexp[row0 + i];
-        if (er != 32767 && e_x != 20000) k = max(-1000, min(1000, 62 - (er + e_x + 1)));
-      } else {
-        k = 0;
-      }
-      ex[i] = (int16_t)k;
-    }
-    __syncthreads();
-  }
-  for (long long base = g0; base < g1; base += kTrip) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[D - 1][u] = load_quad<T>(P + 4 * gg);
-        rl[D - 1][u] = row[gg];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (base + tid + (long long)u * kPbThreads < g1) {
-        const unsigned short rr[4] = {rl[0][u].x, rl[0][u].y, rl[0][u].z, rl[0][u].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = ex[rr[e]];
-          const double sc = pow2(k == kBadRow ? 0 : k);
-          bool ok;
-          if constexpr (scalar_traits<T>::is_complex) {
-            ok = lds_add_i64(&acc[2 * rr[e]], (double)pr[0][u].e[e].re * sc);
-            ok = lds_add_i64(&acc[2 * rr[e] + 1], (double)pr[0][u].e[e].im * sc) && ok;
-          } else {
-            ok = lds_add_i64(&acc[rr[e]], (double)pr[0][u].e[e] * sc);
-          }
-          if (!ok) ex[rr[e]] = (int16_t)kBadRow;  // the row's result is NaN (same value from every writer)
-        }
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        pr[d][u] = pr[d + 1][u];
-        rl[d][u] = rl[d + 1][u];
-      }
-    }
-  }
-  __syncthreads();
-  double dot_acc = 0.0;
-  for (int i = tid; i < rows; i += kPbThreads) {
-    const T xi = xl[row0 + i];
-    const int k = ex[i];
-    const double back = k == kBadRow ? __longlong_as_double(0x7ff8000000000000ll) : pow2(-k);  // NaN for unusable rows
-    acc_t<T> a;
-    if constexpr (scalar_traits<T>::is_complex) a = zc{(double)acc[2 * i] * back, (double)acc[2 * i + 1] * back};
-    else a = (double)acc[i] * back;
-    const T yi = add(narrow<T>(a), rmul(offset, xi));
-    y[row0 + i] = yi;
-    dot_acc += re_cmul(xi, yi);
-  }
-  if (dot_partials) {
-    const double v = wave_sum(dot_acc);
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < kPbWaves; ++w) t += red[w];
-      dot_partials[rb] = t;
-    }
-  }
-}
-
-// ================================================================= fixed-point sums, PRE-SCALED form (single GPU, double / zc)
-// The same sums as pb_phase2_fixed, bit for bit, with the per-entry work moved out of phase 2: the image stores
-// a~_ij = a_ij * 2^-er_i (er_i = exponent of the row's absolute sum; an exact scaling), phase 1 knows the exponent e_x of
-// max|x| BEFORE it starts (per-workgroup maxima left by the kernel that produced x, or by pb_absmax_kernel) and writes
-// the product ALREADY on the row's grid, as a 64-bit integer:
-//     P = rint( fl(a~_ij x_j) * 2^(61 - e_x) )  =  rint( fl(a_ij x_j) * 2^(62 - E_i) ),   E_i = er_i + e_x + 1.
-// Phase 2 is then a pure stream: one integer LDS atomic per entry — no exponent look-up, no multiply, no conversion —
-// and the y slice needs 8 bytes per row instead of 10, so a row block can be half again as long.  Rows that meet an
-// Inf / NaN carry the sentinel INT64_MIN through P and are reported as NaN.
+// ---- fixed-point sums (LL_PB_PHASE2=fixed, the default)
+// Integer addition is associative, so if every product is first rounded to a fixed-point grid the LDS adds may arrive in
+// ANY order — all waves add concurrently like in the arrival-order form — and the result is still the same bits on every
+// launch, for every kernel geometry and every partition of the matrix.
+//   grid of row i:  q_i = 2^(E_i - 62),  E_i = er_i + e_x + 1,  sum_j |a_ij| < 2^er_i (computed when the image is built),
+//   max_k |x_k| < 2^e_x, so that the exact sum of the row, scaled by 1/q_i, fits a 64-bit integer with room to spare.
+// Error per row: each product is rounded to q_i once (<= q_i / 2), the sum itself is exact:
+//   |y_i - exact| <= nnz_i * 2^-63 * 2^E_i  <=  nnz_i * 2^-60 * (sum_j |a_ij|) max|x|      (lanczos_hip.h states this bound)
+// — finer than the unit roundoff of a double-precision sum of terms of that size, and far below eps * ||A|| ||x||, the
+// scale that matters to the Lanczos recurrence; NOT component-wise accurate for rows whose terms are all tiny against
+// (sum_j |a_ij|) max|x| (LL_PB_PHASE2=ordered is).
+// Two realisations that give the same bits:
+//   LATE  (sharded contexts, float storage): phase 1 writes fl(a_ij x_j) and the maximum of |x| over its slice; phase 2
+//         looks up the row's exponent per entry, scales, rounds and adds.
+//   PRE   (single GPU, double / complex double): the image stores a~_ij = a_ij 2^-er_i (exact), phase 1 knows e_x before it
+//         starts (per-workgroup maxima of |x| left by the kernel that produced x, or by pb_absmax_kernel) and writes
+//         rint(fl(a~_ij x_j) 2^(61 - e_x)) = rint(fl(a_ij x_j) 2^(62 - E_i)) as a 64-bit integer; phase 2 is a pure
+//         stream with one integer LDS atomic per entry, and its y slice needs 8 bytes per row instead of 10.
+// Rows that meet an Inf / NaN are reported as NaN (PRE: the sentinel INT64_MIN travels through P).
 constexpr long long kPbBadProduct = (long long)0x8000000000000000ull;
 constexpr int kPbXInf = 20000;   // e_x when max|x| is not finite: every row is reported as NaN
 constexpr int kPbXMinExp = -900; // vectors smaller than 2^-900 everywhere are put on the grid of 2^-900
@@ -438,6 +163,20 @@ __device__ __forceinline__ int pb_exponent_of_max(double t) {
     e = kPbXInf;
   }
   return e;
+}
+// maximum over the workgroup of a per-lane value (result in every lane); scratch: kPbWaves doubles + 1
+__device__ __forceinline__ double pb_block_max(double m, double* scratch) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = scratch[0];
+    for (int w = 1; w < kPbWaves; ++w) t = fmax(t, scratch[w]);
+    scratch[kPbWaves] = t;
+  }
+  __syncthreads();
+  return scratch[kPbWaves];
 }
 
 // Per-workgroup maxima of |x| (|re| + |im| for complex): xmax[b], b < gridDim.x.  NaN entries are skipped (their
@@ -469,42 +208,39 @@ __global__ __launch_bounds__(256) void pb_absmax_kernel(long long n, const T* __
   if (threadIdx.x == 0) xmax[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-template <typename T>
-__global__ __launch_bounds__(kPbThreads) void pb_phase1_pre(int nrb, const int64_t* __restrict__ xoff,
-                                                            const int32_t* __restrict__ ncols_tab,
-                                                            const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
-                                                            const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
-                                                            const T* __restrict__ val, const ushort4* __restrict__ col,
-                                                            const T* __restrict__ xsrc, long long* __restrict__ P,
-                                                            int cb_cols, const double* __restrict__ xmax, int xmax_n,
-                                                            int* __restrict__ ex_out) {
+// ================================================================= phase 1
+// Workgroup b handles column block blk_first + b: the block's entries (4 values + 4 local columns per lane and trip)
+// stream in, ordered by destination row block; product = value * x_lds[col] goes to the product buffer P at its position
+// in row-block order.  The first D - 1 trips are requested before the x slice is staged.
+// PRE (see above): xmax[0 .. xmax_n) are the per-workgroup maxima of |x|; the products are written as integers on the
+// row's grid and workgroup 0 leaves e_x in *ex_out.  Otherwise blockmax (nullable) receives the slice maximum.
+template <typename T, bool PRE, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, const int64_t* __restrict__ xoff,
+                                                        const int32_t* __restrict__ ncols_tab,
+                                                        const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
+                                                        const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
+                                                        const T* __restrict__ val, const ushort4* __restrict__ col,
+                                                        const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols,
+                                                        double* __restrict__ blockmax, const double* __restrict__ xmax,
+                                                        int xmax_n, int* __restrict__ ex_out, long long p_dump) {
   constexpr int R = scalar_traits<T>::reals;
   extern __shared__ double lds[];
-  __shared__ double bm_red[kPbWaves];
-  __shared__ int ex_sh;
+  __shared__ double bm_red[kPbWaves + 1];
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
   long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
                                               (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [nrb + 1]
   long long* db = qs + (nrb + 1);                                                  // [nrb]
   const int tid = threadIdx.x;
-  const int c = blockIdx.x;
+  const int c = blk_first + blockIdx.x;
   const int64_t* sq = seg_q + (size_t)c * (nrb + 1);
   const long long g0 = sq[0] >> 2, g1 = sq[nrb] >> 2;
 
-  quad<T> v;
-  ushort4 cl;
-  long long g = g0 + tid;
-  if (g < g1) {
-    v = load_quad<T>(val + 4 * g);
-    cl = col[g];
-  }
-  {  // exponent of max |x| over the whole vector, from the per-workgroup maxima
-    double m = 0.0;
-    for (int i = tid; i < xmax_n; i += kPbThreads) m = fmax(m, xmax[i]);
+  ColStream<T, D> st;
+  st.val = val;
+  st.col = col;
+  st.glast = g1 > g0 ? g1 - 1 : g0;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
-    if ((tid & 63) == 0) bm_red[tid >> 6] = m;
-  }
+  for (int d = 0; d < D - 1; ++d) st.issue(d, g0 + tid + (long long)d * kPbThreads);
   {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
     const int ncols = ncols_tab[c];
     const T* src = xsrc + xoff[c];
@@ -522,101 +258,283 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1_pre(int nrb, const int64
     const int64_t* sd = seg_dest + (size_t)c * nrb;
     for (int i = tid; i < nrb; i += kPbThreads) db[i] = sd[i];
   }
-  __syncthreads();
-  if (tid == 0) {
-    double t = bm_red[0];
-    for (int w = 1; w < kPbWaves; ++w) t = fmax(t, bm_red[w]);
-    const int e = pb_exponent_of_max(t);
-    ex_sh = e;
-    if (c == 0) *ex_out = e;  // phase 2 turns the sums back with the same exponent
+  int k = 0;  // PRE: the products are scaled by 2^k = 2^(61 - e_x)
+  if constexpr (PRE) {
+    double m = 0.0;
+    for (int i = tid; i < xmax_n; i += kPbThreads) m = fmax(m, xmax[i]);
+    const int e_x = pb_exponent_of_max(pb_block_max(m, bm_red));  // (its barriers also publish the staged slice)
+    if (c == 0 && tid == 0) *ex_out = e_x;  // phase 2 turns the sums back with the same exponent
+    k = e_x == kPbXInf ? 0 : 61 - e_x;      // (Inf in x: phase 2 reports every row as NaN whatever P holds)
+  } else {
+    __syncthreads();
+    if (blockmax != nullptr) {  // LATE: the largest |x| of the slice (phase 2 needs max |x| over all columns)
+      double m = 0.0;
+      const int ncols = ncols_tab[c];
+      for (int i = tid; i < ncols; i += kPbThreads) m = fmax(m, abs1(xs[i]));
+      m = pb_block_max(m, bm_red);
+      if (tid == 0) blockmax[c] = m;  // NaN in the slice: fmax drops it; the products carry it into P and phase 2 reports it
+    }
   }
-  __syncthreads();
-  const int e_x = ex_sh;
-  const int k = e_x == kPbXInf ? 0 : 61 - e_x;  // (Inf in x: phase 2 reports every row as NaN whatever P holds)
   int r = 0;
-  for (; g < g1; g += kPbThreads) {
-    quad<T> vn;
-    ushort4 cn;
-    const long long gn = g + kPbThreads;
-    if (gn < g1) {
-      vn = load_quad<T>(val + 4 * gn);
-      cn = col[gn];
-    }
+  T* const dump = P + p_dump;  // where lanes beyond the block's last quad store (a quad behind the image)
+  auto consume = [&](const quad<T>& v, const ushort4& cl, long long g) {
     const long long qq = 4 * g;
-    while (qq >= qs[r + 1]) ++r;
+    while (r + 1 < nrb && qq >= qs[r + 1]) ++r;
     const unsigned short cc[4] = {cl.x, cl.y, cl.z, cl.w};
-    long long out[4 * R];
+    quad<T> pr;
+    if constexpr (PRE) {
+      long long out[4 * R];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const T pr = mul(v.e[e], xs[cc[e]]);
-      if constexpr (scalar_traits<T>::is_complex) {
-        out[2 * e] = pb_to_fixed(pr.re, k);
-        out[2 * e + 1] = pb_to_fixed(pr.im, k);
-      } else {
-        out[e] = pb_to_fixed(pr, k);
+      for (int e = 0; e < 4; ++e) {
+        const T pe = mul(v.e[e], xs[cc[e]]);
+        if constexpr (scalar_traits<T>::is_complex) {
+          out[2 * e] = pb_to_fixed(pe.re, k);
+          out[2 * e + 1] = pb_to_fixed(pe.im, k);
+        } else {
+          out[e] = pb_to_fixed(pe, k);
+        }
       }
+      __builtin_memcpy(&pr, out, sizeof(pr));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pr.e[e] = mul(v.e[e], xs[cc[e]]);
     }
-    quad<T> raw;
-    __builtin_memcpy(&raw, out, sizeof(raw));
-    store_quad<T>(reinterpret_cast<T*>(P) + db[r] + (qq - qs[r]), raw);
-    v = vn;
-    cl = cn;
+    store_quad<T>(g < g1 ? P + db[r] + (qq - qs[r]) : dump, pr);
+  };
+  for (long long base = g0; base < g1; base += (long long)D * kPbThreads) {  // uniform trip count
+#pragma unroll
+    for (int ph = 0; ph < D; ++ph) {
+      const long long cur = base + tid + (long long)ph * kPbThreads;
+      st.issue((ph + D - 1) % D, cur + (long long)(D - 1) * kPbThreads);
+      consume(st.v[ph], st.c[ph], cur);
+    }
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2_pre(int rb_rows, int64_t n_local,
-                                                            const int64_t* __restrict__ rptr,
-                                                            const ushort4* __restrict__ row,
-                                                            const long long* __restrict__ P,
-                                                            const int16_t* __restrict__ rexp, const int* __restrict__ ex_in,
-                                                            const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                            double* __restrict__ dot_partials) {
+// ================================================================= phase 2
+// One workgroup per ROW block (y slice in LDS): the block's range of P and of the 16-bit local rows streams in and is
+// added into the slice; the epilogue adds offset * x_i (a2), writes y once and accumulates Re(conj(x_i) y_i) (a3).
+template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, int rl, const T& v) {
+  if constexpr (scalar_traits<T>::is_complex) {
+    lds_add(&lds[2 * rl], (double)v.re);
+    lds_add(&lds[2 * rl + 1], (double)v.im);
+  } else {
+    lds_add(&lds[rl], (double)v);
+  }
+}
+// the shared epilogue: value(i) gives row i's sum; y = value + offset x, partial Re<x, y> per workgroup
+template <typename T, typename F>
+__device__ __forceinline__ void pb_phase2_epilogue(int rb, int64_t row0, int rows, const T* __restrict__ xl, T* __restrict__ y,
+                                                   double offset, double* __restrict__ dot_partials, double* red, F&& value) {
+  const int tid = threadIdx.x;
+  constexpr int EU = 4;  // rows per lane per round: the loads of a round are all requested before the first is used
+  double dot_acc = 0.0;
+  for (int i0 = tid; i0 < rows; i0 += EU * kPbThreads) {
+    T xi[EU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int i = i0 + u * kPbThreads;
+      if (i < rows) xi[u] = xl[row0 + i];
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int i = i0 + u * kPbThreads;
+      if (i < rows) {
+        const T yi = add(narrow<T>(value(i)), rmul(offset, xi[u]));
+        y[row0 + i] = yi;
+        dot_acc += re_cmul(xi[u], yi);
+      }
+    }
+  }
+  if (dot_partials) {
+    const double v = wave_sum(dot_acc);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kPbWaves; ++w) t += red[w];
+      dot_partials[rb] = t;
+    }
+  }
+}
+
+// Floating-point sums.  ORDERED: the 16 waves add in turn (a barrier between turns) — a fixed order, so every y_i is the
+// same bits on every launch, and component-wise accurate like the reference's fp64 mv_mul; otherwise arrival order
+// (LL_PB_PHASE2=atomic: not reproducible, A/B timing reference).
+template <typename T, bool ORDERED, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_local,
+                                                        const int64_t* __restrict__ rptr,  // [nrb + 1]
+                                                        const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                        const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                        double* __restrict__ dot_partials) {
   constexpr int R = scalar_traits<T>::reals;
-  constexpr int U = 2, D = 2;
-  extern __shared__ double lds_raw[];
-  long long* acc = reinterpret_cast<long long*>(lds_raw);                    // [rb_rows * R]
-  unsigned* bad = reinterpret_cast<unsigned*>(acc + (size_t)rb_rows * R);    // [(rb_rows + 31) / 32] rows that met Inf / NaN
+  constexpr int U = 2;
+  extern __shared__ double lds[];  // [rb_rows * R]
   __shared__ double red[kPbWaves];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int rb = blockIdx.x;
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  constexpr long long kTrip = (long long)U * kPbThreads;
-  const T* PT = reinterpret_cast<const T*>(P);
-
-  quad<T> pr[D][U];
-  ushort4 rl[D][U];
+  RowStream<T, U, D> st;
+  st.P = P;
+  st.row = row;
+  st.g1 = g1;
+  st.glast = g1 > g0 ? g1 - 1 : g0;
+  st.prologue(g0);
+  for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
+  __syncthreads();
+  st.run(g0, [&](const quad<T>(&p)[U], const ushort4(&r)[U], long long cur) {
+    auto add_mine = [&]() {
 #pragma unroll
-  for (int d = 0; d < D - 1; ++d) {
+      for (int u = 0; u < U; ++u) {
+        if (cur + tid + (long long)u * kPbThreads < g1) {
+          lds_add_elem<T>(lds, r[u].x, p[u].e[0]);
+          lds_add_elem<T>(lds, r[u].y, p[u].e[1]);
+          lds_add_elem<T>(lds, r[u].z, p[u].e[2]);
+          lds_add_elem<T>(lds, r[u].w, p[u].e[3]);
+        }
+      }
+    };
+    if constexpr (ORDERED) {
+      for (int w = 0; w < kPbWaves; ++w) {
+        if (wave == w) add_mine();
+        __syncthreads();
+      }
+    } else {
+      add_mine();
+    }
+  });
+  __syncthreads();
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, [&](int i) {
+    acc_t<T> a;
+    if constexpr (scalar_traits<T>::is_complex) a = zc{lds[2 * i], lds[2 * i + 1]};
+    else a = lds[i];
+    return a;
+  });
+}
+
+// Fixed-point sums, LATE form (see above): P holds fl(a_ij x_j) in the storage type.
+template <typename T, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64_t n_local, int ncb,
+                                                              const int64_t* __restrict__ rptr,
+                                                              const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                              const int16_t* __restrict__ rexp,
+                                                              const double* __restrict__ blockmax,
+                                                              const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                              double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  constexpr int U = 2;
+  extern __shared__ double lds_raw[];
+  long long* acc = reinterpret_cast<long long*>(lds_raw);                   // [rb_rows * R]
+  int16_t* ex = reinterpret_cast<int16_t*>(acc + (size_t)rb_rows * R);      // [rb_rows]: 62 - E_i, or kBadRow
+  __shared__ double red[kPbWaves + 1];
+  constexpr int kBadRow = 32767;
+  const int tid = threadIdx.x;
+  const int rb = blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+  RowStream<T, U, D> st;
+  st.P = P;
+  st.row = row;
+  st.g1 = g1;
+  st.glast = g1 > g0 ? g1 - 1 : g0;
+  st.prologue(g0);
+  {  // exponent of max |x| over ALL columns (every column block left its slice maximum)
+    double m = 0.0;
+    for (int i = tid; i < ncb; i += kPbThreads) m = fmax(m, blockmax[i]);
+    for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
+    const double t = pb_block_max(m, red);
+    int e_x = -2000;  // x == 0: any scale does
+    if (t > 0.0 && isfinite(t)) (void)frexp(t, &e_x);  // t < 2^e
+    else if (!(t == 0.0)) e_x = kPbXInf;               // Inf: every row of the block is reported as NaN
+    for (int i = tid; i < rb_rows; i += kPbThreads) {
+      int k = kBadRow;
+      if (i < rows) {
+        const int er = rexp[row0 + i];
+        if (er != 32767 && e_x != kPbXInf) k = max(-1000, min(1000, 62 - (er + e_x + 1)));
+      } else {
+        k = 0;
+      }
+      ex[i] = (int16_t)k;
+    }
+    __syncthreads();
+  }
+  st.run(g0, [&](const quad<T>(&p)[U], const ushort4(&r)[U], long long cur) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long gg = g0 + d * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[d][u] = load_quad<T>(PT + 4 * gg);
-        rl[d][u] = row[gg];
+      if (cur + tid + (long long)u * kPbThreads < g1) {
+        const unsigned short rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = ex[rr[e]];
+          const double sc = pow2(k == kBadRow ? 0 : k);
+          long long w[R];
+          if constexpr (scalar_traits<T>::is_complex) {
+            w[0] = pb_to_fixed((double)p[u].e[e].re * sc, 0);
+            w[1] = pb_to_fixed((double)p[u].e[e].im * sc, 0);
+          } else {
+            w[0] = pb_to_fixed((double)p[u].e[e] * sc, 0);
+          }
+          bool ok = true;
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            if (w[q] == kPbBadProduct) ok = false;
+            else atomicAdd(reinterpret_cast<unsigned long long*>(&acc[R * rr[e] + q]), (unsigned long long)w[q]);
+          }
+          if (!ok) ex[rr[e]] = (int16_t)kBadRow;  // the row's result is NaN (same value from every writer)
+        }
       }
     }
-  }
+  });
+  __syncthreads();
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, [&](int i) {
+    const int k = ex[i];
+    const double back = k == kBadRow ? __longlong_as_double(0x7ff8000000000000ll) : pow2(-k);  // NaN for unusable rows
+    acc_t<T> a;
+    if constexpr (scalar_traits<T>::is_complex) a = zc{(double)acc[2 * i] * back, (double)acc[2 * i + 1] * back};
+    else a = (double)acc[i] * back;
+    return a;
+  });
+}
+
+// Fixed-point sums, PRE form (see above): P holds 64-bit integers on the row's grid.
+template <typename T, int D>
+__global__ __launch_bounds__(kPbThreads) void pb_phase2_pre(int rb_rows, int64_t n_local,
+                                                            const int64_t* __restrict__ rptr,
+                                                            const ushort4* __restrict__ row, const T* __restrict__ P,
+                                                            const int16_t* __restrict__ rexp, const int* __restrict__ ex_in,
+                                                            const T* __restrict__ xl, T* __restrict__ y, double offset,
+                                                            double* __restrict__ dot_partials) {
+  constexpr int R = scalar_traits<T>::reals;
+  constexpr int U = 2;
+  extern __shared__ double lds_raw[];
+  long long* acc = reinterpret_cast<long long*>(lds_raw);                    // [rb_rows * R]
+  unsigned* bad = reinterpret_cast<unsigned*>(acc + (size_t)rb_rows * R);    // [(rb_rows + 31) / 32] rows that met Inf / NaN
+  __shared__ double red[kPbWaves];
+  const int tid = threadIdx.x;
+  const int rb = blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
+  RowStream<T, U, D> st;
+  st.P = P;
+  st.row = row;
+  st.g1 = g1;
+  st.glast = g1 > g0 ? g1 - 1 : g0;
+  st.prologue(g0);
   for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
   for (int i = tid; i < (rb_rows + 31) / 32; i += kPbThreads) bad[i] = 0u;
   __syncthreads();
-  for (long long base = g0; base < g1; base += kTrip) {
+  st.run(g0, [&](const quad<T>(&p)[U], const ushort4(&r)[U], long long cur) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long gg = base + (D - 1) * kTrip + tid + (long long)u * kPbThreads;
-      if (gg < g1) {
-        pr[D - 1][u] = load_quad<T>(PT + 4 * gg);
-        rl[D - 1][u] = row[gg];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (base + tid + (long long)u * kPbThreads < g1) {
-        const unsigned short rr[4] = {rl[0][u].x, rl[0][u].y, rl[0][u].z, rl[0][u].w};
+      if (cur + tid + (long long)u * kPbThreads < g1) {
+        const unsigned short rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
         long long w[4 * R];
-        __builtin_memcpy(w, &pr[0][u], sizeof(w));
+        __builtin_memcpy(w, &p[u], sizeof(w));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -628,20 +546,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_pre(int rb_rows, int64_t
         }
       }
     }
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        pr[d][u] = pr[d + 1][u];
-        rl[d][u] = rl[d + 1][u];
-      }
-    }
-  }
+  });
   __syncthreads();
   const int e_x = *ex_in;
-  double dot_acc = 0.0;
-  for (int i = tid; i < rows; i += kPbThreads) {
-    const T xi = xl[row0 + i];
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, [&](int i) {
     const int er = rexp[row0 + i];
     const bool unusable = e_x == kPbXInf || er == 32767 || ((bad[i >> 5] >> (i & 31)) & 1u);
     const int k = er + e_x - 61;
@@ -653,20 +561,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_pre(int rb_rows, int64_t
       if constexpr (scalar_traits<T>::is_complex) a = zc{nan, nan};
       else a = nan;
     }
-    const T yi = add(narrow<T>(a), rmul(offset, xi));
-    y[row0 + i] = yi;
-    dot_acc += re_cmul(xi, yi);
-  }
-  if (dot_partials) {
-    const double v = wave_sum(dot_acc);
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < kPbWaves; ++w) t += red[w];
-      dot_partials[rb] = t;
-    }
-  }
+    return a;
+  });
 }
 
 // exponent of every local row's absolute sum: sum_j |a_ij| < 2^rexp[i]  (32767: the row holds Inf / NaN)
@@ -691,21 +587,40 @@ constexpr int kPbLdsCap = 160 * 1024 - 2048;
 template <typename K> void pb_opt_in(K kernel) {
   LL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbLdsCap));
 }
+// trips of loads in flight per lane: three in both phases (two for the 16-byte types in phase 2, where a third trip spills
+// registers).  Measured on config 3 (profiles/r03_spmv_variants.txt): 3/3 0.898 ms, 2/2 0.937, 4/3 0.892, 3/2 0.890, 2/3
+// 0.889 on one box — beyond two trips the differences are inside the 2-4 % position noise of one process.
+template <typename T> constexpr int pb_depth2() { return sizeof(T) < 16 ? 3 : 2; }
+constexpr int kPbDepth1 = 3;
+
 template <typename T> void pb_opt_in_lds() {
   static std::atomic<unsigned long long> mask{0};
   int dev = 0;
   LL_HIP(hipGetDevice(&dev));
   const unsigned long long bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
-  pb_opt_in(&pb_phase1<T>);
-  pb_opt_in(&pb_phase2<T, false, 2>);
-  pb_opt_in(&pb_phase2<T, true, 3>);
-  pb_opt_in(&pb_phase2_fixed<T>);
+  constexpr int D2 = pb_depth2<T>();
+  pb_opt_in(&pb_phase1<T, false, kPbDepth1>);
+  pb_opt_in(&pb_phase2<T, false, D2>);
+  pb_opt_in(&pb_phase2<T, true, D2>);
+  pb_opt_in(&pb_phase2_fixed<T, D2>);
   if constexpr (sizeof(typename scalar_traits<T>::real) == 8) {
-    pb_opt_in(&pb_phase1_pre<T>);
-    pb_opt_in(&pb_phase2_pre<T>);
+    pb_opt_in(&pb_phase1<T, true, kPbDepth1>);
+    pb_opt_in(&pb_phase2_pre<T, D2>);
   }
   mask.fetch_or(bit, std::memory_order_release);
+}
+
+template <typename T, bool PRE>
+void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, const double* xmax, int xmax_n,
+                   hipStream_t s) {
+  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
+  double* bm = (!PRE && op.pb_phase2 == LL_PB_FIXED) ? op.d_pb_blockmax : nullptr;
+  hipLaunchKernelGGL((pb_phase1<T, PRE, kPbDepth1>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first,
+                     op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,
+                     (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols, bm, xmax, xmax_n, op.d_pb_ex,
+                     (long long)op.pb_entries);
+  LL_HIP(hipGetLastError());
 }
 }  // namespace
 
@@ -714,11 +629,7 @@ void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const
   if (blk_count <= 0 || op.pb_nrb <= 0) return;
   LL_REQUIRE(!op.pb_prescaled, "internal: the pre-scaled PB image is driven by launch_spmv_pb only");
   pb_opt_in_lds<T>();
-  const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
-  hipLaunchKernelGGL((pb_phase1<T>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
-                     op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col,
-                     xsrc, (T*)op.d_pb_prod, op.pb_cb_cols, op.pb_phase2 == LL_PB_FIXED ? op.d_pb_blockmax : nullptr);
-  LL_HIP(hipGetLastError());
+  phase1_launch<T, false>(op, blk_first, blk_count, xsrc, nullptr, 0, s);
 }
 
 template <typename T>
@@ -728,18 +639,19 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
   LL_REQUIRE(!op.pb_prescaled, "internal: the pre-scaled PB image is driven by launch_spmv_pb only");
   pb_opt_in_lds<T>();
   const dim3 grid(op.pb_nrb), block(kPbThreads);
-  if (op.pb_phase2 == LL_PB_FIXED) {  // order-independent fixed-point sums
+  constexpr int D2 = pb_depth2<T>();
+  if (op.pb_phase2 == LL_PB_FIXED) {  // order-independent fixed-point sums, LATE form
     const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
-    hipLaunchKernelGGL((pb_phase2_fixed<T>), grid, block, ldsf, s, op.pb_rb_rows, op.n_local, op.pb_ncb, op.d_pb_rptr,
+    hipLaunchKernelGGL((pb_phase2_fixed<T, D2>), grid, block, ldsf, s, op.pb_rb_rows, op.n_local, op.pb_ncb, op.d_pb_rptr,
                        (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp, op.d_pb_blockmax, x_local, y,
                        offset, dot_partials);
   } else {
     const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
     if (op.pb_phase2 == LL_PB_ORDERED)
-      hipLaunchKernelGGL((pb_phase2<T, true, 3>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
+      hipLaunchKernelGGL((pb_phase2<T, true, D2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
                          (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
     else
-      hipLaunchKernelGGL((pb_phase2<T, false, 2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
+      hipLaunchKernelGGL((pb_phase2<T, false, D2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
                          (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
   }
   LL_HIP(hipGetLastError());
@@ -765,13 +677,10 @@ int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, c
         xmax_n = launch_pb_absmax<T>(op, x_own, s);
         xmax = op.d_pb_xmax;
       }
-      const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
-      hipLaunchKernelGGL((pb_phase1_pre<T>), dim3(op.pb_ncb), dim3(kPbThreads), lds1, s, op.pb_nrb, op.d_pb_xoff,
-                         op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col,
-                         x_own, (long long*)op.d_pb_prod, op.pb_cb_cols, xmax, xmax_n, op.d_pb_ex);
+      phase1_launch<T, true>(op, 0, op.pb_ncb, x_own, xmax, xmax_n, s);
       const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>) + (size_t)((op.pb_rb_rows + 31) / 32) * sizeof(unsigned);
-      hipLaunchKernelGGL((pb_phase2_pre<T>), dim3(op.pb_nrb), dim3(kPbThreads), lds2, s, op.pb_rb_rows, op.n_local,
-                         op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const long long*)op.d_pb_prod, op.d_pb_rexp,
+      hipLaunchKernelGGL((pb_phase2_pre<T, pb_depth2<T>()>), dim3(op.pb_nrb), dim3(kPbThreads), lds2, s, op.pb_rb_rows,
+                         op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp,
                          op.d_pb_ex, x_local, y, offset, dot_partials);
       LL_HIP(hipGetLastError());
       return op.pb_nrb;
@@ -968,7 +877,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   // (the fixed-point form of phase 2 keeps a 16-bit exponent per row next to the accumulator)
   // Pre-scaled fixed-point image (spmv_pb.hip, pb_phase1_pre / pb_phase2_pre): double-precision storage types on a
   // single GPU (a sharded run would need max|x| over all ranks before its own-column work may start).
-  const bool prescaled = ctx->comm == nullptr && ctx->tune.pb_phase2 == LL_PB_FIXED && sizeof(typename scalar_traits<T>::real) == 8;
+  const bool prescaled = ctx->comm == nullptr && ctx->tune.pb_prescale && ctx->tune.pb_phase2 == LL_PB_FIXED && sizeof(typename scalar_traits<T>::real) == 8;
   const int64_t row_max = prescaled ? std::min<int64_t>(65536, (kPbLdsCap - 4096) / (int64_t)sizeof(acc_t<T>))
                                     : std::min<int64_t>(65536, (152 * 1024) / (int64_t)(sizeof(acc_t<T>) + sizeof(int16_t)));
   const Tuning& tune = ctx->tune;
@@ -1139,7 +1048,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   up((void**)&op->d_pb_rptr, rptr.data(), rptr.size() * sizeof(int64_t));
   up((void**)&op->d_pb_xoff, xoff.data(), xoff.size() * sizeof(int64_t));
   up((void**)&op->d_pb_ncols, ncols.data(), ncols.size() * sizeof(int32_t));
-  const size_t cap = std::max<size_t>(entries, 16);
+  // 16 entries behind the image: the dump quad of phase 1 and the clamped reads of an empty last block
+  const size_t cap = entries + 16;
   // ONE allocation for the four big streams (values, local columns, local rows, product buffer), starts 2 MiB aligned
   // (staggering the starts against the HBM channel interleave was measured in round 2: no effect).
   {
