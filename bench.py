@@ -59,6 +59,8 @@ def parse_args():
                     help="hand the start vector / input over and take the results back in HOST buffers (the reference's "
                          "std::vector boundary: PCIe copies inside the timed region); default: device buffers, i.e. inputs "
                          "resident in HBM when the timed region starts")
+    ap.add_argument("--no-spmv-variants", action="store_true",
+                    help="do not time the other phase-2 forms of the PB SpMV (spmv.ms_by_kernel then holds the selected kernel only)")
     ap.add_argument("--no-phase-timers", action="store_true",
                     help="skip the instrumented steps after the timed region (no per-phase split, no roofline_orth)")
     ap.add_argument("--phase-timers-inline", action="store_true",
@@ -78,27 +80,43 @@ def spmv_bytes(n, nnz, complex_):
     return (s + 4) * nnz + 4 * (n + 1) + 2 * s * n
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources (what a committed PMC summary was measured on; tools/pmc_summary.py stores it)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "spmv_pb.hip", "dev_helpers.hpp"):
+        with open(os.path.join(ROOT, "lambda-lanczos_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, kernels, dtype_tag):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this workload (tools/pmc_summary.py),
-    or None when no such profile exists.  bench.py cannot collect PMC counters itself; the summary names its source."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this workload (tools/pmc_summary.py), its file
+    name and its age, or (None, None, age) when no profile exists or a kernel of this run is not in it (a renamed or
+    re-templated kernel: the summary is stale, no number is better than an old one).  bench.py cannot collect PMC counters
+    itself."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % workload)))
     if not files:
-        return None, None
+        return None, None, None
     with open(files[-1]) as f:
         d = json.load(f)
+    age = {"summary": os.path.relpath(files[-1], ROOT), "collected_at_head": d.get("collected_at_head"),
+           "kernel_sources_sha16_then": d.get("kernel_sources_sha16"), "kernel_sources_sha16_now": kernel_sources_sha16()}
+    age["kernel_sources_unchanged"] = age["kernel_sources_sha16_then"] == age["kernel_sources_sha16_now"]
     total = 0.0
     for k in kernels:
-        # template arguments after the scalar type (unroll factors, index width) vary: match on the prefix
-        # (phase 2 of the PB SpMV runs as pb_phase2_fixed<...> by default, pb_phase2<...> with LL_PB_PHASE2=ordered)
-        hits = [v for name, v in d["kernels"].items()
-                if name.startswith("%s<%s" % (k, dtype_tag)) or name.startswith("%s_fixed<%s" % (k, dtype_tag))]
+        # template arguments after the scalar type (pipeline depths, index width) vary: match on name + scalar type
+        hits = [v for name, v in d["kernels"].items() if name.startswith("%s<%s" % (k, dtype_tag))]
         if not hits:
-            return None, None
+            age["kernels_match"] = False
+            return None, None, age
         e = max(hits, key=lambda v: v.get("launches", 0))
         total += e["fetch_bytes_mean"] + e["write_bytes_mean"]
-    return total, os.path.relpath(files[-1], ROOT)
+    age["kernels_match"] = True
+    return total, os.path.relpath(files[-1], ROOT), age
 
 
 def pmc_orth_traffic(workload, window):
@@ -267,23 +285,54 @@ def main():
     # lattice: x read once, y written once (+ the real on-site array of config 5)
     b_spmv = (2 * (16 if complex_ else 8) * n + (8 * n if complex_ else 0)) if lattice else spmv_bytes(n, nnz, complex_)
     selected = -1 if lattice else op.selected_spmv()
-    # phase 2 of the PB SpMV: pb_phase2_fixed (order-independent fixed-point sums, the default) or pb_phase2 (LL_PB_PHASE2=...)
-    p2 = "pb_phase2_fixed" if os.environ.get("LL_PB_PHASE2", "fixed") == "fixed" and not os.environ.get("LL_PB_XPROP") else "pb_phase2"
+    # phase 2 of the PB SpMV: fixed-point sums (the default; pb_phase2_pre on one GPU for double / complex double, where
+    # phase 1 already writes integers on the row's grid, pb_phase2_fixed otherwise) or pb_phase2 (LL_PB_PHASE2=ordered|atomic)
+    phase2_form = os.environ.get("LL_PB_PHASE2", "fixed")
+    if phase2_form not in ("ordered", "atomic"):
+        phase2_form = "fixed"
+    p2 = ("pb_phase2_pre" if world == 1 and os.environ.get("LL_PB_PRESCALE", "1") != "0" else "pb_phase2_fixed") \
+        if phase2_form == "fixed" else "pb_phase2"
     kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+" + p2, -1: "stencil_kernel"}
     # The operator timed both kernels on the actual matrix when it was created and released the slower image; those
     # creation-time figures are reported next to the event timing of the kernel that is in use.
     tune = None if lattice else dict(zip(("spmv_stream", "pb_phase1+" + p2), op.autotune_ms()))
-    rounds = []
-    for rnd in range(3):
-        L.spmv(op, xd, yd)
-        barrier()
-        ctx.timer_start()
-        for _ in range(args.spmv_reps):
-            L.spmv(op, xd, yd)
-        rounds.append(max_over_ranks(ctx.timer_stop() / args.spmv_reps))
-    spmv_ms = sorted(rounds)[len(rounds) // 2]
-    spmv_variants = {kernel_names[selected]: spmv_ms}
+    def time_spmv(o):
+        rounds = []
+        for rnd in range(3):
+            L.spmv(o, xd, yd)
+            barrier()
+            ctx.timer_start()
+            for _ in range(args.spmv_reps):
+                L.spmv(o, xd, yd)
+            rounds.append(max_over_ranks(ctx.timer_stop() / args.spmv_reps))
+        return sorted(rounds)[len(rounds) // 2]
+
+    spmv_ms = time_spmv(op)
+    spmv_variants = {"%s [%s]" % (kernel_names[selected], phase2_form) if selected == L.capi.SPMV_PB else kernel_names[selected]: spmv_ms}
     spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
+    if selected == L.capi.SPMV_PB and world == 1 and not args.no_spmv_variants:
+        # The other two phase-2 forms on the SAME matrix in the SAME process (each its own image, built and released here),
+        # so that a slow box and a slow kernel can be told apart from one JSON line.
+        STAGE[0] = "SpMV timing of the other phase-2 forms"
+        saved = {k: os.environ.get(k) for k in ("LL_PB_PHASE2", "LL_SPMV_KERNEL")}
+        try:
+            for form in ("fixed", "ordered", "atomic"):
+                if form == phase2_form:
+                    continue
+                os.environ["LL_PB_PHASE2"], os.environ["LL_SPMV_KERNEL"] = form, "pb"
+                ctx.reload_env()
+                alt = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
+                nm = "pb_phase1+%s [%s]" % ("pb_phase2" if form != "fixed" else "pb_phase2_pre", form)
+                spmv_variants[nm] = time_spmv(alt)
+                alt.close()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            ctx.reload_env()
+        spmv_variants["%s [%s] again, after the others" % (kernel_names[selected], phase2_form)] = time_spmv(op)
 
     # ------------------------------------------------------------ timed steps
     STAGE[0] = "timed Lanczos windows"
@@ -344,6 +393,39 @@ def main():
     total_iters = int(sum(itern))
     value = total_iters / elapsed
     itern_phases = list(itern)
+    # The same steps through the OTHER boundary, in the same process: `value` is the device-buffer figure unless --host-io
+    # was given; value_host_io is always the reference's std::vector boundary (LL:330: start vector up through the pinned
+    # staging buffer, eigenvector / output back), value_device_io always the HBM-resident one.
+    STAGE[0] = "timed windows through the other I/O boundary"
+    if wl == "c5":
+        if args.host_io:
+            d_in2, d_out2 = ctx.to_device(init), ctx.empty((nl,), dtype)
+
+            def step_other():
+                return eng.run(-1j * 5.0, d_in2, out=d_out2)[1]
+        else:
+            def step_other():
+                return eng.run(-1j * 5.0, init)[1]
+    else:
+        keep_io = (eng.init_vector, getattr(eng, "eigenvectors_out", None))
+        other_io = ((ctx.to_device(init), ctx.empty((1, nl), dtype)) if args.host_io else
+                    ((lambda v, *_: np.copyto(v, init)), None))
+
+        def step_other():
+            eng.init_vector, eng.eigenvectors_out = other_io
+            try:
+                eng.run()
+            finally:
+                eng.init_vector, eng.eigenvectors_out = keep_io
+            return eng.getIterationCounts()[0]
+    step_other()
+    barrier()
+    t0o = time.perf_counter()
+    iters_other = sum(step_other() for _ in range(args.steps))
+    barrier()
+    elapsed_other = max_over_ranks(time.perf_counter() - t0o)
+    value_other = iters_other / elapsed_other
+    value_host_io, value_device_io = (value, value_other) if args.host_io else (value_other, value)
     if not inline and not args.no_phase_timers:
         STAGE[0] = "instrumented steps (per-phase timers)"
         ctx.set_profiling(True)
@@ -446,10 +528,10 @@ def main():
             "host_cores_available": os.cpu_count(),
         }
 
-    traffic, traffic_src = (None, None)
+    traffic, traffic_src, traffic_age = (None, None, None)
     orth_traffic, orth_traffic_src = (None, None)
     if world == 1 and not args.n and not lattice:
-        traffic, traffic_src = pmc_traffic(wl, kernel_names[selected].split("+"), "ll::zc" if complex_ else "double")
+        traffic, traffic_src, traffic_age = pmc_traffic(wl, kernel_names[selected].split("+"), "ll::zc" if complex_ else "double")
         if args.eps is None and wl != "c5":
             orth_traffic, orth_traffic_src = pmc_orth_traffic(wl, args.window)
 
@@ -486,6 +568,8 @@ def main():
                        if wl == "c3" and not args.n else
                        "Lanczos iterations/sec (fixed window) + SpMV GB/s, %s" % ("complex fp64" if complex_ else "fp64")),
             "value": value,
+            "value_host_io": value_host_io,      # the same steps with std::vector-style host buffers at the boundary (LL:330)
+            "value_device_io": value_device_io,  # ... with the start vector / result resident in HBM (what `value` is by default)
             "unit": "Lanczos iterations/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -521,9 +605,9 @@ def main():
                      "includes_exchange": world > 1},
             "roofline": {
                 "kernel": kernel_names[selected],
-                "launch": "one SpMV y = A x (pb: two back-to-back kernels; phase 2 with order-independent fixed-point "
-                          "sums), HIP events on the library stream, "
-                          "%d launches averaged" % args.spmv_reps,
+                "launch": "one ll_spmv call y = A x (pb: pb_absmax (14 us; the Lanczos loop gets max|x| from its normalisation "
+                          "kernel instead) + two back-to-back kernels, phase 2 with order-independent fixed-point sums), HIP "
+                          "events on the library stream, %d launches averaged" % args.spmv_reps,
                 "bound": "hbm",
                 "achieved": spmv_gbs,
                 "peak": HBM_PEAK_GBS,
@@ -531,6 +615,7 @@ def main():
                 "frac": spmv_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_age": traffic_age,
                 "achieved_actual_traffic_GBps": (traffic / (spmv_ms * 1e-3) / 1e9) if traffic else None,
             },
             "roofline_orth": {

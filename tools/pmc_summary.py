@@ -33,7 +33,17 @@ def main():
     windows = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     window_iterations = int(sys.argv[5]) if len(sys.argv) > 5 else 100
     fetch, write = load(d + "/pmc_fetch_counter_collection.csv"), load(d + "/pmc_write_counter_collection.csv")
-    res = {"units": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count correction), "
+    import hashlib
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "spmv_pb.hip", "dev_helpers.hpp"):
+        with open(os.path.join(root, "lambda-lanczos_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    res = {"kernel_sources_sha16": h.hexdigest()[:16],  # bench.py compares it with the sources it runs (roofline.traffic_age)
+           "collected_at_head": os.environ.get("LL_PROFILE_HEAD"),  # git HEAD of the tree the profile was taken on (set by the caller)
+           "units": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count correction), "
                     "write = WRITE_SIZE KiB * 1024",
            "calibration": {}, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
@@ -57,7 +67,7 @@ def main():
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["calibration"]))
     for k, v in res["kernels"].items():
-        if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "stencil", "dense_mv", "gemv_basis")):
+        if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "pb_phase2_pre<", "pb_absmax", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "stencil", "dense_mv", "gemv_basis")):
             print(k, {kk: (round(vv / 1e9, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()})
     if windows:
         print("orth_bytes_per_window_GB", res["orth_bytes_per_window"] / 1e9)
