@@ -172,8 +172,10 @@ template <typename T> double* Engine<T>::xmax_buffer() {
 }
 
 template <typename T>
-void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer) {
+void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer,
+                      const ScaleIn<T>* sc) {
   TraceRange trace("ll::apply (mv_mul + offset + alpha)");
+  LL_REQUIRE(sc == nullptr || can_defer_scale(), "internal: this operator cannot normalise its input on the fly");
   hipStream_t s = ctx->stream;
   ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)op->pb_nrb));
   double* const dotp = d_alpha ? ctx->d_alpha_partials : nullptr;
@@ -199,7 +201,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       lo = rlo;
       hi = rhi;
     }
-    nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, dotp, s);
+    nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, dotp, s, sc);
   } else if (op->kind == ll_operator::CSR || op->kind == ll_operator::DENSE) {
     const bool pb = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB;
     const T* x_full = x_local;
@@ -257,14 +259,14 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     }
     if (remote_done) {
     } else if (op->kind == ll_operator::DENSE)
-      nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s);
+      nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
     else if (pb) {
       const bool have_max = xmax_of == (const void*)x_local && xmax_n > 0 && ctx->comm == nullptr;
       nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, have_max ? ctx->d_xmax : nullptr,
                                  have_max ? xmax_n : 0);
     }
     else
-      nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s);
+      nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
   } else {
     LL_REQUIRE(!(ctx->comm != nullptr), "callback operators are not supported on sharded contexts");
     const size_t bytes = (size_t)n_local * sizeof(T);
@@ -489,15 +491,29 @@ void Engine<T>::gemv(const RunList<T>& basis, int64_t m, int nout, const T* coef
 // ================================================================= helpers shared by the loops
 namespace {
 
+// A run-scoped device buffer.  Like the Krylov slabs it comes from, and goes back to, the context's slab cache: a
+// hipMalloc / hipFree pair per run() costs hundreds of microseconds (hipFree synchronises the device) — most of a run on
+// the small problems the reference is used for.
 template <typename T> struct DevBuf {
   T* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+  ll_context* owner = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p && owner) owner->slab_cache.emplace_back((void*)p, bytes);
+    p = nullptr;
   }
   void alloc(ll_context* ctx, size_t count) {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    ctx->dev_malloc((void**)&p, count * sizeof(T), "work vectors");
+    release();
+    owner = ctx;
+    bytes = std::max<size_t>(count * sizeof(T), 16);
+    for (size_t i = 0; i < ctx->slab_cache.size(); ++i)
+      if (ctx->slab_cache[i].second == bytes) {
+        p = (T*)ctx->slab_cache[i].first;
+        ctx->slab_cache.erase(ctx->slab_cache.begin() + (long)i);
+        return;
+      }
+    ctx->dev_malloc((void**)&p, bytes, "work vectors");
   }
 };
 
@@ -533,6 +549,102 @@ struct PhaseTimer {  // optional per-phase device timing (HIP events on the cont
       if (hipEventElapsedTime(&a, evs[i], evs[i + 1]) == hipSuccess) t_op += a * 1e-3;
       if (hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]) == hipSuccess) t_rest += b * 1e-3;
     }
+  }
+};
+
+// One Lanczos iteration as the device sees it, shared by the eigen-solver and the Exponentiator loops:
+//   y = A u_{k-1} + offset u_{k-1}, alpha (a1-a3)  ->  three-term update + Gram-Schmidt against `runs` + norm (a4-a7)
+//   ->  normalisation + publish of the iteration's four scalars (a8).
+// The last step is DEFERRED where the operator kernel can normalise its input on the fly (Engine::can_defer_scale): the
+// iteration then ends with w_k unnormalised in a work buffer and the partial sums of ||w_k||^2; the NEXT iteration's
+// operator kernel folds them, works with u_k = w_k / ||w_k||, writes u_k into the basis slot and publishes — one launch
+// and one read of w per iteration less (three launches become two in the Exponentiator loop, five become four in the
+// eigen-solver's).  flush() does the same work with the stand-alone kernel when no next iteration follows.
+template <typename T> struct LoopState {
+  Engine<T>& E;
+  Basis<T>& U;
+  EventRing& ring;
+  PhaseTimer& timer;
+  int64_t nl;
+  hipStream_t s;
+  bool fuse_launches = true, want_xmax = false, defer = false;
+  DevBuf<T> work[2];      // defer: w_k lives in work[k & 1]
+  bool pending = false;   // iteration pend_k ended without its normalisation / publish
+  typename Engine<T>::Publish pend{nullptr, nullptr, false};
+  int pend_slot = 0;
+  int64_t pend_k = 0;
+  NormRefs refs_prev{nullptr, nullptr, nullptr, 0};
+  double t_enqueue = 0.0;
+
+  LoopState(Engine<T>& e, Basis<T>& u, EventRing& r, PhaseTimer& t, int64_t n_local, hipStream_t st)
+      : E(e), U(u), ring(r), timer(t), nl(n_local), s(st) {}
+  void enable_defer(int64_t ld) {
+    defer = true;
+    for (auto& w : work) w.alloc(E.ctx, (size_t)ld);
+  }
+  void enqueue(int64_t k, double offset, const RunList<T>& runs, int mode) {
+    const double te0 = now_s();
+    const int slot = (int)(k % 4);
+    const T* x = U.vec(k - 1);
+    T* y = defer ? work[k & 1].p : U.vec(k);
+    ScaleIn<T> sc;
+    if (pending) {  // u_{k-1} is still w_{k-1} in its work buffer: this operator kernel normalises it on the fly
+      x = work[(k - 1) & 1].p;
+      sc.partials = pend.partials;
+      sc.nparts = pend.nparts;
+      sc.c1_out = pend.c1;
+      sc.alpha = pend.alpha;
+      sc.c0 = pend.c0;
+      sc.host = pend.host;
+      sc.u_out = U.vec(k - 1);
+    }
+    timer.mark();
+    typename Engine<T>::DeferredAlpha da;
+    E.apply(x, y, offset, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr, pending ? &sc : nullptr);  // P0-P3
+    if (pending) {
+      LL_HIP(hipEventRecord(ring.ev[pend_slot], s));  // iteration k-1's scalars are on their way to the host
+      pending = false;
+    }
+    timer.mark();
+    ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, U.vec(k - 1), E.S(kScalAlpha + slot), refs_prev};  // P4
+    if (da.nparts > 0) {  // the multi-dot folds alpha itself
+      tt.alpha_partials = da.partials;
+      tt.alpha_nparts = da.nparts;
+      tt.alpha_out = E.S(kScalAlpha + slot);
+    }
+    typename Engine<T>::Publish pub{E.ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
+    pub.can_defer = fuse_launches;
+    const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, &pub);  // P5-P7
+    if (pub.deferred && defer) {  // P8 rides in the next operator kernel
+      pending = true;
+      pend = pub;
+      pend_slot = slot;
+      pend_k = k;
+    } else if (pub.deferred) {  // norm fold + publish + normalisation in one launch (P8)
+      double* xm = want_xmax ? E.xmax_buffer() : nullptr;
+      const int g = launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, xm, s);
+      if (xm) {  // the next SpMV reads y: it finds the maxima of |y| ready (fixed-point PB kernels)
+        E.xmax_of = y;
+        E.xmax_n = g;
+      }
+      LL_HIP(hipEventRecord(ring.ev[slot], s));
+    } else {
+      LL_REQUIRE(!defer, "internal: deferred normalisation needs the fused norm fold");
+      if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
+      LL_HIP(hipEventRecord(ring.ev[slot], s));
+      launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
+    }
+    timer.mark();
+    refs_prev = refs;
+    t_enqueue += now_s() - te0;
+  }
+  // the pending iteration is the last one: normalise it into its basis slot and publish its scalars now
+  void flush() {
+    if (!pending) return;
+    launch_scale_publish<T>(nl, U.vec(pend_k), pend.partials, pend.nparts, pend.c1, pend.alpha, pend.c0, pend.host, nullptr, s,
+                            work[pend_k & 1].p);
+    LL_HIP(hipEventRecord(ring.ev[pend_slot], s));
+    pending = false;
   }
 };
 
@@ -645,7 +757,11 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   std::multimap<double, std::vector<T>, std::function<bool(double, double)>> kept(cmp);
 
   int64_t passes = 0, total_iters = 0, second_passes = 0;
-  double t_tridiag = 0.0, t_enqueue = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
+  double t_tridiag = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
+  LoopState<T> LS(E, U, ring, timer, nl, s);
+  LS.fuse_launches = fuse_launches;
+  LS.want_xmax = want_xmax;
+  if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
   // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
@@ -703,46 +819,15 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     bool evs_from_qr = true;  // whether `evs` hold the values of the reference's QR arithmetic (else: bisection values)
     int64_t itern = P.max_iteration;
     bool stopped = false;
-    NormRefs refs_prev = refs0;
-
+    LS.refs_prev = refs0;
+    LS.pending = false;
+    RunList<T> locked_runs;
+    locked_runs.ld = ld;
+    locked_runs.add(d_locked.p, L);  // P5
     auto enqueue = [&](int64_t k) {
-      const double te0 = now_s();
-      const int slot = (int)(k % 4);
-      T* x = U.vec(k - 1);
-      T* y = U.vec(k);
-      timer.mark();
-      typename Engine<T>::DeferredAlpha da;
-      E.apply(x, y, P.eigenvalue_offset, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr);  // P0-P3
-      timer.mark();
-      ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // P4
-      if (da.nparts > 0) {  // the multi-dot folds alpha itself
-        tt.alpha_partials = da.partials;
-        tt.alpha_nparts = da.nparts;
-        tt.alpha_out = E.S(kScalAlpha + slot);
-      }
-      RunList<T> runs;
-      runs.ld = ld;
-      runs.add(d_locked.p, L);  // P5
-      runs.add_basis(U, k);     // P6
-      typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
-      pub.can_defer = fuse_launches;
-      const NormRefs refs = E.orth(y, runs, mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, &pub);  // ... P7
-      if (pub.deferred) {  // norm fold + publish + normalisation in one launch (P8)
-        double* xm = want_xmax ? E.xmax_buffer() : nullptr;
-        const int g = launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, xm, s);
-        if (xm) {  // the next SpMV reads y: it finds the maxima of |y| ready (fixed-point PB kernels)
-          E.xmax_of = y;
-          E.xmax_n = g;
-        }
-        LL_HIP(hipEventRecord(ring.ev[slot], s));
-      } else {
-        if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
-        LL_HIP(hipEventRecord(ring.ev[slot], s));
-        launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
-      }
-      timer.mark();
-      refs_prev = refs;
-      t_enqueue += now_s() - te0;
+      RunList<T> runs = locked_runs;
+      runs.add_basis(U, k);  // P6
+      LS.enqueue(k, P.eigenvalue_offset, runs, mode);
     };
     // Host half of iteration j, part 1 (this thread): wait for the four scalars, take the DGKS decision, append
     // alpha_j / beta_j and hand T_j to the Ritz tracker.  kRedone: a second Gram-Schmidt pass changed u_j, the
@@ -797,7 +882,8 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
           ++second_passes;
           double* cj = E.S(kScalNorms + 3 * slot);
           launch_set_scalar(cj + 1, beta2_j, s);  // what the next three-term update reads as beta_j^2
-          refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+          LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+          LS.pending = false;  // the speculative iteration j+1 was computed from the old u_j: it is enqueued again
           verdict = kRedone;
         } else {
           beta2_j = 0.0;  // w vanished exactly: breakdown (H3)
@@ -818,7 +904,10 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
           stopped = worker.consume(k - 1, lockstep_lag, kMaxLag, absorb);
         }
       }
-      if (!stopped) collect(P.max_iteration);
+      if (!stopped) {
+        LS.flush();
+        collect(P.max_iteration);
+      }
     } else {
       for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
         enqueue(k);
@@ -984,7 +1073,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     stats->total_iterations = total_iters;
     stats->seconds_host_tridiag = t_tridiag;
     stats->last_alpha_len = (int64_t)alpha.size();
-    stats->seconds_host_enqueue = t_enqueue;
+    stats->seconds_host_enqueue = LS.t_enqueue;
     stats->seconds_host_wait = t_wait;
     stats->seconds_setup = t_setup;
     stats->seconds_finish = t_finish;
@@ -1066,44 +1155,17 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   int64_t itern = P.max_iteration;
   bool stopped = false;
 
-  double t_enqueue = 0.0, t_wait = 0.0;
-  auto enqueue = [&](int64_t k) {
-    const double te0 = now_s();
-    const int slot = (int)(k % 4);
-    T* x = U.vec(k - 1);
-    T* y = U.vec(k);
-    timer.mark();
-    typename Engine<T>::DeferredAlpha da;
-    E.apply(x, y, 0.0, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr);  // EX:107-110
-    timer.mark();
-    ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, x, E.S(kScalAlpha + slot), refs_prev};  // EX:112-118
-    if (da.nparts > 0) {  // the multi-dot folds alpha itself (see lanczos_run)
-      tt.alpha_partials = da.partials;
-      tt.alpha_nparts = da.nparts;
-      tt.alpha_out = E.S(kScalAlpha + slot);
-    }
+  double t_wait = 0.0;
+  LoopState<T> LS(E, U, ring, timer, nl, s);
+  LS.fuse_launches = fuse_launches;
+  LS.want_xmax = want_xmax;
+  LS.refs_prev = refs_prev;
+  if (E.can_defer_scale() && fuse_launches && (!P.full_orthogonalize || P.orth_mode == LL_ORTH_CGS_DGKS)) LS.enable_defer(ld);
+  auto enqueue = [&](int64_t k) {  // EX:107-118 (+ EX:120-122 with full_orthogonalize), EX:145, EX:160
     RunList<T> runs;
     runs.ld = ld;
-    if (P.full_orthogonalize) runs.add_basis(U, k);  // EX:120-122
-    typename Engine<T>::Publish pub{ctx->h_pinned + 4 * slot, E.S(kScalAlpha + slot), false};
-    pub.can_defer = fuse_launches;
-    const NormRefs refs = E.orth(y, runs, P.orth_mode, tt, E.S(kScalNorms + 3 * slot), nullptr, true, &pub);  // EX:145
-    if (pub.deferred) {  // norm fold + publish + normalisation (EX:160) in one launch
-      double* xm = want_xmax ? E.xmax_buffer() : nullptr;
-      const int g = launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, xm, s);
-      if (xm) {
-        E.xmax_of = y;
-        E.xmax_n = g;
-      }
-      LL_HIP(hipEventRecord(ring.ev[slot], s));
-    } else {
-      if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
-      LL_HIP(hipEventRecord(ring.ev[slot], s));
-      launch_scale<T>(nl, y, 0.0, &refs, s);  // EX:160
-    }
-    timer.mark();
-    refs_prev = refs;
-    t_enqueue += now_s() - te0;
+    if (P.full_orthogonalize) runs.add_basis(U, k);
+    LS.enqueue(k, 0.0, runs, P.orth_mode);
   };
   // Host half of iteration j, part 1 (this thread): the four scalars, the DGKS decision, alpha_j / beta_j; part 2 (EX:124-158:
   // exp(a T_j) e_1 and the overlap test, O(j^3)) runs on the helper thread like the eigen-solver's Ritz step.
@@ -1141,7 +1203,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
         ++second_passes;
         double* cj = E.S(kScalNorms + 3 * slot);
         launch_set_scalar(cj + 1, beta2_j, s);
-        refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+        LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+        LS.pending = false;  // (see lanczos_run)
         verdict = kRedone;
       } else {
         beta2_j = 0.0;
@@ -1160,7 +1223,10 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
         stopped = worker.consume(k - 1, lockstep_lag, kMaxLag, absorb);
       }
     }
-    if (!stopped) collect(P.max_iteration);
+    if (!stopped) {
+      LS.flush();
+      collect(P.max_iteration);
+    }
   } else {
     for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
       enqueue(k);
@@ -1200,7 +1266,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     stats->seconds_host_tridiag = t_tridiag;
     stats->last_alpha_len = (int64_t)alpha.size();
     stats->second_passes = second_passes;
-    stats->seconds_host_enqueue = t_enqueue;
+    stats->seconds_host_enqueue = LS.t_enqueue;
     stats->seconds_host_wait = t_wait;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     ctx->drain_comm_events(&stats->seconds_comm_gather, &stats->seconds_comm_allreduce);

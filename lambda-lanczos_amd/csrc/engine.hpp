@@ -79,7 +79,18 @@ template <typename T> struct Engine {
   const void* xmax_of = nullptr;
   int xmax_n = 0;
   double* xmax_buffer();  // ctx->d_xmax, allocated on first use
-  void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false, DeferredAlpha* defer = nullptr);
+  // sc (nullable): deferred normalisation — x_local is the unnormalised w_k (ScaleIn, ll_internal.hpp); only where
+  // can_defer_scale() holds.
+  void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false, DeferredAlpha* defer = nullptr,
+             const ScaleIn<T>* sc = nullptr);
+  // The operator kernel can normalise its input on the fly: single GPU, and a kernel that reads x itself (CSR-stream,
+  // lattice, dense).  The PB kernels keep the separate normalisation (they want max|u_k| from it), callbacks hand x to
+  // user code, sharded contexts gather the normalised vector.
+  bool can_defer_scale() const {
+    if (ctx->comm != nullptr || op == nullptr) return false;
+    if (op->kind == ll_operator::STENCIL || op->kind == ll_operator::DENSE) return true;
+    return op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_CSR_STREAM;
+  }
   // Orthogonalise w against the runs with an optional fused three-term update; c = device triple for the norms.
   // Returns the NormRefs every consumer must use for ||w|| afterwards.  h_total (device, nullable): R*nb doubles.
   // first_pass_only (whole-loop drivers, LL_ORTH_CGS_DGKS): enqueue pass 1 only and return refs whose final norm is

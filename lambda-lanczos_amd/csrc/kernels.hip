@@ -21,6 +21,35 @@
 namespace ll {
 
 
+// Sum of `nparts` workgroup partials, formed by EVERY workgroup in the same fixed order (the order of
+// reduce_one_kernel), returned to all lanes.  scratch: 5 doubles of LDS.  kBlock threads.
+__device__ __forceinline__ double fold_partials_all(const double* __restrict__ p, int nparts, double* scratch) {
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += kBlock) acc += p[b];
+  const double tot = block_sum(acc, scratch);
+  if (threadIdx.x == 0) scratch[4] = tot;
+  __syncthreads();
+  return scratch[4];
+}
+// Deferred normalisation (ScaleIn, ll_internal.hpp): 1 / ||w|| for this launch (1 when x is already normalised); workgroup
+// 0 stores ||w||^2 and publishes the previous iteration's scalars.  scratch: 5 doubles of LDS.
+template <typename T> __device__ __forceinline__ double scale_in_factor(const ScaleIn<T>& sc, double* scratch) {
+  if (sc.partials == nullptr) return 1.0;
+  const double tot = fold_partials_all(sc.partials, sc.nparts, scratch);  // the order of scale_publish_kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *sc.c1_out = tot;
+    if (sc.host) {
+      sc.host[0] = sc.alpha ? *sc.alpha : 0.0;
+      sc.host[1] = tot;
+      sc.host[2] = sc.c0 ? *sc.c0 : 0.0;
+      sc.host[3] = tot;
+    }
+  }
+  return 1.0 / sqrt(tot);  // T(1)/norm, LA:77-80
+}
+__device__ __forceinline__ double scale_acc(double s, double a) { return s * a; }
+__device__ __forceinline__ zc scale_acc(double s, zc a) { return zc{s * a.re, s * a.im}; }
+
 // ================================================================= a1/a2/a3: CSR SpMV ("CSR-stream")
 // One tile = a run of whole rows holding <= kSpmvTileNnz nonzeros (built at upload time).  The workgroup streams
 // the tile's (val, col) pairs with perfectly coalesced loads regardless of the row lengths, multiplies by the
@@ -33,11 +62,13 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
                                                       const RP* __restrict__ rp, const int32_t* __restrict__ ci,
                                                       const T* __restrict__ va, const T* __restrict__ xf,
                                                       const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                      double* __restrict__ dot_partials) {
+                                                      double* __restrict__ dot_partials, ScaleIn<T> sc) {
   __shared__ T prod[kSpmvTileNnz];
-  __shared__ double red[4 * scalar_traits<T>::reals];
+  __shared__ double red[4 * scalar_traits<T>::reals + 5];
   const int tid = threadIdx.x;
   double dot_acc = 0.0;
+  // deferred normalisation: xf / xl hold w, the kernel works with u = sfac * w (linear: applied to the row sums and to x_i)
+  const double sfac = scale_in_factor<T>(sc, red);
 
   for (TileWalk tw(ntiles); tw.first < tw.end; tw.first += tw.step) {
     const int t = tw.first;
@@ -58,8 +89,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
         tot = block_sum(acc, red);
       }
       if (tid == 0) {
-        const T xi = xl[r0];
-        T yi = add(narrow<T>(tot), rmul(offset, xi));
+        const T xi = rmul(sfac, xl[r0]);
+        if (sc.u_out) sc.u_out[r0] = xi;
+        T yi = add(narrow<T>(scale_acc(sfac, tot)), rmul(offset, xi));
         y[r0] = yi;
         dot_acc += re_cmul(xi, yi);
       }
@@ -93,8 +125,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
       }
     }
     if (g < nr && l == 0) {
-      const T xi = xl[row];
-      T yi = add(narrow<T>(acc), rmul(offset, xi));
+      const T xi = rmul(sfac, xl[row]);
+      if (sc.u_out) sc.u_out[row] = xi;
+      T yi = add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xi));
       y[row] = yi;
       dot_acc += re_cmul(xi, yi);
     }
@@ -116,20 +149,22 @@ static int spmv_grid(int ntiles, size_t elem_bytes) {
 
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                hipStream_t s) {
+                hipStream_t s, const ScaleIn<T>* scp) {
   const int grid = spmv_grid(op.ntiles, sizeof(T));
+  const ScaleIn<T> sc = scp ? *scp : ScaleIn<T>{};
   if (op.rp64)
     hipLaunchKernelGGL((spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
                        (const int64_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,
-                       dot_partials);
+                       dot_partials, sc);
   else
     hipLaunchKernelGGL((spmv_stream<T, int32_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
                        (const int32_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,
-                       dot_partials);
+                       dot_partials, sc);
   LL_HIP(hipGetLastError());
   return grid;
 }
-#define LL_INST_SPMV(T) template int launch_spmv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
+#define LL_INST_SPMV(T) \
+  template int launch_spmv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t, const ScaleIn<T>*);
 LL_INST_SPMV(double) LL_INST_SPMV(zc) LL_INST_SPMV(float) LL_INST_SPMV(cf)
 
 
@@ -203,17 +238,6 @@ __device__ __forceinline__ void store_strip(T* __restrict__ v, int64_t base, int
     for (int e = 0; e < EPT; ++e)
       if (i0 + e < n) v[i0 + e] = r[e];
   }
-}
-
-// Sum of `nparts` workgroup partials, formed by EVERY workgroup in the same fixed order (the order of
-// reduce_one_kernel), returned to all lanes.  scratch: 5 doubles of LDS.
-__device__ __forceinline__ double fold_partials_all(const double* __restrict__ p, int nparts, double* scratch) {
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < nparts; b += kBlock) acc += p[b];
-  const double tot = block_sum(acc, scratch);
-  if (threadIdx.x == 0) scratch[4] = tot;
-  __syncthreads();
-  return scratch[4];
 }
 
 // One trip of the multi-dot: NV basis strips against the strip of w held in registers; the NV (x2 for complex) wave
@@ -820,7 +844,7 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
                                                                const double* __restrict__ partials, int nparts,
                                                                double* __restrict__ out, const double* __restrict__ alpha,
                                                                const double* __restrict__ c0, double* __restrict__ host,
-                                                               double* __restrict__ xmax) {
+                                                               double* __restrict__ xmax, const T* __restrict__ src) {
   constexpr int EPT = strip<T>::EPT;
   __shared__ double fold_scratch[5];
   const double tot = fold_partials_all(partials, nparts, fold_scratch);  // the order of reduce_publish_kernel
@@ -837,7 +861,7 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int64_t base = sidx * strip<T>::ELEMS;
     T r[EPT];
-    load_strip<T>(v, base, n, r);
+    load_strip<T>(src ? src : v, base, n, r);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       r[e] = rmul(f, r[e]);
@@ -856,17 +880,17 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
 }
 template <typename T>
 int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
-                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s) {
+                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s, const T* src) {
   const int grid = strip_grid(n, strip<T>::ELEMS);
   hipLaunchKernelGGL((scale_publish_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, v, partials, nparts, out, alpha, c0,
-                     host_mapped, xmax_out);
+                     host_mapped, xmax_out, src);
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
-template int launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
-template int launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
-template int launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t);
+template int launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const double*);
+template int launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const zc*);
+template int launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const float*);
+template int launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const cf*);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void three_term_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ up,
@@ -1001,10 +1025,11 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long long ncols, const T* __restrict__ a,
                                                           const T* __restrict__ xf, const T* __restrict__ xl,
                                                           T* __restrict__ y, double offset,
-                                                          double* __restrict__ dot_partials, int vec) {
-  __shared__ double red[4];
+                                                          double* __restrict__ dot_partials, int vec, ScaleIn<T> sc) {
+  __shared__ double red[5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double dot_acc = 0.0;
+  const double sfac = scale_in_factor<T>(sc, red);  // deferred normalisation (ScaleIn)
   for (long long row = (long long)blockIdx.x * 4 + wave; row < nrows; row += (long long)gridDim.x * 4) {
     const T* __restrict__ ar = a + row * ncols;
     acc_t<T> acc = zero<acc_t<T>>();
@@ -1024,8 +1049,9 @@ __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long 
     }
     acc = wave_sum(acc);
     if (lane == 0) {
-      const T xi = xl[row];
-      const T yi = add(narrow<T>(acc), rmul(offset, xi));
+      const T xi = rmul(sfac, xl[row]);
+      if (sc.u_out) sc.u_out[row] = xi;
+      const T yi = add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xi));
       y[row] = yi;
       dot_acc += re_cmul(xi, yi);
     }
@@ -1037,18 +1063,19 @@ __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long 
 }
 template <typename T>
 int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                    hipStream_t s) {
+                    hipStream_t s, const ScaleIn<T>* scp) {
+  const ScaleIn<T> sc = scp ? *scp : ScaleIn<T>{};
   const long long want = (op.n_local + 3) / 4;
   const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
   constexpr long long V = (long long)(16 / sizeof(T)) > 0 ? (long long)(16 / sizeof(T)) : 1;
   const int vec = op.n % V == 0 && (reinterpret_cast<uintptr_t>(x_full) & 15) == 0 ? 1 : 0;  // rows then start 16-B aligned
   hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(grid), dim3(kBlock), 0, s, (long long)op.n_local, (long long)op.n,
-                     (const T*)op.d_dense, x_full, x_local, y, offset, dot_partials, vec);
+                     (const T*)op.d_dense, x_full, x_local, y, offset, dot_partials, vec, sc);
   LL_HIP(hipGetLastError());
   return grid;
 }
 #define LL_INST_DENSE(T) \
-  template int launch_dense_mv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t);
+  template int launch_dense_mv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t, const ScaleIn<T>*);
 LL_INST_DENSE(double) LL_INST_DENSE(zc) LL_INST_DENSE(float) LL_INST_DENSE(cf)
 
 // ================================================================= a1/a2/a3: matrix-free lattice operator
@@ -1113,9 +1140,10 @@ __global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T*
                                                          const T* __restrict__ lo, const T* __restrict__ hi,
                                                          const typename scalar_traits<T>::real* __restrict__ onsite,
                                                          T* __restrict__ y, double offset,
-                                                         double* __restrict__ dot_partials) {
-  __shared__ double red[4];
+                                                         double* __restrict__ dot_partials, ScaleIn<T> sc) {
+  __shared__ double red[5];
   double dot_acc = 0.0;
+  const double sfac = scale_in_factor<T>(sc, red);  // deferred normalisation (ScaleIn): the sites hold w, u = sfac * w
   const long long nl = g.n_local, H = g.halo;
   auto fetch = [&](long long j) -> T { return j < 0 ? lo[H + j] : (j >= nl ? hi[j - nl] : xl[j]); };
   for (long long li = (long long)blockIdx.x * kBlock + threadIdx.x; li < nl; li += (long long)gridDim.x * kBlock) {
@@ -1162,9 +1190,11 @@ __global__ __launch_bounds__(kBlock) void stencil_kernel(StencilGeom g, const T*
         if (have) fma_acc(acc, hop_value(g, d, false, g.has_phase[d] ? bond_phase(g, d, c) : 0.0, (T*)nullptr), fetch(li + off));
       }
     }
-    const T yi = add(narrow<T>(acc), rmul(offset, xi));
+    const T xs = rmul(sfac, xi);
+    if (sc.u_out) sc.u_out[li] = xs;
+    const T yi = add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xs));
     y[li] = yi;
-    dot_acc += re_cmul(xi, yi);
+    dot_acc += re_cmul(xs, yi);
   }
   if (dot_partials) {
     const double tot = block_sum(dot_acc, red);
@@ -1181,10 +1211,11 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
                                                              const T* __restrict__ lo, const T* __restrict__ hi,
                                                              const typename scalar_traits<T>::real* __restrict__ onsite,
                                                              T* __restrict__ y, double offset,
-                                                             double* __restrict__ dot_partials) {
+                                                             double* __restrict__ dot_partials, ScaleIn<T> sc) {
   typedef typename scalar_traits<T>::real R;
-  __shared__ double red[4];
+  __shared__ double red[5];
   double dot_acc = 0.0;
+  const double sfac = scale_in_factor<T>(sc, red);  // deferred normalisation (ScaleIn)
   const long long nl = g.n_local, H = g.halo;
   const int last = g.ndim - 1;
   const long long dl = g.dims[last];
@@ -1299,12 +1330,14 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
         }
       }
     }
-    T out[V];
+    T out[V], us[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      out[e] = add(narrow<T>(acc[e]), rmul(offset, ctr[e]));
-      dot_acc += re_cmul(ctr[e], out[e]);
+      us[e] = rmul(sfac, ctr[e]);
+      out[e] = add(narrow<T>(scale_acc(sfac, acc[e])), rmul(offset, us[e]));
+      dot_acc += re_cmul(us[e], out[e]);
     }
+    if (sc.u_out) store_chunk<T, V>(sc.u_out + li, us);
     store_chunk<T, V>(y + li, out);
   }
   if (dot_partials) {
@@ -1315,7 +1348,8 @@ __global__ __launch_bounds__(kBlock) void stencil_vec_kernel(StencilGeom g, cons
 
 template <typename T>
 int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, const T* halo_hi, T* y, double offset,
-                   double* dot_partials, hipStream_t s) {
+                   double* dot_partials, hipStream_t s, const ScaleIn<T>* scp) {
+  const ScaleIn<T> sc = scp ? *scp : ScaleIn<T>{};
   StencilGeom g;
   g.ndim = op.st.ndim;
   for (int d = 0; d < 3; ++d) {
@@ -1345,10 +1379,10 @@ int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, co
     const int vgrid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, (chunks + kBlock - 1) / kBlock));
     if (op.n < ((long long)1 << 31))
       hipLaunchKernelGGL((stencil_vec_kernel<T, unsigned, V>), dim3(vgrid), dim3(kBlock), 0, s, g, x_local, halo_lo,
-                         halo_hi, (const R*)op.d_onsite, y, offset, dot_partials);
+                         halo_hi, (const R*)op.d_onsite, y, offset, dot_partials, sc);
     else
       hipLaunchKernelGGL((stencil_vec_kernel<T, unsigned long long, V>), dim3(vgrid), dim3(kBlock), 0, s, g, x_local,
-                         halo_lo, halo_hi, (const R*)op.d_onsite, y, offset, dot_partials);
+                         halo_lo, halo_hi, (const R*)op.d_onsite, y, offset, dot_partials, sc);
     LL_HIP(hipGetLastError());
     return vgrid;
   }
@@ -1356,15 +1390,16 @@ int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, co
   const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
   if (op.n < ((long long)1 << 31))
     hipLaunchKernelGGL((stencil_kernel<T, unsigned>), dim3(grid), dim3(kBlock), 0, s, g, x_local, halo_lo, halo_hi,
-                       (const R*)op.d_onsite, y, offset, dot_partials);
+                       (const R*)op.d_onsite, y, offset, dot_partials, sc);
   else
     hipLaunchKernelGGL((stencil_kernel<T, unsigned long long>), dim3(grid), dim3(kBlock), 0, s, g, x_local, halo_lo,
-                       halo_hi, (const R*)op.d_onsite, y, offset, dot_partials);
+                       halo_hi, (const R*)op.d_onsite, y, offset, dot_partials, sc);
   LL_HIP(hipGetLastError());
   return grid;
 }
 #define LL_INST_STENCIL(T) \
-  template int launch_stencil<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t);
+  template int launch_stencil<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t, \
+                                 const ScaleIn<T>*);
 LL_INST_STENCIL(double) LL_INST_STENCIL(zc) LL_INST_STENCIL(float) LL_INST_STENCIL(cf)
 
 // ================================================================= a9/a10: tall-skinny GEMV over the basis

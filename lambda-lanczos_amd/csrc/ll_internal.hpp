@@ -302,11 +302,27 @@ namespace ll {
 // ---------------------------------------------------------------- kernel launchers (kernels.hip)
 // All launchers enqueue on `s` and return immediately.
 
+// Deferred normalisation (a8 folded into the next a1; single-GPU whole-loop drivers, operators that gather x themselves):
+// the operator kernel is handed the UNNORMALISED vector w_k together with the `nparts` partial sums of ||w_k||^2.  Every
+// workgroup folds them in the same fixed order, works with u_k = w_k / ||w_k|| (the operator is linear: the factor is
+// applied to the row sums and to x_i), writes u_k to u_out (the basis slot: every later reader wants it normalised) and
+// workgroup 0 stores ||w_k||^2 to *c1_out and iteration k's four scalars to the pinned host slot — the work of
+// scale_publish_kernel without its launch and without its read of w.
+template <typename T> struct ScaleIn {
+  const double* partials = nullptr;  // null: x is already normalised (everything below is ignored)
+  int nparts = 0;
+  double* c1_out = nullptr;
+  const double* alpha = nullptr;
+  const double* c0 = nullptr;
+  double* host = nullptr;
+  T* u_out = nullptr;
+};
+
 // y = A x_full(cols) + offset * x_local ; dot_partials (nullable): one double per workgroup, Re<x_local, y>.
 // Returns the number of partials written.
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                hipStream_t s);
+                hipStream_t s, const ScaleIn<T>* sc = nullptr);
 // Same contract, propagation-blocked kernels (op.spmv_kind == LL_SPMV_PB; spmv_pb.hip): phase 1 over the own-column
 // blocks (x slices from x_own: the local shard readable up to the shard stride), then over every gather chunk's remote blocks (x slices from x_gathered, laid out
 // per op.gather), then phase 2.  The pieces are exposed so that the sharded driver can run the own-column part under
@@ -329,12 +345,12 @@ template <typename T> void csr_check_device(ll_operator* op);
 // Same contract for the dense row block (op.kind == DENSE).
 template <typename T>
 int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                    hipStream_t s);
+                    hipStream_t s, const ScaleIn<T>* sc = nullptr);
 // Lattice operator (op.kind == STENCIL): site li of the shard reads x at li + off, |off| <= op.st_halo, from
 // halo_lo[st_halo + j] for j < 0, x_local[j] for 0 <= j < n_local and halo_hi[j - n_local] beyond.
 template <typename T>
 int launch_stencil(const ll_operator& op, const T* x_local, const T* halo_lo, const T* halo_hi, T* y, double offset,
-                   double* dot_partials, hipStream_t s);
+                   double* dot_partials, hipStream_t s, const ScaleIn<T>* sc = nullptr);
 // y += offset * x ; partials of Re<x,y> (post-pass for callback operators).
 template <typename T>
 int launch_offset_dot(int64_t n, const T* x, T* y, double offset, double* dot_partials, hipStream_t s);
@@ -385,9 +401,10 @@ template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRef
 // iteration's four scalars (alpha, sum, c0, sum) to the pinned host slot.
 // xmax_out (nullable, kMaxGrid doubles): the per-workgroup maxima of |v| after scaling (|re| + |im| for complex), for the
 // fixed-point SpMV that reads v next.  Returns the grid = number of maxima written.
+// src (nullable): read the unnormalised vector from there instead of from v (out of place).
 template <typename T>
 int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
-                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s);
+                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s, const T* src = nullptr);
 // Plain three-term update with host scalars (primitive API).
 template <typename T>
 void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double beta, double alpha, hipStream_t s);

@@ -327,14 +327,18 @@ def test_device_resident_time_evolution_loop_equals_the_host_loop(ctx):
 
 
 # ------------------------------------------------------------------ launch fusion and kernel geometry: same loop, same numbers
+@pytest.mark.parametrize("kernel", ["pb", "csr"])
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
-def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, llenv):
+def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, kernel, llenv):
     """Single GPU: alpha folded inside the multi-dot and the norm fold + publish inside the normalisation kernel (default)
     against the separate fold / publish kernels (LL_FUSE_LAUNCHES=0, also what sharded contexts run): both sum the same
-    partials in the same order, so alpha/beta traces, iteration counts, eigenvalues and eigenvectors agree bit for bit —
-    for the eigen-solver with full re-orthogonalisation and for the Exponentiator without it."""
+    partials in the same order.  With the PB kernels every number agrees bit for bit; with CSR-stream the default also
+    DEFERS the normalisation into the next operator kernel (A(s w) becomes s (A w)), which changes the last bits only:
+    same iteration counts, traces and results to 1e-13 — for the eigen-solver with full re-orthogonalisation and for the
+    Exponentiator without it."""
     n = 20011
     csr = G.randsym_np(n)
+    llenv.setenv("LL_SPMV_KERNEL", kernel)
     op = L.CsrOperator(ctx, csr[0], csr[1], csr[2].astype(dtype))
     init = G.start_vector(n, 1, dtype)
     out = {}
@@ -350,8 +354,17 @@ def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, llenv):
         out[fuse] = (vals, vecs, eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eo, eit)
     a, b = out["1"], out["0"]
     assert a[2] == b[2] and a[6] == b[6]
-    for i in (0, 1, 3, 4, 5):
-        assert np.array_equal(a[i], b[i]), i
+    if kernel == "pb":
+        for i in (0, 1, 3, 4, 5):
+            assert np.array_equal(a[i], b[i]), i
+    else:
+        scale = float(np.max(np.abs(b[0])))
+        assert np.max(np.abs(a[0] - b[0])) <= 1e-13 * scale
+        assert np.max(np.abs(a[3] - b[3])) <= 1e-12 * scale and np.max(np.abs(a[4] - b[4])) <= 1e-12 * scale
+        for i in range(len(a[1])):
+            assert 1 - overlap(a[1][i], b[1][i]) <= 1e-10
+        assert np.max(np.abs(a[5] - b[5])) <= 1e-12 * np.linalg.norm(init)
+    op.close()
 
 
 def test_small_and_streaming_geometry_agree_in_the_whole_loop(ctx, oracle, llenv):

@@ -32,3 +32,30 @@ fi
 if has bench; then
   timeout 900 python bench.py > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err; echo "bench rc=$?"; cut -c1-1500 gpurun_out/r3_bench_default.json; tail -3 gpurun_out/r3_bench_default.err
 fi
+if has bench_all; then
+  for cfg in "c3:--workload c3" "c2:--workload c2" "c2lattice:--workload c2 --operator lattice" "c5:--workload c5" "c5lattice:--workload c5 --operator lattice" "n1e4:--workload c2 --size 100" "n1e5:--workload c2 --size 316"; do
+    name=${cfg%%:*}; opts=${cfg#*:}
+    timeout 600 python bench.py $opts --cpu-window 0 > gpurun_out/r3_bench_$name.json 2> gpurun_out/r3_bench_$name.err; echo "bench $name rc=$?"
+    python - gpurun_out/r3_bench_$name.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("   value %.1f it/s  host_io %.1f  ms/step %.3f  spmv %.4f ms (frac %.3f)  orth frac %s" % (d["value"], d["value_host_io"], d["ms_per_step"], d["spmv"]["ms"], d["roofline"]["frac"], d["roofline_orth"]["frac"]))
+PY
+  done
+fi
+if has kstats; then
+  export TMPDIR=/tmp
+  for cfg in ${KSTATS_CFGS:-"c5:--workload c5" "c2:--workload c2"}; do
+    name=${cfg%%:*}; opts=${cfg#*:}
+    mkdir -p gpurun_out/prof_r03; d=gpurun_out/prof_r03/ks_$name; rm -rf $d
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o ks -- python3 bench.py $opts --steps 3 --warmup 1 --cpu-window 0 --no-spmv-variants > gpurun_out/prof_r03/ks_$name.json 2> gpurun_out/prof_r03/ks_$name.err
+    echo "kstats $name rc=$?"
+    python3 - $d <<'PY'
+import csv,glob,sys
+for f in glob.glob(sys.argv[1]+'/**/*kernel_stats.csv', recursive=True):
+    rows=list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r:-float(r['TotalDurationNs']))
+    for r in rows[:10]: print(r['Name'][:80].ljust(82), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(8), 'us')
+PY
+  done
+fi
