@@ -258,6 +258,7 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->d_h) (void)hipFree(ctx->d_h);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
     if (ctx->d_xmax) (void)hipFree(ctx->d_xmax);
+    if (ctx->d_norm_partials) (void)hipFree(ctx->d_norm_partials);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_cb) (void)hipHostFree(ctx->h_cb);

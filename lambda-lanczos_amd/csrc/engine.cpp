@@ -404,11 +404,22 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
 
   // ---- pass 1: h = U^H w (+ fused three-term update and ||w||^2), then w -= U h (+ fused ||w||^2)
   int off = 0;
+  int grid = 0;
+  double* norm_partials = ctx->d_partials;  // where the multi-axpy leaves the partial sums of ||w'||^2
+  bool folded_in_maxpy = false;
   for (size_t g = 0; g < groups.size(); ++g) {
     const int nbg = count_of(groups[g]);
     const bool last = g + 1 == groups.size();
-    const int grid = launch_mdot<T>(n_local, w, groups[g], g == 0 ? tt : no_tt, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
-    launch_reduce_cols(ctx->d_partials, grid, R * nbg + 1, h1 + R * off, (last && !sharded) ? c : nullptr, s);
+    const int mgrid = launch_mdot<T>(n_local, w, groups[g], g == 0 ? tt : no_tt, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
+    if (groups.size() == 1 && !sharded && ctx->tune.fuse_launches) {
+      // small vectors, small grids: the multi-axpy folds the coefficients itself (one launch less per iteration)
+      if (!ctx->d_norm_partials) ctx->dev_malloc((void**)&ctx->d_norm_partials, (size_t)kMaxGrid * sizeof(double), "norm partials");
+      folded_in_maxpy = launch_maxpy_folding<T>(n_local, w, groups[0], ctx->d_partials, mgrid, h1, c, ctx->d_norm_partials,
+                                                ctx->tune.blas_small_bytes, &grid, s);
+      if (folded_in_maxpy) norm_partials = ctx->d_norm_partials;
+    }
+    if (!folded_in_maxpy)
+      launch_reduce_cols(ctx->d_partials, mgrid, R * nbg + 1, h1 + R * off, (last && !sharded) ? c : nullptr, s);
     off += nbg;
   }
   // Sharded whole-loop passes: the norm after the pass follows from what the one all-reduce below delivers
@@ -422,21 +433,27 @@ NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm
     if (!derive) launch_copy_scalar(c, h1 + R * nb, s);  // (derive: copied by the derive kernel after the update)
   }
   off = 0;
-  int grid = 0;
-  for (size_t g = 0; g < groups.size(); ++g) {
+  for (size_t g = 0; g < groups.size() && !folded_in_maxpy; ++g) {
     grid = launch_maxpy<T>(n_local, w, groups[g], h1 + R * off, nullptr, ctx->d_partials, ctx->tune.blas_small_bytes, s);
     off += count_of(groups[g]);
   }
-  if (derive) {  // norm + copy of ||w||^2 + (whole-loop drivers) the publish step in one small launch
+  if (derive && publish && publish->can_defer) {  // ... inside the caller's normalisation kernel (launch_scale_derive)
+    publish->derive = true;
+    publish->derive_c0 = h1 + R * nb;
+    publish->derive_h = h1;
+    publish->derive_count = R * nb;
+    publish->c0_out = c;
+    publish->c1 = c + 1;
+  } else if (derive) {  // norm + copy of ||w||^2 + (whole-loop drivers) the publish step in one small launch
     launch_derive_norm(h1 + R * nb, h1, R * nb, c, c + 1, publish ? publish->alpha : nullptr, publish ? publish->host : nullptr, s);
     if (publish) publish->done = true;
   } else if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS && publish->can_defer) {
-    *publish = Publish{publish->host, publish->alpha, true, true, true, ctx->d_partials, grid, c + 1, c};
+    *publish = Publish{publish->host, publish->alpha, true, true, true, norm_partials, grid, c + 1, c};
   } else if (publish && !sharded && first_pass_only && mode == LL_ORTH_CGS_DGKS) {
-    launch_reduce_publish(ctx->d_partials, grid, c + 1, publish->alpha, c, publish->host, s);
+    launch_reduce_publish(norm_partials, grid, c + 1, publish->alpha, c, publish->host, s);
     publish->done = true;
   } else {
-    launch_reduce_cols(ctx->d_partials, grid, 1, c + 1, nullptr, s);
+    launch_reduce_cols(norm_partials, grid, 1, c + 1, nullptr, s);
     all_reduce(c + 1, 1);
   }
   if (first_pass_only && mode == LL_ORTH_CGS_DGKS) {
@@ -627,6 +644,9 @@ template <typename T> struct LoopState {
         E.xmax_of = y;
         E.xmax_n = g;
       }
+      LL_HIP(hipEventRecord(ring.ev[slot], s));
+    } else if (pub.derive) {  // sharded: derived norm + publish + normalisation in one launch
+      launch_scale_derive<T>(nl, y, pub.derive_c0, pub.derive_h, pub.derive_count, pub.c0_out, pub.c1, pub.alpha, pub.host, s);
       LL_HIP(hipEventRecord(ring.ev[slot], s));
     } else {
       LL_REQUIRE(!defer, "internal: deferred normalisation needs the fused norm fold");

@@ -110,6 +110,13 @@ template <typename T> struct Engine {
     int nparts = 0;
     double* c1 = nullptr;
     const double* c0 = nullptr;
+    // sharded contexts with the derived norm: the caller's normalisation kernel forms ||w'||^2 = *derive_c0 - sum h_i^2
+    // itself and publishes (launch_scale_derive); c0_out / c1 receive the two norms.
+    bool derive = false;
+    const double* derive_c0 = nullptr;
+    const double* derive_h = nullptr;
+    int derive_count = 0;
+    double* c0_out = nullptr;
   };
   NormRefs orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,
                 bool first_pass_only = false, Publish* publish = nullptr);

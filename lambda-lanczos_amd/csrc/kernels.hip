@@ -517,18 +517,62 @@ __global__ __launch_bounds__(kBlock) void mdot_small_kernel(int64_t n, T* __rest
   for (int i = tid; i < ncols; i += kBlock) out[i] = cols[i];
 }
 
-template <typename T>
+// dst[j] = sum_b partials[b * ncols + j], j < ncols, formed by the WHOLE workgroup in exactly the order of
+// reduce_cols_kernel (16 columns x 16 row lanes per pass, four chains per lane, rows folded 0..15): the fold of the
+// multi-dot's partials without its launch, for grids small enough that every workgroup can afford to redo it.
+__device__ __forceinline__ void fold_cols_into_lds(const double* __restrict__ partials, int nparts, int ncols, double* dst) {
+  __shared__ double sm[16][17];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  for (int j0 = 0; j0 < ncols; j0 += 16) {
+    const int j = j0 + cx;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (j < ncols) {
+      int b = ry;
+      for (; b + 48 < nparts; b += 64) {
+        a0 += partials[(size_t)b * ncols + j];
+        a1 += partials[(size_t)(b + 16) * ncols + j];
+        a2 += partials[(size_t)(b + 32) * ncols + j];
+        a3 += partials[(size_t)(b + 48) * ncols + j];
+      }
+      for (; b < nparts; b += 16) a0 += partials[(size_t)b * ncols + j];
+    }
+    __syncthreads();  // the previous pass has been read out
+    sm[ry][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ry == 0 && j < ncols) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += sm[r][cx];
+      dst[j] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// FOLD: h is not given; the kernel folds the multi-dot's partials `mp` ([mparts][R*nb + 1]: coefficients, then ||w||^2)
+// itself — every workgroup, same order — and workgroup 0 stores the coefficients to h_out and ||w||^2 to *c0_out.
+template <typename T, bool FOLD>
 __global__ __launch_bounds__(kBlock) void maxpy_small_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs,
                                                              const double* __restrict__ h, int nb, NormRefs pred,
-                                                             int predicated, double* __restrict__ partials) {
+                                                             int predicated, double* __restrict__ partials,
+                                                             const double* __restrict__ mp, int mparts,
+                                                             double* __restrict__ h_out, double* __restrict__ c0_out) {
   constexpr int EPT = small_geom<T>::EPT;
   constexpr int ELEMS = small_geom<T>::ELEMS;
   constexpr int R = scalar_traits<T>::reals;
-  extern __shared__ double lds[];  // [R*nb] coefficients, then the four waves' shares [4][64][EPT*R]
+  extern __shared__ double lds[];  // [R*nb (+1)] coefficients, then the four waves' shares [4][64][EPT*R]
   if (predicated && !second_pass_due(pred)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < R * nb; i += kBlock) lds[i] = h[i];
-  double* share = lds + ((R * nb + 15) & ~15);
+  if constexpr (FOLD) {
+    fold_cols_into_lds(mp, mparts, R * nb + 1, lds);
+    if (blockIdx.x == 0) {
+      for (int i = tid; i < R * nb; i += kBlock) h_out[i] = lds[i];
+      if (tid == 0 && c0_out) *c0_out = lds[R * nb];
+    }
+  } else {
+    for (int i = tid; i < R * nb; i += kBlock) lds[i] = h[i];
+  }
+  double* share = lds + ((R * nb + 1 + 15) & ~15);
   __syncthreads();
   double nn = 0.0;
   const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
@@ -682,9 +726,9 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
   if (blas_small(n, sizeof(T), small_bytes)) {
     constexpr int R = scalar_traits<T>::reals;
     const int grid = strip_grid(n, small_geom<T>::ELEMS);
-    const size_t lds_bytes = ((size_t)((R * nb + 15) & ~15) + (size_t)kBlock * small_geom<T>::EPT * R) * sizeof(double);
-    hipLaunchKernelGGL((maxpy_small_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr, pred ? 1 : 0,
-                       partials);
+    const size_t lds_bytes = ((size_t)((R * nb + 1 + 15) & ~15) + (size_t)kBlock * small_geom<T>::EPT * R) * sizeof(double);
+    hipLaunchKernelGGL((maxpy_small_kernel<T, false>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, h, nb, pr,
+                       pred ? 1 : 0, partials, nullptr, 0, nullptr, nullptr);
     LL_HIP(hipGetLastError());
     return grid;
   }
@@ -695,6 +739,29 @@ int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, con
   LL_HIP(hipGetLastError());
   return grid;
 }
+// The multi-axpy that folds the multi-dot's partials itself (small-vector geometry only): true when the fused kernel was
+// launched — the caller then skips launch_reduce_cols.  Worth it while every workgroup's redundant fold (mparts * ncols
+// loads) stays well below the ~10 us a separate fold launch costs in a launch-bound loop.
+template <typename T>
+bool launch_maxpy_folding(int64_t n, T* w, const BasisSegs<T>& segs, const double* mdot_partials, int mparts, double* h_out,
+                          double* c0_out, double* partials, int64_t small_bytes, int* grid_out, hipStream_t s) {
+  int nb = 0;
+  for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  constexpr int R = scalar_traits<T>::reals;
+  if (!blas_small(n, sizeof(T), small_bytes) || (long long)mparts * (R * nb + 1) > 32768) return false;
+  const int grid = strip_grid(n, small_geom<T>::ELEMS);
+  const size_t lds_bytes = ((size_t)((R * nb + 1 + 15) & ~15) + (size_t)kBlock * small_geom<T>::EPT * R) * sizeof(double);
+  hipLaunchKernelGGL((maxpy_small_kernel<T, true>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nullptr, nb,
+                     NormRefs{nullptr, nullptr, nullptr, 1}, 0, partials, mdot_partials, mparts, h_out, c0_out);
+  LL_HIP(hipGetLastError());
+  *grid_out = grid;
+  return true;
+}
+#define LL_INST_MAXPY_FOLD(T)                                                                                          \
+  template bool launch_maxpy_folding<T>(int64_t, T*, const BasisSegs<T>&, const double*, int, double*, double*, double*, \
+                                        int64_t, int*, hipStream_t);
+LL_INST_MAXPY_FOLD(double) LL_INST_MAXPY_FOLD(zc) LL_INST_MAXPY_FOLD(float) LL_INST_MAXPY_FOLD(cf)
+
 template int launch_maxpy<double>(int64_t, double*, const BasisSegs<double>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
 template int launch_maxpy<zc>(int64_t, zc*, const BasisSegs<zc>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
 template int launch_maxpy<float>(int64_t, float*, const BasisSegs<float>&, const double*, const NormRefs*, double*, int64_t, hipStream_t);
@@ -878,6 +945,58 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
     if (threadIdx.x == 0) xmax[blockIdx.x] = fmax(fmax(fold_scratch[0], fold_scratch[1]), fmax(fold_scratch[2], fold_scratch[3]));
   }
 }
+// Sharded contexts: a8 fused with derive_norm_kernel — every workgroup forms ||w'||^2 = ||w||^2 - sum |h_j|^2 from the
+// all-reduced coefficients (same fixed order as derive_norm_kernel, identical bits on all workgroups and ranks), scales by
+// 1/||w'||; workgroup 0 stores c0 / c1 and the iteration's four scalars to the pinned host slot.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scale_derive_kernel(int64_t n, T* __restrict__ v, const double* __restrict__ c0_src,
+                                                              const double* __restrict__ h, int count, double* __restrict__ c0,
+                                                              double* __restrict__ c1, const double* __restrict__ alpha,
+                                                              double* __restrict__ host) {
+  constexpr int EPT = strip<T>::EPT;
+  __shared__ double red[5];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) acc = fma(h[i], h[i], acc);
+  const double tot = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    const double before = *c0_src;
+    double val = before - tot;
+    val = val > 0.0 ? val : 0.0;
+    red[4] = val;
+    if (blockIdx.x == 0) {
+      *c0 = before;
+      *c1 = val;
+      if (host) {
+        host[0] = alpha ? *alpha : 0.0;
+        host[1] = val;
+        host[2] = before;
+        host[3] = val;
+      }
+    }
+  }
+  __syncthreads();
+  const double f = 1.0 / sqrt(red[4]);
+  const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * strip<T>::ELEMS;
+    T r[EPT];
+    load_strip<T>(v, base, n, r);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) r[e] = rmul(f, r[e]);
+    store_strip<T>(v, base, n, r);
+  }
+}
+template <typename T>
+void launch_scale_derive(int64_t n, T* v, const double* c0_src, const double* h, int count, double* c0, double* c1,
+                         const double* alpha, double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL((scale_derive_kernel<T>), dim3(strip_grid(n, strip<T>::ELEMS)), dim3(kBlock), 0, s, n, v, c0_src, h, count,
+                     c0, c1, alpha, host_mapped);
+  LL_HIP(hipGetLastError());
+}
+#define LL_INST_SCALE_DERIVE(T) \
+  template void launch_scale_derive<T>(int64_t, T*, const double*, const double*, int, double*, double*, const double*, double*, hipStream_t);
+LL_INST_SCALE_DERIVE(double) LL_INST_SCALE_DERIVE(zc) LL_INST_SCALE_DERIVE(float) LL_INST_SCALE_DERIVE(cf)
+
 template <typename T>
 int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
                          const double* c0, double* host_mapped, double* xmax_out, hipStream_t s, const T* src) {

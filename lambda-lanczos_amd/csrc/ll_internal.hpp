@@ -201,6 +201,7 @@ struct ll_context {
   double* d_h = nullptr;         // reduced projection coefficients / small scalars
   size_t h_cap = 0;              // doubles
   double* d_scal = nullptr;      // 64 doubles of device scalars (ring slots, flags)
+  double* d_norm_partials = nullptr;  // kMaxGrid norm partials of the folding multi-axpy (must not alias d_partials)
   double* d_xmax = nullptr;      // kMaxGrid per-workgroup maxima of |u_k| left by the normalisation kernel (lazily sized)
   double* h_pinned = nullptr;    // pinned host mirror for scalar read-back
   size_t pinned_cap = 0;         // doubles
@@ -394,6 +395,12 @@ int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& t
 template <typename T>
 int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
                  int64_t small_bytes, hipStream_t s);
+// The same update with the fold of the multi-dot's partials ([mparts][reals*nb + 1]) done inside the kernel (small-vector
+// geometry, small grids): h_out receives the coefficients, *c0_out (nullable) the ||w||^2 column; `partials` (the norm
+// partials of the result) must not alias mdot_partials.  false: not applicable, nothing was launched.
+template <typename T>
+bool launch_maxpy_folding(int64_t n, T* w, const BasisSegs<T>& segs, const double* mdot_partials, int mparts, double* h_out,
+                          double* c0_out, double* partials, int64_t small_bytes, int* grid_out, hipStream_t s);
 // v *= factor, factor = a (host value) when norms == nullptr, else 1/sqrt(final norm^2).
 template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRefs* norms, hipStream_t s);
 // scale fused with the fold of the post-pass norm and the publish step (single-GPU whole-loop drivers): every workgroup
@@ -401,6 +408,10 @@ template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRef
 // iteration's four scalars (alpha, sum, c0, sum) to the pinned host slot.
 // xmax_out (nullable, kMaxGrid doubles): the per-workgroup maxima of |v| after scaling (|re| + |im| for complex), for the
 // fixed-point SpMV that reads v next.  Returns the grid = number of maxima written.
+// a8 fused with launch_derive_norm (sharded whole-loop drivers): v *= 1 / sqrt(max(*c0_src - sum_i h_i^2, 0)).
+template <typename T>
+void launch_scale_derive(int64_t n, T* v, const double* c0_src, const double* h, int count, double* c0, double* c1,
+                         const double* alpha, double* host_mapped, hipStream_t s);
 // src (nullable): read the unnormalised vector from there instead of from v (out of place).
 template <typename T>
 int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,

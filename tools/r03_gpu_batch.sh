@@ -33,7 +33,7 @@ if has bench; then
   timeout 900 python bench.py > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err; echo "bench rc=$?"; cut -c1-1500 gpurun_out/r3_bench_default.json; tail -3 gpurun_out/r3_bench_default.err
 fi
 if has bench_all; then
-  for cfg in "c3:--workload c3" "c2:--workload c2" "c2lattice:--workload c2 --operator lattice" "c5:--workload c5" "c5lattice:--workload c5 --operator lattice" "n1e4:--workload c2 --size 100" "n1e5:--workload c2 --size 316"; do
+  for cfg in ${BENCH_CFGS:-"c3:--workload c3"} "c2:--workload c2" "c2lattice:--workload c2 --operator lattice" "c5:--workload c5" "c5lattice:--workload c5 --operator lattice" "n1e4:--workload c2 --size 100" "n1e5:--workload c2 --size 316"; do
     name=${cfg%%:*}; opts=${cfg#*:}
     timeout 600 python bench.py $opts --cpu-window 0 > gpurun_out/r3_bench_$name.json 2> gpurun_out/r3_bench_$name.err; echo "bench $name rc=$?"
     python - gpurun_out/r3_bench_$name.json <<'PY'
@@ -57,5 +57,18 @@ for f in glob.glob(sys.argv[1]+'/**/*kernel_stats.csv', recursive=True):
     rows.sort(key=lambda r:-float(r['TotalDurationNs']))
     for r in rows[:10]: print(r['Name'][:80].ljust(82), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(8), 'us')
 PY
+  done
+fi
+if has kgaps; then
+  export TMPDIR=/tmp
+  mkdir -p gpurun_out/prof_r03
+  for cfg in "n1e4:--workload c2 --size 100" "n1e5:--workload c2 --size 316"; do
+    name=${cfg%%:*}; opts=${cfg#*:}
+    for fuse in 1 0; do
+      d=gpurun_out/prof_r03/kg_${name}_f$fuse; rm -rf $d
+      LL_FUSE_LAUNCHES=$fuse timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -o kg -- python3 bench.py $opts --steps 5 --warmup 1 --cpu-window 0 --no-spmv-variants --no-phase-timers > $d.json 2> $d.err
+      echo "kgaps $name fuse=$fuse rc=$? value $(python3 -c "import json;print(json.loads(open('$d.json').read().strip().splitlines()[-1])['value'])")"
+      python3 tools/trace_gaps2.py $(find $d -name "*kernel_trace.csv" | head -1)
+    done
   done
 fi
