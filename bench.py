@@ -285,13 +285,12 @@ def main():
     # lattice: x read once, y written once (+ the real on-site array of config 5)
     b_spmv = (2 * (16 if complex_ else 8) * n + (8 * n if complex_ else 0)) if lattice else spmv_bytes(n, nnz, complex_)
     selected = -1 if lattice else op.selected_spmv()
-    # phase 2 of the PB SpMV: fixed-point sums (the default; pb_phase2_pre on one GPU for double / complex double, where
-    # phase 1 already writes integers on the row's grid, pb_phase2_fixed otherwise) or pb_phase2 (LL_PB_PHASE2=ordered|atomic)
+    # phase 2 of the PB SpMV: pb_phase2_fixed (order-independent fixed-point sums, the default) or pb_phase2
+    # (LL_PB_PHASE2=ordered|atomic)
     phase2_form = os.environ.get("LL_PB_PHASE2", "fixed")
     if phase2_form not in ("ordered", "atomic"):
         phase2_form = "fixed"
-    p2 = ("pb_phase2_pre" if world == 1 and os.environ.get("LL_PB_PRESCALE", "1") != "0" else "pb_phase2_fixed") \
-        if phase2_form == "fixed" else "pb_phase2"
+    p2 = "pb_phase2_fixed" if phase2_form == "fixed" else "pb_phase2"
     kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+" + p2, -1: "stencil_kernel"}
     # The operator timed both kernels on the actual matrix when it was created and released the slower image; those
     # creation-time figures are reported next to the event timing of the kernel that is in use.
@@ -322,7 +321,7 @@ def main():
                 os.environ["LL_PB_PHASE2"], os.environ["LL_SPMV_KERNEL"] = form, "pb"
                 ctx.reload_env()
                 alt = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
-                nm = "pb_phase1+%s [%s]" % ("pb_phase2" if form != "fixed" else "pb_phase2_pre", form)
+                nm = "pb_phase1+%s [%s]" % ("pb_phase2" if form != "fixed" else "pb_phase2_fixed", form)
                 spmv_variants[nm] = time_spmv(alt)
                 alt.close()
         finally:
@@ -605,9 +604,8 @@ def main():
                      "includes_exchange": world > 1},
             "roofline": {
                 "kernel": kernel_names[selected],
-                "launch": "one ll_spmv call y = A x (pb: pb_absmax (14 us; the Lanczos loop gets max|x| from its normalisation "
-                          "kernel instead) + two back-to-back kernels, phase 2 with order-independent fixed-point sums), HIP "
-                          "events on the library stream, %d launches averaged" % args.spmv_reps,
+                "launch": "one ll_spmv call y = A x (pb: two back-to-back kernels, phase 2 with order-independent fixed-point "
+                          "sums), HIP events on the library stream, %d launches averaged" % args.spmv_reps,
                 "bound": "hbm",
                 "achieved": spmv_gbs,
                 "peak": HBM_PEAK_GBS,

@@ -40,6 +40,7 @@ Tuning read_tuning() {
   t.pb_block = (int)std::max<long long>(0, num("LL_PB_BLOCK", 0));
   t.pb_row_block = (int)std::max<long long>(0, num("LL_PB_ROW_BLOCK", 0));
   t.pb_col_block = (int)std::max<long long>(0, num("LL_PB_COL_BLOCK", 0));
+  t.pb_placements = (int)std::max<long long>(1, std::min<long long>(8, num("LL_PB_PLACEMENTS", 4)));
   t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
   t.comm_overlap = flag("LL_COMM_OVERLAP", true);
   t.tridiag_thread = flag("LL_TRIDIAG_THREAD", true);
@@ -55,7 +56,6 @@ Tuning read_tuning() {
   t.force_rp64 = flag("LL_FORCE_RP64", false);
   t.pb_test_all_remote = flag("LL_PB_TEST_ALL_REMOTE", false);
   t.tridiag_test_jitter_us = (int)num("LL_TRIDIAG_TEST_JITTER_US", 0);
-  t.pb_prescale = flag("LL_PB_PRESCALE", true);
   t.stencil_vec = flag("LL_STENCIL_VEC", true);
   {
     const std::string v = str("LL_STALL_TRACE");
@@ -176,7 +176,7 @@ ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
                   (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp,
-                  (void*)d_pb_blockmax, (void*)d_pb_xmax, (void*)d_pb_ex})
+                  (void*)d_pb_blockmax})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -257,7 +257,6 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->d_alpha_partials) (void)hipFree(ctx->d_alpha_partials);
     if (ctx->d_h) (void)hipFree(ctx->d_h);
     if (ctx->d_scal) (void)hipFree(ctx->d_scal);
-    if (ctx->d_xmax) (void)hipFree(ctx->d_xmax);
     if (ctx->d_norm_partials) (void)hipFree(ctx->d_norm_partials);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -586,12 +585,88 @@ void release_image(ll_operator* op, int keep_kind) {
     drop(op->d_pb_arena);
     drop(op->d_pb_rexp);
     drop(op->d_pb_blockmax);
-    drop(op->d_pb_xmax);
-    drop(op->d_pb_ex);
     op->d_pb_val = op->d_pb_prod = nullptr;  // interior pointers of the arena
     op->d_pb_col = op->d_pb_row = nullptr;
     op->pb_ncb = op->pb_nrb = 0;
   }
+}
+
+// Placement of the PB image.  The same image at another address runs up to 5-8 % faster or slower (round 2: "position
+// noise"; round 3, bench.py spmv.ms_by_kernel: 0.922 ms for the operator created first, 0.845 ms for one created later, same
+// process, same x / y) — which HBM stacks and channels the arena's physical pages land on is the draw of the allocation,
+// fixed for its life.  So the draw is repeated: the image is copied (device to device, ~1 ms per GB) into fresh
+// allocations, each is timed with the real kernels, the fastest is kept and the others are freed.  Purely local: no
+// collective decision depends on it.  Returns the best time (ms).
+template <typename T> double tune_pb_placement(ll_operator* op) {
+  ll_context* ctx = op->ctx;
+  hipStream_t s = ctx->stream;
+  if (op->d_pb_arena == nullptr || op->nnz < ((int64_t)1 << 22)) return -1.0;
+  const size_t xn = (size_t)std::max<int64_t>(op->n, op->n_shard * std::max(1, ctx->nranks));
+  struct Scratch {
+    T *x = nullptr, *y = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (x) (void)hipFree(x);
+      if (y) (void)hipFree(y);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } w;
+  ctx->dev_malloc((void**)&w.x, xn * sizeof(T), "placement timing x");
+  ctx->dev_malloc((void**)&w.y, (size_t)std::max<int64_t>(op->n_local, 1) * sizeof(T), "placement timing y");
+  LL_HIP(hipMemsetAsync(w.x, 0, xn * sizeof(T), s));
+  LL_HIP(hipEventCreate(&w.e0));
+  LL_HIP(hipEventCreate(&w.e1));
+  auto time_pb = [&]() {
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+      LL_HIP(hipEventRecord(w.e0, s));
+      launch_spmv_pb<T>(*op, w.x, w.x + op->row_begin, w.x + op->row_begin, w.y, 0.0, nullptr, s);
+      LL_HIP(hipEventRecord(w.e1, s));
+      LL_HIP(hipEventSynchronize(w.e1));
+      float ms = 0.f;
+      LL_HIP(hipEventElapsedTime(&ms, w.e0, w.e1));
+      if (rep > 0) best = std::min(best, (double)ms);
+    }
+    return best;
+  };
+  auto rebase = [&](void* arena) {
+    const ptrdiff_t d = (char*)arena - (char*)op->d_pb_arena;
+    op->d_pb_arena = arena;
+    op->d_pb_val = (char*)op->d_pb_val + d;
+    op->d_pb_col = (uint16_t*)((char*)op->d_pb_col + d);
+    op->d_pb_row = (uint16_t*)((char*)op->d_pb_row + d);
+    op->d_pb_prod = (char*)op->d_pb_prod + d;
+  };
+  // Every candidate stays allocated until all have been timed (an allocation freed at once would simply be handed out
+  // again for the next one); then all but the fastest are freed.
+  double best = time_pb();
+  void* best_arena = op->d_pb_arena;
+  std::vector<void*> losers;
+  struct FreeAll {
+    std::vector<void*>& v;
+    ~FreeAll() {
+      for (void* p : v) (void)hipFree(p);
+    }
+  } free_losers{losers};
+  for (int t = 1; t < ctx->tune.pb_placements; ++t) {
+    void* cand = nullptr;
+    if (hipMalloc(&cand, op->pb_arena_bytes) != hipSuccess) {  // no room for another copy: decide among what we have
+      (void)hipGetLastError();
+      break;
+    }
+    losers.push_back(cand);
+    LL_HIP(hipMemcpyAsync(cand, best_arena, op->pb_arena_static_bytes, hipMemcpyDeviceToDevice, s));
+    rebase(cand);
+    const double ms = time_pb();
+    if (ms < best) {
+      best = ms;
+      losers.back() = best_arena;  // the previous best becomes a loser
+      best_arena = cand;
+    }
+    rebase(best_arena);
+  }
+  return best;
 }
 
 // Time both SpMV kernels on the device with the actual matrix and keep the faster one.  Sharded contexts decide on
@@ -726,6 +801,10 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     if (all_ranks_agree(built)) {
       if (want == 2) op->spmv_kind = LL_SPMV_PB;
       else autotune_spmv<T>(op.get());
+      if (op->spmv_kind == LL_SPMV_PB && ctx->tune.pb_placements > 1) {
+        const double ms = tune_pb_placement<T>(op.get());
+        if (ms > 0.0 && op->tune_ms[LL_SPMV_PB] >= 0.f) op->tune_ms[LL_SPMV_PB] = (float)ms;
+      }
     } else if (built) {
       op->spmv_kind = LL_SPMV_CSR_STREAM;  // some rank could not build it: nobody uses it
     }

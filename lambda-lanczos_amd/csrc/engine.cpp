@@ -166,11 +166,6 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
   LL_HIP(hipStreamSynchronize(ctx->stream));
 }
 
-template <typename T> double* Engine<T>::xmax_buffer() {
-  if (!ctx->d_xmax) ctx->dev_malloc((void**)&ctx->d_xmax, (size_t)kMaxGrid * sizeof(double), "maxima of |u_k|");
-  return ctx->d_xmax;
-}
-
 template <typename T>
 void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer,
                       const ScaleIn<T>* sc) {
@@ -260,11 +255,8 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     if (remote_done) {
     } else if (op->kind == ll_operator::DENSE)
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
-    else if (pb) {
-      const bool have_max = xmax_of == (const void*)x_local && xmax_n > 0 && ctx->comm == nullptr;
-      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, have_max ? ctx->d_xmax : nullptr,
-                                 have_max ? xmax_n : 0);
-    }
+    else if (pb)
+      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s);
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
   } else {
@@ -488,7 +480,6 @@ template <typename T> double Engine<T>::second_pass(T* u, const RunList<T>& runs
   const ThreeTerm<T> no_tt{nullptr, nullptr, nullptr, NormRefs{nullptr, nullptr, nullptr, 0}};
   const NormRefs r = orth(u, runs, LL_ORTH_CGS_DGKS, no_tt, S(kScalScratch), nullptr, true);
   launch_scale<T>(n_local, u, 0.0, &r, ctx->stream);
-  if (xmax_of == (const void*)u) xmax_of = nullptr;  // u changed: the maxima left by its normalisation are stale
   double shrink = 0.0;
   fetch(r.c1, &shrink, 1);
   return shrink;
@@ -584,7 +575,7 @@ template <typename T> struct LoopState {
   PhaseTimer& timer;
   int64_t nl;
   hipStream_t s;
-  bool fuse_launches = true, want_xmax = false, defer = false;
+  bool fuse_launches = true, defer = false;
   DevBuf<T> work[2];      // defer: w_k lives in work[k & 1]
   bool pending = false;   // iteration pend_k ended without its normalisation / publish
   typename Engine<T>::Publish pend{nullptr, nullptr, false};
@@ -638,12 +629,7 @@ template <typename T> struct LoopState {
       pend_slot = slot;
       pend_k = k;
     } else if (pub.deferred) {  // norm fold + publish + normalisation in one launch (P8)
-      double* xm = want_xmax ? E.xmax_buffer() : nullptr;
-      const int g = launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, xm, s);
-      if (xm) {  // the next SpMV reads y: it finds the maxima of |y| ready (fixed-point PB kernels)
-        E.xmax_of = y;
-        E.xmax_n = g;
-      }
+      launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, s);
       LL_HIP(hipEventRecord(ring.ev[slot], s));
     } else if (pub.derive) {  // sharded: derived norm + publish + normalisation in one launch
       launch_scale_derive<T>(nl, y, pub.derive_c0, pub.derive_h, pub.derive_count, pub.c0_out, pub.c1, pub.alpha, pub.host, s);
@@ -661,7 +647,7 @@ template <typename T> struct LoopState {
   // the pending iteration is the last one: normalise it into its basis slot and publish its scalars now
   void flush() {
     if (!pending) return;
-    launch_scale_publish<T>(nl, U.vec(pend_k), pend.partials, pend.nparts, pend.c1, pend.alpha, pend.c0, pend.host, nullptr, s,
+    launch_scale_publish<T>(nl, U.vec(pend_k), pend.partials, pend.nparts, pend.c1, pend.alpha, pend.c0, pend.host, s,
                             work[pend_k & 1].p);
     LL_HIP(hipEventRecord(ring.ev[pend_slot], s));
     pending = false;
@@ -752,8 +738,6 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
   const bool fuse_launches = ctx->tune.fuse_launches;
   Engine<T> E(ctx, op, nl);
-  // the pre-scaled fixed-point SpMV wants max|u_k| before its phase 1 starts: the normalisation kernel leaves it behind
-  const bool want_xmax = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB && op->pb_prescaled;
   constexpr int R = scalar_traits<T>::reals;
 
   Basis<T> U;
@@ -780,7 +764,6 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   double t_tridiag = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
-  LS.want_xmax = want_xmax;
   if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
@@ -797,7 +780,6 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
 
   while (true) {  // restart loop LL:334-354
     const int64_t nroot = spec ? spec->nroot : std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
-    E.xmax_of = nullptr;
     const double t_pass0 = now_s();
     // ---- start vector (LL:231-234)
     if (P.init_vector_dev) {  // start vector already in HBM (copied: the caller's buffer is left untouched)
@@ -1142,8 +1124,6 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   const int64_t nl = op->n_local;
   const int64_t ld = round_up(std::max(nl, op->n_shard), 256);
   Engine<T> E(ctx, op, nl);
-  // the pre-scaled fixed-point SpMV wants max|u_k| before its phase 1 starts: the normalisation kernel leaves it behind
-  const bool want_xmax = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB && op->pb_prescaled;
   st.at("engine");
   const double dgks_thr = ctx->tune.dgks_threshold;
   // Two launches per iteration less on single-GPU runs: alpha is folded by the multi-dot that needs it, and the fold of
@@ -1178,7 +1158,6 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   double t_wait = 0.0;
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
-  LS.want_xmax = want_xmax;
   LS.refs_prev = refs_prev;
   if (E.can_defer_scale() && fuse_launches && (!P.full_orthogonalize || P.orth_mode == LL_ORTH_CGS_DGKS)) LS.enable_defer(ld);
   auto enqueue = [&](int64_t k) {  // EX:107-118 (+ EX:120-122 with full_orthogonalize), EX:145, EX:160

@@ -73,12 +73,6 @@ template <typename T> struct Engine {
     const double* partials = nullptr;
     int nparts = 0;
   };
-  // xmax_of (single GPU): the vector whose per-workgroup maxima of |.| currently sit in ctx->d_xmax (xmax_n of them), left
-  // by the normalisation kernel that produced it; apply() hands them to the fixed-point SpMV when x is that vector.
-  // Anything that modifies the vector afterwards must reset xmax_of.
-  const void* xmax_of = nullptr;
-  int xmax_n = 0;
-  double* xmax_buffer();  // ctx->d_xmax, allocated on first use
   // sc (nullable): deferred normalisation — x_local is the unnormalised w_k (ScaleIn, ll_internal.hpp); only where
   // can_defer_scale() holds.
   void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false, DeferredAlpha* defer = nullptr,

@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
                                                                const double* __restrict__ partials, int nparts,
                                                                double* __restrict__ out, const double* __restrict__ alpha,
                                                                const double* __restrict__ c0, double* __restrict__ host,
-                                                               double* __restrict__ xmax, const T* __restrict__ src) {
+                                                               const T* __restrict__ src) {
   constexpr int EPT = strip<T>::EPT;
   __shared__ double fold_scratch[5];
   const double tot = fold_partials_all(partials, nparts, fold_scratch);  // the order of reduce_publish_kernel
@@ -924,25 +924,13 @@ __global__ __launch_bounds__(kBlock) void scale_publish_kernel(int64_t n, T* __r
   }
   const double f = 1.0 / sqrt(tot);  // T(1)/norm, LA:77-80
   const int64_t nstrips = (n + strip<T>::ELEMS - 1) / strip<T>::ELEMS;
-  double mx = 0.0;
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int64_t base = sidx * strip<T>::ELEMS;
     T r[EPT];
     load_strip<T>(src ? src : v, base, n, r);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      r[e] = rmul(f, r[e]);
-      mx = fmax(mx, abs1(r[e]));  // (elements beyond n are zero-filled by load_strip)
-    }
+    for (int e = 0; e < EPT; ++e) r[e] = rmul(f, r[e]);
     store_strip<T>(v, base, n, r);
-  }
-  if (xmax != nullptr) {  // the maxima of |u_k| for the fixed-point SpMV that reads u_k next (spmv_pb.hip, pb_phase1_pre)
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = fmax(mx, __shfl_down(mx, d, 64));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) fold_scratch[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) xmax[blockIdx.x] = fmax(fmax(fold_scratch[0], fold_scratch[1]), fmax(fold_scratch[2], fold_scratch[3]));
   }
 }
 // Sharded contexts: a8 fused with derive_norm_kernel — every workgroup forms ||w'||^2 = ||w||^2 - sum |h_j|^2 from the
@@ -999,17 +987,17 @@ LL_INST_SCALE_DERIVE(double) LL_INST_SCALE_DERIVE(zc) LL_INST_SCALE_DERIVE(float
 
 template <typename T>
 int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
-                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s, const T* src) {
+                         const double* c0, double* host_mapped, hipStream_t s, const T* src) {
   const int grid = strip_grid(n, strip<T>::ELEMS);
   hipLaunchKernelGGL((scale_publish_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, v, partials, nparts, out, alpha, c0,
-                     host_mapped, xmax_out, src);
+                     host_mapped, src);
   LL_HIP(hipGetLastError());
   return grid;
 }
-template int launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const double*);
-template int launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const zc*);
-template int launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const float*);
-template int launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, double*, hipStream_t, const cf*);
+template int launch_scale_publish<double>(int64_t, double*, const double*, int, double*, const double*, const double*, double*, hipStream_t, const double*);
+template int launch_scale_publish<zc>(int64_t, zc*, const double*, int, double*, const double*, const double*, double*, hipStream_t, const zc*);
+template int launch_scale_publish<float>(int64_t, float*, const double*, int, double*, const double*, const double*, double*, hipStream_t, const float*);
+template int launch_scale_publish<cf>(int64_t, cf*, const double*, int, double*, const double*, const double*, double*, hipStream_t, const cf*);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void three_term_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ up,

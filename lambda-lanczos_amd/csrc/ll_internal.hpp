@@ -154,6 +154,7 @@ struct Tuning {
   int pb_block = 0;                // LL_PB_BLOCK: rows AND columns per block (0: automatic); tests force ragged blocks
   int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
   int pb_col_block = 0;
+  int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
   int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
   bool comm_overlap = true;        // LL_COMM_OVERLAP=0: exchange and compute on one stream (serial A/B reference)
   // --- the loops
@@ -168,7 +169,6 @@ struct Tuning {
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
   bool pb_test_all_remote = false; // LL_PB_TEST_ALL_REMOTE=1: own columns are read from the gathered buffer too
   int tridiag_test_jitter_us = 0;  // LL_TRIDIAG_TEST_JITTER_US: random delay of every helper-thread verdict
-  bool pb_prescale = true;         // LL_PB_PRESCALE=0: single-GPU fixed-point sums through the sharded contexts' kernel pair (A/B)
   bool stencil_vec = true;         // LL_STENCIL_VEC=0: scalar lattice kernel on shapes the vector kernel would take
   double stall_trace_ms = -1.0;    // LL_STALL_TRACE: print where a whole-loop call longer than this spent its time
 };
@@ -202,7 +202,6 @@ struct ll_context {
   size_t h_cap = 0;              // doubles
   double* d_scal = nullptr;      // 64 doubles of device scalars (ring slots, flags)
   double* d_norm_partials = nullptr;  // kMaxGrid norm partials of the folding multi-axpy (must not alias d_partials)
-  double* d_xmax = nullptr;      // kMaxGrid per-workgroup maxima of |u_k| left by the normalisation kernel (lazily sized)
   double* h_pinned = nullptr;    // pinned host mirror for scalar read-back
   size_t pinned_cap = 0;         // doubles
   void* d_coeff = nullptr;       // coefficient upload area for gemv_basis
@@ -263,15 +262,13 @@ struct ll_operator {
   int64_t* d_pb_xoff = nullptr;      // [ncb]        element offset of the block's x slice in ITS source buffer
   int32_t* d_pb_ncols = nullptr;     // [ncb]        columns of the block
   void* d_pb_arena = nullptr;        // the one allocation that holds the four big streams below (interior pointers)
+  size_t pb_arena_bytes = 0, pb_arena_static_bytes = 0;  // its size; the part in front of the product buffer
   void* d_pb_val = nullptr;          // values, column-block order
   uint16_t* d_pb_col = nullptr;      // local column, column-block order
   uint16_t* d_pb_row = nullptr;      // local row, row-block order
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
   int16_t* d_pb_rexp = nullptr;      // LL_PB_PHASE2=fixed: exponent of every local row's absolute sum
   double* d_pb_blockmax = nullptr;   // LL_PB_PHASE2=fixed: max |x| per column block, left by phase 1
-  bool pb_prescaled = false;         // fixed-point sums with phase 1 writing integers on the row's grid (spmv_pb.hip)
-  double* d_pb_xmax = nullptr;       //   per-workgroup maxima of |x| when nobody else provides them (kMaxGrid doubles)
-  int* d_pb_ex = nullptr;            //   exponent of max |x| of the launch in flight (phase 1 -> phase 2)
   int64_t pb_entries = 0;            // padded entry count of the image
   int pb_phase2 = 4;                 // form of phase 2 (ll::LL_PB_FIXED / _ORDERED / _ATOMIC), fixed when the image is built
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
@@ -328,11 +325,9 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
 // blocks (x slices from x_own: the local shard readable up to the shard stride), then over every gather chunk's remote blocks (x slices from x_gathered, laid out
 // per op.gather), then phase 2.  The pieces are exposed so that the sharded driver can run the own-column part under
 // the all-gather and each chunk's part as soon as that chunk has arrived.
-// xmax / xmax_n (nullable): per-workgroup maxima of |x| left behind by the kernel that produced x (the pre-scaled
-// fixed-point form needs max|x| before phase 1 starts; without them it sweeps x once more).
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s, const double* xmax = nullptr, int xmax_n = 0);
+                   double* dot_partials, hipStream_t s);
 template <typename T>
 void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s);
 template <typename T>
@@ -406,8 +401,6 @@ template <typename T> void launch_scale(int64_t n, T* v, double a, const NormRef
 // scale fused with the fold of the post-pass norm and the publish step (single-GPU whole-loop drivers): every workgroup
 // folds the `nparts` norm partials in the same fixed order, v *= 1/sqrt(sum); workgroup 0 stores the sum to *out and the
 // iteration's four scalars (alpha, sum, c0, sum) to the pinned host slot.
-// xmax_out (nullable, kMaxGrid doubles): the per-workgroup maxima of |v| after scaling (|re| + |im| for complex), for the
-// fixed-point SpMV that reads v next.  Returns the grid = number of maxima written.
 // a8 fused with launch_derive_norm (sharded whole-loop drivers): v *= 1 / sqrt(max(*c0_src - sum_i h_i^2, 0)).
 template <typename T>
 void launch_scale_derive(int64_t n, T* v, const double* c0_src, const double* h, int count, double* c0, double* c1,
@@ -415,7 +408,7 @@ void launch_scale_derive(int64_t n, T* v, const double* c0_src, const double* h,
 // src (nullable): read the unnormalised vector from there instead of from v (out of place).
 template <typename T>
 int launch_scale_publish(int64_t n, T* v, const double* partials, int nparts, double* out, const double* alpha,
-                         const double* c0, double* host_mapped, double* xmax_out, hipStream_t s, const T* src = nullptr);
+                         const double* c0, double* host_mapped, hipStream_t s, const T* src = nullptr);
 // Plain three-term update with host scalars (primitive API).
 template <typename T>
 void launch_three_term(int64_t n, T* w, const T* u_prev, const T* u_cur, double beta, double alpha, hipStream_t s);

@@ -77,46 +77,122 @@ template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__
 // beyond the end of its range re-reads the range's last quad (a cache hit) and stores to a dump quad behind the image,
 // only the LDS work is predicated.  With loads under divergent branches the number of outstanding loads is unknown at
 // compile time and every wait degenerates to vmcnt(0) again.
+// The quads of a workgroup's range are dealt out in WAVE CHUNKS (64 lanes x U quads) from a counter in LDS instead of
+// by a fixed stride: the hardware favours a workgroup's oldest waves, so with a fixed partition wave 0 is done long
+// before wave 15 (measured: 94 us against 160 us in phase 1) and the tail of every workgroup runs with a fraction of its
+// loads in flight.  The first D - 1 chunks of every wave are fixed (they are requested before the counter is live).
+template <int U> struct WaveChunks {
+  static constexpr int kQuads = 64 * U;  // quads per chunk
+  unsigned* ctr;                         // LDS: chunks handed out so far (starts at (D - 1) * kPbWaves)
+  long long g0;
+  __device__ __forceinline__ long long fixed(int d) const { return g0 + (long long)((threadIdx.x >> 6) + d * kPbWaves) * kQuads; }
+  __device__ __forceinline__ long long grab() const {
+    unsigned c = 0;
+    if ((threadIdx.x & 63) == 0) c = atomicAdd(ctr, 1u);
+    c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+    return g0 + (long long)c * kQuads;
+  }
+};
 template <typename T, int D> struct ColStream {  // phase 1: (4 values, 4 local columns) per lane per trip
   quad<T> v[D];
   ushort4 c[D];
+  long long base[D];  // first quad of the chunk held in each slot
   const T* val;
   const ushort4* col;
-  long long glast;  // last valid quad of the range (>= its first quad; the image is padded behind its end)
-  __device__ __forceinline__ void issue(int slot, long long g) {
+  long long g1, glast;  // end of the range; last valid quad (>= its first quad; the image is padded behind its end)
+  WaveChunks<1> chunks;
+  __device__ __forceinline__ void issue(int slot, long long cbase) {
+    base[slot] = cbase;
+    const long long g = cbase + (threadIdx.x & 63);
     const long long gc = g < glast ? g : glast;
     v[slot] = load_quad<T>(val + 4 * gc);
     c[slot] = col[gc];
   }
+  __device__ __forceinline__ void prologue() {
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(d, chunks.fixed(d));
+  }
+  // consume(values, columns, quad index of this lane) for every chunk this wave gets; the counter must be live.
+  // (The D phases are spelled out — slot indices must be compile-time constants, and a `return` inside a `#pragma
+  // unroll` loop keeps the compiler from unrolling it.)
+  template <int PH, typename F> __device__ __forceinline__ bool step(F&& consume) {
+    const long long cur = base[PH];
+    if (cur >= g1) return false;  // wave-uniform; chunks are handed out in ascending order
+    issue((PH + D - 1) % D, chunks.grab());
+    consume(v[PH], c[PH], cur + (threadIdx.x & 63));
+    return true;
+  }
+  template <typename F> __device__ __forceinline__ void run(F&& consume) {
+    static_assert(D >= 2 && D <= 4, "pipeline depth");
+    for (;;) {
+      if (!step<0>(consume)) return;
+      if (!step<1>(consume)) return;
+      if constexpr (D > 2) {
+        if (!step<2>(consume)) return;
+      }
+      if constexpr (D > 3) {
+        if (!step<3>(consume)) return;
+      }
+    }
+  }
 };
-template <typename T, int U, int D> struct RowStream {  // phase 2: U x (4 products, 4 local rows) per lane per trip
+// phase 2: U x (4 products, 4 local rows) per lane per trip.  DYN: wave chunks as above; otherwise the fixed stride of
+// the whole workgroup (the wave-ordered form needs every wave in every trip).
+template <typename T, int U, int D, bool DYN> struct RowStream {
   quad<T> p[D][U];
   ushort4 r[D][U];
+  long long base[D];
   const T* P;
   const ushort4* row;
   long long g1, glast;  // end of the range; last valid quad (>= the first quad: the image is padded behind its end)
+  WaveChunks<U> chunks;
   static constexpr long long kTrip = (long long)U * kPbThreads;
-  __device__ __forceinline__ void issue(int slot, long long tbase) {
+  __device__ __forceinline__ long long quad_of(long long cbase, int u) const {
+    return DYN ? cbase + (threadIdx.x & 63) + (long long)u * 64 : cbase + threadIdx.x + (long long)u * kPbThreads;
+  }
+  __device__ __forceinline__ void issue(int slot, long long cbase) {
+    base[slot] = cbase;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long g = tbase + threadIdx.x + (long long)u * kPbThreads;
+      const long long g = quad_of(cbase, u);
       const long long gc = g < glast ? g : glast;
       p[slot][u] = load_quad<T>(P + 4 * gc);
       r[slot][u] = row[gc];
     }
   }
-  // consume(slot contents, trip base) for every trip of [g0, g1), D - 1 trips requested ahead; prologue() first
-  __device__ __forceinline__ void prologue(long long g0) {
+  __device__ __forceinline__ void prologue() {
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) issue(d, g0 + d * kTrip);
+    for (int d = 0; d < D - 1; ++d) issue(d, DYN ? chunks.fixed(d) : chunks.g0 + d * kTrip);
   }
-  template <typename F> __device__ __forceinline__ void run(long long g0, F&& consume) {
-    for (long long base = g0; base < g1; base += D * kTrip) {  // trip counts are uniform over the workgroup
+  // consume(products, rows, quad indices of this lane) for every trip; DYN: the counter must be live
+  long long next_static;
+  template <int PH, typename F> __device__ __forceinline__ bool step(F&& consume) {
+    const long long cur = base[PH];
+    if (cur >= g1) return false;  // uniform over the wave (DYN) / the workgroup
+    long long nxt;
+    if constexpr (DYN) nxt = chunks.grab();
+    else {
+      nxt = next_static;
+      next_static += kTrip;
+    }
+    issue((PH + D - 1) % D, nxt);
+    long long g[U];
 #pragma unroll
-      for (int ph = 0; ph < D; ++ph) {  // (trips beyond g1 in the last round: cache-hit loads, nothing consumed)
-        const long long cur = base + ph * kTrip;
-        issue((ph + D - 1) % D, cur + (D - 1) * kTrip);
-        consume(p[ph], r[ph], cur);
+    for (int u = 0; u < U; ++u) g[u] = quad_of(cur, u);
+    consume(p[PH], r[PH], g);
+    return true;
+  }
+  template <typename F> __device__ __forceinline__ void run(F&& consume) {
+    static_assert(D >= 2 && D <= 4, "pipeline depth");
+    next_static = chunks.g0 + (D - 1) * kTrip;
+    for (;;) {
+      if (!step<0>(consume)) return;
+      if (!step<1>(consume)) return;
+      if constexpr (D > 2) {
+        if (!step<2>(consume)) return;
+      }
+      if constexpr (D > 3) {
+        if (!step<3>(consume)) return;
       }
     }
   }
@@ -137,32 +213,19 @@ __device__ __forceinline__ double pow2(int k) {  // 2^k for |k| <= 1022
 // — finer than the unit roundoff of a double-precision sum of terms of that size, and far below eps * ||A|| ||x||, the
 // scale that matters to the Lanczos recurrence; NOT component-wise accurate for rows whose terms are all tiny against
 // (sum_j |a_ij|) max|x| (LL_PB_PHASE2=ordered is).
-// Two realisations that give the same bits:
-//   LATE  (sharded contexts, float storage): phase 1 writes fl(a_ij x_j) and the maximum of |x| over its slice; phase 2
-//         looks up the row's exponent per entry, scales, rounds and adds.
-//   PRE   (single GPU, double / complex double): the image stores a~_ij = a_ij 2^-er_i (exact), phase 1 knows e_x before it
-//         starts (per-workgroup maxima of |x| left by the kernel that produced x, or by pb_absmax_kernel) and writes
-//         rint(fl(a~_ij x_j) 2^(61 - e_x)) = rint(fl(a_ij x_j) 2^(62 - E_i)) as a 64-bit integer; phase 2 is a pure
-//         stream with one integer LDS atomic per entry, and its y slice needs 8 bytes per row instead of 10.
-// Rows that meet an Inf / NaN are reported as NaN (PRE: the sentinel INT64_MIN travels through P).
-constexpr long long kPbBadProduct = (long long)0x8000000000000000ull;
+// Phase 1 writes fl(a_ij x_j) and the maximum of |x| over its slice; phase 2 looks up the row's exponent per entry, scales,
+// rounds and adds.  Rows that meet an Inf / NaN are reported as NaN.
+// (Round 3 measured a PRE-SCALED form — image values a_ij 2^-er_i, max|x| known before phase 1, 64-bit integers in P,
+// phase 2 a pure stream with one integer atomic per entry: the LDS work of phase 2 turned out to be free (removing the adds
+// altogether changes nothing, profiles/r03_spmv_variants.txt runs C and G) while the float -> int64 conversion makes
+// phase 1 borderline ALU-bound; no gain, removed again.)
+constexpr long long kPbBadProduct = (long long)0x8000000000000000ull;  // "not a finite number below 2^63"
 constexpr int kPbXInf = 20000;   // e_x when max|x| is not finite: every row is reported as NaN
-constexpr int kPbXMinExp = -900; // vectors smaller than 2^-900 everywhere are put on the grid of 2^-900
 
 __device__ __forceinline__ long long pb_to_fixed(double p, int k) {
   const double sc = ldexp(p, k);  // v_ldexp_f64: one instruction, no range restrictions
   if (!(fabs(sc) < 9.0e18)) return kPbBadProduct;
   return (long long)rint(sc);
-}
-__device__ __forceinline__ int pb_exponent_of_max(double t) {
-  int e = kPbXMinExp;
-  if (t > 0.0 && isfinite(t)) {
-    (void)frexp(t, &e);  // t < 2^e
-    e = max(e, kPbXMinExp);
-  } else if (!(t == 0.0)) {
-    e = kPbXInf;
-  }
-  return e;
 }
 // maximum over the workgroup of a per-lane value (result in every lane); scratch: kPbWaves doubles + 1
 __device__ __forceinline__ double pb_block_max(double m, double* scratch) {
@@ -179,53 +242,22 @@ __device__ __forceinline__ double pb_block_max(double m, double* scratch) {
   return scratch[kPbWaves];
 }
 
-// Per-workgroup maxima of |x| (|re| + |im| for complex): xmax[b], b < gridDim.x.  NaN entries are skipped (their
-// products carry them); an Inf makes the maximum Inf.
-template <typename T>
-__global__ __launch_bounds__(256) void pb_absmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ xmax) {
-  __shared__ double red[4];
-  constexpr int V = (int)(16 / sizeof(T));  // elements per 16-byte piece (zc: 1)
-  double m = 0.0;
-  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    const long long nv = n / V;
-    const uint4* x4 = reinterpret_cast<const uint4*>(x);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
-      const uint4 c = x4[i];
-      T e[V];
-      __builtin_memcpy(e, &c, sizeof(c));
-#pragma unroll
-      for (int k = 0; k < V; ++k) m = fmax(m, abs1(e[k]));
-    }
-    if (blockIdx.x == 0)
-      for (long long i = nv * V + threadIdx.x; i < n; i += 256) m = fmax(m, abs1(x[i]));
-  } else {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmax(m, abs1(x[i]));
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) xmax[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
-
 // ================================================================= phase 1
 // Workgroup b handles column block blk_first + b: the block's entries (4 values + 4 local columns per lane and trip)
 // stream in, ordered by destination row block; product = value * x_lds[col] goes to the product buffer P at its position
 // in row-block order.  The first D - 1 trips are requested before the x slice is staged.
-// PRE (see above): xmax[0 .. xmax_n) are the per-workgroup maxima of |x|; the products are written as integers on the
-// row's grid and workgroup 0 leaves e_x in *ex_out.  Otherwise blockmax (nullable) receives the slice maximum.
-template <typename T, bool PRE, int D>
+// blockmax (nullable; fixed-point phase 2) receives the maximum of |x| over the slice.
+template <typename T, int D>
 __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, const int64_t* __restrict__ xoff,
                                                         const int32_t* __restrict__ ncols_tab,
                                                         const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
                                                         const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
                                                         const T* __restrict__ val, const ushort4* __restrict__ col,
                                                         const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols,
-                                                        double* __restrict__ blockmax, const double* __restrict__ xmax,
-                                                        int xmax_n, int* __restrict__ ex_out, long long p_dump) {
-  constexpr int R = scalar_traits<T>::reals;
+                                                        double* __restrict__ blockmax, long long p_dump) {
   extern __shared__ double lds[];
   __shared__ double bm_red[kPbWaves + 1];
+  __shared__ unsigned chunk_ctr;
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
   long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
                                               (((size_t)cb_cols * sizeof(T) + 15) & ~(size_t)15));  // [nrb + 1]
@@ -238,9 +270,12 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
   ColStream<T, D> st;
   st.val = val;
   st.col = col;
+  st.g1 = g1;
   st.glast = g1 > g0 ? g1 - 1 : g0;
-#pragma unroll
-  for (int d = 0; d < D - 1; ++d) st.issue(d, g0 + tid + (long long)d * kPbThreads);
+  st.chunks.ctr = &chunk_ctr;
+  st.chunks.g0 = g0;
+  st.prologue();
+  if (tid == 0) chunk_ctr = (D - 1) * kPbWaves;  // (published by the barriers below)
   {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
     const int ncols = ncols_tab[c];
     const T* src = xsrc + xoff[c];
@@ -258,22 +293,13 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
     const int64_t* sd = seg_dest + (size_t)c * nrb;
     for (int i = tid; i < nrb; i += kPbThreads) db[i] = sd[i];
   }
-  int k = 0;  // PRE: the products are scaled by 2^k = 2^(61 - e_x)
-  if constexpr (PRE) {
+  __syncthreads();
+  if (blockmax != nullptr) {  // the largest |x| of the slice (phase 2 needs max |x| over all columns)
     double m = 0.0;
-    for (int i = tid; i < xmax_n; i += kPbThreads) m = fmax(m, xmax[i]);
-    const int e_x = pb_exponent_of_max(pb_block_max(m, bm_red));  // (its barriers also publish the staged slice)
-    if (c == 0 && tid == 0) *ex_out = e_x;  // phase 2 turns the sums back with the same exponent
-    k = e_x == kPbXInf ? 0 : 61 - e_x;      // (Inf in x: phase 2 reports every row as NaN whatever P holds)
-  } else {
-    __syncthreads();
-    if (blockmax != nullptr) {  // LATE: the largest |x| of the slice (phase 2 needs max |x| over all columns)
-      double m = 0.0;
-      const int ncols = ncols_tab[c];
-      for (int i = tid; i < ncols; i += kPbThreads) m = fmax(m, abs1(xs[i]));
-      m = pb_block_max(m, bm_red);
-      if (tid == 0) blockmax[c] = m;  // NaN in the slice: fmax drops it; the products carry it into P and phase 2 reports it
-    }
+    const int ncols = ncols_tab[c];
+    for (int i = tid; i < ncols; i += kPbThreads) m = fmax(m, abs1(xs[i]));
+    m = pb_block_max(m, bm_red);
+    if (tid == 0) blockmax[c] = m;  // NaN in the slice: fmax drops it; the products carry it into P and phase 2 reports it
   }
   int r = 0;
   T* const dump = P + p_dump;  // where lanes beyond the block's last quad store (a quad behind the image)
@@ -282,33 +308,11 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
     while (r + 1 < nrb && qq >= qs[r + 1]) ++r;
     const unsigned short cc[4] = {cl.x, cl.y, cl.z, cl.w};
     quad<T> pr;
-    if constexpr (PRE) {
-      long long out[4 * R];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const T pe = mul(v.e[e], xs[cc[e]]);
-        if constexpr (scalar_traits<T>::is_complex) {
-          out[2 * e] = pb_to_fixed(pe.re, k);
-          out[2 * e + 1] = pb_to_fixed(pe.im, k);
-        } else {
-          out[e] = pb_to_fixed(pe, k);
-        }
-      }
-      __builtin_memcpy(&pr, out, sizeof(pr));
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pr.e[e] = mul(v.e[e], xs[cc[e]]);
-    }
+    for (int e = 0; e < 4; ++e) pr.e[e] = mul(v.e[e], xs[cc[e]]);
     store_quad<T>(g < g1 ? P + db[r] + (qq - qs[r]) : dump, pr);
   };
-  for (long long base = g0; base < g1; base += (long long)D * kPbThreads) {  // uniform trip count
-#pragma unroll
-    for (int ph = 0; ph < D; ++ph) {
-      const long long cur = base + tid + (long long)ph * kPbThreads;
-      st.issue((ph + D - 1) % D, cur + (long long)(D - 1) * kPbThreads);
-      consume(st.v[ph], st.c[ph], cur);
-    }
-  }
+  st.run(consume);
 }
 
 // ================================================================= phase 2
@@ -377,19 +381,23 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  RowStream<T, U, D> st;
+  __shared__ unsigned chunk_ctr;
+  RowStream<T, U, D, !ORDERED> st;
   st.P = P;
   st.row = row;
   st.g1 = g1;
   st.glast = g1 > g0 ? g1 - 1 : g0;
-  st.prologue(g0);
+  st.chunks.ctr = &chunk_ctr;
+  st.chunks.g0 = g0;
+  st.prologue();
+  if (tid == 0) chunk_ctr = (D - 1) * kPbWaves;
   for (int i = tid; i < rb_rows * R; i += kPbThreads) lds[i] = 0.0;
   __syncthreads();
-  st.run(g0, [&](const quad<T>(&p)[U], const ushort4(&r)[U], long long cur) {
+  st.run([&](const quad<T>(&p)[U], const ushort4(&r)[U], const long long(&g)[U]) {
     auto add_mine = [&]() {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (cur + tid + (long long)u * kPbThreads < g1) {
+        if (g[u] < g1) {
           lds_add_elem<T>(lds, r[u].x, p[u].e[0]);
           lds_add_elem<T>(lds, r[u].y, p[u].e[1]);
           lds_add_elem<T>(lds, r[u].z, p[u].e[2]);
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
   });
 }
 
-// Fixed-point sums, LATE form (see above): P holds fl(a_ij x_j) in the storage type.
+// Fixed-point sums (see above): P holds fl(a_ij x_j) in the storage type.
 template <typename T, int D>
 __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64_t n_local, int ncb,
                                                               const int64_t* __restrict__ rptr,
@@ -436,12 +444,16 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  RowStream<T, U, D> st;
+  __shared__ unsigned chunk_ctr;
+  RowStream<T, U, D, true> st;
   st.P = P;
   st.row = row;
   st.g1 = g1;
   st.glast = g1 > g0 ? g1 - 1 : g0;
-  st.prologue(g0);
+  st.chunks.ctr = &chunk_ctr;
+  st.chunks.g0 = g0;
+  st.prologue();
+  if (tid == 0) chunk_ctr = (D - 1) * kPbWaves;
   {  // exponent of max |x| over ALL columns (every column block left its slice maximum)
     double m = 0.0;
     for (int i = tid; i < ncb; i += kPbThreads) m = fmax(m, blockmax[i]);
@@ -462,10 +474,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
     }
     __syncthreads();
   }
-  st.run(g0, [&](const quad<T>(&p)[U], const ushort4(&r)[U], long long cur) {
+  st.run([&](const quad<T>(&p)[U], const ushort4(&r)[U], const long long(&g)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (cur + tid + (long long)u * kPbThreads < g1) {
+      if (g[u] < g1) {
         const unsigned short rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -496,71 +508,6 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
     acc_t<T> a;
     if constexpr (scalar_traits<T>::is_complex) a = zc{(double)acc[2 * i] * back, (double)acc[2 * i + 1] * back};
     else a = (double)acc[i] * back;
-    return a;
-  });
-}
-
-// Fixed-point sums, PRE form (see above): P holds 64-bit integers on the row's grid.
-template <typename T, int D>
-__global__ __launch_bounds__(kPbThreads) void pb_phase2_pre(int rb_rows, int64_t n_local,
-                                                            const int64_t* __restrict__ rptr,
-                                                            const ushort4* __restrict__ row, const T* __restrict__ P,
-                                                            const int16_t* __restrict__ rexp, const int* __restrict__ ex_in,
-                                                            const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                            double* __restrict__ dot_partials) {
-  constexpr int R = scalar_traits<T>::reals;
-  constexpr int U = 2;
-  extern __shared__ double lds_raw[];
-  long long* acc = reinterpret_cast<long long*>(lds_raw);                    // [rb_rows * R]
-  unsigned* bad = reinterpret_cast<unsigned*>(acc + (size_t)rb_rows * R);    // [(rb_rows + 31) / 32] rows that met Inf / NaN
-  __shared__ double red[kPbWaves];
-  const int tid = threadIdx.x;
-  const int rb = blockIdx.x;
-  const int64_t row0 = (int64_t)rb * rb_rows;
-  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
-  const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
-  RowStream<T, U, D> st;
-  st.P = P;
-  st.row = row;
-  st.g1 = g1;
-  st.glast = g1 > g0 ? g1 - 1 : g0;
-  st.prologue(g0);
-  for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
-  for (int i = tid; i < (rb_rows + 31) / 32; i += kPbThreads) bad[i] = 0u;
-  __syncthreads();
-  st.run(g0, [&](const quad<T>(&p)[U], const ushort4(&r)[U], long long cur) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (cur + tid + (long long)u * kPbThreads < g1) {
-        const unsigned short rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
-        long long w[4 * R];
-        __builtin_memcpy(w, &p[u], sizeof(w));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int q = 0; q < R; ++q) {
-            const long long v = w[R * e + q];
-            if (v == kPbBadProduct) atomicOr(&bad[rr[e] >> 5], 1u << (rr[e] & 31));
-            else atomicAdd(reinterpret_cast<unsigned long long*>(&acc[R * rr[e] + q]), (unsigned long long)v);
-          }
-        }
-      }
-    }
-  });
-  __syncthreads();
-  const int e_x = *ex_in;
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, [&](int i) {
-    const int er = rexp[row0 + i];
-    const bool unusable = e_x == kPbXInf || er == 32767 || ((bad[i >> 5] >> (i & 31)) & 1u);
-    const int k = er + e_x - 61;
-    acc_t<T> a;
-    if constexpr (scalar_traits<T>::is_complex) a = zc{ldexp((double)acc[2 * i], k), ldexp((double)acc[2 * i + 1], k)};
-    else a = ldexp((double)acc[i], k);
-    if (unusable) {
-      const double nan = __longlong_as_double(0x7ff8000000000000ll);
-      if constexpr (scalar_traits<T>::is_complex) a = zc{nan, nan};
-      else a = nan;
-    }
     return a;
   });
 }
@@ -600,26 +547,20 @@ template <typename T> void pb_opt_in_lds() {
   const unsigned long long bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
   constexpr int D2 = pb_depth2<T>();
-  pb_opt_in(&pb_phase1<T, false, kPbDepth1>);
+  pb_opt_in(&pb_phase1<T, kPbDepth1>);
   pb_opt_in(&pb_phase2<T, false, D2>);
   pb_opt_in(&pb_phase2<T, true, D2>);
   pb_opt_in(&pb_phase2_fixed<T, D2>);
-  if constexpr (sizeof(typename scalar_traits<T>::real) == 8) {
-    pb_opt_in(&pb_phase1<T, true, kPbDepth1>);
-    pb_opt_in(&pb_phase2_pre<T, D2>);
-  }
   mask.fetch_or(bit, std::memory_order_release);
 }
 
-template <typename T, bool PRE>
-void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, const double* xmax, int xmax_n,
-                   hipStream_t s) {
+template <typename T>
+void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s) {
   const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
-  double* bm = (!PRE && op.pb_phase2 == LL_PB_FIXED) ? op.d_pb_blockmax : nullptr;
-  hipLaunchKernelGGL((pb_phase1<T, PRE, kPbDepth1>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first,
-                     op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,
-                     (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols, bm, xmax, xmax_n, op.d_pb_ex,
-                     (long long)op.pb_entries);
+  double* bm = op.pb_phase2 == LL_PB_FIXED ? op.d_pb_blockmax : nullptr;
+  hipLaunchKernelGGL((pb_phase1<T, kPbDepth1>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
+                     op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, xsrc,
+                     (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries);
   LL_HIP(hipGetLastError());
 }
 }  // namespace
@@ -627,16 +568,14 @@ void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T*
 template <typename T>
 void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s) {
   if (blk_count <= 0 || op.pb_nrb <= 0) return;
-  LL_REQUIRE(!op.pb_prescaled, "internal: the pre-scaled PB image is driven by launch_spmv_pb only");
   pb_opt_in_lds<T>();
-  phase1_launch<T, false>(op, blk_first, blk_count, xsrc, nullptr, 0, s);
+  phase1_launch<T>(op, blk_first, blk_count, xsrc, s);
 }
 
 template <typename T>
 int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials,
                      hipStream_t s) {
   if (op.pb_nrb <= 0) return 0;
-  LL_REQUIRE(!op.pb_prescaled, "internal: the pre-scaled PB image is driven by launch_spmv_pb only");
   pb_opt_in_lds<T>();
   const dim3 grid(op.pb_nrb), block(kPbThreads);
   constexpr int D2 = pb_depth2<T>();
@@ -658,34 +597,9 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
   return op.pb_nrb;
 }
 
-template <typename T> int launch_pb_absmax(const ll_operator& op, const T* x, hipStream_t s) {
-  const long long n = op.n;
-  const int grid = (int)std::max<long long>(1, std::min<long long>(kCUs * 4, (n * (long long)sizeof(T) / 16 + 255) / 256));
-  hipLaunchKernelGGL((pb_absmax_kernel<T>), dim3(grid), dim3(256), 0, s, n, x, op.d_pb_xmax);
-  LL_HIP(hipGetLastError());
-  return grid;
-}
-
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s, const double* xmax, int xmax_n) {
-  if constexpr (sizeof(typename scalar_traits<T>::real) == 8) {
-    if (op.pb_prescaled) {  // single GPU, fixed-point sums with the products put on their grid by phase 1
-      if (op.pb_nrb <= 0 || op.pb_ncb <= 0) return 0;
-      pb_opt_in_lds<T>();
-      if (xmax == nullptr) {  // nobody left the maxima of |x| behind: one extra sweep over x
-        xmax_n = launch_pb_absmax<T>(op, x_own, s);
-        xmax = op.d_pb_xmax;
-      }
-      phase1_launch<T, true>(op, 0, op.pb_ncb, x_own, xmax, xmax_n, s);
-      const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>) + (size_t)((op.pb_rb_rows + 31) / 32) * sizeof(unsigned);
-      hipLaunchKernelGGL((pb_phase2_pre<T, pb_depth2<T>()>), dim3(op.pb_nrb), dim3(kPbThreads), lds2, s, op.pb_rb_rows,
-                         op.n_local, op.d_pb_rptr, (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp,
-                         op.d_pb_ex, x_local, y, offset, dot_partials);
-      LL_HIP(hipGetLastError());
-      return op.pb_nrb;
-    }
-  }
+                   double* dot_partials, hipStream_t s) {
   launch_pb_phase1<T>(op, 0, op.pb_own_count, x_own, s);
   for (int c = 0; c < op.gather.nchunks; ++c)
     launch_pb_phase1<T>(op, op.pb_chunk_first[c], op.pb_chunk_count[c], x_gathered, s);
@@ -737,11 +651,6 @@ __global__ __launch_bounds__(256) void pb_count_kernel(PbColMap m, int ncb, int 
   for (int i = threadIdx.x; i < ncb; i += 256) cnt[(size_t)i * nrb + r] = hist[i];
 }
 
-__device__ __forceinline__ double pb_scale_value(double v, int k) { return ldexp(v, k); }
-__device__ __forceinline__ float pb_scale_value(float v, int k) { return ldexpf(v, k); }
-__device__ __forceinline__ zc pb_scale_value(zc v, int k) { return zc{ldexp(v.re, k), ldexp(v.im, k)}; }
-__device__ __forceinline__ cf pb_scale_value(cf v, int k) { return cf{ldexpf(v.re, k), ldexpf(v.im, k)}; }
-
 // Pass 2: scatter.  ONE wavefront per row block walks the block's entries in CSR order, 64 at a time; entries of the
 // chunk that fall into the same segment get consecutive slots in lane order (ballot ranking), so the position of
 // every entry is a pure function of the matrix: the image — hence the summation order of phase 2 — is identical
@@ -751,8 +660,7 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
                                                         const RP* __restrict__ rp, const int32_t* __restrict__ ci,
                                                         const T* __restrict__ va, const int64_t* __restrict__ segq,
                                                         const int64_t* __restrict__ segdest, T* __restrict__ pval,
-                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow,
-                                                        const int16_t* __restrict__ rexp /* nullable: pre-scaled image */) {
+                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow) {
   extern __shared__ int fill[];  // [ncb]
   const int r = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < ncb; i += 64) fill[i] = 0;
@@ -790,12 +698,7 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
     if (valid) {
       const long long q = segq[(size_t)key * (nrb + 1) + r] + off;
       const long long qd = segdest[(size_t)key * nrb + r] + off;
-      T v = va[p];
-      if (rexp != nullptr) {  // pre-scaled fixed-point image: a~_ij = a_ij * 2^-er_i (exact)
-        const int er = rexp[rowi];
-        if (er != 32767) v = pb_scale_value(v, -er);
-      }
-      pval[q] = v;
+      pval[q] = va[p];
       pcol[q] = (uint16_t)local;
       prow[qd] = (uint16_t)(rowi - i0);
     }
@@ -875,11 +778,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 
   // ---- row blocks (y slice in LDS, 152 KiB at most)
   // (the fixed-point form of phase 2 keeps a 16-bit exponent per row next to the accumulator)
-  // Pre-scaled fixed-point image (spmv_pb.hip, pb_phase1_pre / pb_phase2_pre): double-precision storage types on a
-  // single GPU (a sharded run would need max|x| over all ranks before its own-column work may start).
-  const bool prescaled = ctx->comm == nullptr && ctx->tune.pb_prescale && ctx->tune.pb_phase2 == LL_PB_FIXED && sizeof(typename scalar_traits<T>::real) == 8;
-  const int64_t row_max = prescaled ? std::min<int64_t>(65536, (kPbLdsCap - 4096) / (int64_t)sizeof(acc_t<T>))
-                                    : std::min<int64_t>(65536, (152 * 1024) / (int64_t)(sizeof(acc_t<T>) + sizeof(int16_t)));
+  // (the fixed-point form of phase 2 keeps a 16-bit exponent per row next to the accumulator)
+  const int64_t row_max = std::min<int64_t>(65536, (152 * 1024) / (int64_t)(sizeof(acc_t<T>) + sizeof(int16_t)));
   const Tuning& tune = ctx->tune;
   auto block_len = [&](int64_t len, int64_t slice_max, int forced) {
     int64_t m = std::max<int64_t>(1, (len + 256 * slice_max - 1) / (256 * slice_max));
@@ -1061,6 +961,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
     const size_t o_prod = up2m(o_row + cap * sizeof(uint16_t)) + 3 * stagger;
     const size_t total = o_prod + cap * sizeof(T);
     ctx->dev_malloc(&op->d_pb_arena, total, "propagation-blocked image (values, indices, product buffer)");
+    op->pb_arena_bytes = total;
+    op->pb_arena_static_bytes = o_prod;  // everything in front of the product buffer is the matrix (copied on re-placement)
     char* base = (char*)op->d_pb_arena;
     op->d_pb_val = base + o_val;
     op->d_pb_col = (uint16_t*)(base + o_col);
@@ -1070,21 +972,23 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   LL_HIP(hipMemsetAsync(op->d_pb_val, 0, cap * sizeof(T), s));  // padding entries: value 0, local indices 0
   LL_HIP(hipMemsetAsync(op->d_pb_col, 0, cap * sizeof(uint16_t), s));
   LL_HIP(hipMemsetAsync(op->d_pb_row, 0, cap * sizeof(uint16_t), s));
-  op->pb_prescaled = prescaled;
-  if (op->pb_phase2 == LL_PB_FIXED) {  // fixed-point sums: per-row exponents of the absolute row sums (before the scatter:
-    // the pre-scaled image stores a_ij * 2^-er_i), per-block maxima of |x| or the maxima the producer of x leaves
-    const size_t per_row = sizeof(acc_t<T>) + (prescaled ? 0 : sizeof(int16_t));
-    LL_REQUIRE((size_t)rb_rows * per_row + (prescaled ? (size_t)(rb_rows + 31) / 32 * 4 : 16) <= (size_t)kPbLdsCap,
+  // ---- pass 2 on the device: place the entries
+  if (op->rp64)
+    hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+  else
+    hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+  LL_HIP(hipGetLastError());
+  if (op->pb_phase2 == LL_PB_FIXED) {  // fixed-point sums: per-row exponents of the absolute row sums, per-block maxima of |x|
+    // the y slice holds 64-bit integers + one 16-bit exponent per row: it must still fit the LDS
+    LL_REQUIRE((size_t)rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16 <= (size_t)kPbLdsCap,
                "LL_PB_PHASE2=fixed: row block too large for the LDS (lower LL_PB_ROW_BLOCK)");
     ctx->dev_malloc((void**)&op->d_pb_rexp, std::max<size_t>((size_t)nr, 8) * sizeof(int16_t), "row exponents");
-    if (prescaled) {
-      ctx->dev_malloc((void**)&op->d_pb_xmax, (size_t)kMaxGrid * sizeof(double), "maxima of |x|");
-      ctx->dev_malloc((void**)&op->d_pb_ex, 16, "exponent of max |x|");
-      LL_HIP(hipMemsetAsync(op->d_pb_ex, 0, 16, s));
-    } else {
-      ctx->dev_malloc((void**)&op->d_pb_blockmax, (size_t)ncb * sizeof(double), "x slice maxima");
-      LL_HIP(hipMemsetAsync(op->d_pb_blockmax, 0, (size_t)ncb * sizeof(double), s));
-    }
+    ctx->dev_malloc((void**)&op->d_pb_blockmax, (size_t)ncb * sizeof(double), "x slice maxima");
+    LL_HIP(hipMemsetAsync(op->d_pb_blockmax, 0, (size_t)ncb * sizeof(double), s));
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (nr + 255) / 256));
     if (op->rp64)
       hipLaunchKernelGGL((pb_rowexp_kernel<T, int64_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int64_t*)op->d_row_ptr,
@@ -1094,17 +998,6 @@ template <typename T> bool pb_build_device(ll_operator* op) {
                          (const T*)op->d_val, op->d_pb_rexp);
     LL_HIP(hipGetLastError());
   }
-  // ---- pass 2 on the device: place the entries
-  const int16_t* scale_by = prescaled ? op->d_pb_rexp : nullptr;
-  if (op->rp64)
-    hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
-                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, scale_by);
-  else
-    hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
-                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, scale_by);
-  LL_HIP(hipGetLastError());
   LL_HIP(hipStreamSynchronize(s));  // the host tables above go out of scope
   return true;
 }
@@ -1112,8 +1005,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 #define LL_INST_PB(T)                                                                                              \
   template void launch_pb_phase1<T>(const ll_operator&, int, int, const T*, hipStream_t);                           \
   template int launch_pb_phase2<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t);                 \
-  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t, \
-                                 const double*, int);                                                               \
+  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t); \
   template bool pb_build_device<T>(ll_operator*);                                                                   \
   template void csr_check_device<T>(ll_operator*);
 LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)

