@@ -72,3 +72,17 @@ if has kgaps; then
     done
   done
 fi
+if has final; then
+  for cfg in "default:" "c3:--workload c3 --cpu-window 0" "c2:--workload c2" "c2lattice:--workload c2 --operator lattice --cpu-window 0" "c5:--workload c5" "c5lattice:--workload c5 --operator lattice --cpu-window 0" "c3band:--workload c3band --cpu-window 0" "c3_window500:--workload c3 --window 500 --steps 2 --cpu-window 0 --no-spmv-variants" "n1e4:--workload c2 --size 100 --cpu-window 0" "n1e5:--workload c2 --size 316 --cpu-window 0" "c3_steps20:--workload c3 --steps 20 --warmup 2 --cpu-window 0 --no-spmv-variants"; do
+    name=${cfg%%:*}; opts=${cfg#*:}
+    timeout 900 python bench.py $opts > gpurun_out/r03_final_bench_$name.json 2> gpurun_out/r03_final_bench_$name.err; echo "final bench $name rc=$?"
+    python - gpurun_out/r03_final_bench_$name.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("   value %.1f it/s  host_io %.1f  ms/step %.3f  spmv %.4f ms (frac %.3f)  orth frac %s  cpu %s" % (d["value"], d["value_host_io"], d["ms_per_step"], d["spmv"]["ms"], d["roofline"]["frac"], d["roofline_orth"]["frac"], (d.get("cpu_baseline") or {}).get("value")))
+PY
+  done
+  for wl in c3 c2; do
+    timeout 900 python tests/convergence_run.py $wl > gpurun_out/r03_convergence_${wl}_defaults.json 2> gpurun_out/r03_convergence_${wl}.err; echo "convergence $wl rc=$?"; cat gpurun_out/r03_convergence_${wl}_defaults.json | cut -c1-600
+  done
+fi
