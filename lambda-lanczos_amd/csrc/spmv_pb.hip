@@ -276,22 +276,50 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
   st.chunks.g0 = g0;
   st.prologue();
   if (tid == 0) chunk_ctr = (D - 1) * kPbWaves;  // (published by the barriers below)
-  {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables
+  {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables.  All loads of a batch are
+    // requested before the first LDS store (clamped addresses, no load under a divergent branch): a load -> store loop
+    // per piece is a chain of memory latencies — 9-17 us per workgroup with nothing else running on the CU.
     const int ncols = ncols_tab[c];
     const T* src = xsrc + xoff[c];
-    constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
-    if (V > 1 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    constexpr int V = (int)(16 / sizeof(T));
+    if (V >= 1 && ncols >= V && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
       const int nv = ncols / V;
       const uint4* s4 = reinterpret_cast<const uint4*>(src);
       uint4* d4 = reinterpret_cast<uint4*>(xs);
-      for (int i = tid; i < nv; i += kPbThreads) d4[i] = s4[i];
+      constexpr int SB = 7;  // 7 x 1024 x 16 B = 112 KiB: every slice in one batch
+      for (int i0 = 0; i0 < nv; i0 += SB * kPbThreads) {
+        uint4 piece[SB];
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+          const int i = i0 + b * kPbThreads + tid;
+          piece[b] = s4[i < nv ? i : nv - 1];
+        }
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+          const int i = i0 + b * kPbThreads + tid;
+          if (i < nv) d4[i] = piece[b];
+        }
+      }
       for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = src[i];
     } else {
       for (int i = tid; i < ncols; i += kPbThreads) xs[i] = src[i];
     }
-    for (int i = tid; i <= nrb; i += kPbThreads) qs[i] = sq[i];
     const int64_t* sd = seg_dest + (size_t)c * nrb;
-    for (int i = tid; i < nrb; i += kPbThreads) db[i] = sd[i];
+    for (int i0 = 0; i0 <= nrb; i0 += 2 * kPbThreads) {
+      long long tq[2], td[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int i = i0 + b * kPbThreads + tid;
+        tq[b] = sq[i <= nrb ? i : nrb];
+        td[b] = sd[i < nrb ? i : (nrb > 0 ? nrb - 1 : 0)];
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int i = i0 + b * kPbThreads + tid;
+        if (i <= nrb) qs[i] = tq[b];
+        if (i < nrb) db[i] = td[b];
+      }
+    }
   }
   __syncthreads();
   if (blockmax != nullptr) {  // the largest |x| of the slice (phase 2 needs max |x| over all columns)
