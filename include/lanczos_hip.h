@@ -363,6 +363,7 @@ typedef struct ll_run_stats {
   int64_t second_passes;       /* iterations whose Gram-Schmidt was repeated (DGKS test decided on the host) */
   double seconds_comm_gather;    /* device time of the all-gathers / halo exchanges (their own stream; 0 unless profiling) */
   double seconds_comm_allreduce; /* device time of the all-reduces (0 unless profiling) */
+  int64_t lagged_iterations;     /* iterations that ran in the one-sweep (lagged) Gram-Schmidt form */
 } ll_run_stats;
 int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 

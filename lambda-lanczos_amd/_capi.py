@@ -90,6 +90,7 @@ class RunStats(C.Structure):
         ("second_passes", i64),
         ("seconds_comm_gather", f64),
         ("seconds_comm_allreduce", f64),
+        ("lagged_iterations", i64),
     ]
 
     def as_dict(self):

@@ -168,9 +168,16 @@ template <typename T> void Engine<T>::fetch(const double* d, double* host, size_
 
 template <typename T>
 void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded, DeferredAlpha* defer,
-                      const ScaleIn<T>* sc) {
+                      const ScaleIn<T>* sc, const double* xnorm2) {
   TraceRange trace("ll::apply (mv_mul + offset + alpha)");
   LL_REQUIRE(sc == nullptr || can_defer_scale(), "internal: this operator cannot normalise its input on the fly");
+  LL_REQUIRE(xnorm2 == nullptr || (can_scale_input() && sc == nullptr), "internal: this operator cannot scale its input");
+  ScaleIn<T> from_norm;  // the non-PB kernels take the norm as a one-element list of "partials" (nothing published)
+  if (xnorm2 && !(op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB)) {
+    from_norm.partials = xnorm2;
+    from_norm.nparts = 1;
+    sc = &from_norm;
+  }
   hipStream_t s = ctx->stream;
   ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)op->pb_nrb));
   double* const dotp = d_alpha ? ctx->d_alpha_partials : nullptr;
@@ -256,7 +263,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     } else if (op->kind == ll_operator::DENSE)
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
     else if (pb)
-      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s);
+      nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, xnorm2);
     else
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
   } else {
@@ -583,14 +590,143 @@ template <typename T> struct LoopState {
   int64_t pend_k = 0;
   NormRefs refs_prev{nullptr, nullptr, nullptr, 0};
   double t_enqueue = 0.0;
+  // Lagged block Gram-Schmidt (kernels.hip, lagged_kernel): ONE sweep over the basis per iteration.  The iteration ends
+  // with the raw w_k in work[k & 1], its coefficients g_k = U^H w_k in hbuf[k & 1] and ||w_k||^2 - |g_k|^2 in *lag_c1; the
+  // next iteration's operator kernel takes w_k / beta_k as its input and the next sweep writes the corrected u_k.
+  bool lagged = false;
+  bool lag_pending = false;
+  int64_t lag_k = 0;
+  const double* lag_c1 = nullptr;
+  int64_t n_lagged = 0;     // iterations enqueued in the lagged form (statistics)
+  bool lag_ok = false;      // this pass: every iteration so far went through enqueue_lagged (the device copy of T is complete)
+  double* hbuf[2] = {nullptr, nullptr};
+  double *hist_alpha = nullptr, *hist_beta = nullptr;
+  size_t t_off = 0;
+  int64_t n_locked = 0;       // locked eigenvectors at the front of every run list (restart passes)
+  const T* locked = nullptr;
+  int64_t ld = 0;
+  int64_t small_bytes = 0;
 
   LoopState(Engine<T>& e, Basis<T>& u, EventRing& r, PhaseTimer& t, int64_t n_local, hipStream_t st)
       : E(e), U(u), ring(r), timer(t), nl(n_local), s(st) {}
-  void enable_defer(int64_t ld) {
+  void enable_defer(int64_t ld_) {
     defer = true;
-    for (auto& w : work) w.alloc(E.ctx, (size_t)ld);
+    ld = ld_;
+    for (auto& w : work)
+      if (!w.p) w.alloc(E.ctx, (size_t)ld_);
+  }
+  void enable_lagged(int64_t ld_) {
+    lagged = true;
+    ld = ld_;
+    small_bytes = E.ctx->tune.blas_small_bytes;
+    for (auto& w : work)
+      if (!w.p) w.alloc(E.ctx, (size_t)ld_);
+    // everything up front: growing ctx->d_h in the middle of a run would free the pending coefficients.  Per parity
+    // of k: g (coefficients) and, t_off further, t (lagged_fold_kernel); then the device copy of alpha / beta.
+    constexpr size_t R = (size_t)Engine<T>::R;
+    t_off = (size_t)kLaggedMaxCols + 8;
+    const size_t half = 2 * t_off + 2 * R + 8;
+    E.ctx->ensure_h(2 * half + 2 * t_off);
+    hbuf[0] = E.ctx->d_h;
+    hbuf[1] = E.ctx->d_h + half;
+    hist_alpha = E.ctx->d_h + 2 * half;
+    hist_beta = hist_alpha + t_off;
+  }
+  // a new Lanczos pass: k restarts at 1.  The compensation of the lagged form needs the recurrence of every basis
+  // vector, so passes that orthogonalise against locked eigenvectors keep the two-sweep form.
+  void begin_pass(const T* locked_vecs, int64_t n_lock) {
+    locked = locked_vecs;
+    n_locked = n_lock;
+    lag_pending = false;
+    lag_ok = lagged && n_lock == 0;
+  }
+  // beta_j changed on the host (second Gram-Schmidt pass on u_{j+1})
+  void set_beta(int64_t j, double value) {
+    if (lag_ok) launch_set_scalar(hist_beta + j, value, s);
+  }
+  RunList<T> basis_runs(int64_t count) {  // locked vectors, then u_0 .. u_{count-1}
+    RunList<T> runs;
+    runs.ld = ld;
+    runs.add(locked, n_locked);
+    runs.add_basis(U, count);
+    return runs;
+  }
+  // u_{lag_k} = (w - U g) / beta with the two-sweep kernels: the pending late update, applied now (the vector is needed
+  // complete: a second Gram-Schmidt pass on it, or the loop leaves the lagged form)
+  void flush_lag() {
+    if (!lag_pending) return;
+    T* dst = U.vec(lag_k);
+    LL_HIP(hipMemcpyAsync(dst, work[lag_k & 1].p, (size_t)nl * sizeof(T), hipMemcpyDeviceToDevice, s));
+    const RunList<T> runs = basis_runs(lag_k);
+    int off = 0;
+    for (auto& g : runs.groups(max_vecs_per_launch<T>())) {
+      launch_maxpy<T>(nl, dst, g, hbuf[lag_k & 1] + Engine<T>::R * off, nullptr, E.ctx->d_partials, small_bytes, s);
+      for (int i = 0; i < g.nseg; ++i) off += g.count[i];
+    }
+    const NormRefs nr{lag_c1, lag_c1, lag_c1, 0};
+    launch_scale<T>(nl, dst, 0.0, &nr, s);
+    lag_pending = false;
+  }
+  // u_j must be complete in its basis slot (second Gram-Schmidt pass on it)
+  void make_final(int64_t j) {
+    if (lag_pending && lag_k == j) flush_lag();
+  }
+  bool enqueue_lagged(int64_t k, double offset, int64_t nb_total) {
+    constexpr int R = Engine<T>::R;
+    if (!lag_ok) return false;
+    const RunList<T> in_memory = basis_runs(lag_pending ? k - 1 : k);  // u_{k-1} is not in memory while its update is pending
+    const std::vector<BasisSegs<T>> groups = in_memory.groups(max_vecs_per_launch<T>());
+    if (nb_total != k || R * nb_total > kLaggedMaxCols || groups.size() > 1 ||
+        (int64_t)nl * (int64_t)sizeof(T) < small_bytes) {  // (the small-vector kernels keep the two-sweep form)
+      lag_ok = false;  // for the rest of the pass: the two-sweep iterations do not record T on the device
+      return false;
+    }
+    const double te0 = now_s();
+    const int slot = (int)(k % 4);
+    T* y = work[k & 1].p;
+    const T* x = lag_pending ? work[(k - 1) & 1].p : U.vec(k - 1);
+    timer.mark();
+    typename Engine<T>::DeferredAlpha da;
+    E.apply(x, y, offset, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr, nullptr, lag_pending ? lag_c1 : nullptr);
+    timer.mark();
+    ThreeTerm<T> tt{k > 1 ? U.vec(k - 2) : nullptr, U.vec(k - 1), E.S(kScalAlpha + slot), refs_prev};
+    if (da.nparts > 0) {
+      tt.alpha_partials = da.partials;
+      tt.alpha_nparts = da.nparts;
+      tt.alpha_out = E.S(kScalAlpha + slot);
+    }
+    const int ncols = R * (int)nb_total + 1;
+    E.ctx->ensure_partials((size_t)kMaxGrid * (size_t)ncols);
+    BasisSegs<T> none;
+    none.nseg = 0;
+    none.ld = ld;
+    int grid;
+    if (lag_pending) {
+      const Lagged<T> lg{work[(k - 1) & 1].p, U.vec(k - 1), hbuf[(k - 1) & 1], hbuf[(k - 1) & 1] + t_off, lag_c1};
+      grid = launch_lagged<T>(nl, y, groups.empty() ? none : groups[0], lg, tt, E.ctx->d_partials, s);
+      ++n_lagged;
+    } else {
+      grid = launch_mdot<T>(nl, y, groups.empty() ? none : groups[0], tt, nullptr, E.ctx->d_partials, small_bytes, s);
+    }
+    double* c = E.S(kScalNorms + 3 * slot);
+    double* hb = hbuf[k & 1];
+    launch_reduce_cols(E.ctx->d_partials, grid, ncols, hb, c, s);  // coefficients -> hb, ||w||^2 -> c[0]
+    const double* pg = lag_pending ? hbuf[(k - 1) & 1] : nullptr;
+    launch_lagged_fold(hb, (int)k, R, hb + t_off, c, c + 1, E.S(kScalAlpha + slot), pg, pg ? pg + t_off : nullptr, lag_c1,
+                       hist_alpha, hist_beta, E.ctx->h_pinned + 4 * slot, s);
+    LL_HIP(hipEventRecord(ring.ev[slot], s));
+    timer.mark();
+    lag_pending = true;
+    lag_k = k;
+    lag_c1 = c + 1;
+    refs_prev = NormRefs{c, c + 1, c + 1, 0};
+    t_enqueue += now_s() - te0;
+    return true;
   }
   void enqueue(int64_t k, double offset, const RunList<T>& runs, int mode) {
+    if (mode == LL_ORTH_CGS_DGKS && !pending && enqueue_lagged(k, offset, runs.total())) return;
+    flush_lag();  // (leaving the lagged form: u_{k-1} must be complete)
+    lag_ok = false;
     const double te0 = now_s();
     const int slot = (int)(k % 4);
     const T* x = U.vec(k - 1);
@@ -765,6 +901,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
   if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
+  if (E.can_scale_input() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
   // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
@@ -823,6 +960,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     bool stopped = false;
     LS.refs_prev = refs0;
     LS.pending = false;
+    LS.begin_pass(d_locked.p, L);
     RunList<T> locked_runs;
     locked_runs.ld = ld;
     locked_runs.add(d_locked.p, L);  // P5
@@ -880,12 +1018,15 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
           again.ld = ld;
           again.add(d_locked.p, L);
           again.add_basis(U, j);
+          LS.make_final(j);
           beta2_j = c1_j * E.second_pass(U.vec(j), again);
           ++second_passes;
           double* cj = E.S(kScalNorms + 3 * slot);
           launch_set_scalar(cj + 1, beta2_j, s);  // what the next three-term update reads as beta_j^2
           LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
           LS.pending = false;  // the speculative iteration j+1 was computed from the old u_j: it is enqueued again
+          LS.lag_pending = false;
+          LS.set_beta(j - 1, std::sqrt(beta2_j));
           verdict = kRedone;
         } else {
           beta2_j = 0.0;  // w vanished exactly: breakdown (H3)
@@ -1080,6 +1221,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     stats->seconds_setup = t_setup;
     stats->seconds_finish = t_finish;
     stats->second_passes = second_passes;
+    stats->lagged_iterations = LS.n_lagged;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     ctx->drain_comm_events(&stats->seconds_comm_gather, &stats->seconds_comm_allreduce);
     stats->seconds_total = now_s() - t_start;
@@ -1160,6 +1302,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   LS.fuse_launches = fuse_launches;
   LS.refs_prev = refs_prev;
   if (E.can_defer_scale() && fuse_launches && (!P.full_orthogonalize || P.orth_mode == LL_ORTH_CGS_DGKS)) LS.enable_defer(ld);
+  if (E.can_scale_input() && fuse_launches && P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
+  LS.begin_pass(nullptr, 0);
   auto enqueue = [&](int64_t k) {  // EX:107-118 (+ EX:120-122 with full_orthogonalize), EX:145, EX:160
     RunList<T> runs;
     runs.ld = ld;
@@ -1198,12 +1342,15 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
         RunList<T> again;
         again.ld = ld;
         again.add_basis(U, j);
+        LS.make_final(j);
         beta2_j = c1_j * E.second_pass(U.vec(j), again);
         ++second_passes;
         double* cj = E.S(kScalNorms + 3 * slot);
         launch_set_scalar(cj + 1, beta2_j, s);
         LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
         LS.pending = false;  // (see lanczos_run)
+        LS.lag_pending = false;
+        LS.set_beta(j - 1, std::sqrt(beta2_j));
         verdict = kRedone;
       } else {
         beta2_j = 0.0;
@@ -1265,6 +1412,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     stats->seconds_host_tridiag = t_tridiag;
     stats->last_alpha_len = (int64_t)alpha.size();
     stats->second_passes = second_passes;
+    stats->lagged_iterations = LS.n_lagged;
     stats->seconds_host_enqueue = LS.t_enqueue;
     stats->seconds_host_wait = t_wait;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);

@@ -37,7 +37,7 @@ template <typename T> __device__ __forceinline__ double scale_in_factor(const Sc
   if (sc.partials == nullptr) return 1.0;
   const double tot = fold_partials_all(sc.partials, sc.nparts, scratch);  // the order of scale_publish_kernel
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *sc.c1_out = tot;
+    if (sc.c1_out) *sc.c1_out = tot;
     if (sc.host) {
       sc.host[0] = sc.alpha ? *sc.alpha : 0.0;
       sc.host[1] = tot;
@@ -360,6 +360,264 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
   double* out = partials + (size_t)blockIdx.x * ncols;
   for (int i = tid; i < ncols; i += kBlock)
     out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
+}
+
+// ================================================================= lagged block Gram-Schmidt: ONE sweep over the basis per iteration
+// Block classical Gram-Schmidt needs the coefficients h = U^H w (a global reduction) before it can update w, hence two
+// sweeps over the basis per iteration (mdot, maxpy above).  The whole-loop drivers on one GPU apply the update ONE
+// ITERATION LATE instead, in the same sweep that computes the next iteration's coefficients.  Notation for iteration k
+// (u_0 .. u_{k-2} complete in the basis, nb = k-1 of them):
+//   r     raw w_{k-1}: neither corrected nor normalised,   g = U^H r,   beta^2 = ||r||^2 - |g|^2   (previous fold),
+//   x~    = r / beta = u_{k-1} + e,  e = U c,  c = g / beta: what the operator kernel was applied to (it scales on the fly),
+//   y     = A x~.
+// One pass per strip forms   wr = y - alpha x~ - beta u_{k-2}             (three-term update on the perturbed input)
+//                            u_{k-1} = (r - sum_j g_j u_j) / beta         (the late update, written to its basis slot)
+//                            m_j = <u_j, wr>  for j < k-1
+//                            w  = wr - sum_{j<k-1} d_j u_j - d_{k-1} u_{k-1}   (compensation, see below; replaces y)
+//                            m_{k-1} = <u_{k-1}, w>,  ||w||^2.
+// The basis streams through ONCE (k+2 vector reads, 2 writes instead of 2k+3 reads, 2 writes).
+//
+// Compensation.  Left alone, the perturbation e feeds itself: (A - alpha) e lies in span(U) with coefficients
+// (T - alpha) c, which become the next iteration's g, so |c| grows by ||T - alpha|| / beta ~ 2 per iteration (1e-16 -> 1
+// in about fifty iterations; measured).  But c is KNOWN, and so is the image of e: the stored
+// vectors satisfy A u_j = beta_{j-1} u_{j-1} + alpha_j u_j + beta_j u_{j+1} to rounding, hence
+//   (A - alpha) e = sum_i d_i u_i,   d = Tbar c - alpha [c; 0]    (Tbar: the (k x k-1) tridiagonal of recorded alpha, beta)
+// is subtracted from w in the same sweep (the u_i stream through anyway), and the measured coefficients are corrected
+// by linearity, <u_j, w> = m_j - d_j.  alpha itself carries the first-order term 2 Re <e, A u_{k-1}> = 2 Re g_{k-2}
+// (only u_{k-2} couples to u_{k-1}); it is removed before use.  What is left in w along span(U) is fresh rounding, as in
+// the two-sweep form: |c| stays at a few eps for hundreds of iterations (tests/test_gpu_round3.py), the recorded
+// alpha / beta agree with the two-sweep form to ~1e-14 relative.  t = Tbar c comes from the fold kernel below
+// (lagged_fold_kernel); d_j = t_j - alpha c_j is formed here because alpha is only known now.
+// The DGKS case (|g|^2 > ||r||^2 / 2: cancellation, the derived norm is inaccurate) is detected by the host from the
+// published norms like before and repaired with the two-sweep kernels on the then complete u_{k-1} (engine.cpp,
+// LoopState).
+// alpha of a lagged iteration without its first-order perturbation term (2 g is exact: same bits wherever formed)
+__device__ __forceinline__ double lagged_alpha(double alpha, double g_last_re) { return fma(-2.0, g_last_re, alpha); }
+
+template <typename T, int NV>
+__device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
+                                            const T (&wr)[strip<T>::EPT], T (&wp)[strip<T>::EPT], T (&uc)[strip<T>::EPT],
+                                            const double* gcol, const double* dcol, double* mine_col, int lane) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int R = scalar_traits<T>::reals;
+  T ur[NV][EPT];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) load_strip<T>(u0 + (int64_t)b * ld, base, n, ur[b]);
+  double a[NV * R];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) {
+    acc_t<T> gj, dj;
+    if constexpr (scalar_traits<T>::is_complex) {
+      gj = zc{gcol[2 * b], gcol[2 * b + 1]};
+      dj = zc{dcol[2 * b], dcol[2 * b + 1]};
+    } else {
+      gj = gcol[b];
+      dj = dcol[b];
+    }
+    acc_t<T> acc = zero<acc_t<T>>();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      fnma_acc(uc[e], gj, ur[b][e]);   // late update of the previous vector
+      fnma_acc(wp[e], dj, ur[b][e]);   // compensation of the new one
+      cfma_acc(acc, ur[b][e], wr[e]);  // this iteration's (raw) coefficient
+    }
+    if constexpr (scalar_traits<T>::is_complex) {
+      a[2 * b] = acc.re;
+      a[2 * b + 1] = acc.im;
+    } else {
+      a[b] = acc;
+    }
+  }
+  wave_sum_transposed<NV * R>(a, lane);
+  constexpr int LPI = 64 / (NV * R);
+  if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs, int nb,
+                                                        Lagged<T> lg, ThreeTerm<T> tt, double* __restrict__ partials) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int ELEMS = strip<T>::ELEMS;
+  constexpr int JB = kJB;
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = R * (nb + 1) + 1;
+  extern __shared__ double lds[];  // [4 waves][ncols] partial columns, [R nb] g, [R (nb + 1)] d
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* gl = lds + (size_t)4 * ncols;
+  double* dl = gl + (size_t)R * nb;
+  for (int i = tid; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
+  double alpha;
+  if (tt.alpha_partials) {  // deferred alpha: fold the operator kernel's partials here (ThreeTerm)
+    __shared__ double fold_scratch[5];
+    alpha = fold_partials_all(tt.alpha_partials, tt.alpha_nparts, fold_scratch);
+    if (blockIdx.x == 0 && tid == 0) *tt.alpha_out = alpha;  // as measured; lagged_fold_kernel corrects it in place
+  } else {
+    alpha = *tt.alpha;
+  }
+  alpha = lagged_alpha(alpha, lg.g[R * (nb - 1)]);  // lagged_fold_kernel publishes the same value
+  const double beta = sqrt(*lg.beta2), s = 1.0 / beta;
+  const double as = alpha * s;
+  for (int i = tid; i < R * nb; i += kBlock) {
+    const double gi = lg.g[i];
+    gl[i] = gi;
+    dl[i] = fma(-as, gi, lg.t[i]);
+  }
+  if (tid < R) dl[R * nb + tid] = lg.t[R * nb + tid];
+  __syncthreads();
+  double* mine = lds + (size_t)wave * ncols;
+  acc_t<T> dlast;
+  if constexpr (scalar_traits<T>::is_complex) dlast = zc{dl[R * nb], dl[R * nb + 1]};
+  else dlast = dl[R * nb];
+
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * ELEMS;
+    T wr[EPT], wp[EPT], uc[EPT];
+    load_strip<T>(w, base, n, wr);
+    load_strip<T>(lg.r, base, n, uc);
+    if (tt.u_prev) {
+      T up[EPT];
+      load_strip<T>(tt.u_prev, base, n, up);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) wr[e] = sub(sub(wr[e], rmul(beta, up[e])), rmul(alpha, rmul(s, uc[e])));
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) wr[e] = sub(wr[e], rmul(alpha, rmul(s, uc[e])));
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) wp[e] = wr[e];
+    int col = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+      int j = 0;
+      for (; j + JB <= cnt; j += JB, col += R * JB)
+        lagged_trip<T, JB>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, gl + col, dl + col, mine + col, lane);
+      if (j + 2 <= cnt) {
+        lagged_trip<T, 2>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, gl + col, dl + col, mine + col, lane);
+        j += 2;
+        col += R * 2;
+      }
+      if (j < cnt) {
+        lagged_trip<T, 1>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, gl + col, dl + col, mine + col, lane);
+        j += 1;
+        col += R;
+      }
+    }
+    // u_{k-1} is complete: normalise, store; finish w with its own component, take the last coefficient and ||w||^2
+    acc_t<T> last = zero<acc_t<T>>();
+    double nn = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      uc[e] = rmul(s, uc[e]);
+      fnma_acc(wp[e], dlast, uc[e]);
+      cfma_acc(last, uc[e], wp[e]);
+      nn += abs2(wp[e]);
+    }
+    store_strip<T>(lg.u_out, base, n, uc);
+    store_strip<T>(w, base, n, wp);
+    if constexpr (scalar_traits<T>::is_complex) {
+      const double lr = wave_sum(last.re), li = wave_sum(last.im);
+      if (lane == 0) {
+        mine[R * nb] += lr;
+        mine[R * nb + 1] += li;
+      }
+    } else {
+      const double lr = wave_sum(last);
+      if (lane == 0) mine[R * nb] += lr;
+    }
+    nn = wave_sum(nn);
+    if (lane == 0) mine[ncols - 1] += nn;
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < ncols; i += kBlock)
+    out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
+}
+template <typename T>
+int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
+                  hipStream_t s) {
+  int nb = 0;
+  for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = R * (nb + 1) + 1;
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  const size_t lds_bytes = ((size_t)4 * ncols + (size_t)R * (2 * nb + 1)) * sizeof(double);
+  hipLaunchKernelGGL((lagged_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nb, lg, tt, partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+#define LL_INST_LAGGED(T) \
+  template int launch_lagged<T>(int64_t, T*, const BasisSegs<T>&, const Lagged<T>&, const ThreeTerm<T>&, double*, hipStream_t);
+LL_INST_LAGGED(double) LL_INST_LAGGED(zc) LL_INST_LAGGED(float) LL_INST_LAGGED(cf)
+
+// The fold of a lagged iteration k (one workgroup; replaces derive_norm_kernel there).  `m` holds the reals * k column
+// sums of the sweep (raw coefficients; the last one was taken on the finished w), *c0 = ||w||^2.
+//   g_i   = m_i - d_i  for the columns the sweep took on wr (prev_g != nullptr: d from the previous fold's t, g and this
+//           iteration's alpha, exactly as the sweep formed it);  g = m after a clean iteration (operator applied to a
+//           complete u_{k-1}: mdot_kernel, nothing to compensate)
+//   c1    = ||w||^2 - |g|^2 = beta_{k-1}^2,  c = g / beta_{k-1}
+//   t     = Tbar c  (reals * (k + 1) values after g): the image of the next operator input's perturbation
+//   alpha_{k-1}, beta_{k-1} appended to the device copy of T; the four per-iteration scalars published to the host.
+__global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m, int k, int reals, double* __restrict__ t_out,
+                                                          const double* __restrict__ c0, double* __restrict__ c1,
+                                                          double* __restrict__ alpha, const double* __restrict__ prev_g,
+                                                          const double* __restrict__ prev_t, const double* __restrict__ prev_c1,
+                                                          double* __restrict__ hist_alpha, double* __restrict__ hist_beta,
+                                                          double* __restrict__ host) {
+  __shared__ double red[4];
+  __shared__ double sh[2];
+  const int tid = threadIdx.x;
+  const int cnt = reals * k;
+  double a = *alpha;
+  if (prev_g) a = lagged_alpha(a, prev_g[reals * (k - 2)]);
+  double acc = 0.0;
+  if (prev_g) {
+    const double as = a * (1.0 / sqrt(*prev_c1));
+    for (int i = tid; i < cnt; i += 256) {
+      double g = m[i];
+      if (i < cnt - reals) {
+        g -= fma(-as, prev_g[i], prev_t[i]);
+        m[i] = g;
+      }
+      acc = fma(g, g, acc);
+    }
+  } else {
+    for (int i = tid; i < cnt; i += 256) acc = fma(m[i], m[i], acc);
+  }
+  const double tot = block_sum(acc, red);
+  if (tid == 0) {
+    const double before = *c0;
+    double v = before - tot;
+    v = v > 0.0 ? v : 0.0;
+    *c1 = v;
+    *alpha = a;
+    hist_alpha[k - 1] = a;
+    hist_beta[k - 1] = sqrt(v);
+    sh[0] = a;
+    sh[1] = sqrt(v);
+    host[0] = a;
+    host[1] = v;
+    host[2] = before;
+    host[3] = v;
+  }
+  __syncthreads();  // (also orders the m[i] updates above before the reads below)
+  const double beta = sh[1], inv = beta > 0.0 ? 1.0 / beta : 0.0;
+  for (int i = tid; i < reals * (k + 1); i += 256) {
+    const int j = i / reals;  // component on u_j
+    double t = 0.0;
+    if (j < k) t = (j == k - 1 ? sh[0] : hist_alpha[j]) * m[i];
+    if (j + 1 < k) t = fma(hist_beta[j], m[i + reals], t);
+    if (j >= 1) t = fma(j - 1 == k - 1 ? beta : hist_beta[j - 1], m[i - reals], t);
+    t_out[i] = t * inv;
+  }
+}
+void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c1, double* alpha,
+                        const double* prev_g, const double* prev_t, const double* prev_c1, double* hist_alpha,
+                        double* hist_beta, double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL(lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, k, reals, t_out, c0, c1, alpha, prev_g, prev_t,
+                     prev_c1, hist_alpha, hist_beta, host_mapped);
+  LL_HIP(hipGetLastError());
 }
 
 // ================================================================= small-vector Gram-Schmidt kernels (vectors < 4 MiB)

@@ -325,13 +325,17 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
 // blocks (x slices from x_own: the local shard readable up to the shard stride), then over every gather chunk's remote blocks (x slices from x_gathered, laid out
 // per op.gather), then phase 2.  The pieces are exposed so that the sharded driver can run the own-column part under
 // the all-gather and each chunk's part as soon as that chunk has arrived.
+// xnorm2 (nullable device scalar): x is an UNNORMALISED vector w with ||w||^2 = *xnorm2; the kernels work with w / ||w||
+// (lagged Gram-Schmidt, kernels.hip).
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s);
+                   double* dot_partials, hipStream_t s, const double* xnorm2 = nullptr);
 template <typename T>
-void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s);
+void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s,
+                      const double* xnorm2 = nullptr);
 template <typename T>
-int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials, hipStream_t s);
+int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials, hipStream_t s,
+                     const double* xnorm2 = nullptr);
 // forms of PB phase 2 (Tuning::pb_phase2, ll_operator::pb_phase2)
 constexpr int LL_PB_ATOMIC = 0, LL_PB_ORDERED = 1, LL_PB_FIXED = 4;
 // Build the propagation-blocked image on the device from the operator's CSR arrays (false: shape not supported).
@@ -386,6 +390,28 @@ template <typename T> struct ThreeTerm {
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
                 double* partials, int64_t small_bytes, hipStream_t s);
+// Lagged block Gram-Schmidt (kernels.hip, lagged_kernel): one sweep that applies the previous iteration's update to
+// r -> u_out, forms w = w - alpha r/beta - beta u_prev minus the compensation of the perturbed operator input, and all
+// coefficients <u_j, .> (segments, then u_out) + ||w||^2.  Partial columns: reals * (nb + 1) + 1 per workgroup.
+// tt.u_cur is ignored.  g: reals * nb coefficients of r, t: reals * (nb + 1) values, both from launch_lagged_fold.
+// LDS: (4 ncols + reals (2 nb + 1)) doubles, so reals * nb <= kLaggedMaxCols.  Streaming geometry only.
+constexpr int kLaggedMaxCols = 1400;
+template <typename T> struct Lagged {
+  const T* r;
+  T* u_out;
+  const double* g;
+  const double* t;
+  const double* beta2;
+};
+template <typename T>
+int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
+                  hipStream_t s);
+// Fold of lagged iteration k (k basis vectors, m: reals * k folded columns, *c0 = ||w||^2): compensated coefficients in
+// place, *c1 = *c0 - |g|^2, t_out (reals * (k + 1)) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha
+// replaced by its corrected value, the iteration's four scalars published.  prev_* = nullptr after a clean iteration.
+void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c1, double* alpha,
+                        const double* prev_g, const double* prev_t, const double* prev_c1, double* hist_alpha,
+                        double* hist_beta, double* host_mapped, hipStream_t s);
 // w -= sum_j h_j u_j over the segments; partial ||w||^2 per workgroup. h: reals*nb doubles on the device.
 template <typename T>
 int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,

@@ -254,8 +254,12 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
                                                         const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
                                                         const T* __restrict__ val, const ushort4* __restrict__ col,
                                                         const T* __restrict__ xsrc, T* __restrict__ P, int cb_cols,
-                                                        double* __restrict__ blockmax, long long p_dump) {
+                                                        double* __restrict__ blockmax, long long p_dump,
+                                                        const double* __restrict__ xnorm2) {
   extern __shared__ double lds[];
+  // xnorm2 (nullable): the input is an UNNORMALISED vector w with ||w||^2 = *xnorm2 (lagged Gram-Schmidt, kernels.hip): the
+  // slice is scaled by 1 / ||w|| while it is staged
+  const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;
   __shared__ double bm_red[kPbWaves + 1];
   __shared__ unsigned chunk_ctr;
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
@@ -297,12 +301,19 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
           const int i = i0 + b * kPbThreads + tid;
+          if (xnorm2) {
+            T el[V];
+            __builtin_memcpy(el, &piece[b], sizeof(uint4));
+#pragma unroll
+            for (int q = 0; q < V; ++q) el[q] = rmul(xs_fac, el[q]);
+            __builtin_memcpy(&piece[b], el, sizeof(uint4));
+          }
           if (i < nv) d4[i] = piece[b];
         }
       }
-      for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = src[i];
+      for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = rmul(xs_fac, src[i]);
     } else {
-      for (int i = tid; i < ncols; i += kPbThreads) xs[i] = src[i];
+      for (int i = tid; i < ncols; i += kPbThreads) xs[i] = rmul(xs_fac, src[i]);
     }
     const int64_t* sd = seg_dest + (size_t)c * nrb;
     for (int i0 = 0; i0 <= nrb; i0 += 2 * kPbThreads) {
@@ -357,7 +368,9 @@ template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, 
 // the shared epilogue: value(i) gives row i's sum; y = value + offset x, partial Re<x, y> per workgroup
 template <typename T, typename F>
 __device__ __forceinline__ void pb_phase2_epilogue(int rb, int64_t row0, int rows, const T* __restrict__ xl, T* __restrict__ y,
-                                                   double offset, double* __restrict__ dot_partials, double* red, F&& value) {
+                                                   double offset, double* __restrict__ dot_partials, double* red,
+                                                   const double* __restrict__ xnorm2, F&& value) {
+  const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;  // unnormalised input (see pb_phase1)
   const int tid = threadIdx.x;
   constexpr int EU = 4;  // rows per lane per round: the loads of a round are all requested before the first is used
   double dot_acc = 0.0;
@@ -366,7 +379,7 @@ __device__ __forceinline__ void pb_phase2_epilogue(int rb, int64_t row0, int row
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int i = i0 + u * kPbThreads;
-      if (i < rows) xi[u] = xl[row0 + i];
+      if (i < rows) xi[u] = rmul(xs_fac, xl[row0 + i]);
     }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
                                                         const int64_t* __restrict__ rptr,  // [nrb + 1]
                                                         const ushort4* __restrict__ row, const T* __restrict__ P,
                                                         const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                        double* __restrict__ dot_partials) {
+                                                        double* __restrict__ dot_partials, const double* __restrict__ xnorm2) {
   constexpr int R = scalar_traits<T>::reals;
   constexpr int U = 2;
   extern __shared__ double lds[];  // [rb_rows * R]
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
     }
   });
   __syncthreads();
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, [&](int i) {
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, [&](int i) {
     acc_t<T> a;
     if constexpr (scalar_traits<T>::is_complex) a = zc{lds[2 * i], lds[2 * i + 1]};
     else a = lds[i];
@@ -459,7 +472,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
                                                               const int16_t* __restrict__ rexp,
                                                               const double* __restrict__ blockmax,
                                                               const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                              double* __restrict__ dot_partials) {
+                                                              double* __restrict__ dot_partials,
+                                                              const double* __restrict__ xnorm2) {
   constexpr int R = scalar_traits<T>::reals;
   constexpr int U = 2;
   extern __shared__ double lds_raw[];
@@ -530,7 +544,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
     }
   });
   __syncthreads();
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, [&](int i) {
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, [&](int i) {
     const int k = ex[i];
     const double back = k == kBadRow ? __longlong_as_double(0x7ff8000000000000ll) : pow2(-k);  // NaN for unusable rows
     acc_t<T> a;
@@ -583,26 +597,26 @@ template <typename T> void pb_opt_in_lds() {
 }
 
 template <typename T>
-void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s) {
+void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, const double* xnorm2, hipStream_t s) {
   const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
   double* bm = op.pb_phase2 == LL_PB_FIXED ? op.d_pb_blockmax : nullptr;
   hipLaunchKernelGGL((pb_phase1<T, kPbDepth1>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
                      op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, xsrc,
-                     (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries);
+                     (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries, xnorm2);
   LL_HIP(hipGetLastError());
 }
 }  // namespace
 
 template <typename T>
-void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s) {
+void launch_pb_phase1(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, hipStream_t s, const double* xnorm2) {
   if (blk_count <= 0 || op.pb_nrb <= 0) return;
   pb_opt_in_lds<T>();
-  phase1_launch<T>(op, blk_first, blk_count, xsrc, s);
+  phase1_launch<T>(op, blk_first, blk_count, xsrc, xnorm2, s);
 }
 
 template <typename T>
 int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offset, double* dot_partials,
-                     hipStream_t s) {
+                     hipStream_t s, const double* xnorm2) {
   if (op.pb_nrb <= 0) return 0;
   pb_opt_in_lds<T>();
   const dim3 grid(op.pb_nrb), block(kPbThreads);
@@ -611,15 +625,15 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
     const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
     hipLaunchKernelGGL((pb_phase2_fixed<T, D2>), grid, block, ldsf, s, op.pb_rb_rows, op.n_local, op.pb_ncb, op.d_pb_rptr,
                        (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp, op.d_pb_blockmax, x_local, y,
-                       offset, dot_partials);
+                       offset, dot_partials, xnorm2);
   } else {
     const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
     if (op.pb_phase2 == LL_PB_ORDERED)
       hipLaunchKernelGGL((pb_phase2<T, true, D2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
-                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
+                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, xnorm2);
     else
       hipLaunchKernelGGL((pb_phase2<T, false, D2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
-                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials);
+                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, xnorm2);
   }
   LL_HIP(hipGetLastError());
   return op.pb_nrb;
@@ -627,11 +641,11 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
 
 template <typename T>
 int launch_spmv_pb(const ll_operator& op, const T* x_gathered, const T* x_own, const T* x_local, T* y, double offset,
-                   double* dot_partials, hipStream_t s) {
-  launch_pb_phase1<T>(op, 0, op.pb_own_count, x_own, s);
+                   double* dot_partials, hipStream_t s, const double* xnorm2) {
+  launch_pb_phase1<T>(op, 0, op.pb_own_count, x_own, s, xnorm2);
   for (int c = 0; c < op.gather.nchunks; ++c)
-    launch_pb_phase1<T>(op, op.pb_chunk_first[c], op.pb_chunk_count[c], x_gathered, s);
-  return launch_pb_phase2<T>(op, x_local, y, offset, dot_partials, s);
+    launch_pb_phase1<T>(op, op.pb_chunk_first[c], op.pb_chunk_count[c], x_gathered, s, xnorm2);
+  return launch_pb_phase2<T>(op, x_local, y, offset, dot_partials, s, xnorm2);
 }
 
 // ================================================================= device-side construction of the image
@@ -1031,9 +1045,10 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 }
 
 #define LL_INST_PB(T)                                                                                              \
-  template void launch_pb_phase1<T>(const ll_operator&, int, int, const T*, hipStream_t);                           \
-  template int launch_pb_phase2<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t);                 \
-  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t); \
+  template void launch_pb_phase1<T>(const ll_operator&, int, int, const T*, hipStream_t, const double*);            \
+  template int launch_pb_phase2<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t, const double*);  \
+  template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t, \
+                                 const double*);                                                                    \
   template bool pb_build_device<T>(ll_operator*);                                                                   \
   template void csr_check_device<T>(ll_operator*);
 LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)

@@ -9,7 +9,7 @@ import pytest
 import lambda_lanczos_amd as L
 from lambda_lanczos_amd import _capi as capi
 from lambda_lanczos_amd import generators as G
-from util import overlap
+from util import inf_norm, overlap
 
 pytestmark = pytest.mark.gpu
 EPS = np.finfo(np.float64).eps
@@ -289,3 +289,53 @@ def test_failed_communicator_self_check_leaves_the_context_unsharded():
     rc = capi.lib().ll_comm_attach(c.handle, C.byref(t), 0, 2)
     assert rc == capi.LL_ERR_RCCL and b"self-check" in capi.lib().ll_last_error()
     c.close()
+
+
+# ------------------------------------------------------------------ lagged (one-sweep) block Gram-Schmidt vs the two-sweep form
+def _lagged_case(name):
+    if name == "randsym":
+        n = 30011
+        return n, G.randsym_np(n), G.start_vector(n, 1), True, 0.0
+    if name == "laplace":   # slowly converging: several hundred iterations
+        m = 173
+        return m * m, G.laplace2d_np(m), G.start_vector(m * m, 2), True, 0.0
+    N = 160                 # complex Hermitian torus, lowest eigenvalue through the reference's offset idiom
+    return N * N, G.torus_np(N), G.start_vector(N * N, 3, np.complex128), False, -10.0
+
+
+@pytest.mark.parametrize("name", ["randsym", "laplace", "torus"])
+def test_lagged_gram_schmidt_keeps_the_recurrence_of_the_two_sweep_form(ctx, llenv, name):
+    """The one-sweep (lagged, compensated) Gram-Schmidt form against the two-sweep kernels on the same operator and
+    start vector, streaming geometry forced on both: same iteration count, alpha / beta traces equal to 1e-11 ||A||
+    over the whole run (an uncompensated lag loses them after ~40 iterations), same eigenpair, residual at the level the
+    Ritz estimate promises.  LL_FUSE_LAUNCHES=0 is the two-sweep comparator."""
+    n, csr, init, find_max, offset = _lagged_case(name)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for fuse in ("0", "1"):
+        llenv.setenv("LL_FUSE_LAUNCHES", fuse)
+        eng = L.LambdaLanczos(op, n, find_max, 1)
+        eng.eigenvalue_offset = offset
+        eng.init_vector = fixed_init(init)
+        vals, vecs = eng.run()
+        got[fuse] = (vals[0], vecs[0], eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eng.last_stats)
+    two, one = got["0"], got["1"]
+    assert two[5]["lagged_iterations"] == 0
+    assert one[5]["lagged_iterations"] >= one[2][0] - 2 - 2 * one[5]["second_passes"]
+    assert one[2] == two[2]
+    scale = inf_norm(csr) + abs(offset)
+    assert np.max(np.abs(one[3] - two[3])) <= 1e-11 * scale
+    assert np.max(np.abs(one[4] - two[4])) <= 1e-11 * scale
+    assert abs(one[0] - two[0]) <= 1e-12 * scale
+    assert 1 - overlap(one[1], two[1]) <= 1e-10
+    res = np.linalg.norm(_csr_matvec(csr, one[1]) - one[0] * one[1])
+    res2 = np.linalg.norm(_csr_matvec(csr, two[1]) - two[0] * two[1])
+    assert res <= 2.0 * res2 + 1e-10 * scale
+    op.close()
+
+
+def _csr_matvec(csr, x):
+    import scipy.sparse as sp
+    rp, ci, v = csr
+    return sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1)) @ x
