@@ -336,7 +336,7 @@ def main():
     # ------------------------------------------------------------ timed steps
     STAGE[0] = "timed Lanczos windows"
     itern = []
-    stats_acc = {"seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0, "seconds_host_enqueue": 0.0,
+    stats_acc = {"lagged_iterations": 0, "seconds_spmv": 0.0, "seconds_orth": 0.0, "seconds_host_tridiag": 0.0, "seconds_host_enqueue": 0.0,
                  "seconds_host_wait": 0.0, "seconds_setup": 0.0, "seconds_finish": 0.0, "seconds_total": 0.0,
                  "seconds_comm_gather": 0.0, "seconds_comm_allreduce": 0.0}
 
@@ -437,10 +437,19 @@ def main():
 
     # Gram-Schmidt kernels of the instrumented windows: algorithmic bytes (minimal-pass model minus the SpMV) / device time
     s = 16 if complex_ else 8
+    two_sweep_bytes = sum(s * n * (2 * k + 9) for it in itern_phases for k in range(1, it + 1))
+    lagged_gs = stats_acc["lagged_iterations"] > 0
     if wl == "c5":
         orth_bytes = sum(s * n * 9 for it in itern_phases for _k in range(1, it + 1))
+        orth_model = "s*n*9 bytes per iteration (no Gram-Schmidt against the basis: Exponentiator default)"
+    elif lagged_gs:
+        # one-sweep (lagged) form: reads y, r, u_{k-2} and the k-1 complete basis vectors, writes w and u_{k-1}
+        orth_bytes = sum(s * n * (k + 4) for it in itern_phases for k in range(1, it + 1))
+        orth_model = ("s*n*(k+4) bytes per iteration: the one-sweep (lagged) Gram-Schmidt form this run used; the two-sweep "
+                      "form of SURVEY 8d needs s*n*(2k+9)")
     else:
-        orth_bytes = sum(s * n * (2 * k + 9) for it in itern_phases for k in range(1, it + 1))
+        orth_bytes = two_sweep_bytes
+        orth_model = "s*n*(2k+9) bytes per iteration (SURVEY 8d minimal-pass model)"
     orth_s = max_over_ranks(stats_acc["seconds_orth"])
     spmv_loop_s = max_over_ranks(stats_acc["seconds_spmv"])
     comm_gather_s = max_over_ranks(stats_acc["seconds_comm_gather"])
@@ -617,7 +626,8 @@ def main():
                 "achieved_actual_traffic_GBps": (traffic / (spmv_ms * 1e-3) / 1e9) if traffic else None,
             },
             "roofline_orth": {
-                "kernel": "mdot+maxpy+scale (three-term, Gram-Schmidt, norm, normalise)",
+                "kernel": ("lagged sweep + folds (three-term, one-sweep Gram-Schmidt, norm)" if lagged_gs else
+                           "mdot+maxpy+scale (three-term, Gram-Schmidt, norm, normalise)"),
                 "bound": "hbm",
                 "achieved": (orth_bytes / orth_s / 1e9) if orth_s > 0 else None,  # None: --no-phase-timers
                 "peak": HBM_PEAK_GBS,
@@ -628,7 +638,9 @@ def main():
                 "traffic_note": "measured HBM bytes of mdot + maxpy + scale per step (one window), PMC counters; "
                                 "achieved = algorithmic bytes of the timed steps / their device time",
                 "algorithmic_bytes_per_step": orth_bytes / max(len(itern_phases), 1),
-                "model": "s*n*(2k+9) bytes per iteration (SURVEY 8d minimal-pass model)",
+                "model": orth_model,
+                "lagged_iterations": stats_acc["lagged_iterations"],
+                "two_sweep_model_bytes_per_step": (two_sweep_bytes / max(len(itern_phases), 1)) if wl != "c5" else None,
             },
             "phases": {
                 "steps": len(itern_phases) if not args.no_phase_timers else 0,

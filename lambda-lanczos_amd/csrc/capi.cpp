@@ -52,7 +52,11 @@ Tuning read_tuning() {
   t.sharded_norm_measured = str("LL_SHARDED_NORM") == "measured";
   t.slab_bytes = std::max<long long>(1, num("LL_SLAB_BYTES", (long long)4 << 30));
   t.blas_small_bytes = num("LL_BLAS_SMALL_BYTES", (long long)4 << 20);
-  t.fuse_launches = flag("LL_FUSE_LAUNCHES", true);
+  {
+    const long long level = num("LL_FUSE_LAUNCHES", 2);
+    t.fuse_launches = level >= 1;
+    t.lagged_gs = level >= 2;
+  }
   t.force_rp64 = flag("LL_FORCE_RP64", false);
   t.pb_test_all_remote = flag("LL_PB_TEST_ALL_REMOTE", false);
   t.tridiag_test_jitter_us = (int)num("LL_TRIDIAG_TEST_JITTER_US", 0);

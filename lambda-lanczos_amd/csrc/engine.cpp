@@ -901,7 +901,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
   if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
-  if (E.can_scale_input() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
+  if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
   // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
@@ -1302,7 +1302,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   LS.fuse_launches = fuse_launches;
   LS.refs_prev = refs_prev;
   if (E.can_defer_scale() && fuse_launches && (!P.full_orthogonalize || P.orth_mode == LL_ORTH_CGS_DGKS)) LS.enable_defer(ld);
-  if (E.can_scale_input() && fuse_launches && P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
+  if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS)
+    LS.enable_lagged(ld);
   LS.begin_pass(nullptr, 0);
   auto enqueue = [&](int64_t k) {  // EX:107-118 (+ EX:120-122 with full_orthogonalize), EX:145, EX:160
     RunList<T> runs;

@@ -383,16 +383,22 @@ __global__ __launch_bounds__(kBlock) void mdot_kernel(int64_t n, T* __restrict__
 // vectors satisfy A u_j = beta_{j-1} u_{j-1} + alpha_j u_j + beta_j u_{j+1} to rounding, hence
 //   (A - alpha) e = sum_i d_i u_i,   d = Tbar c - alpha [c; 0]    (Tbar: the (k x k-1) tridiagonal of recorded alpha, beta)
 // is subtracted from w in the same sweep (the u_i stream through anyway), and the measured coefficients are corrected
-// by linearity, <u_j, w> = m_j - d_j.  alpha itself carries the first-order term 2 Re <e, A u_{k-1}> = 2 Re g_{k-2}
-// (only u_{k-2} couples to u_{k-1}); it is removed before use.  What is left in w along span(U) is fresh rounding, as in
-// the two-sweep form: |c| stays at a few eps for hundreds of iterations (tests/test_gpu_round3.py), the recorded
+// by linearity, <u_j, w> = m_j - d_j.  alpha = <x~, A x~> carries 2 Re <e, A u_{k-1}> = 2 Re g_{k-2} (only u_{k-2} couples
+// to u_{k-1}) and <e, A e> = Re c^H t; both are removed before use (lagged_alpha).  Nothing else is nonlinear in e, so
+// the algebra is exact for ANY size of c (an injected |c| = 0.5 leaves the traces at 1e-14, which matters near breakdown
+// where beta ~ eps makes c = g / beta large without tripping the DGKS test).  What is left in w along span(U) is fresh
+// rounding, as in the two-sweep form: |c| stays at a few eps for hundreds of iterations (tests/test_gpu_round3.py), the recorded
 // alpha / beta agree with the two-sweep form to ~1e-14 relative.  t = Tbar c comes from the fold kernel below
 // (lagged_fold_kernel); d_j = t_j - alpha c_j is formed here because alpha is only known now.
 // The DGKS case (|g|^2 > ||r||^2 / 2: cancellation, the derived norm is inaccurate) is detected by the host from the
 // published norms like before and repaired with the two-sweep kernels on the then complete u_{k-1} (engine.cpp,
 // LoopState).
-// alpha of a lagged iteration without its first-order perturbation term (2 g is exact: same bits wherever formed)
-__device__ __forceinline__ double lagged_alpha(double alpha, double g_last_re) { return fma(-2.0, g_last_re, alpha); }
+// alpha of a lagged iteration without the perturbation's terms: <u + e, A (u + e)> = alpha + 2 Re <e, A u> + <e, A e> with
+// <e, A u_{k-1}> = conj(c_{k-2}) beta_{k-2} = conj(g_{k-2}) and q = <e, A e> = Re c^H t (lagged_fold_kernel).  Same
+// operations in the sweep and in the fold: same bits.
+__device__ __forceinline__ double lagged_alpha(double alpha, double g_last_re, double q) {
+  return fma(-2.0, g_last_re, alpha) - q;
+}
 
 template <typename T, int NV>
 __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
   } else {
     alpha = *tt.alpha;
   }
-  alpha = lagged_alpha(alpha, lg.g[R * (nb - 1)]);  // lagged_fold_kernel publishes the same value
+  alpha = lagged_alpha(alpha, lg.g[R * (nb - 1)], lg.t[R * (nb + 1)]);  // lagged_fold_kernel publishes the same value
   const double beta = sqrt(*lg.beta2), s = 1.0 / beta;
   const double as = alpha * s;
   for (int i = tid; i < R * nb; i += kBlock) {
@@ -557,7 +563,7 @@ LL_INST_LAGGED(double) LL_INST_LAGGED(zc) LL_INST_LAGGED(float) LL_INST_LAGGED(c
 //           iteration's alpha, exactly as the sweep formed it);  g = m after a clean iteration (operator applied to a
 //           complete u_{k-1}: mdot_kernel, nothing to compensate)
 //   c1    = ||w||^2 - |g|^2 = beta_{k-1}^2,  c = g / beta_{k-1}
-//   t     = Tbar c  (reals * (k + 1) values after g): the image of the next operator input's perturbation
+//   t     = Tbar c  (reals * (k + 1) values): the image of the next operator input's perturbation; then q = Re c^H t
 //   alpha_{k-1}, beta_{k-1} appended to the device copy of T; the four per-iteration scalars published to the host.
 __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m, int k, int reals, double* __restrict__ t_out,
                                                           const double* __restrict__ c0, double* __restrict__ c1,
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m
   const int tid = threadIdx.x;
   const int cnt = reals * k;
   double a = *alpha;
-  if (prev_g) a = lagged_alpha(a, prev_g[reals * (k - 2)]);
+  if (prev_g) a = lagged_alpha(a, prev_g[reals * (k - 2)], prev_t[reals * k]);
   double acc = 0.0;
   if (prev_g) {
     const double as = a * (1.0 / sqrt(*prev_c1));
@@ -603,14 +609,19 @@ __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m
   }
   __syncthreads();  // (also orders the m[i] updates above before the reads below)
   const double beta = sh[1], inv = beta > 0.0 ? 1.0 / beta : 0.0;
+  double qacc = 0.0;
   for (int i = tid; i < reals * (k + 1); i += 256) {
     const int j = i / reals;  // component on u_j
     double t = 0.0;
     if (j < k) t = (j == k - 1 ? sh[0] : hist_alpha[j]) * m[i];
     if (j + 1 < k) t = fma(hist_beta[j], m[i + reals], t);
     if (j >= 1) t = fma(j - 1 == k - 1 ? beta : hist_beta[j - 1], m[i - reals], t);
-    t_out[i] = t * inv;
+    t *= inv;
+    t_out[i] = t;
+    if (j < k) qacc = fma(m[i] * inv, t, qacc);
   }
+  const double q = block_sum(qacc, red);
+  if (tid == 0) t_out[reals * (k + 1)] = q;
 }
 void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c1, double* alpha,
                         const double* prev_g, const double* prev_t, const double* prev_c1, double* hist_alpha,

@@ -165,6 +165,7 @@ struct Tuning {
   int64_t slab_bytes = (int64_t)4 << 30;       // LL_SLAB_BYTES: cap of one Krylov-basis slab
   int64_t blas_small_bytes = (int64_t)4 << 20;  // LL_BLAS_SMALL_BYTES: vectors below this use the small-vector kernels
   bool fuse_launches = true;       // LL_FUSE_LAUNCHES=0: separate fold / publish kernels (A/B of the launch fusion)
+  bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
   // --- test hooks (not for users)
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
   bool pb_test_all_remote = false; // LL_PB_TEST_ALL_REMOTE=1: own columns are read from the gathered buffer too
@@ -393,7 +394,7 @@ int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& t
 // Lagged block Gram-Schmidt (kernels.hip, lagged_kernel): one sweep that applies the previous iteration's update to
 // r -> u_out, forms w = w - alpha r/beta - beta u_prev minus the compensation of the perturbed operator input, and all
 // coefficients <u_j, .> (segments, then u_out) + ||w||^2.  Partial columns: reals * (nb + 1) + 1 per workgroup.
-// tt.u_cur is ignored.  g: reals * nb coefficients of r, t: reals * (nb + 1) values, both from launch_lagged_fold.
+// tt.u_cur is ignored.  g: reals * nb coefficients of r, t: reals * (nb + 1) + 1 values, both from launch_lagged_fold.
 // LDS: (4 ncols + reals (2 nb + 1)) doubles, so reals * nb <= kLaggedMaxCols.  Streaming geometry only.
 constexpr int kLaggedMaxCols = 1400;
 template <typename T> struct Lagged {
@@ -407,7 +408,7 @@ template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
                   hipStream_t s);
 // Fold of lagged iteration k (k basis vectors, m: reals * k folded columns, *c0 = ||w||^2): compensated coefficients in
-// place, *c1 = *c0 - |g|^2, t_out (reals * (k + 1)) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha
+// place, *c1 = *c0 - |g|^2, t_out (reals * (k + 1) + 1) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha
 // replaced by its corrected value, the iteration's four scalars published.  prev_* = nullptr after a clean iteration.
 void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c1, double* alpha,
                         const double* prev_g, const double* prev_t, const double* prev_c1, double* hist_alpha,

@@ -276,10 +276,13 @@ def test_tridiag_auto_reproduces_qr_decisions(ctx):
 
 
 # ------------------------------------------------------------------ the host-decided second Gram-Schmidt pass
-def test_exhausted_krylov_space_runs_like_the_oracle(ctx, oracle):
+@pytest.mark.parametrize("geometry", ["default", "streaming"])
+def test_exhausted_krylov_space_runs_like_the_oracle(ctx, oracle, geometry, llenv):
     """An operator with 5 distinct eigenvalues exhausts its Krylov space after 5 iterations: from then on w is rounding
     noise (beta ~ 1e-15, just above the breakdown threshold) and block Gram-Schmidt with the host-decided DGKS test
     must carry the run on exactly like the oracle's sequential MGS (same iteration count, same eigenpair)."""
+    if geometry == "streaming":   # the one-sweep (lagged) Gram-Schmidt form: the noise iterations sit on its DGKS repair path
+        llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
     rng = np.random.default_rng(4)
     n = 300
     q, _ = np.linalg.qr(rng.standard_normal((n, n)))
@@ -299,13 +302,16 @@ def test_exhausted_krylov_space_runs_like_the_oracle(ctx, oracle):
     op.close()
 
 
+@pytest.mark.parametrize("geometry", ["default", "streaming"])
 @pytest.mark.parametrize("what", ["lanczos_two_roots", "expo_full_orth", "lanczos_complex"])
-def test_forced_second_pass_every_iteration(ctx, oracle, what, llenv):
+def test_forced_second_pass_every_iteration(ctx, oracle, what, geometry, llenv):
     """LL_DGKS_THRESHOLD > 1 makes the host decide for a second pass in EVERY iteration: the pipeline is drained,
     Gram-Schmidt is repeated on the normalised vector, beta is rescaled and the speculative next iteration is enqueued
     again.  A second pass on an already orthogonal vector changes nothing but rounding, so traces, iteration counts and
     results must still equal the oracle's."""
     llenv.setenv("LL_DGKS_THRESHOLD", "2.0")
+    if geometry == "streaming":   # streaming kernels => the one-sweep (lagged) Gram-Schmidt form: every speculative
+        llenv.setenv("LL_BLAS_SMALL_BYTES", "0")   # sweep is thrown away and the iteration redone from the repaired vector
     if what == "expo_full_orth":
         csr = G.torus_np(20)
         inp = G.start_vector(400, 1, np.complex128)

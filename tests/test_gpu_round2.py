@@ -330,7 +330,8 @@ def test_device_resident_time_evolution_loop_equals_the_host_loop(ctx):
 @pytest.mark.parametrize("kernel", ["pb", "csr"])
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
 def test_fused_and_separate_folds_give_identical_traces(ctx, dtype, kernel, llenv):
-    """Single GPU: alpha folded inside the multi-dot and the norm fold + publish inside the normalisation kernel (default)
+    """Single GPU: alpha folded inside the multi-dot and the norm fold + publish inside the normalisation kernel
+    (LL_FUSE_LAUNCHES=1; the default level 2 adds the one-sweep Gram-Schmidt form on long vectors, test_gpu_round3.py)
     against the separate fold / publish kernels (LL_FUSE_LAUNCHES=0, also what sharded contexts run): both sum the same
     partials in the same order.  With the PB kernels every number agrees bit for bit; with CSR-stream the default also
     DEFERS the normalisation into the next operator kernel (A(s w) becomes s (A w)), which changes the last bits only:

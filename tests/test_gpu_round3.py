@@ -308,19 +308,19 @@ def test_lagged_gram_schmidt_keeps_the_recurrence_of_the_two_sweep_form(ctx, lle
     """The one-sweep (lagged, compensated) Gram-Schmidt form against the two-sweep kernels on the same operator and
     start vector, streaming geometry forced on both: same iteration count, alpha / beta traces equal to 1e-11 ||A||
     over the whole run (an uncompensated lag loses them after ~40 iterations), same eigenpair, residual at the level the
-    Ritz estimate promises.  LL_FUSE_LAUNCHES=0 is the two-sweep comparator."""
+    Ritz estimate promises.  LL_FUSE_LAUNCHES=1 is the two-sweep comparator."""
     n, csr, init, find_max, offset = _lagged_case(name)
     llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
     op = L.CsrOperator(ctx, *csr)
     got = {}
-    for fuse in ("0", "1"):
+    for fuse in ("1", "2"):
         llenv.setenv("LL_FUSE_LAUNCHES", fuse)
         eng = L.LambdaLanczos(op, n, find_max, 1)
         eng.eigenvalue_offset = offset
         eng.init_vector = fixed_init(init)
         vals, vecs = eng.run()
         got[fuse] = (vals[0], vecs[0], eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eng.last_stats)
-    two, one = got["0"], got["1"]
+    two, one = got["1"], got["2"]
     assert two[5]["lagged_iterations"] == 0
     assert one[5]["lagged_iterations"] >= one[2][0] - 2 - 2 * one[5]["second_passes"]
     assert one[2] == two[2]
@@ -339,3 +339,55 @@ def _csr_matvec(csr, x):
     import scipy.sparse as sp
     rp, ci, v = csr
     return sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, len(rp) - 1)) @ x
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.complex64], ids=["s", "c"])
+def test_lagged_gram_schmidt_single_precision(ctx, llenv, dtype):
+    """float / complex<float> storage through the one-sweep form (streaming geometry forced): against the two-sweep
+    form at float tolerances."""
+    wide = np.float64 if dtype == np.float32 else np.complex128
+    csr = G.randsym_np(20011) if dtype == np.float32 else G.torus_np(120)
+    csr = (csr[0], csr[1], np.ascontiguousarray(csr[2]).astype(dtype))
+    n = csr[0].shape[0] - 1
+    init = G.start_vector(n, 1, wide).astype(dtype)
+    find_max, offset = (True, 0.0) if dtype == np.float32 else (False, -10.0)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for fuse in ("1", "2"):
+        llenv.setenv("LL_FUSE_LAUNCHES", fuse)
+        eng = L.LambdaLanczos(op, n, find_max, 1)
+        eng.eigenvalue_offset = offset
+        eng.init_vector = lambda v, *_: np.copyto(v, init)
+        vals, vecs = eng.run()
+        got[fuse] = (vals[0], vecs[0].astype(wide), eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eng.last_stats)
+    two, one = got["1"], got["2"]
+    f32 = float(np.finfo(np.float32).eps)
+    assert two[5]["lagged_iterations"] == 0 and one[5]["lagged_iterations"] > 0
+    assert abs(one[2][0] - two[2][0]) <= 2
+    m = min(len(one[3]), len(two[3]), 12)       # float traces drift apart at the rate any float Lanczos pair does
+    assert np.max(np.abs(one[3][:m] - two[3][:m])) <= 1e3 * f32 * 16
+    assert abs(one[0] - two[0]) <= 20 * 1e3 * f32 * 16
+    assert 1 - overlap(one[1], two[1]) <= 1e-3
+    op.close()
+
+
+@pytest.mark.parametrize("a", [-1j, -0.5], ids=["unitary", "real_exponent"])
+def test_lagged_gram_schmidt_in_the_exponentiator_with_full_orthogonalisation(ctx, oracle, llenv, a):
+    """Exponentiator::run with full_orthogonalize (EX:120-122) through the one-sweep form, against the oracle."""
+    N = 150
+    n = N * N
+    csr = G.torus_np(N)
+    psi = G.start_vector(n, 5, np.complex128)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    ex = L.Exponentiator(op, n)
+    ex.full_orthogonalize = True
+    if a == -0.5:
+        ex.max_iteration = 40
+    out, it = ex.run(a, psi)
+    o_out, o_it, _ = oracle.expo(csr, a, psi, full_orthogonalize=True, **({"max_iteration": 40} if a == -0.5 else {}))
+    assert ex.last_stats["lagged_iterations"] >= it - 2
+    assert it == o_it
+    assert np.max(np.abs(out - o_out)) <= 1e-11 * np.linalg.norm(psi) * max(1.0, np.linalg.norm(o_out) / np.linalg.norm(psi))
+    op.close()

@@ -45,7 +45,7 @@ PY
 fi
 if has kstats; then
   export TMPDIR=/tmp
-  for cfg in ${KSTATS_CFGS:-"c5:--workload c5" "c2:--workload c2"}; do
+  for cfg in ${KSTATS_CFGS:-"c3:--workload c3" "c5:--workload c5" "c2:--workload c2"}; do
     name=${cfg%%:*}; opts=${cfg#*:}
     mkdir -p gpurun_out/prof_r03; d=gpurun_out/prof_r03/ks_$name; rm -rf $d
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o ks -- python3 bench.py $opts --steps 3 --warmup 1 --cpu-window 0 --no-spmv-variants > gpurun_out/prof_r03/ks_$name.json 2> gpurun_out/prof_r03/ks_$name.err
