@@ -250,12 +250,12 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       comm_timer_end(cs);
       if (overlap) {
         // own-column blocks run under the gather; every chunk's remote blocks start when that chunk has arrived
-        launch_pb_phase1<T>(*op, 0, op->pb_own_count, x_own, s);
+        launch_pb_phase1<T>(*op, 0, op->pb_own_count, x_own, s, xnorm2);
         for (int c = 0; c < plan.nchunks; ++c) {
           LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[c], 0));
-          launch_pb_phase1<T>(*op, op->pb_chunk_first[c], op->pb_chunk_count[c], gathered, s);
+          launch_pb_phase1<T>(*op, op->pb_chunk_first[c], op->pb_chunk_count[c], gathered, s, xnorm2);
         }
-        nparts = launch_pb_phase2<T>(*op, x_local, y, offset, dotp, s);
+        nparts = launch_pb_phase2<T>(*op, x_local, y, offset, dotp, s, xnorm2);
         remote_done = true;
       }
     }
@@ -676,8 +676,9 @@ template <typename T> struct LoopState {
     if (!lag_ok) return false;
     const RunList<T> in_memory = basis_runs(lag_pending ? k - 1 : k);  // u_{k-1} is not in memory while its update is pending
     const std::vector<BasisSegs<T>> groups = in_memory.groups(max_vecs_per_launch<T>());
-    if (nb_total != k || R * nb_total > kLaggedMaxCols || groups.size() > 1 ||
-        (int64_t)nl * (int64_t)sizeof(T) < small_bytes) {  // (the small-vector kernels keep the two-sweep form)
+    // (the small-vector kernels keep the two-sweep form; sharded: decided on the shard stride, the same on every rank)
+    const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;
+    if (nb_total != k || R * nb_total > kLaggedMaxCols || groups.size() > 1 || len * (int64_t)sizeof(T) < small_bytes) {
       lag_ok = false;  // for the rest of the pass: the two-sweep iterations do not record T on the device
       return false;
     }
@@ -710,9 +711,16 @@ template <typename T> struct LoopState {
     }
     double* c = E.S(kScalNorms + 3 * slot);
     double* hb = hbuf[k & 1];
-    launch_reduce_cols(E.ctx->d_partials, grid, ncols, hb, c, s);  // coefficients -> hb, ||w||^2 -> c[0]
+    const double* c0 = c;
+    if (E.ctx->comm == nullptr) {
+      launch_reduce_cols(E.ctx->d_partials, grid, ncols, hb, c, s);  // coefficients -> hb, ||w||^2 -> c[0]
+    } else {  // one all-reduce for the coefficients and ||w||^2; every rank then folds the same numbers to the same bits
+      launch_reduce_cols(E.ctx->d_partials, grid, ncols, hb, nullptr, s);
+      E.all_reduce(hb, (size_t)ncols);
+      c0 = hb + R * nb_total;
+    }
     const double* pg = lag_pending ? hbuf[(k - 1) & 1] : nullptr;
-    launch_lagged_fold(hb, (int)k, R, hb + t_off, c, c + 1, E.S(kScalAlpha + slot), pg, pg ? pg + t_off : nullptr, lag_c1,
+    launch_lagged_fold(hb, (int)k, R, hb + t_off, c0, c, c + 1, E.S(kScalAlpha + slot), pg, pg ? pg + t_off : nullptr, lag_c1,
                        hist_alpha, hist_beta, E.ctx->h_pinned + 4 * slot, s);
     LL_HIP(hipEventRecord(ring.ev[slot], s));
     timer.mark();

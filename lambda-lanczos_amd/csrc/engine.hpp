@@ -75,14 +75,14 @@ template <typename T> struct Engine {
   };
   // sc (nullable): deferred normalisation — x_local is the unnormalised w_k (ScaleIn, ll_internal.hpp); only where
   // can_defer_scale() holds.
-  // xnorm2 (nullable device scalar; unsharded device operators): x_local is an unnormalised vector w with
+  // xnorm2 (nullable device scalar; device operators): x_local is an unnormalised vector w with
   // ||w||^2 = *xnorm2 and the operator works with w / ||w|| (lagged Gram-Schmidt, LoopState).
   void apply(const T* x_local, T* y, double offset, double* d_alpha, bool x_padded = false, DeferredAlpha* defer = nullptr,
              const ScaleIn<T>* sc = nullptr, const double* xnorm2 = nullptr);
-  // any device operator on an unsharded context can take its input unnormalised (the PB kernels scale the x slice while
-  // they stage it, the others through ScaleIn)
+  // any device operator can take its input unnormalised (the PB kernels scale the x slice while they stage it, the
+  // others scale the finished row sum through ScaleIn); sharded contexts gather / exchange the unnormalised shards
   bool can_scale_input() const {
-    if (ctx->comm != nullptr || op == nullptr) return false;
+    if (op == nullptr) return false;
     return op->kind == ll_operator::CSR || op->kind == ll_operator::STENCIL || op->kind == ll_operator::DENSE;
   }
   // The operator kernel can normalise its input on the fly: single GPU, and a kernel that reads x itself (CSR-stream,

@@ -566,7 +566,7 @@ LL_INST_LAGGED(double) LL_INST_LAGGED(zc) LL_INST_LAGGED(float) LL_INST_LAGGED(c
 //   t     = Tbar c  (reals * (k + 1) values): the image of the next operator input's perturbation; then q = Re c^H t
 //   alpha_{k-1}, beta_{k-1} appended to the device copy of T; the four per-iteration scalars published to the host.
 __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m, int k, int reals, double* __restrict__ t_out,
-                                                          const double* __restrict__ c0, double* __restrict__ c1,
+                                                          const double* c0, double* c0_out, double* __restrict__ c1,
                                                           double* __restrict__ alpha, const double* __restrict__ prev_g,
                                                           const double* __restrict__ prev_t, const double* __restrict__ prev_c1,
                                                           double* __restrict__ hist_alpha, double* __restrict__ hist_beta,
@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m
     const double before = *c0;
     double v = before - tot;
     v = v > 0.0 ? v : 0.0;
+    *c0_out = before;  // (sharded: out of the all-reduced buffer)
     *c1 = v;
     *alpha = a;
     hist_alpha[k - 1] = a;
@@ -623,10 +624,10 @@ __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m
   const double q = block_sum(qacc, red);
   if (tid == 0) t_out[reals * (k + 1)] = q;
 }
-void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c1, double* alpha,
-                        const double* prev_g, const double* prev_t, const double* prev_c1, double* hist_alpha,
-                        double* hist_beta, double* host_mapped, hipStream_t s) {
-  hipLaunchKernelGGL(lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, k, reals, t_out, c0, c1, alpha, prev_g, prev_t,
+void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
+                        double* alpha, const double* prev_g, const double* prev_t, const double* prev_c1,
+                        double* hist_alpha, double* hist_beta, double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL(lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, k, reals, t_out, c0, c0_out, c1, alpha, prev_g, prev_t,
                      prev_c1, hist_alpha, hist_beta, host_mapped);
   LL_HIP(hipGetLastError());
 }

@@ -36,7 +36,8 @@ def main():
         eng.init_vector = lambda v, row_begin: np.copyto(v, G.start_vector(v.shape[0], 1, np.float64, row_begin))
         vals, vecs = eng.run()
         res["randsym_" + label] = {"row_begin": rb, "n_local": nl, "vals": vals.tolist(), "vecs": [v.tolist() for v in vecs],
-                                   "iters": eng.getIterationCounts(), "alpha": eng.last_alpha.tolist()}
+                                   "iters": eng.getIterationCounts(), "alpha": eng.last_alpha.tolist(),
+                                   "lagged": int(eng.last_stats["lagged_iterations"])}
         if label == "csr":   # run_iteration with a sharded orthogonalizeTo list: the first eigenvector is locked
             eng.max_iteration = 60
             rv, rx, rit = eng.run_iteration(2, [vecs[0]])
