@@ -328,8 +328,9 @@ template <typename T> void Engine<T>::dot_dev(const T* a, const T* b, double* d_
   all_reduce(d_out, R);
 }
 
-// LDS budget of mdot: 4 waves x ncols doubles <= 48 KiB  =>  ncols <= 1536
-template <typename T> static int max_vecs_per_launch() { return (1536 - 1) / scalar_traits<T>::reals; }
+// LDS budget of mdot / lagged_kernel: 4 waves x ncols doubles in the 160 KB of a CU (one workgroup per CU then, which is
+// how the streaming kernels run on long vectors anyway)  =>  reals * nb <= 5000
+template <typename T> static int max_vecs_per_launch() { return kLaggedMaxCols / scalar_traits<T>::reals; }
 
 template <typename T>
 NormRefs Engine<T>::orth(T* w, const RunList<T>& runs, int mode, const ThreeTerm<T>& tt, double* c, double* h_total,

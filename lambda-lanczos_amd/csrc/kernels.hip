@@ -403,7 +403,8 @@ __device__ __forceinline__ double lagged_alpha(double alpha, double g_last_re, d
 template <typename T, int NV>
 __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
                                             const T (&wr)[strip<T>::EPT], T (&wp)[strip<T>::EPT], T (&uc)[strip<T>::EPT],
-                                            const double* gcol, const double* dcol, double* mine_col, int lane) {
+                                            const double* __restrict__ gcol, const double* __restrict__ tcol, double as,
+                                            double* mine_col, int lane) {
   constexpr int EPT = strip<T>::EPT;
   constexpr int R = scalar_traits<T>::reals;
   T ur[NV][EPT];
@@ -412,13 +413,15 @@ __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld
   double a[NV * R];
 #pragma unroll
   for (int b = 0; b < NV; ++b) {
+    // g_j and d_j = t_j - (alpha / beta) g_j: wave-uniform addresses in read-only memory (scalar loads, no LDS copy, so
+    // the LDS budget belongs to the partial columns alone)
     acc_t<T> gj, dj;
     if constexpr (scalar_traits<T>::is_complex) {
       gj = zc{gcol[2 * b], gcol[2 * b + 1]};
-      dj = zc{dcol[2 * b], dcol[2 * b + 1]};
+      dj = zc{fma(-as, gj.re, tcol[2 * b]), fma(-as, gj.im, tcol[2 * b + 1])};
     } else {
       gj = gcol[b];
-      dj = dcol[b];
+      dj = fma(-as, gj, tcol[b]);
     }
     acc_t<T> acc = zero<acc_t<T>>();
 #pragma unroll
@@ -441,16 +444,16 @@ __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs, int nb,
-                                                        Lagged<T> lg, ThreeTerm<T> tt, double* __restrict__ partials) {
+                                                        Lagged<T> lg, const double* __restrict__ g,
+                                                        const double* __restrict__ t, ThreeTerm<T> tt,
+                                                        double* __restrict__ partials) {
   constexpr int EPT = strip<T>::EPT;
   constexpr int ELEMS = strip<T>::ELEMS;
   constexpr int JB = kJB;
   constexpr int R = scalar_traits<T>::reals;
   const int ncols = R * (nb + 1) + 1;
-  extern __shared__ double lds[];  // [4 waves][ncols] partial columns, [R nb] g, [R (nb + 1)] d
+  extern __shared__ double lds[];  // [4 waves][ncols] partial columns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* gl = lds + (size_t)4 * ncols;
-  double* dl = gl + (size_t)R * nb;
   for (int i = tid; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
   double alpha;
   if (tt.alpha_partials) {  // deferred alpha: fold the operator kernel's partials here (ThreeTerm)
@@ -460,20 +463,14 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
   } else {
     alpha = *tt.alpha;
   }
-  alpha = lagged_alpha(alpha, lg.g[R * (nb - 1)], lg.t[R * (nb + 1)]);  // lagged_fold_kernel publishes the same value
+  alpha = lagged_alpha(alpha, g[R * (nb - 1)], t[R * (nb + 1)]);  // lagged_fold_kernel publishes the same value
   const double beta = sqrt(*lg.beta2), s = 1.0 / beta;
   const double as = alpha * s;
-  for (int i = tid; i < R * nb; i += kBlock) {
-    const double gi = lg.g[i];
-    gl[i] = gi;
-    dl[i] = fma(-as, gi, lg.t[i]);
-  }
-  if (tid < R) dl[R * nb + tid] = lg.t[R * nb + tid];
   __syncthreads();
   double* mine = lds + (size_t)wave * ncols;
-  acc_t<T> dlast;
-  if constexpr (scalar_traits<T>::is_complex) dlast = zc{dl[R * nb], dl[R * nb + 1]};
-  else dlast = dl[R * nb];
+  acc_t<T> dlast;  // the component on u_{k-1} itself
+  if constexpr (scalar_traits<T>::is_complex) dlast = zc{t[R * nb], t[R * nb + 1]};
+  else dlast = t[R * nb];
 
   const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
@@ -498,14 +495,14 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
       const int cnt = segs.count[sg];
       int j = 0;
       for (; j + JB <= cnt; j += JB, col += R * JB)
-        lagged_trip<T, JB>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, gl + col, dl + col, mine + col, lane);
+        lagged_trip<T, JB>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
       if (j + 2 <= cnt) {
-        lagged_trip<T, 2>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, gl + col, dl + col, mine + col, lane);
+        lagged_trip<T, 2>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
         j += 2;
         col += R * 2;
       }
       if (j < cnt) {
-        lagged_trip<T, 1>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, gl + col, dl + col, mine + col, lane);
+        lagged_trip<T, 1>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
         j += 1;
         col += R;
       }
@@ -548,8 +545,8 @@ int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg
   constexpr int R = scalar_traits<T>::reals;
   const int ncols = R * (nb + 1) + 1;
   const int grid = strip_grid(n, strip<T>::ELEMS);
-  const size_t lds_bytes = ((size_t)4 * ncols + (size_t)R * (2 * nb + 1)) * sizeof(double);
-  hipLaunchKernelGGL((lagged_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nb, lg, tt, partials);
+  const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
+  hipLaunchKernelGGL((lagged_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nb, lg, lg.g, lg.t, tt, partials);
   LL_HIP(hipGetLastError());
   return grid;
 }

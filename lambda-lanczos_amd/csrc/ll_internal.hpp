@@ -87,7 +87,7 @@ constexpr int kXcds = 8;
 constexpr int kMaxGrid = kCUs * 8;   // persistent grids: at most 8 workgroups per CU (multiple of 8 XCDs)
 constexpr int kMaxSpmvGrid = kCUs * 16;  // CSR-stream SpMV with 16-byte values (its partial dot products: d_alpha_partials)
 constexpr int kSpmvTileNnz = 1024;   // nonzeros staged through LDS per SpMV tile
-constexpr int kMaxSegs = 8;          // basis segments per multi-dot / multi-axpy launch
+constexpr int kMaxSegs = 26;         // basis segments (slabs) per multi-dot / multi-axpy launch: 5000 vectors in slabs of 200
 
 // A run of basis vectors stored with a common leading dimension: vector j at base + j*ld.
 template <typename T> struct BasisSegs {
@@ -395,8 +395,9 @@ int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& t
 // r -> u_out, forms w = w - alpha r/beta - beta u_prev minus the compensation of the perturbed operator input, and all
 // coefficients <u_j, .> (segments, then u_out) + ||w||^2.  Partial columns: reals * (nb + 1) + 1 per workgroup.
 // tt.u_cur is ignored.  g: reals * nb coefficients of r, t: reals * (nb + 1) + 1 values, both from launch_lagged_fold.
-// LDS: (4 ncols + reals (2 nb + 1)) doubles, so reals * nb <= kLaggedMaxCols.  Streaming geometry only.
-constexpr int kLaggedMaxCols = 1400;
+// LDS: 4 ncols doubles (the waves' partial columns; g and t are read through the scalar cache), 160 KB per workgroup:
+// reals * nb <= kLaggedMaxCols.  Streaming geometry only.
+constexpr int kLaggedMaxCols = 5000;
 template <typename T> struct Lagged {
   const T* r;
   T* u_out;

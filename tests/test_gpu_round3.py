@@ -299,11 +299,14 @@ def _lagged_case(name):
     if name == "laplace":   # slowly converging: several hundred iterations
         m = 173
         return m * m, G.laplace2d_np(m), G.start_vector(m * m, 2), True, 0.0
+    if name == "laplace_long":   # 1800 iterations (eps = 0 never stops): more columns than one 48 KB LDS block of partials
+        m = 150                  # held in rounds 1-2, basis over ten slabs
+        return m * m, G.laplace2d_np(m), G.start_vector(m * m, 4), False, 0.0
     N = 160                 # complex Hermitian torus, lowest eigenvalue through the reference's offset idiom
     return N * N, G.torus_np(N), G.start_vector(N * N, 3, np.complex128), False, -10.0
 
 
-@pytest.mark.parametrize("name", ["randsym", "laplace", "torus"])
+@pytest.mark.parametrize("name", ["randsym", "laplace", "torus", "laplace_long"])
 def test_lagged_gram_schmidt_keeps_the_recurrence_of_the_two_sweep_form(ctx, llenv, name):
     """The one-sweep (lagged, compensated) Gram-Schmidt form against the two-sweep kernels on the same operator and
     start vector, streaming geometry forced on both: same iteration count, alpha / beta traces equal to 1e-11 ||A||
@@ -318,15 +321,37 @@ def test_lagged_gram_schmidt_keeps_the_recurrence_of_the_two_sweep_form(ctx, lle
         eng = L.LambdaLanczos(op, n, find_max, 1)
         eng.eigenvalue_offset = offset
         eng.init_vector = fixed_init(init)
+        if name == "laplace_long":
+            eng.eps = 0.0
+            eng.max_iteration = 1800
         vals, vecs = eng.run()
         got[fuse] = (vals[0], vecs[0], eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eng.last_stats)
     two, one = got["1"], got["2"]
+    if name == "laplace_long":
+        assert one[2] == [1800]
     assert two[5]["lagged_iterations"] == 0
     assert one[5]["lagged_iterations"] >= one[2][0] - 2 - 2 * one[5]["second_passes"]
     assert one[2] == two[2]
     scale = inf_norm(csr) + abs(offset)
-    assert np.max(np.abs(one[3] - two[3])) <= 1e-11 * scale
-    assert np.max(np.abs(one[4] - two[4])) <= 1e-11 * scale
+    if name == "laplace_long":
+        # Past the convergence of the extreme Ritz values the alpha / beta sequence of ANY Lanczos process is an
+        # ill-conditioned function of its rounding errors (two correct implementations drift apart; the drift here starts
+        # around k = 500): compare the traces before that, and afterwards what the traces are for: the spectrum of T
+        # (both ends: converged eigenvalues of A, known analytically) and its size
+        import scipy.linalg as sl
+        assert np.max(np.abs(one[3][:300] - two[3][:300])) <= 1e-11 * scale
+        assert np.max(np.abs(one[4][:300] - two[4][:300])) <= 1e-11 * scale
+        m = int(round(np.sqrt(n)))
+        c = 2.0 - 2.0 * np.cos(np.arange(1, m + 1) * np.pi / (m + 1))
+        exact = np.sort((c[:, None] + c[None, :]).ravel())
+        for tr in (one, two):
+            ritz = sl.eigvalsh_tridiagonal(tr[3], tr[4][:-1])
+            assert np.max(np.abs(ritz[:40] - exact[:40])) <= 1e-11 * scale
+            assert np.max(np.abs(ritz[-40:] - exact[-40:])) <= 1e-11 * scale
+            assert np.all(tr[4] > 1e-3) and np.all(np.isfinite(tr[3]))
+    else:
+        assert np.max(np.abs(one[3] - two[3])) <= 1e-11 * scale
+        assert np.max(np.abs(one[4] - two[4])) <= 1e-11 * scale
     assert abs(one[0] - two[0]) <= 1e-12 * scale
     assert 1 - overlap(one[1], two[1]) <= 1e-10
     res = np.linalg.norm(_csr_matvec(csr, one[1]) - one[0] * one[1])
