@@ -120,7 +120,7 @@ def pmc_traffic(workload, kernels, dtype_tag):
 
 
 def pmc_orth_traffic(workload, window):
-    """Measured HBM bytes of the Gram-Schmidt kernels (mdot + maxpy + scale) per window of `window` iterations, from the
+    """Measured HBM bytes of the Gram-Schmidt kernels (lagged sweep + folds, or mdot + maxpy + scale) per window of `window` iterations, from the
     committed PMC summary of the same workload and window (None when there is none)."""
     import glob
 
@@ -635,7 +635,8 @@ def main():
                 "frac": (orth_bytes / orth_s / 1e9 / HBM_PEAK_GBS) if orth_s > 0 else None,
                 "traffic": orth_traffic,
                 "traffic_source": orth_traffic_src,
-                "traffic_note": "measured HBM bytes of mdot + maxpy + scale per step (one window), PMC counters; "
+                "traffic_note": "measured HBM bytes of the Gram-Schmidt kernels (one-sweep form: lagged sweep + folds; two-sweep "
+                                "form: mdot + maxpy + scale) per step (one window), PMC counters; "
                                 "achieved = algorithmic bytes of the timed steps / their device time",
                 "algorithmic_bytes_per_step": orth_bytes / max(len(itern_phases), 1),
                 "model": orth_model,
