@@ -601,7 +601,9 @@ template <typename T> struct LoopState {
   int64_t n_lagged = 0;     // iterations enqueued in the lagged form (statistics)
   bool lag_ok = false;      // this pass: every iteration so far went through enqueue_lagged (the device copy of T is complete)
   double* hbuf[2] = {nullptr, nullptr};
-  double *hist_alpha = nullptr, *hist_beta = nullptr;
+  double *hist_alpha = nullptr, *hist_beta = nullptr, *d_lambda = nullptr;
+  static constexpr int kLaggedMaxLocked = 512;
+  double lag_beta2_min = 0.0;  // passes with locked vectors: smallest beta^2 the one-sweep form accepts (begin_pass)
   size_t t_off = 0;
   int64_t n_locked = 0;       // locked eigenvectors at the front of every run list (restart passes)
   const T* locked = nullptr;
@@ -627,19 +629,65 @@ template <typename T> struct LoopState {
     constexpr size_t R = (size_t)Engine<T>::R;
     t_off = (size_t)kLaggedMaxCols + 8;
     const size_t half = 2 * t_off + 2 * R + 8;
-    E.ctx->ensure_h(2 * half + 2 * t_off);
+    E.ctx->ensure_h(2 * half + 2 * t_off + (size_t)kLaggedMaxLocked);
     hbuf[0] = E.ctx->d_h;
     hbuf[1] = E.ctx->d_h + half;
     hist_alpha = E.ctx->d_h + 2 * half;
     hist_beta = hist_alpha + t_off;
+    d_lambda = hist_beta + t_off;
   }
-  // a new Lanczos pass: k restarts at 1.  The compensation of the lagged form needs the recurrence of every basis
-  // vector, so passes that orthogonalise against locked eigenvectors keep the two-sweep form.
-  void begin_pass(const T* locked_vecs, int64_t n_lock) {
+  // a new Lanczos pass: k restarts at 1.  The compensation of the lagged form needs the image under the operator of every
+  // vector it orthogonalises against: the recurrence for the Lanczos vectors, lambda_i z_i for a locked EIGENvector
+  // (lambda_shifted: eigenvalues of the operator the loop applies, i.e. including eigenvalue_offset).  A caller's
+  // arbitrary orthogonalizeTo vectors (run_iteration) have no such relation: lambda_shifted = nullptr keeps the
+  // two-sweep form for that pass.
+  // What the compensation neglects for a locked column is c_z r with r = A z - lambda z and c_z ~ ||r|| / beta, i.e. the
+  // SQUARE of the locked vector's residual: it is measured here (one operator application per locked vector and pass) and
+  // the pass takes the one-sweep form only if every ||r_i|| <= 1e-7 max|lambda| (effect on the recurrence <= 1e-14,
+  // relative).  Ritz vectors of clustered or degenerate eigenvalues, or of a pass cut off by max_iteration, do not meet
+  // that and keep the two-sweep form.  All numbers are all-reduced: the same decision on every rank.
+  void begin_pass(const T* locked_vecs, int64_t n_lock, const double* lambda_shifted = nullptr, double offset = 0.0) {
     locked = locked_vecs;
     n_locked = n_lock;
     lag_pending = false;
-    lag_ok = lagged && n_lock == 0;
+    lag_ok = lagged && (n_lock == 0 || (lambda_shifted != nullptr && n_lock <= kLaggedMaxLocked));
+    lag_beta2_min = 0.0;
+    if (!lag_ok || n_lock == 0) return;
+    LL_HIP(hipMemcpyAsync(d_lambda, lambda_shifted, (size_t)n_lock * sizeof(double), hipMemcpyHostToDevice, s));
+    LL_HIP(hipStreamSynchronize(s));  // (pageable source: the caller's array may go away)
+    BasisSegs<T> none;
+    none.nseg = 0;
+    none.ld = ld;
+    E.ctx->ensure_partials(kMaxGrid);
+    double scale = 0.0, worst = 0.0;
+    for (int64_t i = 0; i < n_lock; ++i) {
+      const T* z = locked + i * ld;
+      T* y = work[0].p;
+      E.apply(z, y, offset, nullptr, true);
+      const ThreeTerm<T> tt{nullptr, z, d_lambda + i, NormRefs{nullptr, nullptr, nullptr, 0}};  // y <- y - lambda_i z, ||y||^2
+      const int grid = launch_mdot<T>(nl, y, none, tt, nullptr, E.ctx->d_partials, small_bytes, s);
+      launch_reduce_cols(E.ctx->d_partials, grid, 1, E.S(kScalSpare), nullptr, s);
+      E.all_reduce(E.S(kScalSpare), 1);
+      double r2 = 0.0;
+      E.fetch(E.S(kScalSpare), &r2, 1);
+      worst = std::max(worst, std::sqrt(std::max(r2, 0.0)));
+      scale = std::max(scale, std::fabs(lambda_shifted[i]));
+    }
+    if (!(worst <= 3e-8 * scale)) {
+      lag_ok = false;
+      return;
+    }
+    // c_z ~ ||r|| / beta: the neglected term is <= ||r||^2 / beta; below this beta^2 it would exceed 1e-13 scale and the
+    // loop leaves the one-sweep form for the rest of the pass (lanczos_run, collect)
+    const double bmin = worst * worst / (1e-13 * scale);
+    lag_beta2_min = bmin * bmin;
+  }
+  // iteration j ended with a beta too small for the first-order treatment of the locked columns: complete u_j with the
+  // two-sweep kernels (unless the speculative sweep already has) and continue in the two-sweep form
+  void leave_lagged(int64_t j) {
+    make_final(j);
+    lag_pending = false;
+    lag_ok = false;
   }
   // beta_j changed on the host (second Gram-Schmidt pass on u_{j+1})
   void set_beta(int64_t j, double value) {
@@ -679,7 +727,7 @@ template <typename T> struct LoopState {
     const std::vector<BasisSegs<T>> groups = in_memory.groups(max_vecs_per_launch<T>());
     // (the small-vector kernels keep the two-sweep form; sharded: decided on the shard stride, the same on every rank)
     const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;
-    if (nb_total != k || R * nb_total > kLaggedMaxCols || groups.size() > 1 || len * (int64_t)sizeof(T) < small_bytes) {
+    if (nb_total != k + n_locked || R * nb_total > kLaggedMaxCols || groups.size() > 1 || len * (int64_t)sizeof(T) < small_bytes) {
       lag_ok = false;  // for the rest of the pass: the two-sweep iterations do not record T on the device
       return false;
     }
@@ -721,8 +769,8 @@ template <typename T> struct LoopState {
       c0 = hb + R * nb_total;
     }
     const double* pg = lag_pending ? hbuf[(k - 1) & 1] : nullptr;
-    launch_lagged_fold(hb, (int)k, R, hb + t_off, c0, c, c + 1, E.S(kScalAlpha + slot), pg, pg ? pg + t_off : nullptr, lag_c1,
-                       hist_alpha, hist_beta, E.ctx->h_pinned + 4 * slot, s);
+    launch_lagged_fold(hb, (int)nb_total, (int)n_locked, R, hb + t_off, c0, c, c + 1, E.S(kScalAlpha + slot), pg,
+                       pg ? pg + t_off : nullptr, lag_c1, hist_alpha, hist_beta, d_lambda, E.ctx->h_pinned + 4 * slot, s);
     LL_HIP(hipEventRecord(ring.ev[slot], s));
     timer.mark();
     lag_pending = true;
@@ -969,7 +1017,12 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     bool stopped = false;
     LS.refs_prev = refs0;
     LS.pending = false;
-    LS.begin_pass(d_locked.p, L);
+    // One-sweep form against locked vectors: they must be eigenvectors (LoopState::begin_pass measures their residuals);
+    // a caller's orthogonalizeTo list (run_iteration) is not, and keeps the two-sweep form.
+    std::vector<double> locked_lambda;  // of the operator the loop applies (A + eigenvalue_offset)
+    if (!spec)
+      for (auto& kv : kept) locked_lambda.push_back(kv.first + P.eigenvalue_offset);
+    LS.begin_pass(d_locked.p, L, locked_lambda.empty() ? nullptr : locked_lambda.data(), P.eigenvalue_offset);
     RunList<T> locked_runs;
     locked_runs.ld = ld;
     locked_runs.add(d_locked.p, L);  // P5
@@ -1040,6 +1093,12 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
         } else {
           beta2_j = 0.0;  // w vanished exactly: breakdown (H3)
         }
+      }
+      if (verdict == kContinue && LS.lag_ok && LS.n_locked > 0 && beta2_j < LS.lag_beta2_min) {
+        LS.leave_lagged(j);
+        double* cj = E.S(kScalNorms + 3 * slot);
+        LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+        verdict = kRedone;  // the speculative iteration j+1 took the one-sweep form: it is enqueued again
       }
       alpha.push_back(alpha_j);
       beta.push_back(std::sqrt(beta2_j));

@@ -554,26 +554,30 @@ int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg
   template int launch_lagged<T>(int64_t, T*, const BasisSegs<T>&, const Lagged<T>&, const ThreeTerm<T>&, double*, hipStream_t);
 LL_INST_LAGGED(double) LL_INST_LAGGED(zc) LL_INST_LAGGED(float) LL_INST_LAGGED(cf)
 
-// The fold of a lagged iteration k (one workgroup; replaces derive_norm_kernel there).  `m` holds the reals * k column
-// sums of the sweep (raw coefficients; the last one was taken on the finished w), *c0 = ||w||^2.
+// The fold of a lagged iteration k (one workgroup; replaces derive_norm_kernel there).  Columns: L locked eigenvectors
+// first, then the Lanczos vectors u_0 .. u_{k-1}; K = L + k.  `m` holds the reals * K column sums of the sweep (raw
+// coefficients; the last one was taken on the finished w), *c0 = ||w||^2.
 //   g_i   = m_i - d_i  for the columns the sweep took on wr (prev_g != nullptr: d from the previous fold's t, g and this
 //           iteration's alpha, exactly as the sweep formed it);  g = m after a clean iteration (operator applied to a
 //           complete u_{k-1}: mdot_kernel, nothing to compensate)
 //   c1    = ||w||^2 - |g|^2 = beta_{k-1}^2,  c = g / beta_{k-1}
-//   t     = Tbar c  (reals * (k + 1) values): the image of the next operator input's perturbation; then q = Re c^H t
+//   t     = the image of the next operator input's perturbation in the same columns (reals * (K + 1) values): Tbar c for
+//           the Lanczos columns, lambda_i c_i for a locked eigenvector (A z_i = lambda_i z_i + r_i; c_i r_i is second
+//           order in quantities of the size of the convergence tolerance); then q = Re c^H t
 //   alpha_{k-1}, beta_{k-1} appended to the device copy of T; the four per-iteration scalars published to the host.
-__global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m, int k, int reals, double* __restrict__ t_out,
+__global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m, int K, int L, int reals, double* __restrict__ t_out,
                                                           const double* c0, double* c0_out, double* __restrict__ c1,
                                                           double* __restrict__ alpha, const double* __restrict__ prev_g,
                                                           const double* __restrict__ prev_t, const double* __restrict__ prev_c1,
                                                           double* __restrict__ hist_alpha, double* __restrict__ hist_beta,
-                                                          double* __restrict__ host) {
+                                                          const double* __restrict__ lambda, double* __restrict__ host) {
   __shared__ double red[4];
   __shared__ double sh[2];
   const int tid = threadIdx.x;
-  const int cnt = reals * k;
+  const int k = K - L;
+  const int cnt = reals * K;
   double a = *alpha;
-  if (prev_g) a = lagged_alpha(a, prev_g[reals * (k - 2)], prev_t[reals * k]);
+  if (prev_g) a = lagged_alpha(a, prev_g[reals * (K - 2)], prev_t[reals * K]);
   double acc = 0.0;
   if (prev_g) {
     const double as = a * (1.0 / sqrt(*prev_c1));
@@ -608,24 +612,29 @@ __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m
   __syncthreads();  // (also orders the m[i] updates above before the reads below)
   const double beta = sh[1], inv = beta > 0.0 ? 1.0 / beta : 0.0;
   double qacc = 0.0;
-  for (int i = tid; i < reals * (k + 1); i += 256) {
-    const int j = i / reals;  // component on u_j
+  for (int i = tid; i < reals * (K + 1); i += 256) {
+    const int col = i / reals;
     double t = 0.0;
-    if (j < k) t = (j == k - 1 ? sh[0] : hist_alpha[j]) * m[i];
-    if (j + 1 < k) t = fma(hist_beta[j], m[i + reals], t);
-    if (j >= 1) t = fma(j - 1 == k - 1 ? beta : hist_beta[j - 1], m[i - reals], t);
+    if (col < L) {
+      t = lambda[col] * m[i];
+    } else {
+      const int j = col - L;  // component on u_j
+      if (j < k) t = (j == k - 1 ? sh[0] : hist_alpha[j]) * m[i];
+      if (j + 1 < k) t = fma(hist_beta[j], m[i + reals], t);
+      if (j >= 1) t = fma(j == k ? beta : hist_beta[j - 1], m[i - reals], t);
+    }
     t *= inv;
     t_out[i] = t;
-    if (j < k) qacc = fma(m[i] * inv, t, qacc);
+    if (col < K) qacc = fma(m[i] * inv, t, qacc);
   }
   const double q = block_sum(qacc, red);
-  if (tid == 0) t_out[reals * (k + 1)] = q;
+  if (tid == 0) t_out[reals * (K + 1)] = q;
 }
-void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
+void launch_lagged_fold(double* m, int K, int L, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
                         double* alpha, const double* prev_g, const double* prev_t, const double* prev_c1,
-                        double* hist_alpha, double* hist_beta, double* host_mapped, hipStream_t s) {
-  hipLaunchKernelGGL(lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, k, reals, t_out, c0, c0_out, c1, alpha, prev_g, prev_t,
-                     prev_c1, hist_alpha, hist_beta, host_mapped);
+                        double* hist_alpha, double* hist_beta, const double* lambda, double* host_mapped, hipStream_t s) {
+  hipLaunchKernelGGL(lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, K, L, reals, t_out, c0, c0_out, c1, alpha, prev_g, prev_t,
+                     prev_c1, hist_alpha, hist_beta, lambda, host_mapped);
   LL_HIP(hipGetLastError());
 }
 

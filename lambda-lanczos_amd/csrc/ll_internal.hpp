@@ -408,12 +408,13 @@ template <typename T> struct Lagged {
 template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
                   hipStream_t s);
-// Fold of lagged iteration k (k basis vectors, m: reals * k folded columns, *c0 = ||w||^2, copied to *c0_out): compensated coefficients in
-// place, *c1 = *c0 - |g|^2, t_out (reals * (k + 1) + 1) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha
+// Fold of a lagged iteration (K = L + k columns: L locked eigenvectors with eigenvalues lambda[0..L), then k Lanczos
+// vectors; m: reals * K folded columns, *c0 = ||w||^2, copied to *c0_out): compensated coefficients in place,
+// *c1 = *c0 - |g|^2, t_out (reals * (K + 1) + 1) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha
 // replaced by its corrected value, the iteration's four scalars published.  prev_* = nullptr after a clean iteration.
-void launch_lagged_fold(double* m, int k, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
+void launch_lagged_fold(double* m, int K, int L, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
                         double* alpha, const double* prev_g, const double* prev_t, const double* prev_c1,
-                        double* hist_alpha, double* hist_beta, double* host_mapped, hipStream_t s);
+                        double* hist_alpha, double* hist_beta, const double* lambda, double* host_mapped, hipStream_t s);
 // w -= sum_j h_j u_j over the segments; partial ||w||^2 per workgroup. h: reals*nb doubles on the device.
 template <typename T>
 int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
