@@ -725,9 +725,13 @@ template <typename T> struct LoopState {
     if (!lag_ok) return false;
     const RunList<T> in_memory = basis_runs(lag_pending ? k - 1 : k);  // u_{k-1} is not in memory while its update is pending
     const std::vector<BasisSegs<T>> groups = in_memory.groups(max_vecs_per_launch<T>());
-    // (the small-vector kernels keep the two-sweep form; sharded: decided on the shard stride, the same on every rank)
+    // (short vectors keep the two-sweep form of the small-vector kernels; sharded: decided on the shard stride, the same
+    // on every rank).  The one sweep of the streaming geometry overtakes the two small-vector sweeps from about 1 MiB per
+    // vector, well below the 4 MiB at which the streaming two-sweep kernels do (Laplacian, window 100: n = 2.0e5 14.3 ->
+    // 15.4 k it/s, 3.6e5 10.9 -> 14.0 k, 5.0e5 8.5 -> 12.4 k; n = 1.0e5 would lose 5 %; profiles/r03_small_vector_kernel_gaps.txt)
     const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;
-    if (nb_total != k + n_locked || R * nb_total > kLaggedMaxCols || groups.size() > 1 || len * (int64_t)sizeof(T) < small_bytes) {
+    const int64_t min_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);
+    if (nb_total != k + n_locked || R * nb_total > kLaggedMaxCols || groups.size() > 1 || len * (int64_t)sizeof(T) < min_bytes) {
       lag_ok = false;  // for the rest of the pass: the two-sweep iterations do not record T on the device
       return false;
     }
