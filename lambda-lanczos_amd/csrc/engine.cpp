@@ -757,7 +757,7 @@ template <typename T> struct LoopState {
     int grid;
     if (lag_pending) {
       const Lagged<T> lg{work[(k - 1) & 1].p, U.vec(k - 1), hbuf[(k - 1) & 1], hbuf[(k - 1) & 1] + t_off, lag_c1};
-      grid = launch_lagged<T>(nl, y, groups.empty() ? none : groups[0], lg, tt, E.ctx->d_partials, s);
+      grid = launch_lagged<T>(nl, y, groups.empty() ? none : groups[0], lg, tt, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
       ++n_lagged;
     } else {
       grid = launch_mdot<T>(nl, y, groups.empty() ? none : groups[0], tt, nullptr, E.ctx->d_partials, small_bytes, s);

@@ -400,16 +400,57 @@ __device__ __forceinline__ double lagged_alpha(double alpha, double g_last_re, d
   return fma(-2.0, g_last_re, alpha) - q;
 }
 
-template <typename T, int NV>
+// Strip geometry of the one-sweep kernel: PC 16-byte pieces per lane and vector.  4 (64 B per lane, 16 KiB strips) is the
+// streaming geometry of mdot / maxpy; vectors of 1 .. 3 MB have too few such strips to occupy the chip (n = 2e5 doubles:
+// 99 workgroups, 2.4 TB/s), so they take 2 pieces per lane: twice the workgroups, each wave's chain of trips as long as
+// before but with half the bytes.  Laplacian, window 100, it/s with 4 / 2 / 1 pieces: n = 2.0e5 15.6 k / 18.4 k / 18.2 k,
+// 3.6e5 14.0 k / 14.6 k / 13.7 k, 5.0e5 12.1 k / 10.0 k / 11.5 k, 1e6 7.9 k / 7.2 k / 6.9 k, config 3 604 / 589:
+// 2 pieces below 200 strips of 16 KiB, 4 from there (profiles/r03_small_vector_kernel_gaps.txt).
+template <typename T, int PC> struct lstrip {
+  static constexpr int EPT = (int)(PC * 16 / sizeof(T));
+  static constexpr int ELEMS = kBlock * EPT;
+};
+template <typename T, int PC>
+__device__ __forceinline__ void load_lstrip(const T* __restrict__ v, int64_t base, int64_t n, T (&r)[lstrip<T, PC>::EPT]) {
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+  if (i0 + EPT <= n) {
+    const uint4* p = reinterpret_cast<const uint4*>(v + i0);
+    uint4 c[PC];
+#pragma unroll
+    for (int e = 0; e < PC; ++e) c[e] = p[e];
+    __builtin_memcpy(&r[0], c, sizeof(c));
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) r[e] = (i0 + e < n) ? v[i0 + e] : zero<T>();
+  }
+}
+template <typename T, int PC>
+__device__ __forceinline__ void store_lstrip(T* __restrict__ v, int64_t base, int64_t n, const T (&r)[lstrip<T, PC>::EPT]) {
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  const int64_t i0 = base + (int64_t)threadIdx.x * EPT;
+  if (i0 + EPT <= n) {
+    uint4 c[PC];
+    __builtin_memcpy(c, &r[0], sizeof(c));
+    uint4* p = reinterpret_cast<uint4*>(v + i0);
+#pragma unroll
+    for (int e = 0; e < PC; ++e) p[e] = c[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (i0 + e < n) v[i0 + e] = r[e];
+  }
+}
+template <typename T, int NV, int PC>
 __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
-                                            const T (&wr)[strip<T>::EPT], T (&wp)[strip<T>::EPT], T (&uc)[strip<T>::EPT],
+                                            const T (&wr)[lstrip<T, PC>::EPT], T (&wp)[lstrip<T, PC>::EPT], T (&uc)[lstrip<T, PC>::EPT],
                                             const double* __restrict__ gcol, const double* __restrict__ tcol, double as,
                                             double* mine_col, int lane) {
-  constexpr int EPT = strip<T>::EPT;
+  constexpr int EPT = lstrip<T, PC>::EPT;
   constexpr int R = scalar_traits<T>::reals;
   T ur[NV][EPT];
 #pragma unroll
-  for (int b = 0; b < NV; ++b) load_strip<T>(u0 + (int64_t)b * ld, base, n, ur[b]);
+  for (int b = 0; b < NV; ++b) load_lstrip<T, PC>(u0 + (int64_t)b * ld, base, n, ur[b]);
   double a[NV * R];
 #pragma unroll
   for (int b = 0; b < NV; ++b) {
@@ -442,13 +483,13 @@ __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld
   if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
 }
 
-template <typename T>
+template <typename T, int PC>
 __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs, int nb,
                                                         Lagged<T> lg, const double* __restrict__ g,
                                                         const double* __restrict__ t, ThreeTerm<T> tt,
                                                         double* __restrict__ partials) {
-  constexpr int EPT = strip<T>::EPT;
-  constexpr int ELEMS = strip<T>::ELEMS;
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  constexpr int ELEMS = lstrip<T, PC>::ELEMS;
   constexpr int JB = kJB;
   constexpr int R = scalar_traits<T>::reals;
   const int ncols = R * (nb + 1) + 1;
@@ -476,11 +517,11 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int64_t base = sidx * ELEMS;
     T wr[EPT], wp[EPT], uc[EPT];
-    load_strip<T>(w, base, n, wr);
-    load_strip<T>(lg.r, base, n, uc);
+    load_lstrip<T, PC>(w, base, n, wr);
+    load_lstrip<T, PC>(lg.r, base, n, uc);
     if (tt.u_prev) {
       T up[EPT];
-      load_strip<T>(tt.u_prev, base, n, up);
+      load_lstrip<T, PC>(tt.u_prev, base, n, up);
 #pragma unroll
       for (int e = 0; e < EPT; ++e) wr[e] = sub(sub(wr[e], rmul(beta, up[e])), rmul(alpha, rmul(s, uc[e])));
     } else {
@@ -495,14 +536,14 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
       const int cnt = segs.count[sg];
       int j = 0;
       for (; j + JB <= cnt; j += JB, col += R * JB)
-        lagged_trip<T, JB>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
+        lagged_trip<T, JB, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
       if (j + 2 <= cnt) {
-        lagged_trip<T, 2>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
+        lagged_trip<T, 2, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
         j += 2;
         col += R * 2;
       }
       if (j < cnt) {
-        lagged_trip<T, 1>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
+        lagged_trip<T, 1, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, wr, wp, uc, g + col, t + col, as, mine + col, lane);
         j += 1;
         col += R;
       }
@@ -517,8 +558,8 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
       cfma_acc(last, uc[e], wp[e]);
       nn += abs2(wp[e]);
     }
-    store_strip<T>(lg.u_out, base, n, uc);
-    store_strip<T>(w, base, n, wp);
+    store_lstrip<T, PC>(lg.u_out, base, n, uc);
+    store_lstrip<T, PC>(w, base, n, wp);
     if constexpr (scalar_traits<T>::is_complex) {
       const double lr = wave_sum(last.re), li = wave_sum(last.im);
       if (lane == 0) {
@@ -539,19 +580,29 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
 }
 template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
-                  hipStream_t s) {
+                  int pieces, hipStream_t s) {
   int nb = 0;
   for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
   constexpr int R = scalar_traits<T>::reals;
   const int ncols = R * (nb + 1) + 1;
-  const int grid = strip_grid(n, strip<T>::ELEMS);
   const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
-  hipLaunchKernelGGL((lagged_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nb, lg, lg.g, lg.t, tt, partials);
+  // pieces per lane: enough workgroups for the chip (see lstrip)
+  const int64_t strips16k = (n * (int64_t)sizeof(T) + 16383) / 16384;
+  int pc = strips16k >= kLaggedFullStrips ? 4 : 2;
+  if (pieces == 2 || pieces == 4) pc = pieces;  // test hook (Tuning::lagged_pieces)
+  int grid;
+  if (pc == 4) {
+    grid = strip_grid(n, lstrip<T, 4>::ELEMS);
+    hipLaunchKernelGGL((lagged_kernel<T, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nb, lg, lg.g, lg.t, tt, partials);
+  } else {
+    grid = strip_grid(n, lstrip<T, 2>::ELEMS);
+    hipLaunchKernelGGL((lagged_kernel<T, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, n, w, segs, nb, lg, lg.g, lg.t, tt, partials);
+  }
   LL_HIP(hipGetLastError());
   return grid;
 }
 #define LL_INST_LAGGED(T) \
-  template int launch_lagged<T>(int64_t, T*, const BasisSegs<T>&, const Lagged<T>&, const ThreeTerm<T>&, double*, hipStream_t);
+  template int launch_lagged<T>(int64_t, T*, const BasisSegs<T>&, const Lagged<T>&, const ThreeTerm<T>&, double*, int, hipStream_t);
 LL_INST_LAGGED(double) LL_INST_LAGGED(zc) LL_INST_LAGGED(float) LL_INST_LAGGED(cf)
 
 // The fold of a lagged iteration k (one workgroup; replaces derive_norm_kernel there).  Columns: L locked eigenvectors

@@ -434,6 +434,35 @@ def test_lagged_gram_schmidt_single_precision(ctx, llenv, dtype):
     op.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32], ids=["d", "z", "s"])
+def test_both_strip_geometries_of_the_one_sweep_kernel(ctx, llenv, dtype):
+    """Vectors below 3.2 MB take 32 bytes per lane and vector (twice the workgroups), longer ones 64; LL_TEST_LAGGED_PIECES
+    forces either on the same problem: different partial sums, same traces / eigenpair to rounding, same iteration count."""
+    n = 150001
+    csr = G.randsym_np(n)
+    csr = (csr[0], csr[1], csr[2].astype(dtype))
+    wide = np.complex128 if dtype == np.complex128 else np.float64
+    init = G.start_vector(n, 1, wide).astype(dtype)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    got = []
+    for pc in ("4", "2"):
+        llenv.setenv("LL_TEST_LAGGED_PIECES", pc)
+        eng = L.LambdaLanczos(op, n, True, 1)
+        eng.init_vector = lambda v, *_: np.copyto(v, init)
+        eng.max_iteration = 120
+        vals, vecs = eng.run()
+        assert eng.last_stats["lagged_iterations"] > 50
+        got.append((vals[0], vecs[0].astype(wide), eng.getIterationCounts(), eng.last_alpha, eng.last_beta))
+    a, b = got
+    tol = 1e-12 if dtype != np.float32 else 2e-4
+    assert a[2] == b[2]
+    m = len(a[3]) if dtype != np.float32 else 12
+    assert np.max(np.abs(a[3][:m] - b[3][:m])) <= tol * 30 and np.max(np.abs(a[4][:m] - b[4][:m])) <= tol * 30
+    assert abs(a[0] - b[0]) <= tol * 30 and 1 - overlap(a[1], b[1]) <= (1e-10 if dtype != np.float32 else 1e-3)
+    op.close()
+
+
 @pytest.mark.parametrize("a", [-1j, -0.5], ids=["unitary", "real_exponent"])
 def test_lagged_gram_schmidt_in_the_exponentiator_with_full_orthogonalisation(ctx, oracle, llenv, a):
     """Exponentiator::run with full_orthogonalize (EX:120-122) through the one-sweep form, against the oracle."""
