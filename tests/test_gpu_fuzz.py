@@ -29,8 +29,13 @@ def random_hermitian(rng, n, density, complex_):
 CASES = list(range(36))
 
 
+# geometry "streaming": LL_BLAS_SMALL_BYTES=0 puts these small problems on the streaming kernels, i.e. (orth mode 0) on the
+# one-sweep Gram-Schmidt form with its repair paths: breakdown, invariant subspaces, locked eigenvectors of restart passes
+@pytest.mark.parametrize("geometry", ["default", "streaming"])
 @pytest.mark.parametrize("seed", CASES)
-def test_random_problem_matches_oracle(ctx, oracle, seed, llenv):
+def test_random_problem_matches_oracle(ctx, oracle, seed, geometry, llenv):
+    if geometry == "streaming":
+        llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 2, 3, 5, 17, 64, 200, 777, 2500]))
     complex_ = bool(rng.integers(2))
