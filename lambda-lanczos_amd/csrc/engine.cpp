@@ -624,8 +624,13 @@ template <typename T> struct LoopState {
     small_bytes = E.ctx->tune.blas_small_bytes;
     for (auto& w : work)
       if (!w.p) w.alloc(E.ctx, (size_t)ld_);
-    // everything up front: growing ctx->d_h in the middle of a run would free the pending coefficients.  Per parity
-    // of k: g (coefficients) and, t_off further, t (lagged_fold_kernel); then the device copy of alpha / beta.
+    bind_buffers();
+  }
+  // Everything up front: growing ctx->d_h in the middle of a pass would free the pending coefficients.  Per parity of k:
+  // g (coefficients) and, t_off further, t (lagged_fold_kernel); then the device copy of alpha / beta and the locked
+  // eigenvalues.  Called again at the start of every pass: a two-sweep iteration with more than ~7000 coefficient
+  // columns (Engine::orth) may have grown, i.e. moved, ctx->d_h since.
+  void bind_buffers() {
     constexpr size_t R = (size_t)Engine<T>::R;
     t_off = (size_t)kLaggedMaxCols + 8;
     const size_t half = 2 * t_off + 2 * R + 8;
@@ -652,6 +657,7 @@ template <typename T> struct LoopState {
     lag_pending = false;
     lag_ok = lagged && (n_lock == 0 || (lambda_shifted != nullptr && n_lock <= kLaggedMaxLocked));
     lag_beta2_min = 0.0;
+    if (lagged) bind_buffers();
     if (!lag_ok || n_lock == 0) return;
     LL_HIP(hipMemcpyAsync(d_lambda, lambda_shifted, (size_t)n_lock * sizeof(double), hipMemcpyHostToDevice, s));
     LL_HIP(hipStreamSynchronize(s));  // (pageable source: the caller's array may go away)
