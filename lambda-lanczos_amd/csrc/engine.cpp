@@ -648,8 +648,8 @@ template <typename T> struct LoopState {
   // two-sweep form for that pass.
   // What the compensation neglects for a locked column is c_z r with r = A z - lambda z and c_z ~ ||r|| / beta, i.e. the
   // SQUARE of the locked vector's residual: it is measured here (one operator application per locked vector and pass) and
-  // the pass takes the one-sweep form only if every ||r_i|| <= 1e-7 max|lambda| (effect on the recurrence <= 1e-14,
-  // relative).  Ritz vectors of clustered or degenerate eigenvalues, or of a pass cut off by max_iteration, do not meet
+  // the pass takes the one-sweep form only if every ||r_i|| <= 3e-8 max|lambda| (effect on the recurrence ~ 1e-15 max|lambda|
+  // at a typical beta).  Ritz vectors of clustered or degenerate eigenvalues, or of a pass cut off by max_iteration, do not meet
   // that and keep the two-sweep form.  All numbers are all-reduced: the same decision on every rank.
   void begin_pass(const T* locked_vecs, int64_t n_lock, const double* lambda_shifted = nullptr, double offset = 0.0) {
     locked = locked_vecs;
