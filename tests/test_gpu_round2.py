@@ -76,6 +76,38 @@ def test_c3_full_size_eigenpair_matches_the_real_reference(ctx, c3, reference):
     op.close()
 
 
+def test_c3_full_size_window_100_one_sweep_and_two_sweep_forms_give_the_same_recurrence(ctx, c3, llenv):
+    """Config 3 at n = 1e7, the bench's window of 100 iterations, in the one-sweep (default) and in the two-sweep
+    Gram-Schmidt form (LL_FUSE_LAUNCHES=1): alpha / beta of all 100 iterations to 1e-11 ||A||, Ritz pair to rounding, and
+    the Ritz vector is one: ||A v - theta v|| equals the Lanczos estimate beta_m |s_m| computed from the trace."""
+    import scipy.linalg as sl
+    n, csr = c3
+    init = G.start_vector_fast(n, 1)
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for fuse in ("1", "2"):
+        llenv.setenv("LL_FUSE_LAUNCHES", fuse)
+        eng = L.LambdaLanczos(op, n, True, 1)
+        eng.max_iteration = 100
+        eng.init_vector = fixed_init(init)
+        vals, vecs = eng.run()
+        got[fuse] = (vals[0], vecs[0], eng.last_alpha.copy(), eng.last_beta.copy(), eng.last_stats["lagged_iterations"])
+    two, one = got["1"], got["2"]
+    assert two[4] == 0 and one[4] >= 98
+    anorm = 30.0
+    assert np.max(np.abs(one[2] - two[2])) <= 1e-11 * anorm and np.max(np.abs(one[3] - two[3])) <= 1e-11 * anorm
+    assert abs(one[0] - two[0]) <= 1e-12 * anorm and 1 - overlap(one[1], two[1]) <= 1e-10
+    # residual of the returned pair against the estimate from T_100 (a property of a correct Lanczos basis at any size)
+    xd, yd = ctx.to_device(one[1]), ctx.empty(n)
+    L.spmv(op, xd, yd)
+    res = np.linalg.norm(yd.get() - one[0] * one[1])
+    w, s = sl.eigh_tridiagonal(one[2], one[3][:-1])
+    est = one[3][-1] * abs(s[-1, -1])
+    assert abs(w[-1] - one[0]) <= 1e-11 * anorm
+    assert abs(res - est) <= 1e-9 * anorm
+    op.close()
+
+
 def test_c2_full_size_short_window_traces_match_the_oracle(ctx, oracle):
     """Config 2 at n = 1e6 (1000 x 1000 Laplacian, smallest, offset -8): alpha/beta of a 24-iteration window and the
     Ritz pair against the CPU oracle's reference-order MGS loop."""
