@@ -382,8 +382,10 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
+    lagged_timed = 0
     for _ in range(args.steps):
         itern.append(step())
+        lagged_timed += int((eng.last_stats or {}).get("lagged_iterations", 0))
         if inline:
             for key in stats_acc:
                 stats_acc[key] += eng.last_stats[key]
@@ -438,7 +440,7 @@ def main():
     # Gram-Schmidt kernels of the instrumented windows: algorithmic bytes (minimal-pass model minus the SpMV) / device time
     s = 16 if complex_ else 8
     two_sweep_bytes = sum(s * n * (2 * k + 9) for it in itern_phases for k in range(1, it + 1))
-    lagged_gs = stats_acc["lagged_iterations"] > 0
+    lagged_gs = lagged_timed > 0   # the Gram-Schmidt form of the TIMED steps (ll_run_stats.lagged_iterations)
     if wl == "c5":
         orth_bytes = sum(s * n * 9 for it in itern_phases for _k in range(1, it + 1))
         orth_model = "s*n*9 bytes per iteration (no Gram-Schmidt against the basis: Exponentiator default)"
@@ -600,6 +602,13 @@ def main():
                 "partition": "single GPU" if world == 1 else "1-D row partition over %d GPUs, RCCL %s" % (
                     world, "halo exchange" if lattice else "all-gather of x in chunks on a second stream, own-column SpMV under it"),
                 "orth_mode": args.orth_mode,
+                "gram_schmidt": ("no re-orthogonalisation (Exponentiator default, EX:120)" if wl == "c5" else
+                                 ("full re-orthogonalisation against all previous Lanczos vectors in every iteration, "
+                                  "block classical Gram-Schmidt; " +
+                                  ("ONE sweep over the basis per iteration: the update is applied one iteration late and its "
+                                   "effect on the recurrence is compensated exactly (DESIGN.md 3.2; %d of the %d timed "
+                                   "iterations; LL_FUSE_LAUNCHES=1 runs the two-sweep form)" % (lagged_timed, total_iters)
+                                   if lagged_gs else "two sweeps over the basis per iteration (multi-dot, multi-axpy)"))),
                 "tridiag_mode": int(eng.tridiag_mode) if hasattr(eng, "tridiag_mode") else None,
                 "eps": "engine default" if args.eps is None else args.eps,
                 "io": ("host buffers at the boundary (PCIe copies inside the timed region)" if args.host_io else
@@ -640,7 +649,7 @@ def main():
                                 "achieved = algorithmic bytes of the timed steps / their device time",
                 "algorithmic_bytes_per_step": orth_bytes / max(len(itern_phases), 1),
                 "model": orth_model,
-                "lagged_iterations": stats_acc["lagged_iterations"],
+                "lagged_iterations_timed_steps": lagged_timed,
                 "two_sweep_model_bytes_per_step": (two_sweep_bytes / max(len(itern_phases), 1)) if wl != "c5" else None,
             },
             "phases": {
