@@ -36,9 +36,16 @@ def gpu_engine(ctx, csr, find_max, k, **fields):
 
 
 # ------------------------------------------------------------------ the reference's known-answer tests (T1:128-536)
+# geometry "streaming" (LL_BLAS_SMALL_BYTES=0) puts these small problems on the streaming kernels and, in the block
+# Gram-Schmidt mode, on the one-sweep form with its locked-vector and breakdown paths
+@pytest.mark.parametrize("geometry", ["default", "streaming"])
 @pytest.mark.parametrize("name", sorted(cases.eigen_cases()))
 @pytest.mark.parametrize("orth_mode", [L.ORTH_CGS_DGKS, L.ORTH_MGS])
-def test_reference_known_answers(ctx, oracle, name, orth_mode):
+def test_reference_known_answers(ctx, oracle, name, orth_mode, geometry, llenv):
+    if geometry == "streaming":
+        if orth_mode == L.ORTH_MGS:
+            pytest.skip("the sequential mode has one geometry-independent code path per vector")
+        llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
     case = cases.eigen_cases()[name]
     csr = case["csr"]
     n = csr[0].shape[0] - 1
