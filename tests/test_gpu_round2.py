@@ -183,6 +183,9 @@ def test_overlapped_exchange_equals_the_serial_path_with_a_real_rccl_communicato
         eng.max_iteration = 40
         eng.init_vector = fixed_init(init)
         vals, vecs = eng.run()
+        # (1.6 MB shards: the one-sweep Gram-Schmidt form, i.e. the gather of the unnormalised vector and RCCL's all-reduce
+        # of the sweep's columns in front of lagged_fold_kernel)
+        assert eng.last_stats["lagged_iterations"] >= 35
         xd, yd = c.to_device(init), c.empty(n)
         L.spmv(op, xd, yd, offset=-0.5)
         got[overlap_on] = (eng.last_alpha.copy(), eng.last_beta.copy(), float(vals[0]), vecs[0].copy(), yd.get())
