@@ -58,6 +58,7 @@ Tuning read_tuning() {
     t.lagged_gs = level >= 2;
   }
   t.lagged_pieces = (int)num("LL_TEST_LAGGED_PIECES", 0);
+  t.lagged_min_bytes = num("LL_TEST_LAGGED_MIN_BYTES", -1);
   t.force_rp64 = flag("LL_FORCE_RP64", false);
   t.pb_test_all_remote = flag("LL_PB_TEST_ALL_REMOTE", false);
   t.tridiag_test_jitter_us = (int)num("LL_TRIDIAG_TEST_JITTER_US", 0);

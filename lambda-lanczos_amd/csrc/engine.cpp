@@ -731,12 +731,19 @@ template <typename T> struct LoopState {
     if (!lag_ok) return false;
     const RunList<T> in_memory = basis_runs(lag_pending ? k - 1 : k);  // u_{k-1} is not in memory while its update is pending
     const std::vector<BasisSegs<T>> groups = in_memory.groups(max_vecs_per_launch<T>());
-    // (short vectors keep the two-sweep form of the small-vector kernels; sharded: decided on the shard stride, the same
+    // (very short vectors keep the two-sweep form of the small-vector kernels; sharded: decided on the shard stride, the same
     // on every rank).  The one sweep of the streaming geometry overtakes the two small-vector sweeps from about 1 MiB per
     // vector, well below the 4 MiB at which the streaming two-sweep kernels do (Laplacian, window 100: n = 2.0e5 14.3 ->
     // 15.4 k it/s, 3.6e5 10.9 -> 14.0 k, 5.0e5 8.5 -> 12.4 k; n = 1.0e5 would lose 5 %; profiles/r03_small_vector_kernel_gaps.txt)
     const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;
-    const int64_t min_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);
+    const int64_t stream_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);  // from here the streaming geometry
+    // ... and below it, down to 320 KiB, the one-sweep kernel of the small-vector geometry (lagged_small_kernel): four
+    // launches per iteration against the three of the two small-vector sweeps, but one pass over the basis: Laplacian,
+    // window 100: n = 5.0e4 20.8 -> 25.8 k it/s, 1.0e5 18.3 -> 21.0 k; n = 3.0e4 26.3 -> 25.3 k and n = 1e4 26.4 -> 19.1 k
+    // would lose (profiles/r03_small_vector_kernel_gaps.txt)
+    const int64_t min_default = std::min<int64_t>(stream_bytes, (int64_t)320 << 10);
+    const int64_t min_bytes = E.ctx->tune.lagged_min_bytes >= 0 ? std::min<int64_t>(E.ctx->tune.lagged_min_bytes, stream_bytes)
+                                                                  : min_default;
     if (nb_total != k + n_locked || R * nb_total > kLaggedMaxCols || groups.size() > 1 || len * (int64_t)sizeof(T) < min_bytes) {
       lag_ok = false;  // for the rest of the pass: the two-sweep iterations do not record T on the device
       return false;
@@ -763,7 +770,8 @@ template <typename T> struct LoopState {
     int grid;
     if (lag_pending) {
       const Lagged<T> lg{work[(k - 1) & 1].p, U.vec(k - 1), hbuf[(k - 1) & 1], hbuf[(k - 1) & 1] + t_off, lag_c1};
-      grid = launch_lagged<T>(nl, y, groups.empty() ? none : groups[0], lg, tt, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
+      grid = launch_lagged<T>(nl, y, groups.empty() ? none : groups[0], lg, tt, E.ctx->d_partials, E.ctx->tune.lagged_pieces,
+                              stream_bytes, s);
       ++n_lagged;
     } else {
       grid = launch_mdot<T>(nl, y, groups.empty() ? none : groups[0], tt, nullptr, E.ctx->d_partials, small_bytes, s);

@@ -579,12 +579,24 @@ __global__ __launch_bounds__(kBlock) void lagged_kernel(int64_t n, T* __restrict
     out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
 }
 template <typename T>
+__global__ void lagged_small_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs, int nb, Lagged<T> lg,
+                                    const double* __restrict__ g, const double* __restrict__ t, ThreeTerm<T> tt,
+                                    double* __restrict__ partials);  // (further down, with the small-vector kernels)
+int small_lagged_lds_doubles(int ncols, int ept_times_reals);
+template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
-                  int pieces, hipStream_t s) {
+                  int pieces, int64_t small_limit, hipStream_t s) {
   int nb = 0;
   for (int i = 0; i < segs.nseg; ++i) nb += segs.count[i];
   constexpr int R = scalar_traits<T>::reals;
   const int ncols = R * (nb + 1) + 1;
+  if (n * (int64_t)sizeof(T) < small_limit) {  // small-vector geometry: four waves per 1 KiB strip split the basis
+    const int grid = strip_grid(n, (int)(64 * (16 / sizeof(T))));
+    const size_t lds_small = (size_t)small_lagged_lds_doubles(ncols, (int)(16 / sizeof(T)) * R) * sizeof(double);
+    hipLaunchKernelGGL((lagged_small_kernel<T>), dim3(grid), dim3(kBlock), lds_small, s, n, w, segs, nb, lg, lg.g, lg.t, tt, partials);
+    LL_HIP(hipGetLastError());
+    return grid;
+  }
   const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
   // pieces per lane: enough workgroups for the chip (see lstrip)
   const int64_t strips16k = (n * (int64_t)sizeof(T) + 16383) / 16384;
@@ -602,7 +614,7 @@ int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg
   return grid;
 }
 #define LL_INST_LAGGED(T) \
-  template int launch_lagged<T>(int64_t, T*, const BasisSegs<T>&, const Lagged<T>&, const ThreeTerm<T>&, double*, int, hipStream_t);
+  template int launch_lagged<T>(int64_t, T*, const BasisSegs<T>&, const Lagged<T>&, const ThreeTerm<T>&, double*, int, int64_t, hipStream_t);
 LL_INST_LAGGED(double) LL_INST_LAGGED(zc) LL_INST_LAGGED(float) LL_INST_LAGGED(cf)
 
 // The fold of a lagged iteration k (one workgroup; replaces derive_norm_kernel there).  Columns: L locked eigenvectors
@@ -971,6 +983,181 @@ __global__ __launch_bounds__(kBlock) void maxpy_small_kernel(int64_t n, T* __res
   }
 }
 
+
+int small_lagged_lds_doubles(int ncols, int ept_times_reals) {
+  return ((ncols + 15) & ~15) + 4 * 16 * kSmallTileRow + 2 * kBlock * ept_times_reals;
+}
+// One-sweep Gram-Schmidt (lagged_kernel's algebra, see there) in the SMALL-VECTOR geometry: four waves share a strip of
+// 64 lanes x 16 B and split the basis between them (trips of kSmallJB vectors dealt round-robin).  Every wave takes the
+// coefficients <u_j, wr> of its vectors (LDS-transposed column sums, as in mdot_small_kernel) and accumulates its share
+// of sum g_j u_j (late update of u_{k-1}) and of sum d_j u_j (compensation of w); wave 0 adds the four shares in a fixed
+// order (as in maxpy_small_kernel), finishes u_{k-1} and w, and takes the last coefficient and ||w||^2.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lagged_small_kernel(int64_t n, T* __restrict__ w, BasisSegs<T> segs, int nb,
+                                                              Lagged<T> lg, const double* __restrict__ g,
+                                                              const double* __restrict__ t, ThreeTerm<T> tt,
+                                                              double* __restrict__ partials) {
+  constexpr int EPT = small_geom<T>::EPT;
+  constexpr int ELEMS = small_geom<T>::ELEMS;
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = R * (nb + 1) + 1;
+  extern __shared__ double lds[];  // [ncols] column sums, one [16][65] tile per wave, the waves' shares of the two updates
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* cols = lds;
+  double* tile = lds + ((ncols + 15) & ~15) + wave * (16 * kSmallTileRow);
+  double* share_u = lds + ((ncols + 15) & ~15) + 4 * (16 * kSmallTileRow);
+  double* share_w = share_u + (size_t)kBlock * EPT * R;
+  for (int i = tid; i < ncols; i += kBlock) cols[i] = 0.0;
+  double alpha;
+  if (tt.alpha_partials) {
+    __shared__ double fold_scratch[5];
+    alpha = fold_partials_all(tt.alpha_partials, tt.alpha_nparts, fold_scratch);
+    if (blockIdx.x == 0 && tid == 0) *tt.alpha_out = alpha;  // as measured; lagged_fold_kernel corrects it in place
+  } else {
+    alpha = *tt.alpha;
+  }
+  alpha = lagged_alpha(alpha, g[R * (nb - 1)], t[R * (nb + 1)]);
+  const double beta = sqrt(*lg.beta2), s = 1.0 / beta;
+  const double as = alpha * s;
+  acc_t<T> dlast;
+  if constexpr (scalar_traits<T>::is_complex) dlast = zc{t[R * nb], t[R * nb + 1]};
+  else dlast = t[R * nb];
+  __syncthreads();
+
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {  // same trip count for every wave of the workgroup
+    const int64_t i0 = sidx * ELEMS + (int64_t)lane * EPT;
+    T wr[EPT], rr[EPT];
+    load_small<T>(w, i0, n, wr);
+    load_small<T>(lg.r, i0, n, rr);
+    if (tt.u_prev) {
+      T up[EPT];
+      load_small<T>(tt.u_prev, i0, n, up);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) wr[e] = sub(sub(wr[e], rmul(beta, up[e])), rmul(alpha, rmul(s, rr[e])));
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) wr[e] = sub(wr[e], rmul(alpha, rmul(s, rr[e])));
+    }
+    acc_t<T> du[EPT], dw[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      du[e] = zero<acc_t<T>>();
+      dw[e] = zero<acc_t<T>>();
+    }
+    int trip = 0, col0 = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+      for (int j = 0; j < cnt; j += kSmallJB, ++trip) {
+        if ((trip & 3) != wave) continue;
+        const int nv = min(kSmallJB, cnt - j);
+        T ur[kSmallJB][EPT];
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b)
+          if (b < nv) load_small<T>(ub + (int64_t)(j + b) * segs.ld, i0, n, ur[b]);
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b) {
+          acc_t<T> acc = zero<acc_t<T>>();
+          if (b < nv) {
+            const double* gc = g + col0 + R * (j + b);
+            const double* tc = t + col0 + R * (j + b);
+            acc_t<T> gj, dj;
+            if constexpr (scalar_traits<T>::is_complex) {
+              gj = zc{gc[0], gc[1]};
+              dj = zc{fma(-as, gj.re, tc[0]), fma(-as, gj.im, tc[1])};
+            } else {
+              gj = gc[0];
+              dj = fma(-as, gj, tc[0]);
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+              cfma_acc(acc, ur[b][e], wr[e]);
+              fma_acc(du[e], gj, to_acc(ur[b][e]));
+              fma_acc(dw[e], dj, to_acc(ur[b][e]));
+            }
+          }
+          if constexpr (scalar_traits<T>::is_complex) {
+            tile[(2 * b) * kSmallTileRow + lane] = acc.re;
+            tile[(2 * b + 1) * kSmallTileRow + lane] = acc.im;
+          } else {
+            tile[b * kSmallTileRow + lane] = acc;
+          }
+        }
+        wave_lds_handover();
+        const int i = lane >> 2, q = lane & 3;
+        double sum = 0.0;
+        if (i < nv * R) {
+          const double* row = tile + i * kSmallTileRow + q * 16;
+#pragma unroll
+          for (int tt2 = 0; tt2 < 16; ++tt2) sum += row[tt2];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if (q == 0 && i < nv * R) cols[col0 + R * j + i] += sum;  // this column belongs to this wave alone
+        wave_lds_handover();
+      }
+      col0 += R * cnt;
+    }
+    double* mu = share_u + ((size_t)wave * 64 + lane) * (EPT * R);
+    double* mw = share_w + ((size_t)wave * 64 + lane) * (EPT * R);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      if constexpr (scalar_traits<T>::is_complex) {
+        mu[2 * e] = du[e].re;
+        mu[2 * e + 1] = du[e].im;
+        mw[2 * e] = dw[e].re;
+        mw[2 * e + 1] = dw[e].im;
+      } else {
+        mu[e] = du[e];
+        mw[e] = dw[e];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      T uc[EPT], wp[EPT];
+      acc_t<T> last = zero<acc_t<T>>();
+      double nn = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        acc_t<T> su, sw;
+        auto at = [&](const double* base, int wv, int idx) { return base[((size_t)wv * 64 + lane) * (EPT * R) + idx]; };
+        if constexpr (scalar_traits<T>::is_complex) {
+          su = zc{(at(share_u, 0, 2 * e) + at(share_u, 1, 2 * e)) + (at(share_u, 2, 2 * e) + at(share_u, 3, 2 * e)),
+                  (at(share_u, 0, 2 * e + 1) + at(share_u, 1, 2 * e + 1)) + (at(share_u, 2, 2 * e + 1) + at(share_u, 3, 2 * e + 1))};
+          sw = zc{(at(share_w, 0, 2 * e) + at(share_w, 1, 2 * e)) + (at(share_w, 2, 2 * e) + at(share_w, 3, 2 * e)),
+                  (at(share_w, 0, 2 * e + 1) + at(share_w, 1, 2 * e + 1)) + (at(share_w, 2, 2 * e + 1) + at(share_w, 3, 2 * e + 1))};
+        } else {
+          su = (at(share_u, 0, e) + at(share_u, 1, e)) + (at(share_u, 2, e) + at(share_u, 3, e));
+          sw = (at(share_w, 0, e) + at(share_w, 1, e)) + (at(share_w, 2, e) + at(share_w, 3, e));
+        }
+        uc[e] = rmul(s, narrow<T>(sub(to_acc(rr[e]), su)));
+        wp[e] = narrow<T>(sub(to_acc(wr[e]), sw));
+        fnma_acc(wp[e], dlast, uc[e]);
+        cfma_acc(last, uc[e], wp[e]);
+        nn += abs2(wp[e]);
+      }
+      store_small<T>(lg.u_out, i0, n, uc);
+      store_small<T>(w, i0, n, wp);
+      if constexpr (scalar_traits<T>::is_complex) {
+        const double lr = wave_sum(last.re), li = wave_sum(last.im);
+        if (lane == 0) {
+          cols[R * nb] += lr;
+          cols[R * nb + 1] += li;
+        }
+      } else {
+        const double lr = wave_sum(last);
+        if (lane == 0) cols[R * nb] += lr;
+      }
+      nn = wave_sum(nn);
+      if (lane == 0) cols[ncols - 1] += nn;
+    }
+    __syncthreads();  // the shares are rewritten by the next strip
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < ncols; i += kBlock) out[i] = cols[i];
+}
 
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,

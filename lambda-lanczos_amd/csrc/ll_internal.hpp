@@ -165,6 +165,7 @@ struct Tuning {
   int64_t slab_bytes = (int64_t)4 << 30;       // LL_SLAB_BYTES: cap of one Krylov-basis slab
   int64_t blas_small_bytes = (int64_t)4 << 20;  // LL_BLAS_SMALL_BYTES: vectors below this use the small-vector kernels
   bool fuse_launches = true;       // LL_FUSE_LAUNCHES=0: separate fold / publish kernels (A/B of the launch fusion)
+  long long lagged_min_bytes = -1; // test hook LL_TEST_LAGGED_MIN_BYTES: shortest vector of the one-sweep form (-1 = default)
   int lagged_pieces = 0;           // test hook LL_TEST_LAGGED_PIECES: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
   // --- test hooks (not for users)
@@ -411,7 +412,7 @@ template <typename T> struct Lagged {
 constexpr int kLaggedFullStrips = 200;
 template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
-                  int pieces, hipStream_t s);
+                  int pieces, int64_t small_limit, hipStream_t s);  // vectors below small_limit bytes: lagged_small_kernel
 // Fold of a lagged iteration (K = L + k columns: L locked eigenvectors with eigenvalues lambda[0..L), then k Lanczos
 // vectors; m: reals * K folded columns, *c0 = ||w||^2, copied to *c0_out): compensated coefficients in place,
 // *c1 = *c0 - |g|^2, t_out (reals * (K + 1) + 1) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha

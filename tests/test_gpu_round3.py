@@ -306,6 +306,42 @@ def _lagged_case(name):
     return N * N, G.torus_np(N), G.start_vector(N * N, 3, np.complex128), False, -10.0
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128, np.float32, np.complex64], ids=["d", "z", "s", "c"])
+def test_one_sweep_form_in_the_small_vector_geometry(ctx, llenv, dtype):
+    """Vectors between 320 KiB and 1 MiB take the one-sweep form through lagged_small_kernel (four waves per 1 KiB strip
+    split the basis); LL_TEST_LAGGED_MIN_BYTES=0 puts a 30 011-row problem there.  Against the two-sweep small-vector
+    kernels (LL_FUSE_LAUNCHES=1): same iteration count, traces to 1e-11 ||A|| (float: the first dozen to float rounding)."""
+    single = dtype in (np.float32, np.complex64)
+    wide = np.complex128 if dtype in (np.complex128, np.complex64) else np.float64
+    n = 30011
+    csr = G.randsym_np(n)
+    csr = (csr[0], csr[1], csr[2].astype(dtype))
+    init = G.start_vector(n, 1, wide).astype(dtype)
+    llenv.setenv("LL_TEST_LAGGED_MIN_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for fuse in ("1", "2"):
+        llenv.setenv("LL_FUSE_LAUNCHES", fuse)
+        eng = L.LambdaLanczos(op, n, True, 2)
+        eng.init_vector = lambda v, *_: np.copyto(v, init)
+        vals, vecs = eng.run()
+        got[fuse] = (vals, [v.astype(wide) for v in vecs], eng.getIterationCounts(), eng.last_alpha, eng.last_beta, eng.last_stats)
+    two, one = got["1"], got["2"]
+    assert two[5]["lagged_iterations"] == 0 and one[5]["lagged_iterations"] >= one[2][0] - 2
+    scale = 30.0
+    if single:
+        assert abs(one[2][0] - two[2][0]) <= 2
+        assert np.max(np.abs(one[3][:12] - two[3][:12])) <= 2e-4 * scale and np.max(np.abs(one[0] - two[0])) <= 2e-3 * scale
+    else:
+        assert one[2] == two[2]
+        m = min(len(one[3]), len(two[3]))
+        assert np.max(np.abs(one[3][:m] - two[3][:m])) <= 1e-11 * scale and np.max(np.abs(one[4][:m] - two[4][:m])) <= 1e-11 * scale
+        assert np.max(np.abs(one[0] - two[0])) <= 1e-11 * scale
+        for i in range(2):
+            assert 1 - overlap(one[1][i], two[1][i]) <= 1e-9
+    op.close()
+
+
 @pytest.mark.parametrize("name", ["randsym", "laplace", "torus", "laplace_long"])
 def test_lagged_gram_schmidt_keeps_the_recurrence_of_the_two_sweep_form(ctx, llenv, name):
     """The one-sweep (lagged, compensated) Gram-Schmidt form against the two-sweep kernels on the same operator and
