@@ -66,10 +66,12 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
                                          (2, {"LL_TRIDIAG_TEST_JITTER_US": "1500", "LL_TRIDIAG_LAG": "0"}),
                                          (2, {"LL_BLAS_SMALL_BYTES": "0"}), (3, {"LL_BLAS_SMALL_BYTES": "0"}),
                                          (2, {"LL_BLAS_SMALL_BYTES": "0", "LL_DGKS_THRESHOLD": "2.0"}),
-                                         (3, {"LL_BLAS_SMALL_BYTES": "0", "LL_TRIDIAG_TEST_JITTER_US": "3000"})],
+                                         (3, {"LL_BLAS_SMALL_BYTES": "0", "LL_TRIDIAG_TEST_JITTER_US": "3000"}),
+                                         (2, {"LL_TEST_LAGGED_MIN_BYTES": "0"}), (3, {"LL_TEST_LAGGED_MIN_BYTES": "0"})],
                          ids=["2", "3", "4", "2-forced-second-pass", "2-measured-norm", "3-one-chunk",
                               "3-verdict-jitter", "2-verdict-jitter-lag0", "2-one-sweep", "3-one-sweep",
-                              "2-one-sweep-forced-second-pass", "3-one-sweep-verdict-jitter"])
+                              "2-one-sweep-forced-second-pass", "3-one-sweep-verdict-jitter", "2-one-sweep-small-geometry",
+                              "3-one-sweep-small-geometry"])
 def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, world, extra, llenv):
     ranks = run_ranks(tmp_path, world, **extra)
 
@@ -93,7 +95,7 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
             assert r[key]["alpha"] == ranks[0][key]["alpha"]
         assert sum(r[key]["n_local"] for r in ranks) == n
         # the one-sweep Gram-Schmidt form runs on sharded contexts too (streaming geometry: forced by the *-one-sweep cases)
-        one_sweep = extra.get("LL_BLAS_SMALL_BYTES") == "0"
+        one_sweep = extra.get("LL_BLAS_SMALL_BYTES") == "0" or extra.get("LL_TEST_LAGGED_MIN_BYTES") == "0"
         assert all((r[key]["lagged"] > 0) == one_sweep for r in ranks)
         vals = np.array(ranks[0][key]["vals"])
         assert np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * np.max(np.abs(vals))
