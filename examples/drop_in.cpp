@@ -10,12 +10,22 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <random>
 #include <tuple>
 #include <vector>
 
 using lambda_lanczos::LambdaLanczos;  // the namespace alias keeps existing code compiling
 
-int main() {
+int main(int argc, char** argv) {
+  // A fixed start vector makes the run reproducible (the reference's default draws from std::random_device,
+  // lambda_lanczos.hpp:70-104); any seed works, the optional argument picks another one.
+  const unsigned seed = argc > 1 ? (unsigned)std::strtoul(argv[1], nullptr, 10) : 1u;
+  auto seeded_start = [seed](std::vector<double>& v) {
+    std::mt19937 mt(seed);
+    std::uniform_real_distribution<double> rand(-1.0, 1.0);
+    for (auto& e : v) e = rand(mt);
+  };
   // a ring of n sites with alternating on-site energies and nearest-neighbour hopping, as triplets
   const int n = 2000;
   std::vector<std::tuple<int, int, double>> triplets;
@@ -31,6 +41,7 @@ int main() {
   };
   LambdaLanczos<double> engine(mv_mul, n, false, 2);  // two lowest eigenpairs
   engine.eigenvalue_offset = -3.0;                     // so that the lowest eigenvalues have the largest magnitude
+  engine.init_vector = seeded_start;
   std::vector<double> values;
   std::vector<std::vector<double>> vectors;
   engine.run(values, vectors);
@@ -51,6 +62,7 @@ int main() {
   lambda_lanczos::CsrMatrix<double> A(row_ptr, col, val);
   LambdaLanczos<double> device_engine(A, n, false, 2);
   device_engine.eigenvalue_offset = -A.inf_norm();     // a safe offset from the matrix itself
+  device_engine.init_vector = seeded_start;
   std::vector<double> dvalues;
   std::vector<std::vector<double>> dvectors;
   device_engine.run(dvalues, dvectors);

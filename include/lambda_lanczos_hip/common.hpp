@@ -80,6 +80,7 @@ class Context {
  public:
   explicit Context(int device = 0) {
     ll_context* c = nullptr;
+    check(LL_ABI_CHECK());  // a binary built against an older lanczos_hip.h must not hand its structs to this library
     check(ll_ctx_create(device, &c));
     h_.reset(c, [](ll_context* p) { ll_ctx_destroy(p); });
   }

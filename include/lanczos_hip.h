@@ -44,7 +44,9 @@ extern "C" {
 #endif
 
 #define LL_VERSION_MAJOR 0
-#define LL_VERSION_MINOR 2  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers */
+#define LL_VERSION_MINOR 3  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers
+                             * 3: ll_run_stats.lagged_iterations + reserved tail (the struct grew: code compiled against a
+                             *    minor-2 header must be rebuilt — ll_abi_check refuses it), ll_ctx_reload_env, ll_abi_check */
 
 enum {
   LL_OK = 0,
@@ -64,6 +66,12 @@ typedef struct ll_operator ll_operator; /* the mv_mul plugin: device CSR, host c
 const char* ll_last_error(void);
 /* LL_VERSION_MAJOR * 1000 + LL_VERSION_MINOR */
 int ll_version(void);
+/* ABI handshake: pass the LL_VERSION_* the CALLER was compiled with and sizeof(ll_run_stats) / sizeof(ll_lanczos_params) as
+ * the caller sees them.  LL_OK when the loaded library lays the structs out the same way; LL_ERR_INVALID (with a message
+ * naming both versions) otherwise — the library fills ll_run_stats and reads the parameter structs by ITS layout, so a
+ * stale binary would be overrun.  The C++ facade and the Python binding call it once per process. */
+int ll_abi_check(int caller_major, int caller_minor, size_t sizeof_run_stats, size_t sizeof_lanczos_params);
+#define LL_ABI_CHECK() ll_abi_check(LL_VERSION_MAJOR, LL_VERSION_MINOR, sizeof(ll_run_stats), sizeof(ll_lanczos_params))
 
 /* Create a context on HIP device `device` with its own non-blocking stream. */
 int ll_ctx_create(int device, ll_context** out);
@@ -364,6 +372,7 @@ typedef struct ll_run_stats {
   double seconds_comm_gather;    /* device time of the all-gathers / halo exchanges (their own stream; 0 unless profiling) */
   double seconds_comm_allreduce; /* device time of the all-reduces (0 unless profiling) */
   int64_t lagged_iterations;     /* iterations that ran in the one-sweep (lagged) Gram-Schmidt form */
+  int64_t reserved[8];           /* zero; later statistics are taken from here, so the struct size stays what it is */
 } ll_run_stats;
 int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 

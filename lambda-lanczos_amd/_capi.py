@@ -18,6 +18,9 @@ SPMV_CSR_STREAM, SPMV_PB = 0, 1
 UNIQUE_ID_BYTES = 128
 
 
+ABI_VERSION = (0, 3)  # LL_VERSION_MAJOR, LL_VERSION_MINOR of the include/lanczos_hip.h these mirrors were written against
+
+
 class LanczosHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("liblanczos_hip error %d: %s" % (code, msg))
@@ -91,10 +94,11 @@ class RunStats(C.Structure):
         ("seconds_comm_gather", f64),
         ("seconds_comm_allreduce", f64),
         ("lagged_iterations", i64),
+        ("reserved", i64 * 8),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 P = C.POINTER
@@ -102,6 +106,7 @@ P = C.POINTER
 PROTOTYPES = {
     "ll_last_error": (C.c_char_p, []),
     "ll_version": (C.c_int, []),
+    "ll_abi_check": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_size_t]),
     "ll_ctx_create": (C.c_int, [C.c_int, P(vp)]),
     "ll_ctx_create_on_stream": (C.c_int, [C.c_int, vp, P(vp)]),
     "ll_ctx_destroy": (C.c_int, [vp]),
@@ -202,6 +207,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        # ABI handshake (lanczos_hip.h, ll_abi_check): the ctypes mirrors below must lay the structs out like the library
+        if handle.ll_abi_check(ABI_VERSION[0], ABI_VERSION[1], C.sizeof(RunStats), C.sizeof(LanczosParams)) != LL_OK:
+            raise LanczosHipError(LL_ERR_INVALID, handle.ll_last_error().decode("utf-8", "replace"))
         _lib = handle
     return _lib
 

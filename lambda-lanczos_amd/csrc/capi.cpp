@@ -67,6 +67,7 @@ Tuning read_tuning() {
     const std::string v = str("LL_STALL_TRACE");
     if (!v.empty()) t.stall_trace_ms = std::atof(v.c_str());
   }
+  t.iter_trace = str("LL_ITER_TRACE");
   return t;
 }
 }  // namespace ll
@@ -87,6 +88,13 @@ void ll_context::dev_malloc(void** out, size_t bytes, const char* what) {
     (void)hipGetLastError();
     set_error(std::string("out of device memory: ") + what + " (" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
     throw Failure{LL_ERR_ALLOC};
+  }
+}
+void ll_context::cache_put(void* p, size_t bytes) {
+  slab_cache.emplace_back(p, bytes);
+  while (slab_cache.size() > kSlabCacheMaxEntries) {  // least recently returned first
+    (void)hipFree(slab_cache.front().first);
+    slab_cache.erase(slab_cache.begin());
   }
 }
 void ll_context::ensure_partials(size_t doubles) {
@@ -215,6 +223,17 @@ extern "C" {
 
 const char* ll_last_error(void) { return g_last_error.c_str(); }
 int ll_version(void) { return LL_VERSION_MAJOR * 1000 + LL_VERSION_MINOR; }
+int ll_abi_check(int caller_major, int caller_minor, size_t sizeof_run_stats, size_t sizeof_lanczos_params) {
+  if (caller_major == LL_VERSION_MAJOR && caller_minor == LL_VERSION_MINOR && sizeof_run_stats == sizeof(ll_run_stats) &&
+      sizeof_lanczos_params == sizeof(ll_lanczos_params))
+    return LL_OK;
+  set_error("ABI mismatch: the caller was compiled against lanczos_hip.h " + std::to_string(caller_major) + "." +
+            std::to_string(caller_minor) + " (ll_run_stats " + std::to_string(sizeof_run_stats) + " B, ll_lanczos_params " +
+            std::to_string(sizeof_lanczos_params) + " B), the loaded library is " + std::to_string(LL_VERSION_MAJOR) + "." +
+            std::to_string(LL_VERSION_MINOR) + " (" + std::to_string(sizeof(ll_run_stats)) + " / " +
+            std::to_string(sizeof(ll_lanczos_params)) + " B): rebuild the caller");
+  return LL_ERR_INVALID;
+}
 
 static int ctx_create_impl(int device, void* stream, bool own, ll_context** out) {
   return guarded([&] {
@@ -649,15 +668,25 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
   double best = time_pb();
   void* best_arena = op->d_pb_arena;
   std::vector<void*> losers;
-  struct FreeAll {
+  // Unwinding (a failed copy or launch, thrown through LL_HIP): the operator goes back to the best image found so far and
+  // every other copy is freed exactly once — `losers` never contains the arena the operator is bound to at that point.
+  struct Guard {
     std::vector<void*>& v;
-    ~FreeAll() {
-      for (void* p : v) (void)hipFree(p);
+    void*& best;
+    decltype(rebase)& rb;
+    ~Guard() {
+      rb(best);
+      for (void* p : v)
+        if (p != best) (void)hipFree(p);
     }
-  } free_losers{losers};
+  } guard{losers, best_arena, rebase};
+  // candidates come from the context's allocator: under memory pressure it releases the cached Krylov slabs once before
+  // giving up, so a large matrix is not silently left with fewer draws
   for (int t = 1; t < ctx->tune.pb_placements; ++t) {
     void* cand = nullptr;
-    if (hipMalloc(&cand, op->pb_arena_bytes) != hipSuccess) {  // no room for another copy: decide among what we have
+    try {
+      ctx->dev_malloc(&cand, op->pb_arena_bytes, "PB placement candidate");
+    } catch (const Failure&) {  // no room for another copy: decide among what we have
       (void)hipGetLastError();
       break;
     }

@@ -64,7 +64,7 @@ template <typename T> Basis<T>::~Basis() {
   // slabs go back to the context's cache: the next run() on this context reuses them instead of paying
   // hipMalloc/hipFree of tens of GB per call (ll_ctx_release_cache or ll_ctx_destroy frees them)
   const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
-  for (T* p : chunks) ctx->slab_cache.emplace_back((void*)p, bytes);
+  for (T* p : chunks) ctx->cache_put((void*)p, bytes);
 }
 template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_) {
   ctx = c;
@@ -516,7 +516,7 @@ template <typename T> struct DevBuf {
   size_t bytes = 0;
   ~DevBuf() { release(); }
   void release() {
-    if (p && owner) owner->slab_cache.emplace_back((void*)p, bytes);
+    if (p && owner) owner->cache_put((void*)p, bytes);
     p = nullptr;
   }
   void alloc(ll_context* ctx, size_t count) {
@@ -651,7 +651,10 @@ template <typename T> struct LoopState {
   // the pass takes the one-sweep form only if every ||r_i|| <= 3e-8 max|lambda| (effect on the recurrence ~ 1e-15 max|lambda|
   // at a typical beta).  Ritz vectors of clustered or degenerate eigenvalues, or of a pass cut off by max_iteration, do not meet
   // that and keep the two-sweep form.  All numbers are all-reduced: the same decision on every rank.
-  void begin_pass(const T* locked_vecs, int64_t n_lock, const double* lambda_shifted = nullptr, double offset = 0.0) {
+  // norm_scale: a rank-independent estimate of ||A + offset|| (the previous pass's ||T||_inf, lanczos_run): the gate is
+  // relative to the OPERATOR's size, not to max|lambda + offset|, which collapses when a locked eigenvalue sits near -offset.
+  void begin_pass(const T* locked_vecs, int64_t n_lock, const double* lambda_shifted = nullptr, double offset = 0.0,
+                  double norm_scale = 0.0) {
     locked = locked_vecs;
     n_locked = n_lock;
     lag_pending = false;
@@ -665,18 +668,21 @@ template <typename T> struct LoopState {
     none.nseg = 0;
     none.ld = ld;
     E.ctx->ensure_partials(kMaxGrid);
-    double scale = 0.0, worst = 0.0;
+    double* r2_dev = hbuf[0];  // free until the first iteration of the pass: ||A z_i - lambda_i z_i||^2, i < n_lock
     for (int64_t i = 0; i < n_lock; ++i) {
       const T* z = locked + i * ld;
       T* y = work[0].p;
       E.apply(z, y, offset, nullptr, true);
       const ThreeTerm<T> tt{nullptr, z, d_lambda + i, NormRefs{nullptr, nullptr, nullptr, 0}};  // y <- y - lambda_i z, ||y||^2
       const int grid = launch_mdot<T>(nl, y, none, tt, nullptr, E.ctx->d_partials, small_bytes, s);
-      launch_reduce_cols(E.ctx->d_partials, grid, 1, E.S(kScalSpare), nullptr, s);
-      E.all_reduce(E.S(kScalSpare), 1);
-      double r2 = 0.0;
-      E.fetch(E.S(kScalSpare), &r2, 1);
-      worst = std::max(worst, std::sqrt(std::max(r2, 0.0)));
+      launch_reduce_cols(E.ctx->d_partials, grid, 1, r2_dev + i, nullptr, s);
+    }
+    E.all_reduce(r2_dev, (size_t)n_lock);  // one collective and one fetch for all locked vectors
+    std::vector<double> r2((size_t)n_lock);
+    E.fetch(r2_dev, r2.data(), (size_t)n_lock);
+    double scale = norm_scale, worst = 0.0;
+    for (int64_t i = 0; i < n_lock; ++i) {
+      worst = std::max(worst, std::sqrt(std::max(r2[(size_t)i], 0.0)));
       scale = std::max(scale, std::fabs(lambda_shifted[i]));
     }
     if (!(worst <= 3e-8 * scale)) {
@@ -961,7 +967,6 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     d_locked.alloc(ctx, (size_t)P.num_eigs * ld);
   }
   const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
-  (void)nroot_max;
   ctx->ensure_pinned(16);
   EventRing ring;
   PhaseTimer timer(ctx->profiling, s);
@@ -972,6 +977,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   std::multimap<double, std::vector<T>, std::function<bool(double, double)>> kept(cmp);
 
   int64_t passes = 0, total_iters = 0, second_passes = 0;
+  double t_inf_prev = 0.0;  // max over the passes so far of ||T_m||_inf (same numbers on every rank)
   double t_tridiag = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
@@ -989,6 +995,15 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     if (out_dev) LL_HIP(hipMemcpy(dst, src_host, (size_t)nl * sizeof(T), hipMemcpyHostToDevice));
     else std::memcpy(dst, src_host, (size_t)nl * sizeof(T));
   };
+
+  struct TraceFile {  // LL_ITER_TRACE
+    FILE* f = nullptr;
+    ~TraceFile() {
+      if (f) std::fclose(f);
+    }
+  } trace_holder;
+  if (!ctx->tune.iter_trace.empty()) trace_holder.f = std::fopen(ctx->tune.iter_trace.c_str(), "a");
+  FILE* const trace_file = trace_holder.f;
 
   while (true) {  // restart loop LL:334-354
     const int64_t nroot = spec ? spec->nroot : std::min<int64_t>(P.num_eigs_per_iteration, n - (int64_t)kept.size());  // LL:338
@@ -1040,7 +1055,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     std::vector<double> locked_lambda;  // of the operator the loop applies (A + eigenvalue_offset)
     if (!spec)
       for (auto& kv : kept) locked_lambda.push_back(kv.first + P.eigenvalue_offset);
-    LS.begin_pass(d_locked.p, L, locked_lambda.empty() ? nullptr : locked_lambda.data(), P.eigenvalue_offset);
+    LS.begin_pass(d_locked.p, L, locked_lambda.empty() ? nullptr : locked_lambda.data(), P.eigenvalue_offset, t_inf_prev);
     RunList<T> locked_runs;
     locked_runs.ld = ld;
     locked_runs.add(d_locked.p, L);  // P5
@@ -1120,6 +1135,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       }
       alpha.push_back(alpha_j);
       beta.push_back(std::sqrt(beta2_j));
+      if (trace_file)
+        std::fprintf(trace_file, "iter %lld %lld %.17g %.17g %.17g %.17g %d\n", (long long)passes, (long long)j, alpha_j, beta2_j,
+                     c0_j, c1_j, verdict);
       worker.submit((int64_t)alpha.size(), alpha.data(), beta.data());
       return verdict;
     };
@@ -1146,10 +1164,16 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     }
     while (!stopped && worker.wait_pop(r)) stopped = absorb(r);  // the first stop verdict wins; else the last iteration's values
     itern = last.m;  // == max_iteration without a stop (LL:239,312)
+    if (trace_file) {
+      std::fprintf(trace_file, "stop %lld %lld %d collected %zu\n", (long long)passes, (long long)itern, (int)stopped, alpha.size());
+      std::fflush(trace_file);
+    }
     evs = last.evs;
     evs_from_qr = last.evs_from_qr;
     alpha.resize((size_t)itern);  // iterations the device ran ahead of the verdict are dropped
     beta.resize((size_t)itern);
+    for (size_t i = 0; i < alpha.size(); ++i)  // ||T||_inf of this pass: the operator-size scale of the next pass's gate
+      t_inf_prev = std::max(t_inf_prev, std::fabs(alpha[i]) + (i > 0 ? beta[i - 1] : 0.0) + (i + 1 < alpha.size() ? beta[i] : 0.0));
     LL_HIP(hipStreamSynchronize(s));
 
     // ---- Ritz pairs (LL:312-319, LL:33-62)
@@ -1226,9 +1250,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       RunList<T> basis;
       basis.ld = ld;
       basis.add_basis(U, m);
-      if (!d_ritz.p || d_ritz_cap < nw) {  // only the surviving vectors are formed
-        d_ritz.alloc(ctx, (size_t)nw * ld);
-        d_ritz_cap = nw;
+      if (!d_ritz.p || d_ritz_cap < nw) {  // only the surviving vectors are formed; sized by what a pass can return at
+        d_ritz_cap = std::max<int64_t>(nw, std::min<int64_t>(nroot_max, spec ? spec->nroot : P.num_eigs));  // most, so that
+        d_ritz.alloc(ctx, (size_t)d_ritz_cap * ld);  // repeated runs of one problem reuse ONE cached buffer size
       }
       E.gemv(basis, m, (int)nw, coeff.data(), d_ritz.p, ld);
       for (int64_t w = 0; w < nw; ++w) {

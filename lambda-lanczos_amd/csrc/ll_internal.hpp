@@ -174,6 +174,8 @@ struct Tuning {
   int tridiag_test_jitter_us = 0;  // LL_TRIDIAG_TEST_JITTER_US: random delay of every helper-thread verdict
   bool stencil_vec = true;         // LL_STENCIL_VEC=0: scalar lattice kernel on shapes the vector kernel would take
   double stall_trace_ms = -1.0;    // LL_STALL_TRACE: print where a whole-loop call longer than this spent its time
+  std::string iter_trace;          // LL_ITER_TRACE=path: the eigen-solver loop appends one line per collected iteration
+                                   // (pass k alpha beta^2 c0 c1 second-pass) and one per stop verdict — for parity hunts
 };
 Tuning read_tuning();  // capi.cpp
 }  // namespace ll
@@ -209,7 +211,12 @@ struct ll_context {
   size_t pinned_cap = 0;         // doubles
   void* d_coeff = nullptr;       // coefficient upload area for gemv_basis
   size_t coeff_cap = 0;          // bytes
-  std::vector<std::pair<void*, size_t>> slab_cache;  // Krylov-basis slabs kept between runs (ptr, bytes)
+  std::vector<std::pair<void*, size_t>> slab_cache;  // Krylov-basis slabs kept between runs (ptr, bytes), oldest first
+  // Return a buffer to the cache.  The cache is bounded (kSlabCacheMaxEntries): a long-lived context that solves problems
+  // of many different shapes frees its oldest cached buffers instead of accumulating them (hipFree synchronises the device;
+  // it happens only when the bound is hit, never inside a loop).
+  static constexpr size_t kSlabCacheMaxEntries = 64;
+  void cache_put(void* p, size_t bytes);
   void* d_xfull = nullptr;       // all-gather target (sharded runs)
   size_t xfull_cap = 0;          // bytes
   void* d_halo = nullptr;        // received halos of the lattice operator: [from prev | from next]

@@ -10,6 +10,7 @@
 #include <complex>
 #include <cstdio>
 #include <exception>
+#include <random>
 #include <vector>
 
 using lambda_lanczos::Exponentiator;
@@ -23,6 +24,14 @@ static void check(bool ok, const char* what) {
   }
 }
 
+// a seeded start vector through the reference's public init_vector hook (lambda_lanczos.hpp:133), like the reference's
+// own tests do: the checks below do not depend on what std::random_device returns on the test machine
+static void seeded_start(std::vector<double>& v) {
+  std::mt19937 mt(1);
+  std::uniform_real_distribution<double> rand(-1.0, 1.0);
+  for (double& e : v) e = rand(mt);
+}
+
 int main() {
   try {
     // ---- 1. the 3 x 3 matrix of the reference's first known-answer test (eigenvalues 4, 1, 1), a user lambda as mv_mul
@@ -33,6 +42,7 @@ int main() {
         for (size_t c = 0; c < a.size(); ++c) out[r] += a[r][c] * in[c];
     };
     LambdaLanczos<double> engine(dense, 3, true, 1);
+    engine.init_vector = seeded_start;
     std::vector<double> values;
     std::vector<std::vector<double>> vectors;
     engine.run(values, vectors);
@@ -54,6 +64,7 @@ int main() {
     LambdaLanczos<double> low(chain, n, false, 1);
     low.eigenvalue_offset = -4.0;
     low.eps = 1e-14;
+    low.init_vector = seeded_start;
     auto result = low.run();
     const double pi = std::acos(-1.0);
     check(std::fabs(std::get<0>(result)[0] + 2.0 * std::cos(pi / (n + 1))) < 1e-12, "lowest level of the open chain");
@@ -63,6 +74,7 @@ int main() {
     double top = 0.0;
     std::vector<double> top_vec;
     LambdaLanczos<double> single(dense, 3, true, 1);
+    single.init_vector = seeded_start;
     single.run(top, top_vec);
     check(std::fabs(top - 4.0) < 1e-12 && top_vec.size() == 3, "single-pair overload");
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,29 @@ template <typename T> double misfit(const std::vector<T>& a, const std::vector<T
   return std::abs(1.0 - std::abs(ov));
 }
 
+// Deterministic start vectors, like the reference's own tests (lambda_lanczos_test.cpp:25-45 seed mt19937 with 1): the
+// known-answer cases below must not depend on what std::random_device returns on the test box.
+template <typename T> struct SeededInit {
+  static void fill(std::vector<T>& v, unsigned seed) {
+    std::mt19937 mt(seed);
+    std::uniform_real_distribution<T> rand((T)(-1.0), (T)(1.0));
+    for (auto& e : v) e = rand(mt);
+  }
+};
+template <typename R> struct SeededInit<std::complex<R>> {
+  static void fill(std::vector<std::complex<R>>& v, unsigned seed) {
+    std::mt19937 mt(seed);
+    std::uniform_real_distribution<R> rand((R)(-1.0), (R)(1.0));
+    for (auto& e : v) {
+      const R re = rand(mt), im = rand(mt);
+      e = std::complex<R>(re, im);
+    }
+  }
+};
+template <typename T> std::function<void(std::vector<T>&)> seeded_init(unsigned seed = 1) {
+  return [seed](std::vector<T>& v) { SeededInit<T>::fill(v, seed); };
+}
+
 template <typename T> struct EigCase {
   const char* name;                       // reference test this data comes from
   std::vector<std::vector<T>> matrix;
@@ -65,6 +89,7 @@ template <typename T> void run_case(const EigCase<T>& c) {
   engine.num_eigs = c.num_eigs;           // public data members, as in the reference's tests
   engine.eigenvalue_offset = c.offset;
   if (c.eps > 0) engine.eps = c.eps;
+  engine.init_vector = seeded_init<T>(1);
   std::vector<ll::util::real_t<T>> values;   // real_t<T>, as in the reference (lambda_lanczos.hpp:330)
   std::vector<std::vector<T>> vectors;
   engine.run(values, vectors);            // outputs are sized by the library
@@ -191,6 +216,7 @@ static void device_operator() {
   ll::CsrMatrix<double> A(rp, ci, va);
   ll::LambdaLanczos<double> engine(A, (size_t)n, false, 1);
   engine.eigenvalue_offset = -8.0;
+  engine.init_vector = seeded_init<double>(1);
   double value;
   std::vector<double> vec;
   engine.run(value, vec);
@@ -206,6 +232,7 @@ static void operator_zoo() {
     ll::LambdaLanczos<double> engine(chain, n, false, 1);
     engine.eps = 1e-14;
     engine.eigenvalue_offset = -chain.inf_norm() * 5;  // the reference's test uses -10
+    engine.init_vector = seeded_init<double>(1);
     double value;
     std::vector<double> vec;
     engine.run(value, vec);
@@ -227,6 +254,7 @@ static void operator_zoo() {
     ll::DenseMatrix<double> A(m);
     ll::LambdaLanczos<double> engine(A, 8, false, 3);
     engine.eps = 1e-7;
+    engine.init_vector = seeded_init<double>(1);
     std::vector<double> values;
     std::vector<std::vector<double>> vectors;
     engine.run(values, vectors);

@@ -11,8 +11,11 @@ outputs the reference produced for them.  No reference source is stored.  Cases 
   traces.json            alpha/beta traces, iteration counts, Ritz pairs on the SURVEY 8d generators (splitmix start)
   exponentiator.json     T2 problems + torus 32x32 (config 5 in small)
   run_iteration.json     LambdaLanczos::run_iteration called directly (LL:216-322): nroot pairs, caller's orthogonalizeTo
+  long_runs.json         runs of several hundred iterations to convergence / exhaustion (the Gram-Schmidt forms of the HIP path
+                         against the reference's sequential MGS, LL:260): alpha/beta, counts, values, sampled vector entries
 
     python tests/golden/make_golden.py run_iteration      # regenerate one file only
+    python tests/golden/make_golden.py long_runs          # (about 6 minutes of single-core reference time)
 """
 import json
 import os
@@ -70,10 +73,73 @@ def make_run_iteration(ref):
     dump("run_iteration.json", out)
 
 
+def drop_in_ring(n=2000):
+    """The matrix of examples/drop_in.cpp: ring with alternating on-site energies, as CSR."""
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        rows += [i, i, i]
+        cols += [i, (i + 1) % n, (i + n - 1) % n]
+        vals += [0.3 if i % 2 else -0.3, -1.0, -1.0]
+    return G.coo_to_csr(n, rows, cols, np.array(vals))
+
+
+def sample_indices(n, count=512):
+    """Fixed, generator-defined positions at which long_runs.json keeps eigenvector entries."""
+    return (G.splitmix64(np.arange(count, dtype=np.uint64) + np.uint64(0xABCDEF)) % np.uint64(n)).astype(np.int64)
+
+
+def long_run_specs():
+    """name -> spec; shared with tests/test_gpu_long_runs.py (which rebuilds the matrices from the same generators)."""
+    return {
+        # Krylov space exhausted at m = 1002 (1002 distinct eigenvalues); the reference stops at 1003 / ~985
+        "ring2000_two_lowest_s1": dict(gen="drop_in_ring", args=[2000], find_max=False, offset=-3.0, num_eigs=2, seed=1),
+        "ring2000_two_lowest_s2": dict(gen="drop_in_ring", args=[2000], find_max=False, offset=-3.0, num_eigs=2, seed=2),
+        "ring2000_two_lowest_s3": dict(gen="drop_in_ring", args=[2000], find_max=False, offset=-3.0, num_eigs=2, seed=3),
+        "randsym1e5_converge": dict(gen="randsym", args=[100000], find_max=True, offset=0.0, num_eigs=1, seed=1),
+        "laplace200_converge": dict(gen="laplace2d", args=[200], find_max=False, offset=-8.0, num_eigs=1, seed=1),
+        "randsym1e6_fixed120": dict(gen="randsym", args=[1000000], find_max=True, offset=0.0, num_eigs=1, seed=1,
+                                    max_iteration=120),
+        "randsym1e5_three_roots": dict(gen="randsym", args=[100000], find_max=True, offset=0.0, num_eigs=3, seed=1),
+    }
+
+
+def long_run_matrix(spec):
+    if spec["gen"] == "drop_in_ring":
+        return drop_in_ring(*spec["args"])
+    return getattr(G, spec["gen"])(*spec["args"])
+
+
+def make_long_runs(ref):
+    import time
+
+    out = {}
+    for name, s in long_run_specs().items():
+        t0 = time.time()
+        csr = long_run_matrix(s)
+        n = csr[0].shape[0] - 1
+        init = G.start_vector(n, s["seed"])
+        r = ref.lanczos(csr, init, s["find_max"], num_eigs=s["num_eigs"], offset=s["offset"],
+                        max_iteration=s.get("max_iteration"))
+        first = r
+        if s["num_eigs"] > 1:  # the trace of pass 1 (the shim records the last pass): pass 1 does not depend on num_eigs
+            first = ref.lanczos(csr, init, s["find_max"], num_eigs=1, offset=s["offset"], max_iteration=s.get("max_iteration"))
+        idx = sample_indices(n)
+        out[name] = dict(s, n=n, start="generators.start_vector(n, seed)", iter_counts=r["iter_counts"],
+                         eigenvalues=r["eigenvalues"].tolist(), alpha_pass1=first["alpha"].tolist(),
+                         beta_pass1=first["beta"][:-1].tolist(),
+                         sample="make_golden.sample_indices(n)",
+                         eigenvector_samples=[v[idx].tolist() for v in r["eigenvectors"]])
+        print(name, "iter_counts", r["iter_counts"], "values", r["eigenvalues"], "%.1f s" % (time.time() - t0), flush=True)
+    dump("long_runs.json", out)
+
+
 def main():
     ref = oracle_lib.reference()
     if len(sys.argv) > 1 and sys.argv[1] == "run_iteration":
         make_run_iteration(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "long_runs":
+        make_long_runs(ref)
         return
     make_run_iteration(ref)
 
@@ -150,6 +216,7 @@ def main():
         ex["torus32_dt%g" % dt] = {"gen": "torus_np(32)", "start": "generators.start_vector(1024, 1, complex128)",
                                    "a": c2list(np.array([-1j * dt])), "output": c2list(o), "itern": it}
     dump("exponentiator.json", ex)
+    make_long_runs(ref)
 
 
 if __name__ == "__main__":

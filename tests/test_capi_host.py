@@ -36,7 +36,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # and the ctypes table binds exactly that set
     assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
-    assert lib.ll_version() == 2
+    assert lib.ll_version() == capi.ABI_VERSION[0] * 1000 + capi.ABI_VERSION[1] == 3
+
+
+def test_abi_handshake_refuses_a_caller_built_against_another_header():
+    """ll_abi_check (lanczos_hip.h): a binary compiled against an older header sees smaller structs than the library fills —
+    it must be told so instead of being overrun (the C++ facade and this binding call it once per process)."""
+    import ctypes as C
+
+    lib = capi.lib()
+    assert lib.ll_abi_check(0, 3, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_OK
+    assert lib.ll_abi_check(0, 2, C.sizeof(capi.RunStats) - 72, C.sizeof(capi.LanczosParams)) == capi.LL_ERR_INVALID
+    assert b"rebuild the caller" in lib.ll_last_error()
 
 
 def test_header_cites_the_reference_interface():
