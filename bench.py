@@ -65,6 +65,8 @@ def parse_args():
                     help="skip the instrumented steps after the timed region (no per-phase split, no roofline_orth)")
     ap.add_argument("--phase-timers-inline", action="store_true",
                     help="record the per-phase HIP events inside the timed steps instead of in separate steps after them")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short config-2 / config-5 / host-callback legs that follow the headline run at N = 1")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a job that has not finished prints a diagnostic and exits with code 3 "
                          "(a hung collective must not look like a slow run); 0 = off")
@@ -135,6 +137,159 @@ def pmc_orth_traffic(workload, window):
 
 
 STAGE = ["start"]  # where the job is, for the watchdog's diagnostic
+
+
+def _events_ms(ctx, fn, reps):
+    """HIP-event time of `reps` calls of fn on the library stream, per call, median of three rounds."""
+    rounds = []
+    for _ in range(3):
+        fn()
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        rounds.append(ctx.timer_stop() / reps)
+    return sorted(rounds)[1]
+
+
+def other_config_c2(ctx, L, G):
+    """BASELINE config 2 in the same process: 5-point Laplacian n = 1e6, smallest pair, offset -8; two steps of window 100 from
+    device buffers, the SpMV kernel by HIP events, and a 24-iteration window against the real reference (or the oracle port)."""
+    import oracle_lib
+
+    side, n, window = 1000, 1000 * 1000, 100
+    csr = G.laplace2d(side)
+    init = G.start_vector_fast(n, 1)
+    op = L.CsrOperator(ctx, *csr)
+    nnz = int(csr[0][-1])
+    xd, yd = ctx.to_device(init / np.linalg.norm(init)), ctx.empty(n, np.float64)
+    ms = _events_ms(ctx, lambda: L.spmv(op, xd, yd), 50)
+    b = spmv_bytes(n, nnz, False)
+    eng = L.LambdaLanczos(op, n, False, 1)
+    eng.eigenvalue_offset = -8.0
+    eng.max_iteration = window
+    eng.init_vector = ctx.to_device(init)
+    eng.eigenvectors_out = ctx.empty((1, n), np.float64)
+    eng.run()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(2):
+        eng.run()
+        its += eng.getIterationCounts()[0]
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    lagged = int(eng.last_stats["lagged_iterations"])
+    kind = "reference" if oracle_lib.have_reference() else "port"
+    chk = oracle_lib.reference() if kind == "reference" else oracle_lib.oracle()
+    w = 24
+    r = chk.lanczos(csr, init, False, max_iteration=w, offset=-8.0)
+    eng.max_iteration = w
+    eng.eigenvectors_out = None
+    eng.init_vector = lambda v, *_: np.copyto(v, init)
+    vals, vecs = eng.run()
+    norm = 8.0 + 8.0
+    da = float(np.max(np.abs(eng.last_alpha - r["alpha"][:w])))
+    db = float(np.max(np.abs(eng.last_beta[: w - 1] - r["beta"][: w - 1])))
+    dl = float(abs(vals[0] - r["eigenvalues"][0]))
+    ov = float(1.0 - abs(np.vdot(vecs[0], r["eigenvectors"][0])))
+    out = {"workload": "5-point Laplacian 1000x1000 fp64, smallest pair, eigenvalue_offset -8", "n": n, "nnz": nnz,
+           "value": its / dt, "unit": "Lanczos iterations/s", "steps": 2, "window": window, "ms_per_step": dt / 2 * 1e3,
+           "lagged_iterations_last_step": lagged, "io": "device buffers",
+           "spmv": {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed"}.get(op.selected_spmv())},
+           "cpu_same_window": {"kind": kind, "window": w, "value": w / r["t_total"], "seconds": r["t_total"], "cores": 1},
+           "parity_same_window": {"window": w, "max_abs_dalpha": da, "max_abs_dbeta": db, "abs_dlambda": dl,
+                                  "eigenvector_one_minus_overlap": ov,
+                                  "tolerance": "|dalpha|,|dbeta| <= 1e-10*||A+offset||_inf (16), |dlambda| <= 1e-10*max(1,|lambda+offset|), 1-overlap <= 1e-8",
+                                  "ok": bool(da <= 1e-10 * norm and db <= 1e-10 * norm and dl <= 1e-10 * 8.0 and ov <= 1e-8)}}
+    op.close()
+    return out
+
+
+def other_config_c5(ctx, L, G):
+    """BASELINE config 5 in the same process: complex Hermitian torus n = 1e6, exp(-5iH) v to convergence from device buffers,
+    the complex SpMV by HIP events, and the whole run against the real Exponentiator (or the oracle port)."""
+    import oracle_lib
+
+    side, n = 1000, 1000 * 1000
+    csr = G.torus(side)
+    init = G.start_vector_fast(n, 1, np.complex128)
+    op = L.CsrOperator(ctx, *csr)
+    nnz = int(csr[0][-1])
+    xd, yd = ctx.to_device(init / np.linalg.norm(init)), ctx.empty(n, np.complex128)
+    ms = _events_ms(ctx, lambda: L.spmv(op, xd, yd), 50)
+    b = spmv_bytes(n, nnz, True)
+    eng = L.Exponentiator(op, n)
+    d_in, d_out = ctx.to_device(init), ctx.empty((n,), np.complex128)
+    eng.run(-5.0j, d_in, out=d_out)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(5):
+        its += eng.run(-5.0j, d_in, out=d_out)[1]
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    kind = "reference" if oracle_lib.have_reference() else "port"
+    chk = oracle_lib.reference() if kind == "reference" else oracle_lib.oracle()
+    o_out, o_it, o_t = chk.expo(csr, -5.0j, init)
+    g_out, g_it = eng.run(-5.0j, init)
+    err = float(np.max(np.abs(g_out - o_out)) / np.linalg.norm(init))
+    ovl = float(1.0 - abs(np.vdot(o_out, g_out)) / (np.linalg.norm(o_out) * np.linalg.norm(g_out)))
+    unit = float(abs(np.linalg.norm(g_out) / np.linalg.norm(init) - 1.0))
+    out = {"workload": "complex Hermitian torus 1000x1000 (c128), Exponentiator exp(-5iH) v to convergence", "n": n, "nnz": nnz,
+           "value": its / dt, "unit": "Lanczos iterations/s", "steps": 5, "iterations_per_step": its / 5, "ms_per_step": dt / 5 * 1e3,
+           "io": "device buffers",
+           "spmv": {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed"}.get(op.selected_spmv())},
+           "cpu_whole_run": {"kind": kind, "value": o_it / o_t["t_total"], "seconds": o_t["t_total"], "iterations": int(o_it), "cores": 1},
+           "parity_whole_run": {"iterations_cpu": int(o_it), "iterations_gpu": int(g_it), "max_abs_diff_over_input_norm": err,
+                                "one_minus_overlap": ovl, "norm_drift": unit,
+                                "tolerance": "|out_gpu - out_cpu| <= 1e-10 |in|, 1 - overlap <= 10 eps, | |out|/|in| - 1 | <= 1e-12, iterations within 1",
+                                "ok": bool(err <= 1e-10 and ovl <= 10 * 2.3e-16 + 1e-15 and unit <= 1e-12 and abs(int(o_it) - int(g_it)) <= 1)}}
+    op.close()
+    return out
+
+
+def callback_leg(ctx, L, csr, n, init, find_max, offset, window, device_value):
+    """The unmodified-user-lambda path (LL:126,200-208) on the headline matrix: the same CSR as a HOST mv_mul (scipy's CSR row
+    loop), `window` iterations.  Every iteration moves one n-vector down and one up over PCIe and runs the user's code on
+    the host; the split below says where a user of the plain drop-in spends the time."""
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((csr[2], csr[1], csr[0]), shape=(n, n))
+    t_cb = [0.0, 0]
+
+    def mv_mul(x, out):
+        t = time.perf_counter()
+        out += A @ x
+        t_cb[0] += time.perf_counter() - t
+        t_cb[1] += 1
+
+    op = L.HostOperator(ctx, mv_mul, n)
+    eng = L.LambdaLanczos(op, n, find_max, 1)
+    eng.eigenvalue_offset = offset
+    eng.max_iteration = window
+    eng.init_vector = lambda v, *_: np.copyto(v, init)
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    vals, _ = eng.run()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    st = eng.last_stats
+    its = eng.getIterationCounts()[0]
+    op.close()
+    copies = max(st["seconds_spmv"] - t_cb[0], 0.0)
+    return {"value_callback": its / dt, "unit": "Lanczos iterations/s", "window": window, "iterations": its,
+            "callback_calls": t_cb[1], "eigenvalue": float(vals[0]),
+            "per_iteration_ms": {"user_mv_mul_on_host": t_cb[0] / its * 1e3,
+                                 "d2h_plus_h2d_of_one_vector_each_and_offset_dot": copies / its * 1e3,
+                                 "gram_schmidt_on_device": st["seconds_orth"] / its * 1e3,
+                                 "everything": dt / its * 1e3},
+            "bytes_over_pcie_per_iteration": 2 * 8 * n,
+            "device_operator_same_window_value": device_value,
+            "note": "mv_mul = scipy CSR row loop on one host core; the device-resident operator runs the same window at "
+                    "device_operator_same_window_value"}
 
 
 def start_watchdog(seconds, rank):
@@ -571,6 +726,25 @@ def main():
                                                        "OpenMP threads (best of 16/32/64; not how the reference runs)"),
                        "spmv_GBps": b_spmv * r2["iter_counts"][0] / max(r2["t_mv"], 1e-12) / 1e9}
 
+    # ------------------------------------------------------------ the other single-GPU configs and the callback path
+    other, cb_leg = None, None
+    if world == 1 and wl == "c3" and not args.n and not args.no_other_configs:
+        STAGE[0] = "host-callback leg"
+        try:
+            cb_leg = callback_leg(ctx, L, csr, n, init, find_max, offset, max(args.cpu_window, 8),
+                                  cpu["gpu_same_window_value"] if cpu else None)
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
+            cb_leg = {"error": repr(e)}
+        other = {}
+        for key, fn in (("c2", other_config_c2), ("c5", other_config_c5)):
+            STAGE[0] = "other config " + key
+            t_leg = time.perf_counter()
+            try:
+                other[key] = fn(ctx, L, G)
+            except Exception as e:  # noqa: BLE001
+                other[key] = {"error": repr(e)}
+            other[key]["leg_wall_s"] = time.perf_counter() - t_leg
+
     if rank == 0:
         line = {
             # BASELINE.json's metric string for its own configuration; a descriptive one for the other workloads
@@ -673,6 +847,8 @@ def main():
             },
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
+            "callback_path": cb_leg,
+            "other_configs": other,
         }
         print(json.dumps(line), flush=True)
 

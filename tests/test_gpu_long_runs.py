@@ -116,8 +116,10 @@ def test_exhausted_krylov_space_both_operator_paths(ctx, path, seed):
 # ------------------------------------------------------------------ one-sweep form, run to convergence
 @pytest.mark.parametrize("name", ["randsym1e5_converge", "laplace200_converge"])
 def test_one_sweep_form_to_convergence_matches_the_reference(ctx, name):
-    """randsym n = 1e5 (407 reference iterations) and the 200 x 200 Laplacian with offset -8 (708): default geometry — vectors of
-    800 / 320 KB take the one-sweep kernel of the small-vector geometry (lagged_small_kernel) in every iteration but the first."""
+    """randsym n = 1e5 (352 reference iterations) and the 200 x 200 Laplacian with offset -8 (729), default geometry.  The 800 KB
+    vectors of the first take the one-sweep kernel of the small-vector geometry (lagged_small_kernel) in every iteration but the
+    first; the 320 000-byte vectors of the second sit just below the 320 KiB switch and keep the two-sweep small-vector kernels
+    (block CGS + DGKS) for all 729 iterations — both forms against the reference's sequential MGS."""
     gold = GOLD[name]
     csr = MG.long_run_matrix(gold)
     n = gold["n"]
@@ -127,7 +129,10 @@ def test_one_sweep_form_to_convergence_matches_the_reference(ctx, name):
     eng.init_vector = fixed_init(G.start_vector(n, gold["seed"]))
     vals, vecs = eng.run()
     itern = eng.getIterationCounts()[0]
-    assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
+    if n * 8 >= 320 << 10:
+        assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
+    else:
+        assert eng.last_stats["lagged_iterations"] == 0, eng.last_stats
     check_counts(eng.getIterationCounts(), gold)
     check_trace(eng, gold, csr)
     check_values(vals, gold)

@@ -13,6 +13,7 @@
 int main(int argc, char** argv) {
   const unsigned first = argc > 1 ? (unsigned)std::strtoul(argv[1], nullptr, 10) : 1u;
   const unsigned count = argc > 2 ? (unsigned)std::strtoul(argv[2], nullptr, 10) : 100u;
+  const size_t num_eigs = argc > 3 ? (size_t)std::strtoul(argv[3], nullptr, 10) : 2u;  // 1: the first pass only
   const int n = 2000;
   std::vector<std::tuple<int, int, double>> triplets;
   for (int i = 0; i < n; ++i) {
@@ -30,7 +31,7 @@ int main(int argc, char** argv) {
   std::vector<unsigned> drawn;
   for (unsigned seed = first; seed < first + count; ++seed) {
     drawn.clear();
-    lambda_lanczos::LambdaLanczos<double> engine(mv_mul, n, false, 2);
+    lambda_lanczos::LambdaLanczos<double> engine(mv_mul, n, false, num_eigs);
     engine.eigenvalue_offset = -3.0;
     engine.init_vector = [seed, from_device, &drawn](std::vector<double>& v) {
       unsigned sd = seed;
@@ -48,11 +49,13 @@ int main(int argc, char** argv) {
     calls = 0;
     engine.run(values, vectors);
     const auto& c = engine.getIterationCounts();
-    const bool ok = c.size() >= 2 && c[0] == 1003 && c.back() > 900 && c.back() < 1000 &&
-                    std::abs(values[0] + 2.022374841616) < 2e-11 && std::abs(values[1] + 2.022365081214) < 2e-11;
+    // pass 1 exhausts the Krylov space at 1002 and stops at 1003 for every start vector seen so far; a LATER pass that starts
+    // from the same vector converges near 985, one that starts from a fresh random vector ends at 1001, 1002 or ~1850
+    const bool ok = !c.empty() && c[0] == 1003 && std::abs(values[0] + 2.022374841616) < 2e-11 &&
+                    (values.size() < 2 || std::abs(values[1] + 2.022365081214) < 2e-11);
     if (!ok) {
       ++bad;
-      std::printf("seed %u: E0 = %.12f E1 = %.12f counts", seed, values[0], values[1]);
+      std::printf("seed %u: E0 = %.12f E1 = %.12f counts", seed, values[0], values.size() > 1 ? values[1] : 0.0);
       for (auto x : c) std::printf(" %zu", x);
       std::printf(" calls %zu seeds", calls);
       for (auto d : drawn) std::printf(" %u", d);
