@@ -283,6 +283,20 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         set_error("mv_mul host callback returned " + std::to_string(rc));
         throw Failure{LL_ERR_CALLBACK};
       }
+      if (!ctx->tune.iter_trace.empty()) {  // LL_ITER_TRACE: what the user's code saw and returned (a stale or torn buffer shows here)
+        if (FILE* f = std::fopen(ctx->tune.iter_trace.c_str(), "a")) {
+          double sin2 = 0.0, sout2 = 0.0, dot = 0.0;
+          const typename scalar_traits<T>::real* a = (const typename scalar_traits<T>::real*)h_in;
+          const typename scalar_traits<T>::real* b = (const typename scalar_traits<T>::real*)h_out;
+          for (int64_t i = 0; i < n_local * R; ++i) {
+            sin2 += (double)a[i] * a[i];
+            sout2 += (double)b[i] * b[i];
+            dot += (double)a[i] * b[i];
+          }
+          std::fprintf(f, "cb x=%p |in|^2=%.17g |out|^2=%.17g <in,out>=%.17g\n", (const void*)x_local, sin2, sout2, dot);
+          std::fclose(f);
+        }
+      }
       // no second synchronisation: the next callback waits for this upload (ev_cb) before it reuses the buffer
       LL_HIP(hipMemcpyAsync(y, h_out, bytes, hipMemcpyHostToDevice, s));
       if (!ctx->ev_cb) LL_HIP(hipEventCreateWithFlags(&ctx->ev_cb, hipEventDisableTiming));

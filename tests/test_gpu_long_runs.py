@@ -110,6 +110,20 @@ def test_exhausted_krylov_space_both_operator_paths(ctx, path, seed):
     eng1.run()
     check_trace(eng1, gold, csr, upto=1000)
     assert abs(eng1.getIterationCounts()[0] - gold["iter_counts"][0]) <= 2
+    if "fresh_pass" in gold:
+        # What run() does by default in a restart pass: a FRESH random start vector (LL:70-104), orthogonalised against the
+        # locked pairs.  Every eigenvalue of this ring but two is doubly degenerate, so the fresh vector brings the partner of
+        # the locked E1 back as the lowest Ritz value; the pass exhausts its Krylov space at m = 1001 and either breaks down
+        # there (the reference: beta_1001 < 10 eps) or continues on rounding noise (1002 or ~1850 iterations: the reference
+        # itself ends anywhere in that set for other vectors) — the converged Ritz VALUES are the invariant that is checked.
+        fresh = gold["fresh_pass"]
+        engf = L.LambdaLanczos(op, n, False, 1)
+        engf.eigenvalue_offset = gold["offset"]
+        engf.init_vector = fixed_init(G.start_vector(n, gold["fresh_seed"]))
+        fv, _, fit = engf.run_iteration(5, orthogonalize_to=vecs)
+        assert fit >= 1001, fit
+        for got, ref in zip(fv, fresh["eigenvalues"]):
+            assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref + gold["offset"])), (fv, fresh["eigenvalues"])
     op.close()
 
 
