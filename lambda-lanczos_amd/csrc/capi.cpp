@@ -43,6 +43,7 @@ Tuning read_tuning() {
   t.pb_placements = (int)std::max<long long>(1, std::min<long long>(8, num("LL_PB_PLACEMENTS", 4)));
   t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
   t.comm_overlap = flag("LL_COMM_OVERLAP", true);
+  t.csr_split = flag("LL_CSR_SPLIT", true);
   t.tridiag_thread = flag("LL_TRIDIAG_THREAD", true);
   t.tridiag_lag = (int)num("LL_TRIDIAG_LAG", 3);
   {
@@ -190,7 +191,8 @@ ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
                   (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp,
-                  (void*)d_pb_blockmax})
+                  (void*)d_pb_blockmax, d_rp_own, d_rp_rem, (void*)d_col_own, (void*)d_col_rem, d_val_own, d_val_rem,
+                  (void*)d_tiles_own, (void*)d_tiles_rem})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -563,6 +565,71 @@ void finish_csr(ll_operator* op, const int64_t* rp_host) {
   (void)ctx;
 }
 
+// Sharded contexts that keep the CSR-stream kernel: split the image by column ownership so that the own-column product
+// runs under the all-gather (the PB image has its own own / remote block ranges).  Built on the device from
+// the CSR arrays (they may never have been on the host); one int32 per row crosses the bus for the prefix sums.
+template <typename T> void build_csr_split(ll_operator* op) {
+  ll_context* ctx = op->ctx;
+  hipStream_t s = ctx->stream;
+  const int64_t nr = op->n_local;
+  if (nr <= 0 || op->d_row_ptr == nullptr) return;
+  int32_t* d_cnt = nullptr;
+  ctx->dev_malloc((void**)&d_cnt, (size_t)nr * sizeof(int32_t), "own-column counts");
+  struct Free1 {
+    void* p;
+    ~Free1() { (void)hipFree(p); }
+  } free_cnt{d_cnt};
+  launch_csr_count_own<T>(*op, d_cnt, s);
+  std::vector<int32_t> cnt((size_t)nr);
+  std::vector<int64_t> rp((size_t)nr + 1);
+  LL_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (op->rp64) {
+    LL_HIP(hipMemcpyAsync(rp.data(), op->d_row_ptr, (size_t)(nr + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    LL_HIP(hipStreamSynchronize(s));
+  } else {
+    std::vector<int32_t> rp32((size_t)nr + 1);
+    LL_HIP(hipMemcpyAsync(rp32.data(), op->d_row_ptr, (size_t)(nr + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LL_HIP(hipStreamSynchronize(s));
+    for (int64_t i = 0; i <= nr; ++i) rp[(size_t)i] = rp32[(size_t)i];
+  }
+  std::vector<int64_t> rp_own((size_t)nr + 1), rp_rem((size_t)nr + 1);
+  rp_own[0] = rp_rem[0] = 0;
+  for (int64_t i = 0; i < nr; ++i) {
+    rp_own[(size_t)i + 1] = rp_own[(size_t)i] + cnt[(size_t)i];
+    rp_rem[(size_t)i + 1] = rp_rem[(size_t)i] + (rp[(size_t)i + 1] - rp[(size_t)i] - cnt[(size_t)i]);
+  }
+  auto upload_rp = [&](const std::vector<int64_t>& v, void** dst) {
+    if (op->rp64) {
+      ctx->dev_malloc(dst, v.size() * sizeof(int64_t), "split row offsets");
+      LL_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    } else {
+      std::vector<int32_t> v32(v.size());
+      for (size_t i = 0; i < v.size(); ++i) v32[i] = (int32_t)v[i];
+      ctx->dev_malloc(dst, v32.size() * sizeof(int32_t), "split row offsets");
+      LL_HIP(hipMemcpy(*dst, v32.data(), v32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  };
+  auto upload_tiles = [&](const std::vector<int64_t>& v, int32_t** dst, int* ntiles) {
+    std::vector<int32_t> tiles;
+    build_tiles(v.data(), nr, tiles);
+    *ntiles = (int)tiles.size() - 1;
+    ctx->dev_malloc((void**)dst, tiles.size() * sizeof(int32_t), "split SpMV tiles");
+    LL_HIP(hipMemcpy(*dst, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  };
+  upload_rp(rp_own, &op->d_rp_own);
+  upload_rp(rp_rem, &op->d_rp_rem);
+  upload_tiles(rp_own, &op->d_tiles_own, &op->ntiles_own);
+  upload_tiles(rp_rem, &op->d_tiles_rem, &op->ntiles_rem);
+  const size_t n_own = (size_t)rp_own[(size_t)nr], n_rem = (size_t)rp_rem[(size_t)nr];
+  ctx->dev_malloc((void**)&op->d_col_own, std::max<size_t>(n_own, 1) * sizeof(int32_t), "own-column indices");
+  ctx->dev_malloc(&op->d_val_own, std::max<size_t>(n_own, 1) * sizeof(T), "own-column values");
+  ctx->dev_malloc((void**)&op->d_col_rem, std::max<size_t>(n_rem, 1) * sizeof(int32_t), "remote-column indices");
+  ctx->dev_malloc(&op->d_val_rem, std::max<size_t>(n_rem, 1) * sizeof(T), "remote-column values");
+  launch_csr_split<T>(*op, s);
+  LL_HIP(hipStreamSynchronize(s));
+  op->csr_split = true;
+}
+
 // Row ranges of a sharded operator must be the ll_partition() ones (equal shard strides).
 void set_partition(ll_context* ctx, ll_operator* op, int64_t n, int64_t row_begin, int64_t n_local) {
   op->n = n;
@@ -845,6 +912,8 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     }
   }
   release_unselected_image(op.get());
+  // (every rank takes this branch or none: the kernel choice above is collective, the switch comes from the environment)
+  if (ctx->nranks > 1 && ctx->tune.csr_split && op->d_row_ptr != nullptr) build_csr_split<T>(op.get());
   *out = op.release();
 }
 

@@ -206,6 +206,10 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     nparts = launch_stencil<T>(*op, x_local, lo, hi, y, offset, dotp, s, sc);
   } else if (op->kind == ll_operator::CSR || op->kind == ll_operator::DENSE) {
     const bool pb = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB;
+    // CSR-stream on a sharded context: the image is split by column ownership (capi.cpp build_csr_split); the dense row
+    // block splits by column range without a second image
+    const bool split = ctx->comm != nullptr && ((op->kind == ll_operator::CSR && !pb && op->csr_split) ||
+                                                (op->kind == ll_operator::DENSE && ctx->tune.csr_split));
     const T* x_full = x_local;
     const T* x_own = x_local;  // what the own-column blocks of the PB kernels read
     bool remote_done = false;
@@ -235,7 +239,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         plan.start[0] = 0;
         plan.len[0] = op->n_shard;
       }
-      const bool overlap = pb && ctx->tune.comm_overlap && ctx->comm_stream != nullptr;
+      const bool overlap = (pb || split) && ctx->tune.comm_overlap && ctx->comm_stream != nullptr;
       hipStream_t cs = overlap ? ctx->comm_stream : s;
       comm_timer_begin(cs);
       if (overlap) {
@@ -248,7 +252,20 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         if (overlap) LL_HIP(hipEventRecord(ctx->ev_chunk[c], cs));
       }
       comm_timer_end(cs);
-      if (overlap) {
+      if (split) {
+        // the own-column product (no exchange needed) runs under the gather, the other ranks' columns are added when the
+        // gathered vector has arrived; LL_COMM_OVERLAP=0 issues the same two kernels behind the gather on one stream
+        if (op->kind == ll_operator::DENSE) {
+          launch_dense_mv<T>(*op, x_local, x_local, y, offset, nullptr, s, sc, 1);
+          if (overlap) LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[0], 0));
+          nparts = launch_dense_mv<T>(*op, gathered, x_local, y, offset, dotp, s, sc, 2);
+        } else {
+          launch_spmv<T>(*op, x_local, x_local, y, offset, nullptr, s, sc, 1);
+          if (overlap) LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[0], 0));
+          nparts = launch_spmv<T>(*op, gathered, x_local, y, offset, dotp, s, sc, 2);
+        }
+        remote_done = true;
+      } else if (overlap) {
         // own-column blocks run under the gather; every chunk's remote blocks start when that chunk has arrived
         launch_pb_phase1<T>(*op, 0, op->pb_own_count, x_own, s, xnorm2);
         for (int c = 0; c < plan.nchunks; ++c) {

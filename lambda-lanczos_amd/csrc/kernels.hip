@@ -62,7 +62,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
                                                       const RP* __restrict__ rp, const int32_t* __restrict__ ci,
                                                       const T* __restrict__ va, const T* __restrict__ xf,
                                                       const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                      double* __restrict__ dot_partials, ScaleIn<T> sc) {
+                                                      double* __restrict__ dot_partials, ScaleIn<T> sc, int part) {
+  // part (sharded operators whose image is split by column ownership, capi.cpp build_csr_split): 0 = the whole matrix in
+  // one pass; 1 = the own-column part, y = A_own x + offset x (runs under the all-gather, no dot product yet);
+  // 2 = the other ranks' columns, y += A_rem x, then Re<x, y> of the finished rows.
   __shared__ T prod[kSpmvTileNnz];
   __shared__ double red[4 * scalar_traits<T>::reals + 5];
   const int tid = threadIdx.x;
@@ -91,9 +94,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
       if (tid == 0) {
         const T xi = rmul(sfac, xl[r0]);
         if (sc.u_out) sc.u_out[r0] = xi;
-        T yi = add(narrow<T>(scale_acc(sfac, tot)), rmul(offset, xi));
+        T yi = part == 2 ? add(y[r0], narrow<T>(scale_acc(sfac, tot))) : add(narrow<T>(scale_acc(sfac, tot)), rmul(offset, xi));
         y[r0] = yi;
-        dot_acc += re_cmul(xi, yi);
+        if (part != 1) dot_acc += re_cmul(xi, yi);
       }
       continue;
     }
@@ -127,9 +130,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream(int ntiles, const int32_t*
     if (g < nr && l == 0) {
       const T xi = rmul(sfac, xl[row]);
       if (sc.u_out) sc.u_out[row] = xi;
-      T yi = add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xi));
+      T yi = part == 2 ? add(y[row], narrow<T>(scale_acc(sfac, acc))) : add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xi));
       y[row] = yi;
-      dot_acc += re_cmul(xi, yi);
+      if (part != 1) dot_acc += re_cmul(xi, yi);
     }
   }
   if (dot_partials) {
@@ -149,22 +152,86 @@ static int spmv_grid(int ntiles, size_t elem_bytes) {
 
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                hipStream_t s, const ScaleIn<T>* scp) {
-  const int grid = spmv_grid(op.ntiles, sizeof(T));
+                hipStream_t s, const ScaleIn<T>* scp, int part) {
+  // part 1 / 2: the two halves of a column-split image (x_full = the local shard for part 1, the gathered vector for part 2)
+  const int ntiles = part == 1 ? op.ntiles_own : (part == 2 ? op.ntiles_rem : op.ntiles);
+  const int32_t* tiles = part == 1 ? op.d_tiles_own : (part == 2 ? op.d_tiles_rem : op.d_tile_rows);
+  const void* rp = part == 1 ? op.d_rp_own : (part == 2 ? op.d_rp_rem : op.d_row_ptr);
+  const int32_t* ci = part == 1 ? op.d_col_own : (part == 2 ? op.d_col_rem : op.d_col);
+  const void* va = part == 1 ? op.d_val_own : (part == 2 ? op.d_val_rem : op.d_val);
+  const int grid = spmv_grid(ntiles, sizeof(T));
   const ScaleIn<T> sc = scp ? *scp : ScaleIn<T>{};
   if (op.rp64)
-    hipLaunchKernelGGL((spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
-                       (const int64_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,
-                       dot_partials, sc);
+    hipLaunchKernelGGL((spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, ntiles, tiles, (const int64_t*)rp, ci,
+                       (const T*)va, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, sc, part);
   else
-    hipLaunchKernelGGL((spmv_stream<T, int32_t>), dim3(grid), dim3(kBlock), 0, s, op.ntiles, op.d_tile_rows,
-                       (const int32_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, x_full, x_local, y, offset,
-                       dot_partials, sc);
+    hipLaunchKernelGGL((spmv_stream<T, int32_t>), dim3(grid), dim3(kBlock), 0, s, ntiles, tiles, (const int32_t*)rp, ci,
+                       (const T*)va, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, sc, part);
   LL_HIP(hipGetLastError());
   return grid;
 }
-#define LL_INST_SPMV(T) \
-  template int launch_spmv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t, const ScaleIn<T>*);
+
+// ---- column split of a sharded CSR image: entries over the rank's own columns (rebased to the local shard) and the rest
+template <typename RP>
+__global__ __launch_bounds__(256) void csr_count_own_kernel(long long n_local, long long col0, long long col1,
+                                                            const RP* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                            int32_t* __restrict__ own_cnt) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_local; i += (long long)gridDim.x * 256) {
+    int c = 0;
+    for (long long p = (long long)rp[i]; p < (long long)rp[i + 1]; ++p) c += (ci[p] >= col0 && ci[p] < col1) ? 1 : 0;
+    own_cnt[i] = c;
+  }
+}
+template <typename T, typename RP>
+__global__ __launch_bounds__(256) void csr_split_kernel(long long n_local, long long col0, long long col1,
+                                                        const RP* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                        const T* __restrict__ va, const RP* __restrict__ rp_own,
+                                                        const RP* __restrict__ rp_rem, int32_t* __restrict__ ci_own,
+                                                        T* __restrict__ va_own, int32_t* __restrict__ ci_rem,
+                                                        T* __restrict__ va_rem) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_local; i += (long long)gridDim.x * 256) {
+    long long qo = (long long)rp_own[i], qr = (long long)rp_rem[i];
+    for (long long p = (long long)rp[i]; p < (long long)rp[i + 1]; ++p) {  // the order inside a row is kept in both halves
+      const int c = ci[p];
+      if (c >= col0 && c < col1) {
+        ci_own[qo] = (int32_t)(c - col0);
+        va_own[qo++] = va[p];
+      } else {
+        ci_rem[qr] = c;
+        va_rem[qr++] = va[p];
+      }
+    }
+  }
+}
+template <typename T>
+void launch_csr_count_own(const ll_operator& op, int32_t* own_cnt, hipStream_t s) {
+  const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, (op.n_local + 255) / 256));
+  const long long c0 = op.row_begin, c1 = op.row_begin + op.n_local;
+  if (op.rp64)
+    hipLaunchKernelGGL((csr_count_own_kernel<int64_t>), dim3(grid), dim3(256), 0, s, (long long)op.n_local, c0, c1,
+                       (const int64_t*)op.d_row_ptr, op.d_col, own_cnt);
+  else
+    hipLaunchKernelGGL((csr_count_own_kernel<int32_t>), dim3(grid), dim3(256), 0, s, (long long)op.n_local, c0, c1,
+                       (const int32_t*)op.d_row_ptr, op.d_col, own_cnt);
+  LL_HIP(hipGetLastError());
+}
+template <typename T> void launch_csr_split(const ll_operator& op, hipStream_t s) {
+  const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, (op.n_local + 255) / 256));
+  const long long c0 = op.row_begin, c1 = op.row_begin + op.n_local;
+  if (op.rp64)
+    hipLaunchKernelGGL((csr_split_kernel<T, int64_t>), dim3(grid), dim3(256), 0, s, (long long)op.n_local, c0, c1,
+                       (const int64_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, (const int64_t*)op.d_rp_own,
+                       (const int64_t*)op.d_rp_rem, op.d_col_own, (T*)op.d_val_own, op.d_col_rem, (T*)op.d_val_rem);
+  else
+    hipLaunchKernelGGL((csr_split_kernel<T, int32_t>), dim3(grid), dim3(256), 0, s, (long long)op.n_local, c0, c1,
+                       (const int32_t*)op.d_row_ptr, op.d_col, (const T*)op.d_val, (const int32_t*)op.d_rp_own,
+                       (const int32_t*)op.d_rp_rem, op.d_col_own, (T*)op.d_val_own, op.d_col_rem, (T*)op.d_val_rem);
+  LL_HIP(hipGetLastError());
+}
+#define LL_INST_SPMV(T)                                                                                                       \
+  template int launch_spmv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t, const ScaleIn<T>*, int); \
+  template void launch_csr_count_own<T>(const ll_operator&, int32_t*, hipStream_t);                                            \
+  template void launch_csr_split<T>(const ll_operator&, hipStream_t);
 LL_INST_SPMV(double) LL_INST_SPMV(zc) LL_INST_SPMV(float) LL_INST_SPMV(cf)
 
 
@@ -1642,11 +1709,16 @@ template <typename T, int V> __device__ __forceinline__ void store_chunk(T* __re
 // One wavefront per row: the row streams in with coalesced loads, x comes from L2, the 64 partial sums fold with
 // shuffles; offset, y write and the alpha partial are fused like in the CSR kernels.  Bound by the matrix stream
 // (sizeof(T) * n_local * n bytes per apply).
+// Column ranges [a0, a1) and [b0, b1) of every row are multiplied (the second may be empty); x element of column j is
+// xf[j - xshift].  part: 0 = whole rows; 1 = the rank's own columns, y = A_own x + offset x (under the all-gather, no dot
+// product yet); 2 = the other ranks' columns, y += A_rem x, then Re<x, y> (sharded contexts, Engine::apply).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long long ncols, const T* __restrict__ a,
                                                           const T* __restrict__ xf, const T* __restrict__ xl,
                                                           T* __restrict__ y, double offset,
-                                                          double* __restrict__ dot_partials, int vec, ScaleIn<T> sc) {
+                                                          double* __restrict__ dot_partials, int vec, ScaleIn<T> sc,
+                                                          long long a0, long long a1, long long b0, long long b1,
+                                                          long long xshift, int part) {
   __shared__ double red[5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double dot_acc = 0.0;
@@ -1654,27 +1726,30 @@ __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long 
   for (long long row = (long long)blockIdx.x * 4 + wave; row < nrows; row += (long long)gridDim.x * 4) {
     const T* __restrict__ ar = a + row * ncols;
     acc_t<T> acc = zero<acc_t<T>>();
-    if (vec) {  // 16-byte loads: V elements per lane per trip (ncols % V == 0, bases 16-byte aligned)
-      constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
+    for (int rng = 0; rng < 2; ++rng) {
+      const long long j0 = rng == 0 ? a0 : b0, j1 = rng == 0 ? a1 : b1;
+      if (vec) {  // 16-byte loads: V elements per lane per trip (range bounds, ncols and xshift multiples of V, bases 16-byte aligned)
+        constexpr int V = (int)(16 / sizeof(T)) > 0 ? (int)(16 / sizeof(T)) : 1;
 #pragma unroll 4
-      for (long long j = (long long)lane * V; j < ncols; j += 64 * V) {
-        T av[V], xv[V];
-        load_chunk<T, V>(ar + j, av);
-        load_chunk<T, V>(xf + j, xv);
+        for (long long j = j0 + (long long)lane * V; j < j1; j += 64 * V) {
+          T av[V], xv[V];
+          load_chunk<T, V>(ar + j, av);
+          load_chunk<T, V>(xf + (j - xshift), xv);
 #pragma unroll
-        for (int e = 0; e < V; ++e) fma_acc(acc, av[e], xv[e]);
-      }
-    } else {
+          for (int e = 0; e < V; ++e) fma_acc(acc, av[e], xv[e]);
+        }
+      } else {
 #pragma unroll 4
-      for (long long j = lane; j < ncols; j += 64) fma_acc(acc, ar[j], xf[j]);
+        for (long long j = j0 + lane; j < j1; j += 64) fma_acc(acc, ar[j], xf[j - xshift]);
+      }
     }
     acc = wave_sum(acc);
     if (lane == 0) {
       const T xi = rmul(sfac, xl[row]);
       if (sc.u_out) sc.u_out[row] = xi;
-      const T yi = add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xi));
+      const T yi = part == 2 ? add(y[row], narrow<T>(scale_acc(sfac, acc))) : add(narrow<T>(scale_acc(sfac, acc)), rmul(offset, xi));
       y[row] = yi;
-      dot_acc += re_cmul(xi, yi);
+      if (part != 1) dot_acc += re_cmul(xi, yi);
     }
   }
   if (dot_partials) {
@@ -1684,19 +1759,31 @@ __global__ __launch_bounds__(kBlock) void dense_mv_kernel(long long nrows, long 
 }
 template <typename T>
 int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                    hipStream_t s, const ScaleIn<T>* scp) {
+                    hipStream_t s, const ScaleIn<T>* scp, int part) {
   const ScaleIn<T> sc = scp ? *scp : ScaleIn<T>{};
   const long long want = (op.n_local + 3) / 4;
   const int grid = (int)std::max<long long>(1, std::min<long long>(kMaxGrid, want));
   constexpr long long V = (long long)(16 / sizeof(T)) > 0 ? (long long)(16 / sizeof(T)) : 1;
-  const int vec = op.n % V == 0 && (reinterpret_cast<uintptr_t>(x_full) & 15) == 0 ? 1 : 0;  // rows then start 16-B aligned
+  long long a0 = 0, a1 = op.n, b0 = 0, b1 = 0, xshift = 0;
+  if (part == 1) {  // x_full = the local shard
+    a0 = op.row_begin;
+    a1 = op.row_begin + op.n_local;
+    xshift = op.row_begin;
+  } else if (part == 2) {  // x_full = the gathered vector (global order: equal shard strides)
+    a1 = op.row_begin;
+    b0 = op.row_begin + op.n_local;
+    b1 = op.n;
+  }
+  const bool aligned = op.n % V == 0 && a0 % V == 0 && a1 % V == 0 && b0 % V == 0 && b1 % V == 0 && xshift % V == 0;
+  const int vec = aligned && (reinterpret_cast<uintptr_t>(x_full) & 15) == 0 ? 1 : 0;  // rows then start 16-B aligned
   hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(grid), dim3(kBlock), 0, s, (long long)op.n_local, (long long)op.n,
-                     (const T*)op.d_dense, x_full, x_local, y, offset, dot_partials, vec, sc);
+                     (const T*)op.d_dense, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, vec, sc, a0, a1, b0, b1,
+                     xshift, part);
   LL_HIP(hipGetLastError());
   return grid;
 }
 #define LL_INST_DENSE(T) \
-  template int launch_dense_mv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t, const ScaleIn<T>*);
+  template int launch_dense_mv<T>(const ll_operator&, const T*, const T*, T*, double, double*, hipStream_t, const ScaleIn<T>*, int);
 LL_INST_DENSE(double) LL_INST_DENSE(zc) LL_INST_DENSE(float) LL_INST_DENSE(cf)
 
 // ================================================================= a1/a2/a3: matrix-free lattice operator

@@ -156,6 +156,7 @@ struct Tuning {
   int pb_col_block = 0;
   int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
   int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
+  bool csr_split = true;           // LL_CSR_SPLIT=0: sharded CSR-stream / dense operators gather first, then multiply (round-3 form)
   bool comm_overlap = true;        // LL_COMM_OVERLAP=0: exchange and compute on one stream (serial A/B reference)
   // --- the loops
   bool tridiag_thread = true;      // LL_TRIDIAG_THREAD=0: host Ritz step inline instead of on the helper thread
@@ -262,6 +263,15 @@ struct ll_operator {
   bool owns_arrays = true;
   int32_t* d_tile_rows = nullptr;  // ntiles+1 row boundaries of the SpMV tiles
   int ntiles = 0;
+  // Sharded contexts, CSR-stream selected: the same rows split by column ownership (capi.cpp build_csr_split) — the
+  // entries over the rank's OWN columns (indices rebased to the local shard; their product needs no exchange and runs
+  // under the all-gather) and the entries over the other ranks' columns (global indices into the gathered vector).
+  bool csr_split = false;
+  void *d_rp_own = nullptr, *d_rp_rem = nullptr;  // row offsets, int32 or int64 like d_row_ptr
+  int32_t *d_col_own = nullptr, *d_col_rem = nullptr;
+  void *d_val_own = nullptr, *d_val_rem = nullptr;
+  int32_t *d_tiles_own = nullptr, *d_tiles_rem = nullptr;
+  int ntiles_own = 0, ntiles_rem = 0;
   // propagation-blocked image of the same matrix (spmv_pb.hip pb_phase1 / pb_phase2)
   int spmv_kind = 0;                 // LL_SPMV_*
   float tune_ms[2] = {-1.f, -1.f};   // what the creation-time autotune measured for LL_SPMV_CSR_STREAM / LL_SPMV_PB (-1: not timed)
@@ -328,9 +338,13 @@ template <typename T> struct ScaleIn {
 
 // y = A x_full(cols) + offset * x_local ; dot_partials (nullable): one double per workgroup, Re<x_local, y>.
 // Returns the number of partials written.
+// part: 0 = the whole image; 1 / 2 = the own-column / other-columns half of a column-split image (ll_operator::csr_split).
 template <typename T>
 int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                hipStream_t s, const ScaleIn<T>* sc = nullptr);
+                hipStream_t s, const ScaleIn<T>* sc = nullptr, int part = 0);
+// build helpers of the column split (kernels.hip): own-column entries per row; scatter into the two halves
+template <typename T> void launch_csr_count_own(const ll_operator& op, int32_t* own_cnt, hipStream_t s);
+template <typename T> void launch_csr_split(const ll_operator& op, hipStream_t s);
 // Same contract, propagation-blocked kernels (op.spmv_kind == LL_SPMV_PB; spmv_pb.hip): phase 1 over the own-column
 // blocks (x slices from x_own: the local shard readable up to the shard stride), then over every gather chunk's remote blocks (x slices from x_gathered, laid out
 // per op.gather), then phase 2.  The pieces are exposed so that the sharded driver can run the own-column part under
@@ -355,7 +369,7 @@ template <typename T> void csr_check_device(ll_operator* op);
 // Same contract for the dense row block (op.kind == DENSE).
 template <typename T>
 int launch_dense_mv(const ll_operator& op, const T* x_full, const T* x_local, T* y, double offset, double* dot_partials,
-                    hipStream_t s, const ScaleIn<T>* sc = nullptr);
+                    hipStream_t s, const ScaleIn<T>* sc = nullptr, int part = 0);
 // Lattice operator (op.kind == STENCIL): site li of the shard reads x at li + off, |off| <= op.st_halo, from
 // halo_lo[st_halo + j] for j < 0, x_local[j] for 0 <= j < n_local and halo_hi[j - n_local] beyond.
 template <typename T>

@@ -53,6 +53,9 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
         assert ra["laplace"] == rb["laplace"]
 
 
+# The CSR-stream and dense operators of a sharded context multiply the rank's OWN columns under the all-gather and add the
+# other ranks' columns when the vector has arrived (column-split image, capi.cpp build_csr_split; every case below runs it);
+# "csr-gather-then-multiply" (LL_CSR_SPLIT=0) is the round-3 form: gather first, then one kernel over whole rows.
 # forced second pass: every iteration takes the host-decided second Gram-Schmidt pass (drain, repeat, re-enqueue): the
 # replicated decision must keep the ranks' collective sequences aligned, results unchanged up to rounding.
 # measured norm: the post-pass norm from maxpy's partial sums + an all-reduce instead of ||w||^2 - sum |h_j|^2.
@@ -67,11 +70,12 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
                                          (2, {"LL_BLAS_SMALL_BYTES": "0"}), (3, {"LL_BLAS_SMALL_BYTES": "0"}),
                                          (2, {"LL_BLAS_SMALL_BYTES": "0", "LL_DGKS_THRESHOLD": "2.0"}),
                                          (3, {"LL_BLAS_SMALL_BYTES": "0", "LL_TRIDIAG_TEST_JITTER_US": "3000"}),
-                                         (2, {"LL_TEST_LAGGED_MIN_BYTES": "0"}), (3, {"LL_TEST_LAGGED_MIN_BYTES": "0"})],
+                                         (2, {"LL_TEST_LAGGED_MIN_BYTES": "0"}), (3, {"LL_TEST_LAGGED_MIN_BYTES": "0"}),
+                                         (3, {"LL_CSR_SPLIT": "0"})],
                          ids=["2", "3", "4", "2-forced-second-pass", "2-measured-norm", "3-one-chunk",
                               "3-verdict-jitter", "2-verdict-jitter-lag0", "2-one-sweep", "3-one-sweep",
                               "2-one-sweep-forced-second-pass", "3-one-sweep-verdict-jitter", "2-one-sweep-small-geometry",
-                              "3-one-sweep-small-geometry"])
+                              "3-one-sweep-small-geometry", "3-csr-gather-then-multiply"])
 def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, world, extra, llenv):
     ranks = run_ranks(tmp_path, world, **extra)
 
