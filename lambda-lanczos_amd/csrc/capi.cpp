@@ -44,6 +44,7 @@ Tuning read_tuning() {
   t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
   t.comm_overlap = flag("LL_COMM_OVERLAP", true);
   t.csr_split = flag("LL_CSR_SPLIT", true);
+  t.spmv_tile_balance = flag("LL_SPMV_TILE_BALANCE", true);
   t.tridiag_thread = flag("LL_TRIDIAG_THREAD", true);
   t.tridiag_lag = (int)num("LL_TRIDIAG_LAG", 3);
   {
@@ -528,17 +529,44 @@ inline double abs2_host(float v) { return (double)v * (double)v; }
 inline double abs2_host(zc v) { return v.re * v.re + v.im * v.im; }
 inline double abs2_host(cf v) { return (double)v.re * (double)v.re + (double)v.im * (double)v.im; }
 
-// SpMV tiles: runs of whole rows with <= kSpmvTileNnz nonzeros and <= kBlock rows; a longer row is alone.
-void build_tiles(const int64_t* rp, int64_t nrows, std::vector<int32_t>& tiles) {
+// SpMV tiles: runs of whole rows with <= cap nonzeros and <= kBlock rows; a longer row is alone.
+void build_tiles_cap(const int64_t* rp, int64_t nrows, int64_t cap, std::vector<int32_t>& tiles) {
   tiles.clear();
   tiles.push_back(0);
   int64_t r = 0;
   while (r < nrows) {
     int64_t r1 = r;
-    while (r1 < nrows && (r1 - r) < kBlock && rp[r1 + 1] - rp[r] <= kSpmvTileNnz) ++r1;
+    while (r1 < nrows && (r1 - r) < kBlock && rp[r1 + 1] - rp[r] <= cap) ++r1;
     if (r1 == r) r1 = r + 1;
     tiles.push_back((int32_t)r1);
     r = r1;
+  }
+}
+// The kernel walks the tiles with a persistent grid of at most `grid_cap` workgroups, every workgroup the same number of
+// tiles +-1 (TileWalk).  With only a few tiles per workgroup that +-1 is a large share of the kernel: config 2 (4 880
+// tiles of 1 024 nonzeros on 2 048 workgroups) runs three rounds of which the last is 38 % full.  So when fewer than
+// eight rounds are needed the tile size is lowered until the tiles fill whole rounds: every workgroup then walks exactly
+// `rounds` tiles, each a little shorter: config 2's SpMV 18.35 -> 17.37 us (54.5 -> 57.5 % of the roofline).  Only from three
+// rounds up: a tile costs mostly latency, so with one or two rounds (config 5: 4 883 tiles on 4 096 workgroups) a few
+// workgroups walking a second full tile are cheaper than all of them walking two shorter ones (25.0 -> 30.6 us when
+// balanced; gpurun A/B of round 4).  (LL_SPMV_TILE_BALANCE=0: always kSpmvTileNnz.)
+void build_tiles(const int64_t* rp, int64_t nrows, std::vector<int32_t>& tiles, int grid_cap = 0, bool balance = true) {
+  build_tiles_cap(rp, nrows, kSpmvTileNnz, tiles);
+  const int64_t nt = (int64_t)tiles.size() - 1;
+  if (!balance || grid_cap <= 0 || nt <= grid_cap / 2 || nt >= 8 * (int64_t)grid_cap) return;
+  const int64_t rounds = (nt + grid_cap - 1) / grid_cap;
+  if (rounds < 3) return;
+  const int64_t nnz = rp[nrows];
+  std::vector<int32_t> best;
+  // rows do not cut evenly: shrink the cap until the tile count fits rounds x grid (a few tries)
+  for (double slack : {0.995, 0.97, 0.94, 0.90}) {
+    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(kSpmvTileNnz, (int64_t)((double)nnz / ((double)rounds * grid_cap * slack)) + 1));
+    std::vector<int32_t> t;
+    build_tiles_cap(rp, nrows, cap, t);
+    if ((int64_t)t.size() - 1 <= rounds * grid_cap) {
+      tiles.swap(t);
+      return;
+    }
   }
 }
 
@@ -547,7 +575,7 @@ void finish_csr(ll_operator* op, const int64_t* rp_host) {
   ll_context* ctx = op->ctx;
   const int64_t nr = op->n_local;
   std::vector<int32_t> tiles;
-  build_tiles(rp_host, nr, tiles);
+  build_tiles(rp_host, nr, tiles, sizeof(T) >= 16 ? kMaxSpmvGrid : kMaxGrid, ctx->tune.spmv_tile_balance);
   op->ntiles = (int)tiles.size() - 1;
   ctx->dev_malloc((void**)&op->d_tile_rows, tiles.size() * sizeof(int32_t), "SpMV tiles");
   LL_HIP(hipMemcpy(op->d_tile_rows, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -611,7 +639,7 @@ template <typename T> void build_csr_split(ll_operator* op) {
   };
   auto upload_tiles = [&](const std::vector<int64_t>& v, int32_t** dst, int* ntiles) {
     std::vector<int32_t> tiles;
-    build_tiles(v.data(), nr, tiles);
+    build_tiles(v.data(), nr, tiles, sizeof(T) >= 16 ? kMaxSpmvGrid : kMaxGrid, ctx->tune.spmv_tile_balance);
     *ntiles = (int)tiles.size() - 1;
     ctx->dev_malloc((void**)dst, tiles.size() * sizeof(int32_t), "split SpMV tiles");
     LL_HIP(hipMemcpy(*dst, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -156,6 +156,7 @@ struct Tuning {
   int pb_col_block = 0;
   int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
   int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
+  bool spmv_tile_balance = true;   // LL_SPMV_TILE_BALANCE=0: CSR-stream tiles always hold up to 1024 nonzeros (capi.cpp build_tiles)
   bool csr_split = true;           // LL_CSR_SPLIT=0: sharded CSR-stream / dense operators gather first, then multiply (round-3 form)
   bool comm_overlap = true;        // LL_COMM_OVERLAP=0: exchange and compute on one stream (serial A/B reference)
   // --- the loops
