@@ -1034,6 +1034,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     }
   } trace_holder;
   if (!ctx->tune.iter_trace.empty()) trace_holder.f = std::fopen(ctx->tune.iter_trace.c_str(), "a");
+  if (trace_holder.f) std::setvbuf(trace_holder.f, nullptr, _IOLBF, 0);  // line by line: the callback lines (Engine::apply) interleave in order
   FILE* const trace_file = trace_holder.f;
 
   while (true) {  // restart loop LL:334-354
