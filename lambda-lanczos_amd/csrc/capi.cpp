@@ -41,6 +41,7 @@ Tuning read_tuning() {
   t.pb_row_block = (int)std::max<long long>(0, num("LL_PB_ROW_BLOCK", 0));
   t.pb_col_block = (int)std::max<long long>(0, num("LL_PB_COL_BLOCK", 0));
   t.pb_placements = (int)std::max<long long>(1, std::min<long long>(8, num("LL_PB_PLACEMENTS", 4)));
+  t.pb_xpre = flag("LL_PB_XPRE", true);
   t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
   t.comm_overlap = flag("LL_COMM_OVERLAP", true);
   t.csr_split = flag("LL_CSR_SPLIT", true);

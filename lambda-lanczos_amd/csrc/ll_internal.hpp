@@ -155,6 +155,7 @@ struct Tuning {
   int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
   int pb_col_block = 0;
   int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
+  bool pb_xpre = true;             // LL_PB_XPRE=0: phase 2 of the PB SpMV loads x_i in its epilogue (A/B of the early request)
   int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
   bool spmv_tile_balance = true;   // LL_SPMV_TILE_BALANCE=0: CSR-stream tiles always hold up to 1024 nonzeros (capi.cpp build_tiles)
   bool csr_split = true;           // LL_CSR_SPLIT=0: sharded CSR-stream / dense operators gather first, then multiply (round-3 form)
@@ -295,6 +296,7 @@ struct ll_operator {
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
+  bool pb_xpre = true;                         // fixed-point phase 2 requests the epilogue's x_i before its stream (LL_PB_XPRE)
   int pb_own_count = 0;                        // table range [0, own_count)
   int pb_chunk_first[ll::kMaxGatherChunks] = {0};  // remote blocks of gather chunk c: [first, first + count)
   int pb_chunk_count[ll::kMaxGatherChunks] = {0};

@@ -220,6 +220,7 @@ __device__ __forceinline__ double pow2(int k) {  // 2^k for |k| <= 1022
 // altogether changes nothing, profiles/r03_spmv_variants.txt runs C and G) while the float -> int64 conversion makes
 // phase 1 borderline ALU-bound; no gain, removed again.)
 constexpr long long kPbBadProduct = (long long)0x8000000000000000ull;  // "not a finite number below 2^63"
+constexpr int kPbXPre = 16;      // rows per lane whose x_i the fixed-point phase 2 holds in registers (row blocks of <= 16 384 rows)
 constexpr int kPbXInf = 20000;   // e_x when max|x| is not finite: every row is reported as NaN
 
 __device__ __forceinline__ long long pb_to_fixed(double p, int k) {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
                                                               const double* __restrict__ blockmax,
                                                               const T* __restrict__ xl, T* __restrict__ y, double offset,
                                                               double* __restrict__ dot_partials,
-                                                              const double* __restrict__ xnorm2) {
+                                                              const double* __restrict__ xnorm2, int xprefetch) {
   constexpr int R = scalar_traits<T>::reals;
   constexpr int U = 2;
   extern __shared__ double lds_raw[];
@@ -487,6 +488,20 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const long long g0 = rptr[rb] >> 2, g1 = rptr[rb + 1] >> 2;
   __shared__ unsigned chunk_ctr;
+  // The epilogue needs x_i of the block's rows (offset term, alpha).  Requested HERE, before the stream's first trips and
+  // held in registers: the loads are older than every load of the stream, so they have arrived long before the epilogue,
+  // which otherwise spends 3-4 dependent rounds of global loads per workgroup with nothing else running on the CU
+  // (8-byte types with at most kPbXPre rows per lane; LL_PB_XPRE=0 in the launcher: load them in the epilogue, round-3 form).
+  T xpre[kPbXPre];
+  if constexpr (sizeof(T) <= 8) {
+    if (xprefetch) {
+#pragma unroll
+      for (int u = 0; u < kPbXPre; ++u) {
+        const int i = tid + u * kPbThreads;
+        xpre[u] = xl[row0 + (i < rows ? i : rows - 1)];
+      }
+    }
+  }
   RowStream<T, U, D, true> st;
   st.P = P;
   st.row = row;
@@ -544,14 +559,43 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
     }
   });
   __syncthreads();
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, [&](int i) {
+  auto value = [&](int i) {
     const int k = ex[i];
     const double back = k == kBadRow ? __longlong_as_double(0x7ff8000000000000ll) : pow2(-k);  // NaN for unusable rows
     acc_t<T> a;
     if constexpr (scalar_traits<T>::is_complex) a = zc{(double)acc[2 * i] * back, (double)acc[2 * i + 1] * back};
     else a = (double)acc[i] * back;
     return a;
-  });
+  };
+  if constexpr (sizeof(T) <= 8) {
+    if (xprefetch) {  // same arithmetic, same order of the per-lane dot sum (rows tid, tid + 1024, ...) as the loading form
+      const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;
+      double dot_acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < kPbXPre; ++u) {
+        const int i = tid + u * kPbThreads;
+        if (i < rows) {
+          const T xi = rmul(xs_fac, xpre[u]);
+          const T yi = add(narrow<T>(value(i)), rmul(offset, xi));
+          y[row0 + i] = yi;
+          dot_acc += re_cmul(xi, yi);
+        }
+      }
+      if (dot_partials) {
+        const double v = wave_sum(dot_acc);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          for (int w = 0; w < kPbWaves; ++w) t += red[w];
+          dot_partials[rb] = t;
+        }
+      }
+      return;
+    }
+  }
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, value);
 }
 
 // exponent of every local row's absolute sum: sum_j |a_ij| < 2^rexp[i]  (32767: the row holds Inf / NaN)
@@ -625,7 +669,7 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
     const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
     hipLaunchKernelGGL((pb_phase2_fixed<T, D2>), grid, block, ldsf, s, op.pb_rb_rows, op.n_local, op.pb_ncb, op.d_pb_rptr,
                        (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp, op.d_pb_blockmax, x_local, y,
-                       offset, dot_partials, xnorm2);
+                       offset, dot_partials, xnorm2, (op.pb_xpre && op.pb_rb_rows <= kPbXPre * kPbThreads) ? 1 : 0);
   } else {
     const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
     if (op.pb_phase2 == LL_PB_ORDERED)
@@ -974,6 +1018,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_rb_rows = (int)rb_rows;
   op->pb_own_count = own_total;
   op->pb_entries = (int64_t)entries;
+  op->pb_xpre = tune.pb_xpre;
   op->gather = gp;
   // Phase 2 form, fixed per operator at creation (LL_PB_PHASE2).  Default "fixed": order-independent fixed-point sums
   // (integer LDS adds, all waves at once) — bit-reproducible for every launch, kernel geometry and partition, and 2-5 %
