@@ -135,6 +135,102 @@ def two_per_sweep(explicit_tail):
     return np.array(al[:m]), np.array(be[:m]), U, worst
 
 
+def two_per_sweep_predicted():
+    """The kernel-shaped variant: everything the sweep WRITES (u_p, u_{p+1} and the next raw vector) is formed with coefficients
+    known BEFORE the sweep — g and rho from the previous fold, the 3 x 3 Gram matrix of (r, y1, y2) from a small kernel, and the
+    stored-basis coefficients of y1 and y2 PREDICTED through the recorded tridiagonal:
+        <u_j, y1> = <A u_j, r>   = be[j-1] g[j-1] + al[j] g[j] + be[j] g[j+1]          (g[p] := <u_p, r> = rho)
+        <u_j, y2> = <A u_j, z>   = the same stencil on  zU = U^T z = h1 - a1 g,  zU[p] = <u_p, z>
+    The one pass over the basis forms the three outputs with those coefficients and MEASURES h1 = U^T y1, h2 = U^T y2; the fold
+    then computes, from the measured numbers, the recurrence coefficients and the exact inner products of the next raw vector
+    with every stored vector (its new g and rho).  What the predicted coefficients leave along span(U) is fresh rounding."""
+    U = np.zeros((K + 2, n)); U[0] = v0
+    al, be = [], []
+    y = A @ U[0]; a = U[0] @ y; w = y - a * U[0]
+    al.append(a)
+    p = 1
+    r = w; g = U[:p] @ r; rho = np.sqrt(r @ r - g @ g); be.append(rho)
+    maxdev = 0.0
+    while len(al) + 2 <= K:
+        P = p
+        y1 = A @ r
+        rr = r @ r; ry1 = r @ y1
+        a1 = ry1 / rr
+        z = y1 - a1 * r
+        y2 = A @ z
+        G3 = np.array([[rr, ry1, r @ y2], [ry1, y1 @ y1, y1 @ y2], [r @ y2, y1 @ y2, y2 @ y2]])   # small kernel over r, y1, y2
+        alh, beh = np.array(al), np.array(be)
+
+        def stencil(v, vP):
+            """(T applied to the coefficient vector v of length P, with the pending entry vP at index P)"""
+            out = alh * v
+            out[1:] += beh[:P - 1] * v[:-1]
+            out[:-1] += beh[:P - 1] * v[1:]
+            out[P - 1] += beh[P - 1] * vP
+            return out
+        # ---- predictions (before the sweep)
+        h1p = stencil(g, rho)
+        up_y1 = (ry1 - g @ h1p) / rho                    # <u_p, y1> with the predicted h1
+        zU = h1p - a1 * g
+        zP = up_y1 - a1 * rho
+        h2p = stencil(zU, zP)
+
+        def algebra(h1, h2):
+            Uf = np.stack([g, h1, h2], axis=1)
+            def gram(c, d):
+                return c[0] @ d[0] + c[0] @ (Uf @ d[1]) + d[0] @ (Uf @ c[1]) + c[1] @ (G3 @ d[1])
+            def A_U(cu):
+                out = alh * cu
+                out[1:] += beh[:P - 1] * cu[:-1]
+                out[:-1] += beh[:P - 1] * cu[1:]
+                c3 = np.zeros(3)
+                out = out - beh[P - 1] * cu[P - 1] * g / rho; c3[0] += beh[P - 1] * cu[P - 1] / rho
+                return out, c3
+            def A_frame(c):
+                ou, o3 = A_U(c[0])
+                return ou, o3 + np.array([0.0, c[1][0] + a1 * c[1][1], c[1][1]])
+            def axpy(c, s_, d):
+                return (c[0] + s_ * d[0], c[1] + s_ * d[1])
+            def orthU(c):      # against every stored vector at once: <u_j, c> = c_U[j] + Uf[j] . c_3
+                return (c[0] - (c[0] + Uf @ c[1]), c[1])
+            cup = (-g / rho, np.array([1.0, 0, 0]) / rho)
+            Aup = A_frame(cup)
+            a_p = gram(cup, Aup)
+            w = axpy(Aup, -a_p, cup)
+            w = (w[0].copy(), w[1]); w[0][P - 1] -= rho
+            w = orthU(w); w = axpy(w, -gram(cup, w), cup)
+            b_p = np.sqrt(gram(w, w))
+            cup1 = (w[0] / b_p, w[1] / b_p)
+            Aup1 = A_frame(cup1)
+            a_p1 = gram(cup1, Aup1)
+            w2 = axpy(Aup1, -a_p1, cup1)
+            w2 = axpy(w2, -b_p, cup)
+            w2 = orthU(w2); w2 = axpy(w2, -gram(cup, w2), cup); w2 = axpy(w2, -gram(cup1, w2), cup1)
+            return cup, cup1, w2, a_p, b_p, a_p1, gram
+        cup_p, cup1_p, w2_p, *_ = algebra(h1p, h2p)
+        # ---- ONE sweep: outputs with the predicted coefficients, measurements of h1, h2
+        U[p] = cup_p[0] @ U[:P] + cup_p[1][0] * r
+        U[p + 1] = cup1_p[0] @ U[:P] + cup1_p[1] @ np.stack([r, y1, y2])
+        rn = w2_p[0] @ U[:P] + w2_p[1] @ np.stack([r, y1, y2])
+        h1 = U[:P] @ y1
+        h2 = U[:P] @ y2
+        maxdev = max(maxdev, np.abs(h1 - h1p).max(), np.abs(h2 - h2p).max())
+        # ---- fold: the numbers of the recurrence from the MEASURED inner products; inner products of rn with the stored basis
+        cup, cup1, w2, a_p, b_p, a_p1, gram = algebra(h1, h2)
+        al += [a_p, a_p1]; be += [b_p]
+        Uf = np.stack([g, h1, h2], axis=1)
+        gn_old = w2_p[0] + Uf @ w2_p[1]                       # <u_j, rn>, j < P (measured Gram, predicted coefficients)
+        gn_p = gram(cup_p, w2_p); gn_p1 = gram(cup1_p, w2_p)  # with the two vectors written by this sweep
+        rn2 = gram(w2_p, w2_p)
+        p += 2
+        r = rn
+        g = np.concatenate([gn_old, [gn_p, gn_p1]])
+        rho = np.sqrt(rn2 - g @ g)
+        be.append(rho)
+    m = min(len(al), K)
+    return np.array(al[:m]), np.array(be[:m]), U, maxdev
+
+
 def main():
     ra, rb, RU = reference()
     lines = ["model: n = %d random symmetric + diagonal 2..12, %d iterations; reference = full re-orthogonalisation" % (n, K)]
@@ -153,6 +249,13 @@ def main():
                       np.abs(U[:m] @ U[:m].T - np.eye(m)).max(), worst)]
         for k in (10, 100, m - 1):
             lines.append("  k = %3d: dalpha %.1e dbeta %.1e" % (k, abs(a[k] - ra[k]), abs(b[min(k, mb - 1)] - rb[min(k, mb - 1)])))
+    a, b, U, dev = two_per_sweep_predicted()
+    m = min(len(a), len(ra)); mb = m - 1
+    lines += ["two iterations per sweep, ONE pass over the basis per pair (outputs from predicted coefficients, fold from measured ones): %d iterations compared" % m,
+              "  max|dalpha| %.2e   max|dbeta| %.2e   orthogonality max|U^T U - I| = %.2e   max |measured - predicted coefficient| = %.1e" % (
+                  np.max(np.abs(a[:m] - ra[:m])), np.max(np.abs(b[:mb] - rb[:mb])), np.abs(U[:m] @ U[:m].T - np.eye(m)).max(), dev)]
+    for k in (10, 100, m - 1):
+        lines.append("  k = %3d: dalpha %.1e dbeta %.1e" % (k, abs(a[k] - ra[k]), abs(b[min(k, mb - 1)] - rb[min(k, mb - 1)])))
     text = "\n".join(lines) + "\n"
     print(text)
     import os
