@@ -15,15 +15,9 @@
 #include <vector>
 
 #include "../lanczos_hip.h"
+#include "util.hpp"  // lambda_lanczos::util::{real_t, inner_prod, norm, normalize, schmidt_orth, m_norm, sort_eigenpairs, ...}
 
 namespace lambda_lanczos_hip {
-
-namespace util {
-// real_t<T>: T for real types, R for std::complex<R> (reference: util/common.hpp:80-102)
-template <typename T> struct realTypeMap { typedef T type; };
-template <typename T> struct realTypeMap<std::complex<T>> { typedef T type; };
-template <typename T> using real_t = typename realTypeMap<T>::type;
-}  // namespace util
 
 // The reference never throws (asserts only); device / RCCL failures need a channel, so the facade throws.
 struct Error : std::runtime_error {
@@ -86,6 +80,7 @@ class Context {
   }
   Context(int device, void* hip_stream) {
     ll_context* c = nullptr;
+    check(LL_ABI_CHECK());
     check(ll_ctx_create_on_stream(device, hip_stream, &c));
     h_.reset(c, [](ll_context* p) { ll_ctx_destroy(p); });
   }
@@ -207,6 +202,30 @@ template <typename T> class LatticeOperator : public DeviceOperator<T> {
   }
 };
 
+// VectorRandomInitializer<T> (lambda_lanczos.hpp:70-104; the public init_vector member points at its init, :133): every
+// element — real and imaginary part for complex T — uniform in [-1, 1] from a std::random_device-seeded mt19937.
+// Callable like the reference's, so user code that invokes engine.init_vector(v) or names the class keeps working.
+template <typename T> struct VectorRandomInitializer {
+  static void init(std::vector<T>& v) {
+    std::random_device dev;
+    std::mt19937 mt(dev());
+    std::uniform_real_distribution<T> rand((T)(-1.0), (T)(1.0));
+    for (auto& e : v) e = rand(mt);
+  }
+};
+template <typename R> struct VectorRandomInitializer<std::complex<R>> {
+  static void init(std::vector<std::complex<R>>& v) {
+    std::random_device dev;
+    std::mt19937 mt(dev());
+    std::uniform_real_distribution<R> rand((R)(-1.0), (R)(1.0));
+    for (auto& e : v) {
+      const R re = rand(mt);  // real part first, like the reference's constructor-argument order in practice
+      const R im = rand(mt);
+      e = std::complex<R>(re, im);
+    }
+  }
+};
+
 namespace detail {
 // Host-callback trampoline: the reference's mv_mul signature works on std::vector, the C ABI on raw pointers.
 template <typename T> struct HostOp {
@@ -227,29 +246,9 @@ template <typename T> struct HostOp {
   }
 };
 
-// The default of the public init_vector member (lambda_lanczos.hpp:133 points it at VectorRandomInitializer<T>::init,
-// :70-104): every element — real and imaginary part for complex T — uniform in [-1, 1] from a std::random_device
-// seeded mt19937.  Callable like the reference's, so user code that invokes engine.init_vector(v) keeps working.
-template <typename T> struct RandomInit {
-  static void init(std::vector<T>& v) {
-    std::random_device dev;
-    std::mt19937 mt(dev());
-    std::uniform_real_distribution<T> rand((T)(-1.0), (T)(1.0));
-    for (auto& e : v) e = rand(mt);
-  }
-};
-template <typename R> struct RandomInit<std::complex<R>> {
-  static void init(std::vector<std::complex<R>>& v) {
-    std::random_device dev;
-    std::mt19937 mt(dev());
-    std::uniform_real_distribution<R> rand((R)(-1.0), (R)(1.0));
-    for (auto& e : v) {
-      const R re = rand(mt);  // real part first, like the reference's constructor-argument order in practice
-      const R im = rand(mt);
-      e = std::complex<R>(re, im);
-    }
-  }
-};
+// The default of the public init_vector member: the reference's VectorRandomInitializer<T> under its own name (above,
+// outside detail); RandomInit is the name earlier rounds of this facade used.
+template <typename T> using RandomInit = VectorRandomInitializer<T>;
 
 template <typename T> struct InitHook {
   std::function<void(std::vector<T>&)> fn;

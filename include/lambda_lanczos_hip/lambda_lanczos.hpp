@@ -27,7 +27,7 @@ template <typename T> class LambdaLanczos {
  public:
   // ---- the reference's public data members (lambda_lanczos.hpp:126-181), same names / types / defaults
   std::function<void(const std::vector<T>& in, std::vector<T>& out)> mv_mul;            // :126
-  std::function<void(std::vector<T>& vec)> init_vector = detail::RandomInit<T>::init;     // :133 (callable default, :70-104)
+  std::function<void(std::vector<T>& vec)> init_vector = VectorRandomInitializer<T>::init;  // :133 (callable default, :70-104)
   size_t matrix_size;                                                                     // :136
   size_t max_iteration;                                                                   // :138
   real_t<T> eps = std::numeric_limits<real_t<T>>::epsilon() * 1e3;                        // :150
@@ -192,6 +192,37 @@ template <typename T> class LambdaLanczos {
   std::vector<size_t> iter_counts_;
   mutable ll_run_stats last_stats_{};  // run_iteration is const like the reference's (lambda_lanczos.hpp:216-220)
 };
+
+// lambda_lanczos::tridiagonal_impl::tridiagonal_eigenpairs / tridiagonal_eigenvalues
+// (lambda_lanczos_tridiagonal_impl.hpp:290-361; called directly by the reference's own tests, test/lambda_lanczos_test.cpp:765,795):
+// all eigenvalues (ascending) and, on request, the eigenvectors (eigenvectors[k] = k-th vector) of the symmetric tridiagonal
+// matrix with diagonal alpha and sub-diagonal beta, by the library's host solver (ll_tridiag_eig: the reference's implicit-QR
+// arithmetic step for step, bit-identical results); returns the count of forced breaks.  Host code, no device needed.
+namespace tridiagonal_impl {
+template <typename T>
+inline size_t tridiagonal_eigenpairs(const std::vector<T>& alpha, const std::vector<T>& beta, std::vector<T>& eigenvalues,
+                                     std::vector<std::vector<T>>& eigenvectors, bool compute_eigenvector = true) {
+  static_assert(std::is_floating_point<T>::value, "tridiagonal_eigenpairs<T>: T must be a real floating-point type");
+  const size_t m = alpha.size();
+  std::vector<double> a(alpha.begin(), alpha.end()), b(m ? m : 1, 0.0), ev(m), q;
+  for (size_t i = 0; i + 1 < m && i < beta.size(); ++i) b[i] = (double)beta[i];
+  if (compute_eigenvector) q.resize(m * m);
+  int64_t unconverged = 0;
+  check(ll_tridiag_eig((int64_t)m, a.data(), b.data(), ev.data(), compute_eigenvector ? q.data() : nullptr, &unconverged));
+  eigenvalues.assign(ev.begin(), ev.end());
+  if (compute_eigenvector) {
+    eigenvectors.assign(m, std::vector<T>(m));
+    for (size_t j = 0; j < m; ++j)
+      for (size_t i = 0; i < m; ++i) eigenvectors[j][i] = (T)q[j * m + i];
+  }
+  return (size_t)unconverged;
+}
+template <typename T>
+inline size_t tridiagonal_eigenvalues(const std::vector<T>& alpha, const std::vector<T>& beta, std::vector<T>& eigenvalues) {
+  std::vector<std::vector<T>> none;
+  return tridiagonal_eigenpairs(alpha, beta, eigenvalues, none, false);
+}
+}  // namespace tridiagonal_impl
 
 }  // namespace lambda_lanczos_hip
 

@@ -108,6 +108,11 @@ def long_run_specs():
         "randsym1e6_fixed120": dict(gen="randsym", args=[1000000], find_max=True, offset=0.0, num_eigs=1, seed=1,
                                     max_iteration=120),
         "randsym1e5_three_roots": dict(gen="randsym", args=[100000], find_max=True, offset=0.0, num_eigs=3, seed=1),
+        # Round 5: the STREAMING one-sweep kernel (lagged_kernel, vectors >= 1 MiB) over whole runs.  400 x 400 Laplacian,
+        # smallest pair, offset -8: 1.28 MB vectors, ~1400 reference iterations; complex torus 300 x 300 (config 5's matrix in
+        # small), smallest pair, offset -10: 1.44 MB vectors, several hundred iterations.
+        "laplace400_converge": dict(gen="laplace2d", args=[400], find_max=False, offset=-8.0, num_eigs=1, seed=1),
+        "torus300_converge": dict(gen="torus", args=[300], find_max=False, offset=-10.0, num_eigs=1, seed=1, complex=True),
     }
 
 
@@ -131,7 +136,8 @@ def make_long_runs(ref, only=None):
         t0 = time.time()
         csr = long_run_matrix(s)
         n = csr[0].shape[0] - 1
-        init = ref.init_mt19937(s["mt19937_seed"], n) if "mt19937_seed" in s else G.start_vector(n, s["seed"])
+        dtype = np.complex128 if s.get("complex") else np.float64
+        init = ref.init_mt19937(s["mt19937_seed"], n) if "mt19937_seed" in s else G.start_vector(n, s["seed"], dtype)
         r = ref.lanczos(csr, init, s["find_max"], num_eigs=s["num_eigs"], offset=s["offset"],
                         max_iteration=s.get("max_iteration"))
         first = r
@@ -142,7 +148,8 @@ def make_long_runs(ref, only=None):
                          eigenvalues=r["eigenvalues"].tolist(), alpha_pass1=first["alpha"].tolist(),
                          beta_pass1=first["beta"][:-1].tolist(),
                          sample="make_golden.sample_indices(n)",
-                         eigenvector_samples=[v[idx].tolist() for v in r["eigenvectors"]])
+                         eigenvector_samples=[c2list(v[idx]) if s.get("complex") else v[idx].tolist()
+                                              for v in r["eigenvectors"]])
         if "mt19937_seed" in s:
             out[name]["start"] = "the reference's own initialiser: std::mt19937(seed) + uniform_real_distribution(-1, 1) (LL:70-104)"
             out[name]["start_vector"] = init.tolist()

@@ -73,6 +73,36 @@ def test_the_same_source_builds_and_passes_with_the_real_reference_headers():
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
 
 
+UTIL_SRC = os.path.join(ROOT, "tests", "cpp", "compat_util_test.cpp")
+
+
+def test_util_seam_compiles_and_passes_through_the_compat_include_path():
+    """lambda_lanczos::util::{inner_prod, norm, scalar_mul, normalize, m_norm, schmidt_orth, typed_conj, sort_eigenpairs,
+    vectorToString, sgn, initAsIdentity, real_t}, tridiagonal_impl::tridiagonal_eigenpairs / _eigenvalues and
+    VectorRandomInitializer<T> the way the reference's own tests call them (test/lambda_lanczos_test.cpp:54,75-87,99,107,122,765;
+    test/exponentiator_test.cpp:21,66,130), with the T1 pins (23 - 2i, m_norm = 6, {-1, 2, 5}).  Host helpers: runs without a device."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(UTIL_SRC) as f:
+        src = f.read()
+    assert "lambda_lanczos_hip" not in src and "lanczos_hip.h" not in src
+    exe = os.path.join(OUT_DIR, "compat_util_test")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include", "compat"), UTIL_SRC,
+           "-o", exe, "-L" + LIB_DIR, "-llanczos_hip", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PASSED" in r.stdout and r.stdout.count("[case]") == 7, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/lambda_lanczos"), reason="reference checkout not present")
+def test_util_seam_source_passes_with_the_real_reference_headers():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    exe = os.path.join(OUT_DIR, "compat_util_test_reference")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I/root/reference/include", UTIL_SRC, "-o", exe], check=True,
+                   capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PASSED" in r.stdout and r.stdout.count("[case]") == 7, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_unchanged_reference_style_source_runs_through_the_compat_include_path():
     build_compat()
