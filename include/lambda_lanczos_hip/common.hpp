@@ -42,6 +42,10 @@ template <typename T> struct abi;
                           const T* va, ll_operator** o) {                                                                \
       return ll_op_create_csr_##SFX(c, nr, nc, rb, rp, ci, va, o);                                                       \
     }                                                                                                                    \
+    static int create_csr_opt(ll_context* c, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,   \
+                              const T* va, const ll_csr_options* opt, ll_operator** o) {                                 \
+      return ll_op_create_csr_opt_##SFX(c, nr, nc, rb, rp, ci, va, opt, o);                                              \
+    }                                                                                                                    \
     static int create_dense(ll_context* c, int64_t nr, int64_t nc, int64_t rb, const T* a, ll_operator** o) {            \
       return ll_op_create_dense_##SFX(c, nr, nc, rb, a, o);                                                              \
     }                                                                                                                    \
@@ -132,16 +136,40 @@ template <typename T> class DeviceOperator {
 
 // CSR matrix: rows [row_begin, row_begin + n_rows) of an n_cols x n_cols symmetric/Hermitian operator (the whole
 // matrix on a single GPU).
+//
+// Accuracy of y = A x — what stands in for the user's fp64 mv_mul loop (lambda_lanczos.hpp:120-126).  The default class
+// (Accuracy::Default -> norm-wise where the propagation-blocked kernel is selected) bounds the error of every row by
+// eps * sum_j |a_ij||x_j| + nnz_i 2^-60 ||A||_inf max|x|: right for Lanczos vectors of extended states and what the Krylov
+// recurrence needs, but not component-wise for strongly LOCALISED vectors.  A caller who knows their vectors are localised
+// passes Accuracy::Componentwise (floating-point sums in a fixed order: the accuracy of a plain fp64 row loop, 3-5 % slower
+// on such matrices) — per operator, no environment variable; set_accuracy() moves an existing operator between the classes.
+enum class Accuracy : int {
+  Default = LL_ACCURACY_DEFAULT,
+  Normwise = LL_ACCURACY_NORMWISE,
+  Componentwise = LL_ACCURACY_COMPONENTWISE
+};
 template <typename T> class CsrMatrix : public DeviceOperator<T> {
  public:
   CsrMatrix(const std::vector<int64_t>& row_ptr, const std::vector<int32_t>& col, const std::vector<T>& val,
-            Context ctx = Context::default_context(), int64_t n_cols = -1, int64_t row_begin = 0)
+            Context ctx = Context::default_context(), int64_t n_cols = -1, int64_t row_begin = 0,
+            Accuracy accuracy = Accuracy::Default)
       : DeviceOperator<T>(ctx) {
     const int64_t n_rows = (int64_t)row_ptr.size() - 1;
     if (n_cols < 0) n_cols = n_rows;
     ll_operator* op = nullptr;
-    check(abi<T>::create_csr(ctx.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(), val.data(), &op));
+    ll_csr_options opt;
+    check(ll_csr_options_default(&opt));
+    opt.accuracy = (int32_t)accuracy;
+    check(abi<T>::create_csr_opt(ctx.get(), n_rows, n_cols, row_begin, row_ptr.data(), col.data(), val.data(), &opt, &op));
     this->adopt(op, n_cols, n_rows);
+  }
+  CsrMatrix(const std::vector<int64_t>& row_ptr, const std::vector<int32_t>& col, const std::vector<T>& val, Accuracy accuracy)
+      : CsrMatrix(row_ptr, col, val, Context::default_context(), -1, 0, accuracy) {}
+  void set_accuracy(Accuracy a) { check(ll_op_set_accuracy(this->get(), (int)a)); }
+  Accuracy accuracy() const {
+    int a = 0;
+    check(ll_op_accuracy(this->get(), &a));
+    return (Accuracy)a;
   }
 };
 

@@ -44,9 +44,11 @@ extern "C" {
 #endif
 
 #define LL_VERSION_MAJOR 0
-#define LL_VERSION_MINOR 3  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers
+#define LL_VERSION_MINOR 4  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers
                              * 3: ll_run_stats.lagged_iterations + reserved tail (the struct grew: code compiled against a
-                             *    minor-2 header must be rebuilt — ll_abi_check refuses it), ll_ctx_reload_env, ll_abi_check */
+                             *    minor-2 header must be rebuilt — ll_abi_check refuses it), ll_ctx_reload_env, ll_abi_check
+                             * 4: additive — ll_csr_options / ll_op_create_csr_opt_*, ll_op_set_accuracy, ll_op_accuracy, the tiled
+                             *    SpMV kernel id; no struct changed, callers built against minor 3 keep working */
 
 enum {
   LL_OK = 0,
@@ -69,7 +71,10 @@ int ll_version(void);
 /* ABI handshake: pass the LL_VERSION_* the CALLER was compiled with and sizeof(ll_run_stats) / sizeof(ll_lanczos_params) as
  * the caller sees them.  LL_OK when the loaded library lays the structs out the same way; LL_ERR_INVALID (with a message
  * naming both versions) otherwise — the library fills ll_run_stats and reads the parameter structs by ITS layout, so a
- * stale binary would be overrun.  The C++ facade and the Python binding call it once per process. */
+ * stale binary would be overrun.  Minors that only ADD entry points accept older callers (any minor from 3 up to the library's
+ * own, same struct sizes).  The handshake exists since minor 3: a binary built against an older header never calls it and is
+ * not protected — it must be rebuilt.  The C++ facade (both Context constructors) and the Python binding call it once per
+ * process. */
 int ll_abi_check(int caller_major, int caller_minor, size_t sizeof_run_stats, size_t sizeof_lanczos_params);
 #define LL_ABI_CHECK() ll_abi_check(LL_VERSION_MAJOR, LL_VERSION_MINOR, sizeof(ll_run_stats), sizeof(ll_lanczos_params))
 
@@ -239,10 +244,39 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  *   below (sum_j |a_ij|) max|x| lose RELATIVE accuracy: their absolute error stays below nnz_i 2^-60 ||A||_inf ||x||_inf, which
  *   is what the Lanczos recurrence and the Exponentiator need (tests/test_gpu_round3.py asserts both bounds and whole
  *   runs from x = e_0 against the real reference), but it is not the component-wise accuracy of an fp64 row loop.
- *   Callers who need that from ll_spmv_* on such vectors set LL_PB_PHASE2=ordered (3-5 % slower) or LL_SPMV_KERNEL=csr.
+ *   Callers who need that on such vectors ask for LL_ACCURACY_COMPONENTWISE (ll_csr_options.accuracy / ll_op_set_accuracy below;
+ *   3-5 % slower); the environment's LL_PB_PHASE2=ordered or LL_SPMV_KERNEL=csr does the same for every operator of a context.
  *   Rows that meet an Inf / NaN are reported as NaN.  float / complex float storage: the product a_ij x_j is rounded to
  *   the storage type once (exactly what a float multiply gives) before it is summed in fixed point / double. */
 enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1 };
+/* The ACCURACY CLASS above as a per-operator choice of the caller (who knows whether the vectors are localised), not of
+ * the environment:
+ *   LL_ACCURACY_DEFAULT        what the context's environment says (LL_PB_PHASE2; norm-wise when unset)
+ *   LL_ACCURACY_NORMWISE       the order-independent fixed-point sums where the PB kernel is selected (fastest, bit-identical
+ *                              for every partition of the matrix); CSR-stream operators are component-wise anyway
+ *   LL_ACCURACY_COMPONENTWISE  floating-point sums in a fixed order in every kernel: the accuracy of the user's own fp64
+ *                              row loop (LL:120-126), still bit-reproducible run to run, 3-5 % slower on PB operators
+ * ll_csr_options carries it (and the kernel choice, and where the arrays live) into ll_op_create_csr_opt_*; an existing
+ * operator is moved between the classes by ll_op_set_accuracy (same image, another phase-2 kernel: no rebuild);
+ * ll_op_accuracy reports the class of the kernel that is selected now (never LL_ACCURACY_DEFAULT). */
+enum { LL_ACCURACY_DEFAULT = 0, LL_ACCURACY_NORMWISE = 1, LL_ACCURACY_COMPONENTWISE = 2 };
+typedef struct ll_csr_options {
+  int32_t accuracy;          /* LL_ACCURACY_* */
+  int32_t kernel;            /* -1: the environment decides (timing of both unless LL_SPMV_KERNEL); LL_SPMV_CSR_STREAM / LL_SPMV_PB */
+  int32_t arrays_on_device;  /* 0: row_ptr / col / val are host arrays (copied); 1: device arrays as in ll_op_create_csr_dev_* */
+  int32_t reserved[5];       /* zero */
+} ll_csr_options;
+int ll_csr_options_default(ll_csr_options* opt); /* {LL_ACCURACY_DEFAULT, -1, 0, zeros}: then identical to ll_op_create_csr_* */
+int ll_op_create_csr_opt_d(ll_context* ctx, int64_t n_rows, int64_t n_cols, int64_t row_begin, const int64_t* row_ptr,
+                           const int32_t* col, const double* val, const ll_csr_options* opt, ll_operator** out);
+int ll_op_create_csr_opt_z(ll_context* ctx, int64_t n_rows, int64_t n_cols, int64_t row_begin, const int64_t* row_ptr,
+                           const int32_t* col, const void* val, const ll_csr_options* opt, ll_operator** out);
+int ll_op_create_csr_opt_s(ll_context* ctx, int64_t n_rows, int64_t n_cols, int64_t row_begin, const int64_t* row_ptr,
+                           const int32_t* col, const float* val, const ll_csr_options* opt, ll_operator** out);
+int ll_op_create_csr_opt_c(ll_context* ctx, int64_t n_rows, int64_t n_cols, int64_t row_begin, const int64_t* row_ptr,
+                           const int32_t* col, const void* val, const ll_csr_options* opt, ll_operator** out);
+int ll_op_set_accuracy(ll_operator* op, int accuracy);        /* LL_ACCURACY_NORMWISE | LL_ACCURACY_COMPONENTWISE */
+int ll_op_accuracy(const ll_operator* op, int* accuracy_out);
 int ll_op_select_spmv(ll_operator* op, int kind);
 int ll_op_selected_spmv(const ll_operator* op, int* kind_out);
 /* Milliseconds the creation-time timing measured per kernel on this rank (-1: that kernel was not timed). */

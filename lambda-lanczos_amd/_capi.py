@@ -15,10 +15,11 @@ LL_OK, LL_ERR_INVALID, LL_ERR_HIP, LL_ERR_RCCL, LL_ERR_ALLOC, LL_ERR_CALLBACK = 
 ORTH_CGS_DGKS, ORTH_CGS2, ORTH_MGS = 0, 1, 2
 TRIDIAG_QR, TRIDIAG_BISECT, TRIDIAG_AUTO = 0, 1, 2
 SPMV_CSR_STREAM, SPMV_PB = 0, 1
+ACCURACY_DEFAULT, ACCURACY_NORMWISE, ACCURACY_COMPONENTWISE = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 
-ABI_VERSION = (0, 3)  # LL_VERSION_MAJOR, LL_VERSION_MINOR of the include/lanczos_hip.h these mirrors were written against
+ABI_VERSION = (0, 4)  # LL_VERSION_MAJOR, LL_VERSION_MINOR of the include/lanczos_hip.h these mirrors were written against
 
 
 class LanczosHipError(RuntimeError):
@@ -50,6 +51,10 @@ class LanczosParams(C.Structure):
         ("init_user", vp),
         ("init_vector_dev", vp),
     ]
+
+
+class CsrOptions(C.Structure):
+    _fields_ = [("accuracy", i32), ("kernel", i32), ("arrays_on_device", i32), ("reserved", i32 * 5)]
 
 
 class ExpoParams(C.Structure):
@@ -132,6 +137,11 @@ PROTOTYPES = {
     "ll_op_create_csr_z": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_create_csr_dev_d": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_create_csr_dev_z": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(vp)]),
+    "ll_csr_options_default": (C.c_int, [P(CsrOptions)]),
+    "ll_op_create_csr_opt_d": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(CsrOptions), P(vp)]),
+    "ll_op_create_csr_opt_z": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, P(CsrOptions), P(vp)]),
+    "ll_op_set_accuracy": (C.c_int, [vp, C.c_int]),
+    "ll_op_accuracy": (C.c_int, [vp, P(C.c_int)]),
     "ll_op_create_coo_d": (C.c_int, [vp, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_create_coo_z": (C.c_int, [vp, i64, i64, vp, vp, vp, P(vp)]),
     "ll_op_inf_norm": (C.c_int, [vp, P(f64)]),

@@ -228,7 +228,8 @@ extern "C" {
 const char* ll_last_error(void) { return g_last_error.c_str(); }
 int ll_version(void) { return LL_VERSION_MAJOR * 1000 + LL_VERSION_MINOR; }
 int ll_abi_check(int caller_major, int caller_minor, size_t sizeof_run_stats, size_t sizeof_lanczos_params) {
-  if (caller_major == LL_VERSION_MAJOR && caller_minor == LL_VERSION_MINOR && sizeof_run_stats == sizeof(ll_run_stats) &&
+  // minors 3 -> 4 only added entry points: a caller compiled against any of them sees the same structs
+  if (caller_major == LL_VERSION_MAJOR && caller_minor >= 3 && caller_minor <= LL_VERSION_MINOR && sizeof_run_stats == sizeof(ll_run_stats) &&
       sizeof_lanczos_params == sizeof(ll_lanczos_params))
     return LL_OK;
   set_error("ABI mismatch: the caller was compiled against lanczos_hip.h " + std::to_string(caller_major) + "." +
@@ -856,8 +857,13 @@ template <typename T> void autotune_spmv(ll_operator* op) {
 
 template <typename T>
 void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, const int64_t* rp, const int32_t* ci,
-                const void* va, bool on_device, ll_operator** out) {
+                const void* va, bool on_device, ll_operator** out, const ll_csr_options* opt = nullptr) {
   use(ctx);
+  if (opt != nullptr) {
+    LL_REQUIRE(opt->accuracy >= LL_ACCURACY_DEFAULT && opt->accuracy <= LL_ACCURACY_COMPONENTWISE, "ll_csr_options.accuracy");
+    LL_REQUIRE(opt->kernel >= -1 && opt->kernel <= LL_SPMV_PB, "ll_csr_options.kernel");
+    on_device = opt->arrays_on_device != 0;
+  }
   LL_REQUIRE(out && rp && (ci || nr == 0) && (va || nr == 0), "null argument");
   LL_REQUIRE(nr >= 0 && nc >= 1 && row_begin >= 0 && row_begin + nr <= nc, "bad shape");
   LL_REQUIRE(nr < (int64_t)0x7fffffff && nc < (int64_t)0x7fffffff, "dimension exceeds int32 indices");
@@ -875,6 +881,7 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   op->is_complex = scalar_traits<T>::is_complex;
   op->elem_bytes = (int)sizeof(T);
   op->ctx = ctx;
+  op->accuracy_req = opt != nullptr ? opt->accuracy : LL_ACCURACY_DEFAULT;
   set_partition(ctx, op.get(), nc, row_begin, nr);
   op->nnz = rp_host[nr];
   const size_t nnz = (size_t)op->nnz;
@@ -893,7 +900,8 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   // for host and device inputs alike, whatever kernel gets selected
   csr_check_device<T>(op.get());
   op->spmv_kind = LL_SPMV_CSR_STREAM;
-  const int want = ctx->tune.spmv_kernel;  // 0 auto, 1 csr, 2 pb (LL_SPMV_KERNEL)
+  // 0 auto, 1 csr, 2 pb (LL_SPMV_KERNEL); the caller's ll_csr_options.kernel outranks the environment
+  const int want = (opt != nullptr && opt->kernel >= 0) ? opt->kernel + 1 : ctx->tune.spmv_kernel;
   // Sharded contexts take every decision below COLLECTIVELY (an empty shard, or a shard whose shape rules the image
   // out, must not leave the ranks with different kernels: the exchange plan and the collectives issued depend on it).
   auto all_ranks_agree = [&](bool mine) {
@@ -1048,6 +1056,30 @@ int ll_op_create_csr_z(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, cons
                        const void* va, ll_operator** out) {
   return guarded([&] { create_csr<zc>(ctx, nr, nc, rb, rp, ci, va, false, out); });
 }
+int ll_csr_options_default(ll_csr_options* opt) {
+  return guarded([&] {
+    LL_REQUIRE(opt != nullptr, "null options");
+    std::memset(opt, 0, sizeof(*opt));
+    opt->accuracy = LL_ACCURACY_DEFAULT;
+    opt->kernel = -1;
+  });
+}
+int ll_op_create_csr_opt_d(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const double* va, const ll_csr_options* opt, ll_operator** out) {
+  return guarded([&] { create_csr<double>(ctx, nr, nc, rb, rp, ci, va, false, out, opt); });
+}
+int ll_op_create_csr_opt_z(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const void* va, const ll_csr_options* opt, ll_operator** out) {
+  return guarded([&] { create_csr<zc>(ctx, nr, nc, rb, rp, ci, va, false, out, opt); });
+}
+int ll_op_create_csr_opt_s(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const float* va, const ll_csr_options* opt, ll_operator** out) {
+  return guarded([&] { create_csr<float>(ctx, nr, nc, rb, rp, ci, va, false, out, opt); });
+}
+int ll_op_create_csr_opt_c(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
+                           const void* va, const ll_csr_options* opt, ll_operator** out) {
+  return guarded([&] { create_csr<cf>(ctx, nr, nc, rb, rp, ci, va, false, out, opt); });
+}
 int ll_op_create_csr_dev_d(ll_context* ctx, int64_t nr, int64_t nc, int64_t rb, const int64_t* rp, const int32_t* ci,
                            const double* va, ll_operator** out) {
   return guarded([&] { create_csr<double>(ctx, nr, nc, rb, rp, ci, va, true, out); });
@@ -1156,6 +1188,29 @@ int ll_op_select_spmv(ll_operator* op, int kind) {
     LL_REQUIRE(kind != LL_SPMV_CSR_STREAM || op->d_row_ptr != nullptr,
                "operator has released its CSR image (PB was selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");
     op->spmv_kind = kind;
+  });
+}
+int ll_op_set_accuracy(ll_operator* op, int accuracy) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
+    LL_REQUIRE(accuracy == LL_ACCURACY_NORMWISE || accuracy == LL_ACCURACY_COMPONENTWISE,
+               "accuracy must be LL_ACCURACY_NORMWISE or LL_ACCURACY_COMPONENTWISE");
+    op->accuracy_req = accuracy;
+    if (op->d_pb_val == nullptr) return;  // CSR-stream only: component-wise whatever is asked for
+    if (accuracy == LL_ACCURACY_COMPONENTWISE) {
+      if (op->pb_phase2 == LL_PB_FIXED) op->pb_phase2 = LL_PB_ORDERED;
+    } else {
+      LL_REQUIRE(op->d_pb_rexp != nullptr && op->d_pb_blockmax != nullptr,
+                 "this image was built without the row exponents of the fixed-point sums (row block too large for them)");
+      op->pb_phase2 = LL_PB_FIXED;
+    }
+  });
+}
+int ll_op_accuracy(const ll_operator* op, int* accuracy_out) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr && accuracy_out != nullptr, "null argument");
+    const bool fixed = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB && op->pb_phase2 == LL_PB_FIXED;
+    *accuracy_out = fixed ? LL_ACCURACY_NORMWISE : LL_ACCURACY_COMPONENTWISE;
   });
 }
 int ll_op_selected_spmv(const ll_operator* op, int* kind_out) {

@@ -292,7 +292,9 @@ struct ll_operator {
   int16_t* d_pb_rexp = nullptr;      // LL_PB_PHASE2=fixed: exponent of every local row's absolute sum
   double* d_pb_blockmax = nullptr;   // LL_PB_PHASE2=fixed: max |x| per column block, left by phase 1
   int64_t pb_entries = 0;            // padded entry count of the image
-  int pb_phase2 = 4;                 // form of phase 2 (ll::LL_PB_FIXED / _ORDERED / _ATOMIC), fixed when the image is built
+  int pb_phase2 = 4;                 // form of phase 2 (ll::LL_PB_FIXED / _ORDERED / _ATOMIC): set when the image is built,
+                                     // changed by ll_op_set_accuracy (both forms read the same image)
+  int accuracy_req = 0;              // LL_ACCURACY_* asked for at creation (ll_csr_options.accuracy); 0 = the environment decides
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.

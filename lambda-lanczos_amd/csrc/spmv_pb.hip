@@ -1025,7 +1025,10 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   // faster than the wave-ordered form (profiles/r02_spmv_variants_run10_fixed_default.jsonl).  "ordered": floating-
   // point adds, the 16 waves in turn (barriers) — reproducible and component-wise accurate; "atomic": floating-point
   // adds in arrival order (not reproducible; A/B timing reference).
-  op->pb_phase2 = tune.pb_phase2;
+  // The caller's choice through ll_csr_options.accuracy / ll_op_set_accuracy (include/lanczos_hip.h) outranks the environment.
+  op->pb_phase2 = op->accuracy_req == LL_ACCURACY_COMPONENTWISE
+                      ? (tune.pb_phase2 == LL_PB_ATOMIC ? LL_PB_ATOMIC : LL_PB_ORDERED)
+                      : (op->accuracy_req == LL_ACCURACY_NORMWISE ? LL_PB_FIXED : tune.pb_phase2);
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, bytes, "propagation-blocking tables");
     LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
@@ -1069,10 +1072,14 @@ template <typename T> bool pb_build_device(ll_operator* op) {
                        (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
                        op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
   LL_HIP(hipGetLastError());
-  if (op->pb_phase2 == LL_PB_FIXED) {  // fixed-point sums: per-row exponents of the absolute row sums, per-block maxima of |x|
-    // the y slice holds 64-bit integers + one 16-bit exponent per row: it must still fit the LDS
-    LL_REQUIRE((size_t)rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16 <= (size_t)kPbLdsCap,
-               "LL_PB_PHASE2=fixed: row block too large for the LDS (lower LL_PB_ROW_BLOCK)");
+  // Fixed-point sums need per-row exponents of the absolute row sums and per-block maxima of |x|.  They are built for EVERY
+  // image whose row block leaves room for them (2 bytes per row; the CSR arrays they come from may be released after creation),
+  // so that ll_op_set_accuracy can move the operator between the two accuracy classes later.
+  // the y slice holds 64-bit integers + one 16-bit exponent per row: it must still fit the LDS
+  const bool fixed_fits = (size_t)rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16 <= (size_t)kPbLdsCap;
+  if (op->pb_phase2 == LL_PB_FIXED)
+    LL_REQUIRE(fixed_fits, "LL_PB_PHASE2=fixed: row block too large for the LDS (lower LL_PB_ROW_BLOCK)");
+  if (fixed_fits) {
     ctx->dev_malloc((void**)&op->d_pb_rexp, std::max<size_t>((size_t)nr, 8) * sizeof(int16_t), "row exponents");
     ctx->dev_malloc((void**)&op->d_pb_blockmax, (size_t)ncb * sizeof(double), "x slice maxima");
     LL_HIP(hipMemsetAsync(op->d_pb_blockmax, 0, (size_t)ncb * sizeof(double), s));

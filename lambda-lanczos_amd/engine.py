@@ -183,7 +183,9 @@ class _Operator:
 class CsrOperator(_Operator):
     """Device-resident CSR matrix (rows [row_begin, row_begin+len(row_ptr)-1) of an n_cols x n_cols operator)."""
 
-    def __init__(self, ctx, row_ptr, col, val, n_cols=None, row_begin=0):
+    def __init__(self, ctx, row_ptr, col, val, n_cols=None, row_begin=0, accuracy=None, kernel=None):
+        """accuracy: None (the environment decides), capi.ACCURACY_NORMWISE or capi.ACCURACY_COMPONENTWISE — the accuracy class
+        of y = A x (include/lanczos_hip.h, ll_csr_options); kernel: None (timed at creation), capi.SPMV_CSR_STREAM / SPMV_PB."""
         self.ctx = ctx
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
         col = np.ascontiguousarray(col, dtype=np.int32)
@@ -194,8 +196,16 @@ class CsrOperator(_Operator):
         self.n = int(n_cols if n_cols is not None else n_rows)
         self.n_local, self.row_begin = n_rows, int(row_begin)
         h = C.c_void_p()
-        fn = getattr(lib(), "ll_op_create_csr_" + sfx)
-        check(fn(ctx.handle, n_rows, self.n, self.row_begin, ptr(row_ptr), ptr(col), ptr(val), C.byref(h)))
+        if accuracy is None and kernel is None:
+            fn = getattr(lib(), "ll_op_create_csr_" + sfx)
+            check(fn(ctx.handle, n_rows, self.n, self.row_begin, ptr(row_ptr), ptr(col), ptr(val), C.byref(h)))
+        else:
+            opt = capi.CsrOptions()
+            check(lib().ll_csr_options_default(C.byref(opt)))
+            opt.accuracy = capi.ACCURACY_DEFAULT if accuracy is None else int(accuracy)
+            opt.kernel = -1 if kernel is None else int(kernel)
+            fn = getattr(lib(), "ll_op_create_csr_opt_" + sfx)
+            check(fn(ctx.handle, n_rows, self.n, self.row_begin, ptr(row_ptr), ptr(col), ptr(val), C.byref(opt), C.byref(h)))
         self.handle = h
         self.nnz = int(row_ptr[-1])
 
@@ -222,6 +232,16 @@ class CsrOperator(_Operator):
     def select_spmv(self, kind):
         """capi.SPMV_PB or capi.SPMV_CSR_STREAM (default: whichever timed faster at creation)."""
         check(lib().ll_op_select_spmv(self.handle, int(kind)))
+
+    def set_accuracy(self, accuracy):
+        """capi.ACCURACY_NORMWISE or capi.ACCURACY_COMPONENTWISE (ll_op_set_accuracy): same image, another summation kernel."""
+        check(lib().ll_op_set_accuracy(self.handle, int(accuracy)))
+
+    def accuracy(self):
+        """The accuracy class of the kernel selected now (ll_op_accuracy)."""
+        a = C.c_int()
+        check(lib().ll_op_accuracy(self.handle, C.byref(a)))
+        return a.value
 
     def autotune_ms(self):
         """(csr_stream_ms, pb_ms) measured when the operator was created (-1: not timed)."""

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # and the ctypes table binds exactly that set
     assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
-    assert lib.ll_version() == capi.ABI_VERSION[0] * 1000 + capi.ABI_VERSION[1] == 3
+    assert lib.ll_version() == capi.ABI_VERSION[0] * 1000 + capi.ABI_VERSION[1] == 4
 
 
 def test_abi_handshake_refuses_a_caller_built_against_another_header():
@@ -45,7 +45,11 @@ def test_abi_handshake_refuses_a_caller_built_against_another_header():
     import ctypes as C
 
     lib = capi.lib()
+    # minor 4 only added entry points: callers built against minor 3 (same structs) and against minor 4 are both accepted,
+    # a caller built against a NEWER header than the loaded library is not
     assert lib.ll_abi_check(0, 3, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_OK
+    assert lib.ll_abi_check(0, 4, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_OK
+    assert lib.ll_abi_check(0, 5, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_ERR_INVALID
     assert lib.ll_abi_check(0, 2, C.sizeof(capi.RunStats) - 72, C.sizeof(capi.LanczosParams)) == capi.LL_ERR_INVALID
     assert b"rebuild the caller" in lib.ll_last_error()
 

@@ -73,9 +73,9 @@ def _wide_inputs(kind, csr, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["d", "z"])
 @pytest.mark.parametrize("kind", ["decades", "e0", "row_scales"])
 def test_fixed_point_spmv_meets_its_stated_normwise_bound(ctx, llenv, kind, dtype, block):
-    """lanczos_hip.h states, for the default PB kernel (LL_PB_PHASE2=fixed),
+    """lanczos_hip.h states, for the default PB kernel (LL_ACCURACY_NORMWISE),
          |y_i - (A x)_i| <= eps sum_j |a_ij||x_j| + nnz_i 2^-60 (sum_j |a_ij|) max_k |x_k|,
-    and the component-wise bound c nnz_i eps sum_j |a_ij||x_j| for the floating-point forms (CSR-stream, ordered).  On
+    and the component-wise bound c nnz_i eps sum_j |a_ij||x_j| for LL_ACCURACY_COMPONENTWISE (CSR-stream, PB ordered).  On
     inputs with a huge dynamic range the two differ: both are asserted, each for the kernels it is stated for, and the
     `decades` case must actually separate them (some row of the fixed-point result violates the component-wise bound)."""
     csr, x = _wide_inputs(kind, G.randsym_np(5000), dtype)
@@ -92,21 +92,39 @@ def test_fixed_point_spmv_meets_its_stated_normwise_bound(ctx, llenv, kind, dtyp
             e = np.maximum(e, np.abs(np.imag(y).astype(np.longdouble) - yi))
         return e
 
-    llenv.setenv("LL_SPMV_KERNEL", "pb")
+    # The accuracy class is the CALLER's per-operator choice through the boundary (ll_csr_options.accuracy at creation,
+    # ll_op_set_accuracy afterwards) — no environment variable selects the summation here.
     if block:
-        llenv.setenv("LL_PB_BLOCK", block)
+        llenv.setenv("LL_PB_BLOCK", block)   # (block geometry only: ragged blocks)
     got = {}
-    for phase2 in ("fixed", "ordered"):
-        llenv.setenv("LL_PB_PHASE2", phase2)
-        op = L.CsrOperator(ctx, *csr)
-        assert op.selected_spmv() == capi.SPMV_PB
+    for name, acc in (("fixed", capi.ACCURACY_NORMWISE), ("ordered", capi.ACCURACY_COMPONENTWISE)):
+        op = L.CsrOperator(ctx, *csr, accuracy=acc, kernel=capi.SPMV_PB)
+        assert op.selected_spmv() == capi.SPMV_PB and op.accuracy() == acc
         L.spmv(op, xd, yd)
-        got[phase2] = yd.get()
+        got[name] = yd.get()
+        # the same operator moved to the other class and back: same image, the other summation kernel, the other class's bits
+        other = capi.ACCURACY_COMPONENTWISE if acc == capi.ACCURACY_NORMWISE else capi.ACCURACY_NORMWISE
+        op.set_accuracy(other)
+        assert op.accuracy() == other
+        L.spmv(op, xd, yd)
+        got[name + "_switched"] = yd.get()
+        op.set_accuracy(acc)
+        L.spmv(op, xd, yd)
+        assert np.array_equal(yd.get(), got[name])
         op.close()
-    llenv.setenv("LL_SPMV_KERNEL", "csr")
-    op = L.CsrOperator(ctx, *csr)
+    assert np.array_equal(got["fixed_switched"], got["ordered"]) and np.array_equal(got["ordered_switched"], got["fixed"])
+    op = L.CsrOperator(ctx, *csr, kernel=capi.SPMV_CSR_STREAM)
+    assert op.selected_spmv() == capi.SPMV_CSR_STREAM and op.accuracy() == capi.ACCURACY_COMPONENTWISE
     L.spmv(op, xd, yd)
     got["csr"] = yd.get()
+    op.set_accuracy(capi.ACCURACY_NORMWISE)   # CSR-stream has one (component-wise) form: accepted, nothing changes
+    assert op.accuracy() == capi.ACCURACY_COMPONENTWISE
+    op.close()
+    # default options == the plain constructor: norm-wise where PB is selected
+    op = L.CsrOperator(ctx, *csr, kernel=capi.SPMV_PB)
+    assert op.accuracy() == capi.ACCURACY_NORMWISE
+    L.spmv(op, xd, yd)
+    assert np.array_equal(yd.get(), got["fixed"])
     op.close()
     assert all(np.all(np.isfinite(v)) for v in got.values())
     tiny = np.longdouble(1e-320)
