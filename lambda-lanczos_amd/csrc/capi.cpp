@@ -660,6 +660,41 @@ template <typename T> void build_csr_split(ll_operator* op) {
   op->csr_split = true;
 }
 
+// Undo a (possibly partial) column split: the operator runs gather-then-multiply on its unsplit image.
+void release_csr_split(ll_operator* op) {
+  auto drop = [](auto*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+  };
+  drop(op->d_rp_own);
+  drop(op->d_rp_rem);
+  drop(op->d_col_own);
+  drop(op->d_col_rem);
+  drop(op->d_val_own);
+  drop(op->d_val_rem);
+  drop(op->d_tiles_own);
+  drop(op->d_tiles_rem);
+  op->ntiles_own = op->ntiles_rem = 0;
+  op->csr_split = false;
+}
+// The unsplit CSR arrays of an operator that runs on its column-split image (the row offsets stay: 4 bytes per row, and
+// they mark the operator as one that still has a CSR-stream image).
+void release_unsplit_csr(ll_operator* op) {
+  auto drop = [](auto*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+  };
+  if (op->owns_arrays) {
+    drop(op->d_col);
+    drop(op->d_val);
+  } else {
+    op->d_col = nullptr;  // the caller's arrays: just forget them
+    op->d_val = nullptr;
+  }
+  drop(op->d_tile_rows);
+  op->ntiles = 0;
+}
+
 // Row ranges of a sharded operator must be the ll_partition() ones (equal shard strides).
 void set_partition(ll_context* ctx, ll_operator* op, int64_t n, int64_t row_begin, int64_t n_local) {
   op->n = n;
@@ -950,7 +985,21 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   }
   release_unselected_image(op.get());
   // (every rank takes this branch or none: the kernel choice above is collective, the switch comes from the environment)
-  if (ctx->nranks > 1 && ctx->tune.csr_split && op->d_row_ptr != nullptr) build_csr_split<T>(op.get());
+  if (ctx->nranks > 1 && ctx->tune.csr_split && op->d_row_ptr != nullptr) {
+    // The split image is a second copy of the matrix.  When it does not fit next to the original (a shard that already fell
+    // back to CSR-stream because the PB image did not fit), the operator stays usable in the gather-then-multiply form — safe
+    // per rank: split and unsplit ranks issue the same single all-gather.
+    try {
+      build_csr_split<T>(op.get());
+    } catch (const Failure& f) {
+      if (f.code != LL_ERR_ALLOC) throw;
+      (void)hipGetLastError();
+      release_csr_split(op.get());
+    }
+    // Once split, the unsplit arrays are never read again on this context: return them (steady-state footprint 1 x the matrix)
+    // unless LL_SPMV_KEEP_BOTH=1 asked for every image to stay.
+    if (op->csr_split && !ctx->tune.keep_both && op->spmv_kind == LL_SPMV_CSR_STREAM) release_unsplit_csr(op.get());
+  }
   *out = op.release();
 }
 

@@ -281,8 +281,11 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
     else if (pb)
       nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, xnorm2);
-    else
+    else {
+      LL_REQUIRE(op->d_col != nullptr || op->nnz == 0,
+                 "this operator kept only its column-split image (created on a sharded context) and needs that communicator");
       nparts = launch_spmv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
+    }
   } else {
     LL_REQUIRE(!(ctx->comm != nullptr), "callback operators are not supported on sharded contexts");
     const size_t bytes = (size_t)n_local * sizeof(T);
