@@ -197,7 +197,8 @@ def other_config_c2(ctx, L, G):
            "value": its / dt, "unit": "Lanczos iterations/s", "steps": 2, "window": window, "ms_per_step": dt / 2 * 1e3,
            "lagged_iterations_last_step": lagged, "io": "device buffers",
            "spmv": {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed"}.get(op.selected_spmv())},
+                    "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed",
+                               L.capi.SPMV_TILED: "tl_xmax+tl_spmv"}.get(op.selected_spmv())},
            "cpu_same_window": {"kind": kind, "window": w, "value": w / r["t_total"], "seconds": r["t_total"], "cores": 1},
            "parity_same_window": {"window": w, "max_abs_dalpha": da, "max_abs_dbeta": db, "abs_dlambda": dl,
                                   "eigenvector_one_minus_overlap": ov,
@@ -241,7 +242,8 @@ def other_config_c5(ctx, L, G):
            "value": its / dt, "unit": "Lanczos iterations/s", "steps": 5, "iterations_per_step": its / 5, "ms_per_step": dt / 5 * 1e3,
            "io": "device buffers",
            "spmv": {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed"}.get(op.selected_spmv())},
+                    "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed",
+                               L.capi.SPMV_TILED: "tl_xmax+tl_spmv"}.get(op.selected_spmv())},
            "cpu_whole_run": {"kind": kind, "value": o_it / o_t["t_total"], "seconds": o_t["t_total"], "iterations": int(o_it), "cores": 1},
            "parity_whole_run": {"iterations_cpu": int(o_it), "iterations_gpu": int(g_it), "max_abs_diff_over_input_norm": err,
                                 "one_minus_overlap": ovl, "norm_drift": unit,
@@ -446,10 +448,12 @@ def main():
     if phase2_form not in ("ordered", "atomic"):
         phase2_form = "fixed"
     p2 = "pb_phase2_fixed" if phase2_form == "fixed" else "pb_phase2"
-    kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+" + p2, -1: "stencil_kernel"}
+    kernel_names = {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+" + p2, L.capi.SPMV_TILED: "tl_xmax+tl_spmv",
+                    -1: "stencil_kernel"}
     # The operator timed both kernels on the actual matrix when it was created and released the slower image; those
     # creation-time figures are reported next to the event timing of the kernel that is in use.
-    tune = None if lattice else dict(zip(("spmv_stream", "pb_phase1+" + p2), op.autotune_ms()))
+    tune = None if lattice else {kernel_names[k]: op.autotune_ms_of(k) for k in
+                                 (L.capi.SPMV_CSR_STREAM, L.capi.SPMV_PB, L.capi.SPMV_TILED)}
     def time_spmv(o):
         rounds = []
         for rnd in range(3):
@@ -791,7 +795,7 @@ def main():
             },
             "rccl_ranks_seen": ranks_seen,
             "spmv": {"GBps": spmv_gbs, "ms": spmv_ms, "algorithmic_bytes": b_spmv, "frac_of_8TBps": spmv_gbs / HBM_PEAK_GBS,
-                     "kernel": kernel_names[selected] + " (picked by timing both at upload; the other image is released)",
+                     "kernel": kernel_names[selected] + " (picked by timing the candidates at upload; the other images are released)",
                      "ms_by_kernel": spmv_variants, "creation_time_autotune_ms": tune,
                      "includes_exchange": world > 1},
             "roofline": {

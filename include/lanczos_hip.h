@@ -227,15 +227,21 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  *                       SpMV is two fully coalesced streaming sweeps with x and y slices in LDS and no global gather;
  *                       best for matrices without column locality (BASELINE config 3).  On sharded contexts its
  *                       own-column part runs under the all-gather.
- * ll_op_create_csr_{d,z} and _csr_dev_ build both images, time them on the device with the actual matrix (sharded
- * contexts: summed over the ranks, so every rank takes the same decision), keep the faster one and RELEASE the other
- * (for BASELINE config 3 that returns 1.8 GB of CSR arrays).  Environment: LL_SPMV_KERNEL=csr|pb skips the timing,
- * LL_SPMV_KEEP_BOTH=1 keeps both images so that ll_op_select_spmv can switch later (A/B timing, tests).
+ *   LL_SPMV_TILED       2-D tiling for matrices WITH column locality (bands, stencils, lattices — the operators the reference
+ *                       itself ships, sample3_dynamic.cpp:17-22): one workgroup per row block keeps the y slice AND, tile by
+ *                       tile, the x slice in LDS and streams 12 B per nonzero (fp64) — no global gather, no product buffer.
+ *                       Built only when the row blocks touch few column tiles (a random matrix is not eligible); single
+ *                       GPU; sums in fixed point like LL_SPMV_PB's default form (same integers: the result does not depend
+ *                       on the tiling), i.e. the NORM-wise accuracy class below — not offered with LL_ACCURACY_COMPONENTWISE.
+ * ll_op_create_csr_{d,z} and _csr_dev_ build the images, time them on the device with the actual matrix (sharded
+ * contexts: summed over the ranks, so every rank takes the same decision), keep the fastest and RELEASE the others
+ * (for BASELINE config 3 that returns 1.8 GB of CSR arrays).  Environment: LL_SPMV_KERNEL=csr|pb|tiled skips the timing,
+ * LL_SPMV_KEEP_BOTH=1 keeps every image so that ll_op_select_spmv can switch later (A/B timing, tests).
  *
  * ACCURACY of y = A x (this is what replaces the user's fp64 mv_mul, LL:243 / EX:108):
- *   LL_SPMV_CSR_STREAM and LL_SPMV_PB with LL_PB_PHASE2=ordered|atomic sum the products in floating point:
+ *   LL_SPMV_CSR_STREAM and LL_SPMV_PB with floating-point sums (LL_ACCURACY_COMPONENTWISE; LL_PB_PHASE2=ordered|atomic):
  *     |y_i - (A x)_i| <= ~nnz_i * eps * sum_j |a_ij| |x_j|             (COMPONENT-wise, like a plain fp64 row loop).
- *   LL_SPMV_PB in its default form (LL_PB_PHASE2=fixed) rounds every product to a per-row fixed-point grid and adds
+ *   LL_SPMV_PB in its default form (LL_PB_PHASE2=fixed) and LL_SPMV_TILED round every product to a per-row fixed-point grid and add
  *   64-bit integers (order-independent: same bits for every launch, block geometry and partition of the matrix):
  *     |y_i - (A x)_i| <= eps * sum_j |a_ij| |x_j|  +  nnz_i * 2^-60 * (sum_j |a_ij|) * max_k |x_k|   (NORM-wise)
  *   where max_k runs over the WHOLE input vector.  For vectors whose entries are of comparable size (Lanczos vectors of
@@ -248,7 +254,7 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  *   3-5 % slower); the environment's LL_PB_PHASE2=ordered or LL_SPMV_KERNEL=csr does the same for every operator of a context.
  *   Rows that meet an Inf / NaN are reported as NaN.  float / complex float storage: the product a_ij x_j is rounded to
  *   the storage type once (exactly what a float multiply gives) before it is summed in fixed point / double. */
-enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1 };
+enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1, LL_SPMV_TILED = 2 };
 /* The ACCURACY CLASS above as a per-operator choice of the caller (who knows whether the vectors are localised), not of
  * the environment:
  *   LL_ACCURACY_DEFAULT        what the context's environment says (LL_PB_PHASE2; norm-wise when unset)
@@ -281,6 +287,7 @@ int ll_op_select_spmv(ll_operator* op, int kind);
 int ll_op_selected_spmv(const ll_operator* op, int* kind_out);
 /* Milliseconds the creation-time timing measured per kernel on this rank (-1: that kernel was not timed). */
 int ll_op_autotune_ms(const ll_operator* op, double* csr_stream_ms, double* pb_ms);
+int ll_op_autotune_ms_of(const ll_operator* op, int kind /* LL_SPMV_* */, double* ms);
 int ll_op_destroy(ll_operator* op);
 /* Global dimension n, local rows, nnz held locally (0 for callbacks). */
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz_local);

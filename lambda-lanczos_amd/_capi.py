@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lanczos_hip.h")
 LL_OK, LL_ERR_INVALID, LL_ERR_HIP, LL_ERR_RCCL, LL_ERR_ALLOC, LL_ERR_CALLBACK = range(6)
 ORTH_CGS_DGKS, ORTH_CGS2, ORTH_MGS = 0, 1, 2
 TRIDIAG_QR, TRIDIAG_BISECT, TRIDIAG_AUTO = 0, 1, 2
-SPMV_CSR_STREAM, SPMV_PB = 0, 1
+SPMV_CSR_STREAM, SPMV_PB, SPMV_TILED = 0, 1, 2
 ACCURACY_DEFAULT, ACCURACY_NORMWISE, ACCURACY_COMPONENTWISE = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
@@ -156,6 +156,7 @@ PROTOTYPES = {
     "ll_op_select_spmv": (C.c_int, [vp, C.c_int]),
     "ll_op_selected_spmv": (C.c_int, [vp, P(C.c_int)]),
     "ll_op_autotune_ms": (C.c_int, [vp, P(f64), P(f64)]),
+    "ll_op_autotune_ms_of": (C.c_int, [vp, C.c_int, P(f64)]),
     "ll_op_destroy": (C.c_int, [vp]),
     "ll_op_info": (C.c_int, [vp, P(i64), P(i64), P(i64)]),
     "ll_spmv_d": (C.c_int, [vp, vp, vp, vp, f64, P(f64)]),

@@ -33,8 +33,9 @@ Tuning read_tuning() {
     return v.empty() ? dflt : std::atoll(v.c_str());
   };
   const std::string k = str("LL_SPMV_KERNEL");
-  t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : 0);
+  t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : (k == "tiled" ? 3 : 0));
   t.keep_both = flag("LL_SPMV_KEEP_BOTH", false);
+  t.tl_force = flag("LL_TL_FORCE", false);
   const std::string p2 = str("LL_PB_PHASE2");
   t.pb_phase2 = p2 == "atomic" ? LL_PB_ATOMIC : (p2 == "ordered" ? LL_PB_ORDERED : LL_PB_FIXED);
   t.pb_block = (int)std::max<long long>(0, num("LL_PB_BLOCK", 0));
@@ -194,7 +195,8 @@ ll_operator::~ll_operator() {
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
                   (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp,
                   (void*)d_pb_blockmax, d_rp_own, d_rp_rem, (void*)d_col_own, (void*)d_col_rem, d_val_own, d_val_rem,
-                  (void*)d_tiles_own, (void*)d_tiles_rem})
+                  (void*)d_tiles_own, (void*)d_tiles_rem, (void*)d_tl_first, (void*)d_tl_col, (void*)d_tl_quad, d_tl_val,
+                  (void*)d_tl_idx, (void*)d_tl_rexp, (void*)d_tl_xmax})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -722,7 +724,7 @@ void release_image(ll_operator* op, int keep_kind) {
     if (p) (void)hipFree((void*)p);
     p = nullptr;
   };
-  if (keep_kind == LL_SPMV_PB) {  // CSR-stream needs row_ptr / col / val / tiles; PB needs none of them
+  if (keep_kind != LL_SPMV_CSR_STREAM) {  // CSR-stream needs row_ptr / col / val / tiles; the other kernels need none of them
     if (op->owns_arrays) {
       drop(op->d_col);
       drop(op->d_val);
@@ -733,7 +735,8 @@ void release_image(ll_operator* op, int keep_kind) {
     drop(op->d_row_ptr);
     drop(op->d_tile_rows);
     op->ntiles = 0;
-  } else {
+  }
+  if (keep_kind != LL_SPMV_PB) {
     drop(op->d_pb_segq);
     drop(op->d_pb_segdest);
     drop(op->d_pb_rptr);
@@ -746,6 +749,25 @@ void release_image(ll_operator* op, int keep_kind) {
     op->d_pb_col = op->d_pb_row = nullptr;
     op->pb_ncb = op->pb_nrb = 0;
   }
+  if (keep_kind != LL_SPMV_TILED) tl_release(op);
+}
+// the part of the PB image that is allocated so far (a failed or refused build)
+void release_pb_image(ll_operator* op) {
+  auto drop = [](auto*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+  };
+  drop(op->d_pb_segq);
+  drop(op->d_pb_segdest);
+  drop(op->d_pb_rptr);
+  drop(op->d_pb_xoff);
+  drop(op->d_pb_ncols);
+  drop(op->d_pb_arena);
+  drop(op->d_pb_rexp);
+  drop(op->d_pb_blockmax);
+  op->d_pb_val = op->d_pb_prod = nullptr;
+  op->d_pb_col = op->d_pb_row = nullptr;
+  op->pb_ncb = op->pb_nrb = 0;
 }
 
 // Placement of the PB image.  The same image at another address runs up to 5-8 % faster or slower (round 2: "position
@@ -861,12 +883,15 @@ template <typename T> void autotune_spmv(ll_operator* op) {
   LL_HIP(hipMemsetAsync(w.x, 0, xn * sizeof(T), s));
   LL_HIP(hipEventCreate(&w.e0));
   LL_HIP(hipEventCreate(&w.e1));
-  double t_kind[2] = {1e30, 1e30};
-  for (int kind : {LL_SPMV_CSR_STREAM, LL_SPMV_PB}) {
+  double t_kind[3] = {1e30, 1e30, 1e30};
+  for (int kind : {LL_SPMV_CSR_STREAM, LL_SPMV_PB, LL_SPMV_TILED}) {
+    if (kind == LL_SPMV_PB && op->d_pb_val == nullptr) continue;     // image not built: not a candidate
+    if (kind == LL_SPMV_TILED && op->tl_nrb <= 0) continue;
     try {
       for (int rep = 0; rep < 3; ++rep) {
         LL_HIP(hipEventRecord(w.e0, s));
         if (kind == LL_SPMV_PB) launch_spmv_pb<T>(*op, w.x, w.x + op->row_begin, w.x + op->row_begin, w.y, 0.0, nullptr, s);
+        else if (kind == LL_SPMV_TILED) launch_spmv_tiled<T>(*op, w.x, w.y, 0.0, nullptr, s);
         else launch_spmv<T>(*op, w.x, w.x + op->row_begin, w.y, 0.0, nullptr, s);
         LL_HIP(hipEventRecord(w.e1, s));
         LL_HIP(hipEventSynchronize(w.e1));
@@ -879,15 +904,16 @@ template <typename T> void autotune_spmv(ll_operator* op) {
       t_kind[kind] = 1e30;
     }
   }
-  op->tune_ms[0] = (float)t_kind[0];
-  op->tune_ms[1] = (float)t_kind[1];
-  if (ctx->comm != nullptr) {
+  for (int k = 0; k < 3; ++k) op->tune_ms[k] = t_kind[k] < 1e29 ? (float)t_kind[k] : -1.f;
+  if (ctx->comm != nullptr) {  // (the tiled kernel is single-GPU only: never a candidate here)
     LL_HIP(hipMemcpyAsync(w.t, t_kind, 2 * sizeof(double), hipMemcpyHostToDevice, s));
     comm_allreduce_sum(ctx->comm, w.t, 2, s);
     LL_HIP(hipMemcpyAsync(t_kind, w.t, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     LL_HIP(hipStreamSynchronize(s));
   }
-  op->spmv_kind = t_kind[LL_SPMV_PB] < t_kind[LL_SPMV_CSR_STREAM] ? LL_SPMV_PB : LL_SPMV_CSR_STREAM;
+  op->spmv_kind = LL_SPMV_CSR_STREAM;
+  if (t_kind[LL_SPMV_PB] < t_kind[op->spmv_kind]) op->spmv_kind = LL_SPMV_PB;
+  if (t_kind[LL_SPMV_TILED] < t_kind[op->spmv_kind]) op->spmv_kind = LL_SPMV_TILED;
 }
 
 template <typename T>
@@ -896,7 +922,7 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
   use(ctx);
   if (opt != nullptr) {
     LL_REQUIRE(opt->accuracy >= LL_ACCURACY_DEFAULT && opt->accuracy <= LL_ACCURACY_COMPONENTWISE, "ll_csr_options.accuracy");
-    LL_REQUIRE(opt->kernel >= -1 && opt->kernel <= LL_SPMV_PB, "ll_csr_options.kernel");
+    LL_REQUIRE(opt->kernel >= -1 && opt->kernel <= LL_SPMV_TILED, "ll_csr_options.kernel");
     on_device = opt->arrays_on_device != 0;
   }
   LL_REQUIRE(out && rp && (ci || nr == 0) && (va || nr == 0), "null argument");
@@ -957,7 +983,12 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     (void)hipFree(d);
     return sum == 0.0;
   };
-  if (want != 1 && (nnz > 0 || ctx->comm != nullptr)) {
+  // 0 auto, 1 csr, 2 pb, 3 tiled.  The tiled kernel sums in fixed point only (norm-wise class): a caller or an environment
+  // that asks for component-wise sums does not get it.
+  const bool componentwise = op->accuracy_req == LL_ACCURACY_COMPONENTWISE ||
+                             (op->accuracy_req == LL_ACCURACY_DEFAULT && ctx->tune.pb_phase2 != LL_PB_FIXED);
+  bool pb_ok = false, tl_ok = false;
+  if (want != 1 && want != 3 && (nnz > 0 || ctx->comm != nullptr)) {
     // the propagation-blocked image is built on the device from the CSR arrays (histogram + scatter kernels)
     bool built = false;
     try {
@@ -971,17 +1002,31 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
       (void)hipGetLastError();
       built = false;
     }
-    if (!built) release_image(op.get(), LL_SPMV_CSR_STREAM);  // whatever part of the image was allocated
-    if (all_ranks_agree(built)) {
-      if (want == 2) op->spmv_kind = LL_SPMV_PB;
-      else autotune_spmv<T>(op.get());
-      if (op->spmv_kind == LL_SPMV_PB && ctx->tune.pb_placements > 1) {
-        const double ms = tune_pb_placement<T>(op.get());
-        if (ms > 0.0 && op->tune_ms[LL_SPMV_PB] >= 0.f) op->tune_ms[LL_SPMV_PB] = (float)ms;
+    if (!built) release_pb_image(op.get());  // whatever part of the image was allocated
+    pb_ok = all_ranks_agree(built);
+    if (built && !pb_ok) release_pb_image(op.get());  // some rank could not build it: nobody uses it
+  }
+  if ((want == 0 || want == 3) && nnz > 0 && ctx->comm == nullptr) {
+    // the 2-D tiled image: only for matrices whose row blocks touch few column tiles (tl_build_device decides)
+    LL_REQUIRE(!(want == 3 && componentwise), "the tiled SpMV kernel sums in fixed point: not available with component-wise accuracy");
+    if (!componentwise) {
+      try {
+        tl_ok = tl_build_device<T>(op.get());
+      } catch (const Failure& f) {
+        if (!(f.code == LL_ERR_ALLOC && want == 0)) throw;
+        (void)hipGetLastError();
+        tl_release(op.get());
+        tl_ok = false;
       }
-    } else if (built) {
-      op->spmv_kind = LL_SPMV_CSR_STREAM;  // some rank could not build it: nobody uses it
     }
+    LL_REQUIRE(!(want == 3 && !tl_ok), "this matrix is not eligible for the tiled SpMV kernel (its row blocks touch too many column tiles)");
+  }
+  if (want == 2 && pb_ok) op->spmv_kind = LL_SPMV_PB;
+  else if (want == 3) op->spmv_kind = LL_SPMV_TILED;
+  else if (want == 0 && (pb_ok || tl_ok)) autotune_spmv<T>(op.get());
+  if (op->spmv_kind == LL_SPMV_PB && ctx->tune.pb_placements > 1) {
+    const double ms = tune_pb_placement<T>(op.get());
+    if (ms > 0.0 && op->tune_ms[LL_SPMV_PB] >= 0.f) op->tune_ms[LL_SPMV_PB] = (float)ms;
   }
   release_unselected_image(op.get());
   // (every rank takes this branch or none: the kernel choice above is collective, the switch comes from the environment)
@@ -1230,12 +1275,13 @@ int ll_op_destroy(ll_operator* op) {
 int ll_op_select_spmv(ll_operator* op, int kind) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
-    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB,
-               "unknown SpMV kernel");
+    LL_REQUIRE(kind == LL_SPMV_CSR_STREAM || kind == LL_SPMV_PB || kind == LL_SPMV_TILED, "unknown SpMV kernel");
     LL_REQUIRE(kind != LL_SPMV_PB || op->d_pb_val != nullptr,
-               "operator has no propagation-blocked image (not selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");
-    LL_REQUIRE(kind != LL_SPMV_CSR_STREAM || op->d_row_ptr != nullptr,
-               "operator has released its CSR image (PB was selected at creation; LL_SPMV_KEEP_BOTH=1 keeps both)");
+               "operator has no propagation-blocked image (not selected at creation; LL_SPMV_KEEP_BOTH=1 keeps every image)");
+    LL_REQUIRE(kind != LL_SPMV_CSR_STREAM || (op->d_row_ptr != nullptr && (op->d_col != nullptr || op->nnz == 0 || op->csr_split)),
+               "operator has released its CSR image (another kernel was selected at creation; LL_SPMV_KEEP_BOTH=1 keeps every image)");
+    LL_REQUIRE(kind != LL_SPMV_TILED || op->tl_nrb > 0,
+               "operator has no tiled image (matrix not eligible, or not selected at creation; LL_SPMV_KEEP_BOTH=1 keeps every image)");
     op->spmv_kind = kind;
   });
 }
@@ -1244,8 +1290,16 @@ int ll_op_set_accuracy(ll_operator* op, int accuracy) {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
     LL_REQUIRE(accuracy == LL_ACCURACY_NORMWISE || accuracy == LL_ACCURACY_COMPONENTWISE,
                "accuracy must be LL_ACCURACY_NORMWISE or LL_ACCURACY_COMPONENTWISE");
+    if (accuracy == LL_ACCURACY_COMPONENTWISE && op->spmv_kind == LL_SPMV_TILED) {
+      // the tiled kernel has the fixed-point sums only: move to an image with floating-point sums, if one was kept
+      if (op->d_row_ptr != nullptr && (op->d_col != nullptr || op->nnz == 0)) op->spmv_kind = LL_SPMV_CSR_STREAM;
+      else if (op->d_pb_val != nullptr) op->spmv_kind = LL_SPMV_PB;
+      else
+        LL_REQUIRE(false, "this operator kept only its tiled image (fixed-point sums): ask for LL_ACCURACY_COMPONENTWISE when it is "
+                          "created (ll_csr_options.accuracy), or keep every image with LL_SPMV_KEEP_BOTH=1");
+    }
     op->accuracy_req = accuracy;
-    if (op->d_pb_val == nullptr) return;  // CSR-stream only: component-wise whatever is asked for
+    if (op->d_pb_val == nullptr) return;  // no PB image: CSR-stream is component-wise, the tiled kernel norm-wise, whatever is asked
     if (accuracy == LL_ACCURACY_COMPONENTWISE) {
       if (op->pb_phase2 == LL_PB_FIXED) op->pb_phase2 = LL_PB_ORDERED;
     } else {
@@ -1258,7 +1312,8 @@ int ll_op_set_accuracy(ll_operator* op, int accuracy) {
 int ll_op_accuracy(const ll_operator* op, int* accuracy_out) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && accuracy_out != nullptr, "null argument");
-    const bool fixed = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB && op->pb_phase2 == LL_PB_FIXED;
+    const bool fixed = op->kind == ll_operator::CSR && ((op->spmv_kind == LL_SPMV_PB && op->pb_phase2 == LL_PB_FIXED) ||
+                                                        op->spmv_kind == LL_SPMV_TILED);
     *accuracy_out = fixed ? LL_ACCURACY_NORMWISE : LL_ACCURACY_COMPONENTWISE;
   });
 }
@@ -1273,6 +1328,12 @@ int ll_op_autotune_ms(const ll_operator* op, double* csr_stream_ms, double* pb_m
     LL_REQUIRE(op != nullptr, "null operator");
     if (csr_stream_ms) *csr_stream_ms = (double)op->tune_ms[LL_SPMV_CSR_STREAM];
     if (pb_ms) *pb_ms = (double)op->tune_ms[LL_SPMV_PB];
+  });
+}
+int ll_op_autotune_ms_of(const ll_operator* op, int kind, double* ms) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr && ms != nullptr && kind >= LL_SPMV_CSR_STREAM && kind <= LL_SPMV_TILED, "bad argument");
+    *ms = (double)op->tune_ms[kind];
   });
 }
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz) {

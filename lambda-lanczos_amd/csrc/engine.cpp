@@ -173,13 +173,13 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
   LL_REQUIRE(sc == nullptr || can_defer_scale(), "internal: this operator cannot normalise its input on the fly");
   LL_REQUIRE(xnorm2 == nullptr || (can_scale_input() && sc == nullptr), "internal: this operator cannot scale its input");
   ScaleIn<T> from_norm;  // the non-PB kernels take the norm as a one-element list of "partials" (nothing published)
-  if (xnorm2 && !(op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB)) {
+  if (xnorm2 && !(op->kind == ll_operator::CSR && (op->spmv_kind == LL_SPMV_PB || op->spmv_kind == LL_SPMV_TILED))) {
     from_norm.partials = xnorm2;
     from_norm.nparts = 1;
     sc = &from_norm;
   }
   hipStream_t s = ctx->stream;
-  ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)op->pb_nrb));
+  ctx->ensure_alpha_partials(std::max<size_t>(kMaxSpmvGrid, (size_t)std::max(op->pb_nrb, op->tl_nrb)));
   double* const dotp = d_alpha ? ctx->d_alpha_partials : nullptr;
   int nparts = 0;
   if (op->kind == ll_operator::STENCIL) {
@@ -281,6 +281,8 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
     else if (pb)
       nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, xnorm2);
+    else if (op->spmv_kind == LL_SPMV_TILED)  // single GPU only (never selected on a sharded context): x_local is the whole x
+      nparts = launch_spmv_tiled<T>(*op, x_local, y, offset, dotp, s, xnorm2);
     else {
       LL_REQUIRE(op->d_col != nullptr || op->nnz == 0,
                  "this operator kept only its column-split image (created on a sharded context) and needs that communicator");

@@ -173,6 +173,7 @@ struct Tuning {
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
   // --- test hooks (not for users)
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
+  bool tl_force = false;           // LL_TL_FORCE=1: build the tiled image even for matrices that are not eligible (parity tests on small cases)
   bool pb_test_all_remote = false; // LL_PB_TEST_ALL_REMOTE=1: own columns are read from the gathered buffer too
   int tridiag_test_jitter_us = 0;  // LL_TRIDIAG_TEST_JITTER_US: random delay of every helper-thread verdict
   bool stencil_vec = true;         // LL_STENCIL_VEC=0: scalar lattice kernel on shapes the vector kernel would take
@@ -276,7 +277,7 @@ struct ll_operator {
   int ntiles_own = 0, ntiles_rem = 0;
   // propagation-blocked image of the same matrix (spmv_pb.hip pb_phase1 / pb_phase2)
   int spmv_kind = 0;                 // LL_SPMV_*
-  float tune_ms[2] = {-1.f, -1.f};   // what the creation-time autotune measured for LL_SPMV_CSR_STREAM / LL_SPMV_PB (-1: not timed)
+  float tune_ms[3] = {-1.f, -1.f, -1.f};  // what the creation-time autotune measured per LL_SPMV_* kernel (-1: not timed)
   int pb_ncb = 0, pb_nrb = 0, pb_cb_cols = 0, pb_rb_rows = 0;   // cb_cols = longest column block (LDS sizing)
   int64_t* d_pb_segq = nullptr;      // [ncb][nrb+1] entry offsets of the segments in column-block order
   int64_t* d_pb_segdest = nullptr;   // [ncb][nrb]   position of each segment in row-block order
@@ -295,6 +296,17 @@ struct ll_operator {
   int pb_phase2 = 4;                 // form of phase 2 (ll::LL_PB_FIXED / _ORDERED / _ATOMIC): set when the image is built,
                                      // changed by ll_op_set_accuracy (both forms read the same image)
   int accuracy_req = 0;              // LL_ACCURACY_* asked for at creation (ll_csr_options.accuracy); 0 = the environment decides
+  // 2-D tiled image (spmv_pb.hip, tl_*; LL_SPMV_TILED): row blocks with the y slice in LDS, each walking its non-empty
+  // column tiles of 16 KiB of x; entries = value (pre-scaled by the row's exponent) + packed 16-bit local column / row
+  int tl_nrb = 0, tl_rb_rows = 0, tl_ncb = 0;
+  int64_t tl_entries = 0, tl_tiles = 0;
+  int32_t* d_tl_first = nullptr;     // [nrb + 1]     first tile of each row block in the tile list
+  int32_t* d_tl_col = nullptr;       // [ntiles]      column tile index
+  int64_t* d_tl_quad = nullptr;      // [ntiles + 1]  first quad (4 entries) of each tile in the entry stream
+  void* d_tl_val = nullptr;          // values in tile order
+  uint32_t* d_tl_idx = nullptr;      // local column | local row << 16
+  int16_t* d_tl_rexp = nullptr;      // exponent of every row's absolute sum (the scale the values were divided by)
+  double* d_tl_xmax = nullptr;       // per-workgroup maxima of |x| left by the pre-pass of every launch
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
@@ -369,6 +381,13 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
 constexpr int LL_PB_ATOMIC = 0, LL_PB_ORDERED = 1, LL_PB_FIXED = 4;
 // Build the propagation-blocked image on the device from the operator's CSR arrays (false: shape not supported).
 template <typename T> bool pb_build_device(ll_operator* op);
+// The 2-D tiled kernel for matrices with column locality (spmv_pb.hip): same contract as launch_spmv on a single GPU
+// (x = the whole vector); build returns false when the matrix is not eligible (too many column tiles per row block).
+template <typename T> bool tl_build_device(ll_operator* op);
+void tl_release(ll_operator* op);
+template <typename T>
+int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, double* dot_partials, hipStream_t s,
+                      const double* xnorm2 = nullptr);
 // Column range check + max absolute row sum of the local rows (sets op->inf_norm), on the device.
 template <typename T> void csr_check_device(ll_operator* op);
 // Same contract for the dense row block (op.kind == DENSE).

@@ -741,12 +741,21 @@ __global__ __launch_bounds__(256) void pb_count_kernel(PbColMap m, int ncb, int 
 // chunk that fall into the same segment get consecutive slots in lane order (ballot ranking), so the position of
 // every entry is a pure function of the matrix: the image — hence the summation order of phase 2 — is identical
 // from build to build.  Inside a segment both orders agree (row-major, original order within a row).
-template <typename T, typename RP>
+// TILED (the 2-D tiled image, tl_* below): ONE order — the segments of a row block are consecutive (segq is laid out row
+// block by row block, segdest is not used) — the two 16-bit local indices of an entry are packed into one 32-bit word
+// (pcol is that array, prow is not used) and the value is stored PRE-SCALED by 2^-er_i (rexp: exponent of the row's
+// absolute sum), an exact operation that takes the per-row exponent out of the kernel's inner loop.
+__device__ __forceinline__ double scale_pow2(double v, int k) { return ldexp(v, k); }
+__device__ __forceinline__ float scale_pow2(float v, int k) { return ldexpf(v, k); }
+__device__ __forceinline__ zc scale_pow2(zc v, int k) { return zc{ldexp(v.re, k), ldexp(v.im, k)}; }
+__device__ __forceinline__ cf scale_pow2(cf v, int k) { return cf{ldexpf(v.re, k), ldexpf(v.im, k)}; }
+template <typename T, typename RP, bool TILED = false>
 __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int nrb, int rb_rows, long long n_local,
                                                         const RP* __restrict__ rp, const int32_t* __restrict__ ci,
                                                         const T* __restrict__ va, const int64_t* __restrict__ segq,
                                                         const int64_t* __restrict__ segdest, T* __restrict__ pval,
-                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow) {
+                                                        uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow,
+                                                        const int16_t* __restrict__ rexp = nullptr) {
   extern __shared__ int fill[];  // [ncb]
   const int r = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < ncb; i += 64) fill[i] = 0;
@@ -783,10 +792,16 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
     }
     if (valid) {
       const long long q = segq[(size_t)key * (nrb + 1) + r] + off;
-      const long long qd = segdest[(size_t)key * nrb + r] + off;
-      pval[q] = va[p];
-      pcol[q] = (uint16_t)local;
-      prow[qd] = (uint16_t)(rowi - i0);
+      if constexpr (TILED) {
+        const int er = rexp[rowi];
+        pval[q] = (er == 32767 || er <= -1100) ? va[p] : scale_pow2(va[p], -er);  // (rows with Inf / NaN, empty rows: as is)
+        reinterpret_cast<uint32_t*>(pcol)[q] = (uint32_t)local | ((uint32_t)(rowi - i0) << 16);
+      } else {
+        const long long qd = segdest[(size_t)key * nrb + r] + off;
+        pval[q] = va[p];
+        pcol[q] = (uint16_t)local;
+        prow[qd] = (uint16_t)(rowi - i0);
+      }
     }
   }
 }
@@ -1096,12 +1111,432 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   return true;
 }
 
+
+// ================================================================= 2-D tiled SpMV for matrices with column locality
+// (a1/a2/a3 like the kernels above; third candidate of the creation-time timing, LL_SPMV_TILED)
+// Propagation blocking pays a 16 B/nnz round trip of the products through memory because, for a matrix WITHOUT column
+// locality, the x values a row block needs are spread over the whole vector.  When the columns of a row block fall into
+// few column tiles (bands, stencils, lattices — every operator the reference itself ships: sample3_dynamic.cpp:17-22,
+// exponentiator_test.cpp:113-121) both slices fit the LDS at once and nothing has to leave the CU:
+//   one workgroup per ROW block (y slice = 64-bit fixed-point accumulators in LDS, as in pb_phase2_fixed);
+//   it walks the block's NON-EMPTY column tiles (16 KiB of x each, double-buffered in LDS, re-staged from L2 / Infinity
+//   Cache: neighbouring row blocks share their tiles) and streams the tile's entries — value + 16-bit local column +
+//   16-bit local row = 12 B/nnz for fp64, the algorithmic bytes of CSR — multiplying out of one LDS slice and adding
+//   into the other.  No global gather, no product buffer: HBM sees the matrix once, x a few times, y once.
+// Pipeline: every lane keeps D trips of entry loads in flight in a static ring (as above); the NEXT tile's x piece
+// (16 bytes per lane) is requested one tile ahead and parked in registers; one workgroup barrier per tile.
+// Sums: the same order-independent fixed-point scheme as pb_phase2_fixed, with the per-row exponent folded into the
+// stored values when the image is built (a power of two: exact) — so the integers that are added are the ones the PB
+// kernel adds, the result does not depend on the tile geometry, and the accuracy class is the NORM-wise one stated in
+// lanczos_hip.h.  max|x| over the whole vector comes from a small pre-pass (tl_xmax_kernel: one read of x).
+constexpr int kTlTileBytes = 16 * 1024;  // one x tile: one 16-byte piece per lane of the workgroup
+constexpr int kTlXmaxParts = 512;
+constexpr int kTlDepth = 3;
+
+template <typename T>
+__global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ parts) {
+  __shared__ double red[4];
+  double m = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmax(m, abs1(x[i]));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // (an Inf in x survives fmax; a NaN is dropped here and reaches the rows it touches through its products)
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+template <typename T, int D, bool ALIGNED>
+__global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_t n_local, int64_t n_cols,
+                                                             const int32_t* __restrict__ tfirst,   // [nrb + 1]
+                                                             const int32_t* __restrict__ tcol,     // [ntiles]
+                                                             const int64_t* __restrict__ tquad,    // [ntiles + 1]
+                                                             const T* __restrict__ val, const uint4* __restrict__ idx,
+                                                             const int16_t* __restrict__ rexp,
+                                                             const double* __restrict__ xmax_parts, int n_xmax,
+                                                             const T* __restrict__ x, const T* __restrict__ xl,
+                                                             T* __restrict__ y, double offset,
+                                                             double* __restrict__ dot_partials,
+                                                             const double* __restrict__ xnorm2) {
+  constexpr int R = scalar_traits<T>::reals;
+  constexpr int C = kTlTileBytes / (int)sizeof(T);  // columns per tile
+  constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte piece
+  extern __shared__ double lds_raw[];
+  long long* acc = reinterpret_cast<long long*>(lds_raw);                        // [rb_rows * R]
+  T* xs = reinterpret_cast<T*>(acc + (size_t)rb_rows * R);                       // [2][C]
+  unsigned* bad = reinterpret_cast<unsigned*>(xs + 2 * C);                       // [(rb_rows + 31) / 32] rows that met Inf / NaN
+  __shared__ double red[kPbWaves + 1];
+  const int tid = threadIdx.x;
+  const int rb = blockIdx.x;
+  const int64_t row0 = (int64_t)rb * rb_rows;
+  const int rows = (int)min((int64_t)rb_rows, n_local - row0);
+  const int t0 = tfirst[rb], t1 = tfirst[rb + 1];
+  const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;  // unnormalised input (see pb_phase1)
+  const long long q_end = tquad[t1];
+  const long long q_last = q_end > tquad[t0] ? q_end - 1 : tquad[t0];  // (the image is padded by one quad behind its end)
+
+  // ---- the stream: a cursor over (tile, trip) pairs; D - 1 trips are requested ahead of the one being consumed.
+  // Every trip requests the SAME four loads, unconditionally and in straight-line code — the lane's quad of values (2), its
+  // packed indices (1) and its 16-byte piece of the trip's x tile (1; requested again by every trip of a tile that spans
+  // several trips: an L2 hit) — so the compiler can wait for exactly the oldest trip (s_waitcnt vmcnt(N), see above).
+  struct Cursor {
+    int t;            // tile (index into the tile list)
+    long long q, q1;  // first quad of this trip, end of the tile
+  };
+  auto advance = [&](Cursor& c) {
+    c.q += kPbThreads;
+    if (c.q >= c.q1 && c.t < t1) {  // next tile (the tiles of a row block are consecutive in the stream)
+      ++c.t;
+      c.q = c.q1;
+      c.q1 = c.t < t1 ? tquad[c.t + 1] : c.q1;
+    }
+  };
+  quad<T> v[D];
+  uint4 ix[D], xp[D];
+  long long gq[D], gend[D];
+  auto issue = [&](int slot, const Cursor& c) {
+    const long long g = c.q + tid;
+    const long long gc = g < q_last ? g : q_last;
+    gq[slot] = g;
+    gend[slot] = c.t < t1 ? c.q1 : g;  // beyond the row block: nothing valid
+    v[slot] = load_quad<T>(val + 4 * gc);
+    ix[slot] = idx[gc];
+    // the lane's piece of x tile tcol[c.t]; elements beyond the vector's end are never referenced by an entry
+    const int ct = tcol[c.t < t1 ? c.t : (t1 > t0 ? t1 - 1 : t0)];
+    const long long off = (long long)ct * C + (long long)tid * V;
+    if constexpr (ALIGNED) {
+      // a piece that would reach beyond the end is read V-aligned from the last whole piece position that is still inside
+      // (n_cols >= V is guaranteed by the launcher) and shifted into place below (store_piece)
+      const long long lim = n_cols - V;
+      xp[slot] = *reinterpret_cast<const uint4*>(x + (off <= lim ? off : lim));
+    } else {
+      T el[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) el[q] = x[off + q < n_cols ? off + q : n_cols - 1];
+      __builtin_memcpy(&xp[slot], el, sizeof(uint4));
+    }
+  };
+  auto store_piece = [&](int buf, int ct, uint4 piece) {
+    T el[V];
+    __builtin_memcpy(el, &piece, sizeof(uint4));
+    if constexpr (ALIGNED) {
+      const long long off = (long long)ct * C + (long long)tid * V;
+      const int d = (int)max(0ll, off - (n_cols - V));  // the piece was read d elements further left (only at the vector's end)
+      if (d > 0) {
+        T sh[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) sh[q] = zero<T>();
+#pragma unroll
+        for (int q = 0; q < V; ++q)
+          if (q + d < V) sh[q] = el[q + d];
+#pragma unroll
+        for (int q = 0; q < V; ++q) el[q] = sh[q];
+      }
+    }
+    if (xnorm2) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) el[q] = rmul(xs_fac, el[q]);
+    }
+    uint4 out;
+    __builtin_memcpy(&out, el, sizeof(uint4));
+    reinterpret_cast<uint4*>(xs + (size_t)buf * C)[tid] = out;
+  };
+  // ---- accumulators, scale of the fixed-point grid
+  for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
+  for (int i = tid; i < (rb_rows + 31) / 32; i += kPbThreads) bad[i] = 0u;
+  int e_x = -2000;  // x == 0: any scale does
+  {
+    double m = 0.0;
+    for (int i = tid; i < n_xmax; i += kPbThreads) m = fmax(m, xmax_parts[i]);
+    const double t = pb_block_max(m, red) * xs_fac;  // (ends with a barrier: the LDS stores above are visible)
+    if (t > 0.0 && isfinite(t)) (void)frexp(t, &e_x);
+    else if (!(t == 0.0)) e_x = kPbXInf;
+  }
+  // integer = (PRE-SCALED value * x) * 2^kx; row i's sum is acc_i * 2^(er_i - kx)   (pb_phase2_fixed: k = 62 - (er + e_x + 1))
+  const int kx = e_x == kPbXInf ? 0 : max(-1000, min(1000, 61 - e_x));
+
+  // (No branch on `valid`: a lane beyond the end of its tile holds a re-read of a valid quad and adds ZERO to that quad's
+  // rows — every trip then waits for and uses its loads on every path, which keeps the wait counts of the ring exact.)
+  auto consume = [&](const quad<T>& vv, const uint4& ii, bool valid, int buf) {
+    const T* xb = xs + (size_t)buf * C;
+    const unsigned w4[4] = {ii.x, ii.y, ii.z, ii.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned lc = w4[e] & 0xffffu, lr = w4[e] >> 16;
+      const T p = mul(vv.e[e], xb[lc]);
+      long long w[R];
+      if constexpr (scalar_traits<T>::is_complex) {
+        w[0] = pb_to_fixed((double)p.re, kx);
+        w[1] = pb_to_fixed((double)p.im, kx);
+      } else {
+        w[0] = pb_to_fixed((double)p, kx);
+      }
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        if (w[q] == kPbBadProduct) ok = false;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[R * lr + q]), (valid && w[q] != kPbBadProduct) ? (unsigned long long)w[q] : 0ull);
+      }
+      if (!ok && valid) atomicOr(&bad[lr >> 5], 1u << (lr & 31));
+    }
+  };
+  // one trip.  The FIRST trip of a tile parks the tile's x pieces in the buffer the tile before the previous one used
+  // (every wave has left that tile: it has passed the barrier of the previous tile's first trip) and meets the others.
+  // (The first D - 1 trips are requested HERE, right in front of the loop and after everything else of the prologue has
+  // drained: the loop is then entered with exactly the pending loads its back edge carries, and the compiler's wait counts
+  // stay exact in every phase; requested earlier, the merge of the two paths costs a full drain in the loop's first phase.)
+  Cursor cur{t0, tquad[t0], t0 < t1 ? tquad[t0 + 1] : tquad[t0]};
+  Cursor nxt = cur;
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+    __builtin_amdgcn_sched_barrier(0);  // keep the trips' loads in trip order (the wait counts of the loop assume it)
+    issue(d, nxt);
+    advance(nxt);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  bool tile_start = true;
+  auto step = [&](auto ph) -> bool {
+    constexpr int PH = decltype(ph)::value;
+    if (cur.t >= t1) return false;  // uniform over the workgroup
+    const int buf = (cur.t - t0) & 1;
+    if (tile_start) {
+      store_piece(buf, tcol[cur.t], xp[PH]);
+      __syncthreads();
+    }
+    const bool valid = gq[PH] < gend[PH];
+    const quad<T> vv = v[PH];
+    const uint4 ii = ix[PH];
+    issue((PH + D - 1) % D, nxt);
+    advance(nxt);
+    consume(vv, ii, valid, buf);
+    const int t_before = cur.t;
+    advance(cur);
+    tile_start = cur.t != t_before;
+    return true;
+  };
+  for (;;) {
+    if (!step(std::integral_constant<int, 0>{})) break;
+    if (!step(std::integral_constant<int, 1>{})) break;
+    if constexpr (D > 2) {
+      if (!step(std::integral_constant<int, 2>{})) break;
+    }
+    if constexpr (D > 3) {
+      if (!step(std::integral_constant<int, 3>{})) break;
+    }
+  }
+  __syncthreads();
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  auto value = [&](int i) {
+    const int er = rexp[row0 + i];
+    const bool unusable = er == 32767 || e_x == kPbXInf || ((bad[i >> 5] >> (i & 31)) & 1u);
+    const int back = er - kx;  // 2^back restores the row's scale (empty rows: er = -1100, acc = 0)
+    acc_t<T> a;
+    if constexpr (scalar_traits<T>::is_complex)
+      a = unusable ? zc{nan, nan} : zc{ldexp((double)acc[2 * i], back), ldexp((double)acc[2 * i + 1], back)};
+    else
+      a = unusable ? nan : ldexp((double)acc[i], back);
+    return a;
+  };
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, value);
+}
+
+namespace {
+template <typename T> constexpr int tl_cols() { return kTlTileBytes / (int)sizeof(T); }
+template <typename T> size_t tl_lds_bytes(int rb_rows) {
+  return (size_t)rb_rows * sizeof(acc_t<T>) + 2 * (size_t)kTlTileBytes + (size_t)((rb_rows + 31) / 32) * sizeof(unsigned) + 16;
+}
+template <typename T> void tl_opt_in_lds() {
+  static std::atomic<unsigned long long> mask{0};
+  int dev = 0;
+  LL_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return;
+  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, true>);
+  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, false>);
+  mask.fetch_or(bit, std::memory_order_release);
+}
+}  // namespace
+
+template <typename T>
+int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, double* dot_partials, hipStream_t s,
+                      const double* xnorm2) {
+  if (op.tl_nrb <= 0) return 0;
+  tl_opt_in_lds<T>();
+  const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>(kTlXmaxParts, (op.n + 255) / 256));
+  hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(xgrid), dim3(256), 0, s, (long long)op.n, x, op.d_tl_xmax);
+  // 16-byte pieces of x: the fast form needs an aligned vector of at least one piece
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && op.n >= (int64_t)(16 / sizeof(T));
+  if (aligned)
+    hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, true>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,
+                       op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,
+                       (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset,
+                       dot_partials, xnorm2);
+  else
+    hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, false>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,
+                       op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,
+                       (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset,
+                       dot_partials, xnorm2);
+  LL_HIP(hipGetLastError());
+  return op.tl_nrb;
+}
+
+// Build the tiled image on the device from the operator's CSR arrays.  false: the matrix is not eligible — its row
+// blocks touch too many column tiles (re-staging x would cost more than the matrix stream itself: matrices without
+// column locality, which keep PB) or the shape does not fit the tables — and nothing stays allocated.
+template <typename T> bool tl_build_device(ll_operator* op) {
+  ll_context* ctx = op->ctx;
+  hipStream_t s = ctx->stream;
+  const int64_t nr = op->n_local;
+  if (ctx->nranks > 1 || nr <= 0 || op->nnz <= 0) return false;  // single GPU (sharded contexts keep CSR-stream / PB)
+  const Tuning& tune = ctx->tune;
+  constexpr int C = tl_cols<T>();
+  // ---- row blocks: as long as the LDS allows (the longer the block, the smaller the share of re-staged x per entry),
+  //      in whole rounds of 256 workgroups
+  const int64_t row_max = std::min<int64_t>(65536, ((int64_t)kPbLdsCap - 2 * kTlTileBytes - 2048 - 64) / (int64_t)sizeof(acc_t<T>) / 256 * 256);
+  int64_t rounds = std::max<int64_t>(1, (nr + 256 * row_max - 1) / (256 * row_max));
+  int64_t rb_rows = std::min<int64_t>(row_max, std::max<int64_t>(16, (nr + 256 * rounds - 1) / (256 * rounds)));
+  if (tune.pb_block > 0) rb_rows = std::min<int64_t>(row_max, std::max(4, tune.pb_block));
+  if (tune.pb_row_block > 0) rb_rows = std::min<int64_t>(row_max, std::max(4, tune.pb_row_block));
+  rb_rows = (rb_rows + 1) & ~(int64_t)1;  // even: the x buffers behind the accumulators stay 16-byte aligned
+  const int64_t nrb = (nr + rb_rows - 1) / rb_rows;
+  const int64_t ncb = (op->n + C - 1) / C;
+  if (ncb * (int64_t)sizeof(int) > 60 * 1024) return false;   // LDS histogram of the build kernels
+  if (ncb * nrb > (int64_t)24 << 20) return false;            // count table
+  PbColMap m;
+  std::memset(&m, 0, sizeof(m));
+  m.shard = op->n;
+  m.nranks = 1;
+  m.rank = 0;
+  m.nchunks = 1;
+  m.cstart[0] = 0;
+  m.clen[0] = (int)std::min<int64_t>(op->n, 0x7fffffff);
+  m.bl[0] = C;
+  m.nb[0] = (int)ncb;
+  m.own_base[0] = 0;
+  m.rem_base[0] = (int)ncb;
+  // ---- entries per (column tile, row block)
+  int32_t* d_cnt = nullptr;
+  ctx->dev_malloc((void**)&d_cnt, (size_t)ncb * nrb * sizeof(int32_t), "tile counts");
+  struct Free1 {
+    void* p;
+    ~Free1() {
+      if (p) (void)hipFree(p);
+    }
+  } free_cnt{d_cnt};
+  const size_t hist_bytes = (size_t)ncb * sizeof(int);
+  if (op->rp64)
+    hipLaunchKernelGGL((pb_count_kernel<int64_t>), dim3((int)nrb), dim3(256), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, d_cnt);
+  else
+    hipLaunchKernelGGL((pb_count_kernel<int32_t>), dim3((int)nrb), dim3(256), hist_bytes, s, m, (int)ncb, (int)nrb,
+                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, d_cnt);
+  LL_HIP(hipGetLastError());
+  std::vector<int32_t> cnt32((size_t)ncb * nrb);
+  LL_HIP(hipMemcpyAsync(cnt32.data(), d_cnt, cnt32.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LL_HIP(hipStreamSynchronize(s));
+  // ---- tile list (non-empty tiles only), row block by row block; every tile padded to 16 entries (whole quads, the
+  //      stream of a tile starts on a 128-byte line of both arrays)
+  const int64_t pad = 16;
+  std::vector<int32_t> tfirst((size_t)nrb + 1), tcol;
+  std::vector<int64_t> tquad, segq((size_t)ncb * (nrb + 1), 0);
+  int64_t q = 0;
+  for (int64_t r = 0; r < nrb; ++r) {
+    tfirst[(size_t)r] = (int32_t)tcol.size();
+    for (int64_t c = 0; c < ncb; ++c) {
+      const int64_t k = cnt32[(size_t)c * nrb + r];
+      segq[(size_t)c * (nrb + 1) + r] = q;
+      if (k == 0) continue;
+      tcol.push_back((int32_t)c);
+      tquad.push_back(q >> 2);
+      q += (k + pad - 1) / pad * pad;
+    }
+  }
+  tfirst[(size_t)nrb] = (int32_t)tcol.size();
+  tquad.push_back(q >> 2);
+  const int64_t entries = q;
+  const int64_t ntiles = (int64_t)tcol.size();
+  // ---- eligibility: the re-staged x slices must cost less than the matrix stream, and the padding must stay small
+  const double staged = (double)ntiles * kTlTileBytes, stream = (double)entries * (sizeof(T) + 4);
+  const bool eligible = staged <= stream && (double)entries <= 1.25 * (double)op->nnz + 16.0 * (double)nrb;
+  if (ntiles == 0 || !(eligible || tune.tl_force)) return false;
+  if (ntiles > 0x7ffffff0) return false;
+  op->tl_nrb = (int)nrb;
+  op->tl_rb_rows = (int)rb_rows;
+  op->tl_ncb = (int)ncb;
+  op->tl_entries = entries;
+  op->tl_tiles = ntiles;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    ctx->dev_malloc(dst, std::max<size_t>(bytes, 16), "tiled-image tables");
+    LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
+  };
+  int64_t* d_segq = nullptr;
+  struct Free2 {
+    int64_t*& p;
+    ~Free2() {
+      if (p) (void)hipFree(p);
+    }
+  } free_segq{d_segq};
+  try {
+    up((void**)&op->d_tl_first, tfirst.data(), tfirst.size() * sizeof(int32_t));
+    up((void**)&op->d_tl_col, tcol.data(), tcol.size() * sizeof(int32_t));
+    up((void**)&op->d_tl_quad, tquad.data(), tquad.size() * sizeof(int64_t));
+    up((void**)&d_segq, segq.data(), segq.size() * sizeof(int64_t));
+    const size_t cap = (size_t)entries + 16;  // one quad behind the image: clamped reads of lanes beyond the end
+    ctx->dev_malloc(&op->d_tl_val, cap * sizeof(T), "tiled image (values)");
+    ctx->dev_malloc((void**)&op->d_tl_idx, cap * sizeof(uint32_t), "tiled image (local indices)");
+    ctx->dev_malloc((void**)&op->d_tl_rexp, std::max<size_t>((size_t)nr, 8) * sizeof(int16_t), "row exponents");
+    ctx->dev_malloc((void**)&op->d_tl_xmax, (size_t)kTlXmaxParts * sizeof(double), "x maxima");
+    LL_HIP(hipMemsetAsync(op->d_tl_val, 0, cap * sizeof(T), s));  // padding entries: value 0, local indices 0
+    LL_HIP(hipMemsetAsync(op->d_tl_idx, 0, cap * sizeof(uint32_t), s));
+    LL_HIP(hipMemsetAsync(op->d_tl_xmax, 0, (size_t)kTlXmaxParts * sizeof(double), s));
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (nr + 255) / 256));
+    if (op->rp64)
+      hipLaunchKernelGGL((pb_rowexp_kernel<T, int64_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int64_t*)op->d_row_ptr,
+                         (const T*)op->d_val, op->d_tl_rexp);
+    else
+      hipLaunchKernelGGL((pb_rowexp_kernel<T, int32_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int32_t*)op->d_row_ptr,
+                         (const T*)op->d_val, op->d_tl_rexp);
+    LL_HIP(hipGetLastError());
+    if (op->rp64)
+      hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t, true>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                         (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val, d_segq,
+                         nullptr, (T*)op->d_tl_val, reinterpret_cast<uint16_t*>(op->d_tl_idx), nullptr, op->d_tl_rexp);
+    else
+      hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t, true>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
+                         (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val, d_segq,
+                         nullptr, (T*)op->d_tl_val, reinterpret_cast<uint16_t*>(op->d_tl_idx), nullptr, op->d_tl_rexp);
+    LL_HIP(hipGetLastError());
+    LL_HIP(hipStreamSynchronize(s));  // the host tables above go out of scope
+  } catch (...) {
+    tl_release(op);
+    throw;
+  }
+  return true;
+}
+
+void tl_release(ll_operator* op) {
+  auto drop = [](auto*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+  };
+  drop(op->d_tl_first);
+  drop(op->d_tl_col);
+  drop(op->d_tl_quad);
+  drop(op->d_tl_val);
+  drop(op->d_tl_idx);
+  drop(op->d_tl_rexp);
+  drop(op->d_tl_xmax);
+  op->tl_nrb = 0;
+}
+
 #define LL_INST_PB(T)                                                                                              \
   template void launch_pb_phase1<T>(const ll_operator&, int, int, const T*, hipStream_t, const double*);            \
   template int launch_pb_phase2<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t, const double*);  \
   template int launch_spmv_pb<T>(const ll_operator&, const T*, const T*, const T*, T*, double, double*, hipStream_t, \
                                  const double*);                                                                    \
   template bool pb_build_device<T>(ll_operator*);                                                                   \
+  template bool tl_build_device<T>(ll_operator*);                                                                   \
+  template int launch_spmv_tiled<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t, const double*);  \
   template void csr_check_device<T>(ll_operator*);
 LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)
 

@@ -249,6 +249,12 @@ class CsrOperator(_Operator):
         check(lib().ll_op_autotune_ms(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def autotune_ms_of(self, kind):
+        """Creation-time timing of one kernel (capi.SPMV_*), -1 when it was not a candidate."""
+        a = C.c_double()
+        check(lib().ll_op_autotune_ms_of(self.handle, int(kind), C.byref(a)))
+        return a.value
+
     def selected_spmv(self):
         k = C.c_int()
         check(lib().ll_op_selected_spmv(self.handle, C.byref(k)))

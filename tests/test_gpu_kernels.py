@@ -24,6 +24,7 @@ def csr_cases():
         "banded5000": G.randsym_np(5000, band=64),
         "torus24": G.torus_np(24),
         "ring_complex": G.ring_csr(100, -1.0, np.complex128),
+        "banded20000": G.randsym_np(20000, band=300),   # ten column tiles of the tiled kernel, two or three per row block
     }
     # ragged: empty rows, a row longer than one LDS tile (>1024 nnz), single-entry rows
     n = 3000
@@ -49,8 +50,12 @@ KERNELS = {"csr_stream": ("csr", None, None),
            "pb_fixed": ("pb", None, "fixed"), "pb_fixed_small_blocks": ("pb", "37", "fixed"),
            "pb_fixed_ragged_blocks": ("pb", "53", "fixed"),
            "pb_ordered": ("pb", None, "ordered"), "pb_ordered_small_blocks": ("pb", "37", "ordered"),
-           "pb_atomic": ("pb", None, "atomic"), "pb_atomic_small_blocks": ("pb", "37", "atomic")}
-KIND = {"csr": 0, "pb": 1}
+           "pb_atomic": ("pb", None, "atomic"), "pb_atomic_small_blocks": ("pb", "37", "atomic"),
+           # the 2-D tiled kernel (LL_TL_FORCE: these small matrices are not all eligible on their own): default row blocks,
+           # tiny and ragged row blocks (many row blocks per column tile, empty tiles, one-quad tiles)
+           "tiled": ("tiled", None, None), "tiled_small_blocks": ("tiled", "37", None),
+           "tiled_ragged_blocks": ("tiled", "53", None)}
+KIND = {"csr": 0, "pb": 1, "tiled": 2}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -63,6 +68,8 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, llenv):
     x = rnd(n, dtype, 3)
     which, block, phase2 = KERNELS[kernel]
     llenv.setenv("LL_SPMV_KERNEL", which)
+    if which == "tiled":
+        llenv.setenv("LL_TL_FORCE", "1")
     if block:
         llenv.setenv("LL_PB_BLOCK", block)
     if phase2:
@@ -92,7 +99,7 @@ def test_spmv_matches_oracle(ctx, oracle, name, offset, kernel, llenv):
     op.close()
 
 
-@pytest.mark.parametrize("name", ["randsym5000", "ragged", "ragged_z", "torus24"])
+@pytest.mark.parametrize("name", ["randsym5000", "ragged", "ragged_z", "torus24", "banded20000"])
 def test_pb_fixed_point_sums_do_not_depend_on_the_block_geometry(ctx, name, llenv):
     """Integer addition is associative: the fixed-point phase 2 gives the same bits for every block geometry (hence for
     every partition of the matrix); the wave-ordered floating-point form agrees with it to rounding."""
@@ -114,6 +121,20 @@ def test_pb_fixed_point_sums_do_not_depend_on_the_block_geometry(ctx, name, llen
         llenv.delenv("LL_PB_BLOCK")
     for block in ("37", "53", "1000"):
         assert np.array_equal(fx[None], fx[block]), block
+    # ... and the 2-D tiled kernel adds the SAME integers (it stores the values pre-scaled by the row's exponent, an exact
+    # operation, instead of looking the exponent up per entry): its result equals the PB kernel's bit for bit, whatever the tiling
+    llenv.setenv("LL_SPMV_KERNEL", "tiled")
+    llenv.setenv("LL_TL_FORCE", "1")
+    for block in (None, "37", "1000"):
+        if block:
+            llenv.setenv("LL_PB_BLOCK", block)
+        op = L.CsrOperator(ctx, *csr)
+        assert op.selected_spmv() == 2
+        L.spmv(op, xd, yd, offset=0.5)
+        assert np.array_equal(fx[None], yd.get()), ("tiled", block)
+        op.close()
+        llenv.delenv("LL_PB_BLOCK")
+    llenv.setenv("LL_SPMV_KERNEL", "pb")
     llenv.setenv("LL_PB_PHASE2", "ordered")
     op = L.CsrOperator(ctx, *csr)
     L.spmv(op, xd, yd, offset=0.5)
