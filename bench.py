@@ -542,9 +542,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     lagged_timed = 0
+    pair_timed = 0
     for _ in range(args.steps):
         itern.append(step())
         lagged_timed += int((eng.last_stats or {}).get("lagged_iterations", 0))
+        pair_timed += int((eng.last_stats or {}).get("pair_iterations", 0))
         if inline:
             for key in stats_acc:
                 stats_acc[key] += eng.last_stats[key]
@@ -603,6 +605,23 @@ def main():
     if wl == "c5":
         orth_bytes = sum(s * n * 9 for it in itern_phases for _k in range(1, it + 1))
         orth_model = "s*n*9 bytes per iteration (no Gram-Schmidt against the basis: Exponentiator default)"
+    elif lagged_gs and pair_timed > 0:
+        # pair form: iterations 1 and 2 single (s*n*(k+4)), then pairs (k, k+1): the first three-term kernel (3R 1W) + ONE sweep
+        # that reads the k-2 stored vectors and the four raw ones and writes u_{k-2}, u_{k-1} and the compensated r4
+        def pair_window(it):
+            tot, k = 0, 1
+            while k <= it:
+                if k >= 3:
+                    tot += s * n * (k + 9)
+                    k += 2
+                else:
+                    tot += s * n * (k + 4)
+                    k += 1
+            return tot
+        orth_bytes = sum(pair_window(it) for it in itern_phases)
+        orth_model = ("TWO iterations per sweep (pair form, %d of the %d timed iterations): s*n*(k+9) bytes per pair (k, k+1) = "
+                      "three-term kernel (3R 1W) + one sweep over k-2 stored and 4 raw vectors (3 written); the one-sweep form needs "
+                      "s*n*(k+4) per iteration, the two-sweep form of SURVEY 8d s*n*(2k+9)" % (pair_timed, total_iters))
     elif lagged_gs:
         # one-sweep (lagged) form: reads y, r, u_{k-2} and the k-1 complete basis vectors, writes w and u_{k-1}
         orth_bytes = sum(s * n * (k + 4) for it in itern_phases for k in range(1, it + 1))
@@ -783,9 +802,12 @@ def main():
                 "gram_schmidt": ("no re-orthogonalisation (Exponentiator default, EX:120)" if wl == "c5" else
                                  ("full re-orthogonalisation against all previous Lanczos vectors in every iteration, "
                                   "block classical Gram-Schmidt; " +
-                                  ("ONE sweep over the basis per iteration: the update is applied one iteration late and its "
-                                   "effect on the recurrence is compensated exactly (DESIGN.md 3.2; %d of the %d timed "
-                                   "iterations; LL_FUSE_LAUNCHES=1 runs the two-sweep form)" % (lagged_timed, total_iters)
+                                  (("ONE sweep over the basis per TWO iterations (pair form, DESIGN.md 3.2: %d of the %d timed "
+                                    "iterations; LL_PAIR_GS=0 runs one sweep per iteration, LL_FUSE_LAUNCHES=1 two)" % (pair_timed, total_iters))
+                                   if pair_timed > 0 else
+                                   ("ONE sweep over the basis per iteration: the update is applied one iteration late and its "
+                                    "effect on the recurrence is compensated exactly (DESIGN.md 3.2; %d of the %d timed "
+                                    "iterations; LL_FUSE_LAUNCHES=1 runs the two-sweep form)" % (lagged_timed, total_iters))
                                    if lagged_gs else "two sweeps over the basis per iteration (multi-dot, multi-axpy)"))),
                 "tridiag_mode": int(eng.tridiag_mode) if hasattr(eng, "tridiag_mode") else None,
                 "eps": "engine default" if args.eps is None else args.eps,
@@ -813,7 +835,8 @@ def main():
                 "achieved_actual_traffic_GBps": (traffic / (spmv_ms * 1e-3) / 1e9) if traffic else None,
             },
             "roofline_orth": {
-                "kernel": ("lagged sweep + folds (three-term, one-sweep Gram-Schmidt, norm)" if lagged_gs else
+                "kernel": ("pair_three_term + pair_sweep + folds (two iterations per sweep)" if (lagged_gs and pair_timed > 0) else
+                           "lagged sweep + folds (three-term, one-sweep Gram-Schmidt, norm)" if lagged_gs else
                            "mdot+maxpy+scale (three-term, Gram-Schmidt, norm, normalise)"),
                 "bound": "hbm",
                 "achieved": (orth_bytes / orth_s / 1e9) if orth_s > 0 else None,  # None: --no-phase-timers
@@ -828,6 +851,7 @@ def main():
                 "algorithmic_bytes_per_step": orth_bytes / max(len(itern_phases), 1),
                 "model": orth_model,
                 "lagged_iterations_timed_steps": lagged_timed,
+                "pair_iterations_timed_steps": pair_timed,
                 "two_sweep_model_bytes_per_step": (two_sweep_bytes / max(len(itern_phases), 1)) if wl != "c5" else None,
             },
             "phases": {

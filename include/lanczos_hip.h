@@ -413,7 +413,11 @@ typedef struct ll_run_stats {
   double seconds_comm_gather;    /* device time of the all-gathers / halo exchanges (their own stream; 0 unless profiling) */
   double seconds_comm_allreduce; /* device time of the all-reduces (0 unless profiling) */
   int64_t lagged_iterations;     /* iterations that ran in the one-sweep (lagged) Gram-Schmidt form */
-  int64_t reserved[8];           /* zero; later statistics are taken from here, so the struct size stays what it is */
+  int64_t pair_iterations;       /* ... of which: iterations that shared ONE sweep over the basis with their neighbour (two
+                                  * iterations per sweep; taken from the reserved tail: same struct size) */
+  int64_t pair_gate_trips;       /* times a pass left the two-iterations-per-sweep form because a coefficient of a raw vector
+                                  * exceeded its gate (exhausted Krylov space / breakdown): 0 in ordinary runs */
+  int64_t reserved[6];           /* zero; later statistics are taken from here, so the struct size stays what it is */
 } ll_run_stats;
 int ll_ctx_set_profiling(ll_context* ctx, int enabled);
 

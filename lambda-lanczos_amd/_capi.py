@@ -99,7 +99,9 @@ class RunStats(C.Structure):
         ("seconds_comm_gather", f64),
         ("seconds_comm_allreduce", f64),
         ("lagged_iterations", i64),
-        ("reserved", i64 * 8),
+        ("pair_iterations", i64),
+        ("pair_gate_trips", i64),
+        ("reserved", i64 * 6),
     ]
 
     def as_dict(self):

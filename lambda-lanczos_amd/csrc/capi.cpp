@@ -36,6 +36,7 @@ Tuning read_tuning() {
   t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : (k == "tiled" ? 3 : 0));
   t.keep_both = flag("LL_SPMV_KEEP_BOTH", false);
   t.tl_force = flag("LL_TL_FORCE", false);
+  t.pair_gs = flag("LL_PAIR_GS", true);
   const std::string p2 = str("LL_PB_PHASE2");
   t.pb_phase2 = p2 == "atomic" ? LL_PB_ATOMIC : (p2 == "ordered" ? LL_PB_ORDERED : LL_PB_FIXED);
   t.pb_block = (int)std::max<long long>(0, num("LL_PB_BLOCK", 0));
@@ -96,9 +97,19 @@ void ll_context::dev_malloc(void** out, size_t bytes, const char* what) {
 }
 void ll_context::cache_put(void* p, size_t bytes) {
   slab_cache.emplace_back(p, bytes);
-  while (slab_cache.size() > kSlabCacheMaxEntries) {  // least recently returned first
-    (void)hipFree(slab_cache.front().first);
-    slab_cache.erase(slab_cache.begin());
+  // Bounded: over the limit, a buffer of a DIFFERENT size than the one just returned goes first (oldest of those) — a Basis
+  // that returns more slabs than the bound must not push out its own first slabs, which the next run of the same problem
+  // would have to allocate again (hipFree synchronises the device); only when every entry has the incoming size does the
+  // oldest one go.  One pass per eviction; evictions happen at the bound only, never inside a loop.
+  while (slab_cache.size() > kSlabCacheMaxEntries) {
+    size_t victim = 0;
+    for (size_t i = 0; i + 1 < slab_cache.size(); ++i)
+      if (slab_cache[i].second != bytes) {
+        victim = i;
+        break;
+      }
+    (void)hipFree(slab_cache[victim].first);
+    slab_cache.erase(slab_cache.begin() + (long)victim);
   }
 }
 void ll_context::ensure_partials(size_t doubles) {

@@ -208,8 +208,12 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     const bool pb = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_PB;
     // CSR-stream on a sharded context: the image is split by column ownership (capi.cpp build_csr_split); the dense row
     // block splits by column range without a second image
+    // (dense: only when the shard's column range starts and ends on 16-byte pieces of the rows — with an unaligned boundary both
+    // parts would take the scalar path of dense_mv_kernel, and gather-then-multiply, which vectorises whole rows, is faster)
+    constexpr int64_t V = (int64_t)(16 / sizeof(T)) > 0 ? (int64_t)(16 / sizeof(T)) : 1;
+    const bool dense_split_ok = op->n % V == 0 && op->row_begin % V == 0 && (op->row_begin + op->n_local) % V == 0;
     const bool split = ctx->comm != nullptr && ((op->kind == ll_operator::CSR && !pb && op->csr_split) ||
-                                                (op->kind == ll_operator::DENSE && ctx->tune.csr_split));
+                                                (op->kind == ll_operator::DENSE && ctx->tune.csr_split && dense_split_ok));
     const T* x_full = x_local;
     const T* x_own = x_local;  // what the own-column blocks of the PB kernels read
     bool remote_done = false;
@@ -646,8 +650,47 @@ template <typename T> struct LoopState {
   int64_t ld = 0;
   int64_t small_bytes = 0;
 
+  // Pair form (kernels.hip, "pair" section; tools/pair_gs_model.py): TWO iterations per sweep over the basis.  State between
+  // sweeps: u_0 .. u_{pair_P-1} complete in the basis; two raw vectors pending, pr1 -> u_P and pr2 -> u_{P+1}, with their
+  // measured coefficients (g1p; g2p followed by <u_P, pr2>) and the squared norms of their orthogonal parts (rho1p, rho2p).
+  bool pair_enabled = false;
+  bool pair_allowed = true;   // this pass: a coefficient above kPairGate switches the form off for the rest of the pass
+  bool pair_pending = false;
+  int64_t pair_P = 0;
+  int64_t n_pair = 0;         // iterations enqueued in the pair form (statistics; includes speculative ones that were dropped)
+  int64_t n_gate_trips = 0;   // passes that left the pair form through the coefficient gate
+  DevBuf<T> pwork[2];         // with work[0..1]: the four raw vectors of a pair
+  DevBuf<double> pbuf;        // coefficient records, predictions, scalars (its own allocation: ctx->d_h may move)
+  const T *pr1 = nullptr, *pr2 = nullptr;
+  int pset = 0;               // which pair of buffers holds pr1 / pr2: 0 = work, 1 = pwork
+  const double *g1p = nullptr, *g2p = nullptr, *rho1p = nullptr, *rho2p = nullptr;
+  double *prec[4] = {nullptr, nullptr, nullptr, nullptr}, *pzero = nullptr, *pp3 = nullptr, *pp4 = nullptr, *pfold = nullptr,
+         *pcols = nullptr, *pscal = nullptr;
+  int prec_set = 0;           // records prec[2 * prec_set], prec[2 * prec_set + 1] hold the pending pair's coefficients
+  bool slot_pair[4] = {false, false, false, false};  // the scalars of this ring slot came from a pair fold (its gate is valid)
+  static constexpr size_t kPairRec = (size_t)kLaggedMaxCols + 32;
+
   LoopState(Engine<T>& e, Basis<T>& u, EventRing& r, PhaseTimer& t, int64_t n_local, hipStream_t st)
       : E(e), U(u), ring(r), timer(t), nl(n_local), s(st) {}
+  void enable_pair() {  // after enable_lagged
+    if (!lagged) return;
+    pair_enabled = true;
+    for (auto& w : pwork)
+      if (!w.p) w.alloc(E.ctx, (size_t)ld);
+    // 4 records + zero record + p3 + p4 + fold scratch + folded columns + 64 scalars
+    pbuf.alloc(E.ctx, 9 * kPairRec + 64);
+    double* b = pbuf.p;
+    for (int i = 0; i < 4; ++i) prec[i] = b + (size_t)i * kPairRec;
+    pzero = b + 4 * kPairRec;
+    pp3 = b + 5 * kPairRec;
+    pp4 = b + 6 * kPairRec;
+    pfold = b + 7 * kPairRec;
+    pcols = b + 8 * kPairRec;
+    pscal = b + 9 * kPairRec;
+    LL_HIP(hipMemsetAsync(pzero, 0, kPairRec * sizeof(double), s));
+    launch_set_scalar(pscal + 0, 1.0, s);  // pscal[0] = 1 (rho1^2 of a vector that is already complete)
+    // pscal[8 + 2 i], [9 + 2 i]: rho^2 pair i (alternating); pscal[16 ..]: |r3|^2, <r1, r3>
+  }
   void enable_defer(int64_t ld_) {
     defer = true;
     ld = ld_;
@@ -687,13 +730,18 @@ template <typename T> struct LoopState {
   // the pass takes the one-sweep form only if every ||r_i|| <= 3e-8 max|lambda| (effect on the recurrence ~ 1e-15 max|lambda|
   // at a typical beta).  Ritz vectors of clustered or degenerate eigenvalues, or of a pass cut off by max_iteration, do not meet
   // that and keep the two-sweep form.  All numbers are all-reduced: the same decision on every rank.
-  // norm_scale: a rank-independent estimate of ||A + offset|| (the previous pass's ||T||_inf, lanczos_run): the gate is
+  // norm_scale: a rank-independent estimate of the OPERATOR's size (the previous passes' ||T||_inf, lanczos_run: at least
+  // ||A + offset||_2 restricted to the Krylov space, at most 3 x ||A + offset||_2 — so "3e-8 scale" below means at most
+  // 9e-8 ||A + offset||_2 and the neglected term at most ~1e-14 ||A + offset||_2 at a typical beta): the gate is
   // relative to the OPERATOR's size, not to max|lambda + offset|, which collapses when a locked eigenvalue sits near -offset.
   void begin_pass(const T* locked_vecs, int64_t n_lock, const double* lambda_shifted = nullptr, double offset = 0.0,
                   double norm_scale = 0.0) {
     locked = locked_vecs;
     n_locked = n_lock;
     lag_pending = false;
+    pair_pending = false;
+    pair_allowed = true;
+    for (auto& b : slot_pair) b = false;
     lag_ok = lagged && (n_lock == 0 || (lambda_shifted != nullptr && n_lock <= kLaggedMaxLocked));
     lag_beta2_min = 0.0;
     if (lagged) bind_buffers();
@@ -766,7 +814,125 @@ template <typename T> struct LoopState {
   }
   // u_j must be complete in its basis slot (second Gram-Schmidt pass on it)
   void make_final(int64_t j) {
+    if (pair_pending && j >= pair_P) pair_flush();
     if (lag_pending && lag_k == j) flush_lag();
+  }
+  // Leave the pair form: complete the two pending vectors with their measured coefficients (two-sweep kernels).  Afterwards
+  // u_0 .. u_{P+1} are complete, nothing is pending, and iteration P + 2 can be enqueued from a clean state.
+  void pair_flush() {
+    if (!pair_pending) return;
+    constexpr int R = Engine<T>::R;
+    const int64_t P = pair_P;
+    const T* src[2] = {pr1, pr2};
+    const double* coef[2] = {g1p, g2p};  // g2p: R * P coefficients against the basis, then <u_P, pr2>: one contiguous list
+    const double* rho[2] = {rho1p, rho2p};
+    for (int v = 0; v < 2; ++v) {
+      T* dst = U.vec(P + v);
+      if (dst != src[v]) LL_HIP(hipMemcpyAsync(dst, src[v], (size_t)nl * sizeof(T), hipMemcpyDeviceToDevice, s));
+      const RunList<T> runs = basis_runs(P + v);
+      int off = 0;
+      for (auto& g : runs.groups(max_vecs_per_launch<T>())) {
+        launch_maxpy<T>(nl, dst, g, coef[v] + R * off, nullptr, E.ctx->d_partials, small_bytes, s);
+        for (int i = 0; i < g.nseg; ++i) off += g.count[i];
+      }
+      const NormRefs nr{rho[v], rho[v], rho[v], 0};
+      launch_scale<T>(nl, dst, 0.0, &nr, s);
+    }
+    pair_pending = false;
+    lag_pending = false;
+    refs_prev = NormRefs{rho2p, rho2p, rho2p, 0};  // beta^2 of the last completed vector, for the next three-term update
+  }
+  // Iterations k and k + 1 in the pair form.  Entered from the one-sweep state (iteration k - 1 pending with its measured
+  // coefficients: u_{k-2} plays the part of an already complete first vector, g1 = 0, rho1 = 1) or continued from a pair.
+  bool enqueue_pair(int64_t k, double offset) {
+    constexpr int R = Engine<T>::R;
+    if (!pair_enabled || !pair_allowed || !lag_ok || n_locked != 0 || E.ctx->comm != nullptr) return false;
+    int64_t P;
+    const T *r1, *r2;
+    const double *g1, *g2, *rho1sq, *rho2sq;
+    int out_set, out_rec;
+    if (pair_pending) {
+      if (pair_P + 2 != k) return false;
+      P = pair_P;
+      r1 = pr1;
+      r2 = pr2;
+      g1 = g1p;
+      g2 = g2p;
+      rho1sq = rho1p;
+      rho2sq = rho2p;
+      out_set = pset ^ 1;
+      out_rec = prec_set ^ 1;
+    } else if (lag_pending && lag_k == k - 1 && k >= 3) {
+      P = k - 2;
+      r1 = U.vec(k - 2);
+      r2 = work[(k - 1) & 1].p;
+      g1 = pzero;
+      g2 = hbuf[(k - 1) & 1];   // k - 1 = P + 1 coefficients: against u_0 .. u_{P-1}, then <u_P, r2>
+      rho1sq = pscal + 0;
+      rho2sq = lag_c1;
+      out_set = 1;
+      out_rec = 0;
+    } else {
+      return false;
+    }
+    const int ncols = 2 * R * (int)P + 5 * R + 1;
+    const int64_t stream_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);
+    if (ncols > kLaggedMaxCols || nl * (int64_t)sizeof(T) < stream_bytes) return false;
+    const RunList<T> stored = basis_runs(P);
+    const std::vector<BasisSegs<T>> groups = stored.groups(max_vecs_per_launch<T>());
+    if (groups.size() != 1) return false;
+    const double te0 = now_s();
+    T* r3 = out_set ? pwork[0].p : work[0].p;
+    T* r4 = out_set ? pwork[1].p : work[1].p;
+    double* rec3 = prec[2 * out_rec];
+    double* rec4 = prec[2 * out_rec + 1];
+    double* nxt = pscal + 8 + 2 * out_rec;
+    double* t3 = pscal + 16;  // |r3|^2, <r1, r3>
+    const double* gam = g2 + R * P;
+    const int sa = (int)(k % 4), sb = (int)((k + 1) % 4);
+    double* e1 = E.S(kScalAlpha + sa);
+    double* e2 = E.S(kScalAlpha + sb);
+    E.ctx->ensure_partials((size_t)kMaxGrid * (size_t)std::max(ncols, 1 + R));
+    // ---- iteration k: operator on r2 / rho2, three-term with raw vectors
+    timer.mark();
+    typename Engine<T>::DeferredAlpha da1, da2;
+    E.apply(r2, r3, offset, e1, true, fuse_launches ? &da1 : nullptr, nullptr, rho2sq);
+    timer.mark();
+    int grid = launch_pair_three_term<T>(nl, r3, r2, r1, e1, da1.nparts > 0 ? da1.partials : nullptr, da1.nparts, rho2sq, rho1sq,
+                                         E.ctx->d_partials, s);
+    launch_reduce_cols(E.ctx->d_partials, grid, 1 + R, t3, nullptr, s);
+    timer.mark();
+    // ---- iteration k + 1: operator on r3 / |r3|; its three-term update is formed inside the sweep
+    timer.mark();
+    E.apply(r3, r4, offset, e2, true, fuse_launches ? &da2 : nullptr, nullptr, t3);
+    timer.mark();
+    // ---- one sweep for both
+    launch_pair_predict((int)P, R, g1, g2, rho1sq, rho2sq, gam, t3, e1, e2, da2.nparts > 0 ? da2.partials : nullptr, da2.nparts,
+                        hist_alpha, hist_beta, pp3, pp4, s);
+    grid = launch_pair_sweep<T>(nl, groups[0], (int)P, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), g1, g2, gam, pp4, rho1sq, rho2sq,
+                                e2, t3, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
+    launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
+    launch_pair_fold(pcols, (int)P, R, pp4, g2, gam, rho2sq, t3, e1, e2, rec3, rec4, nxt, hist_alpha, hist_beta, pfold,
+                     E.ctx->h_pinned + 4 * sa, E.ctx->h_pinned + 4 * sb, E.ctx->h_pinned + 16 + sa, E.ctx->h_pinned + 16 + sb, s);
+    LL_HIP(hipEventRecord(ring.ev[sa], s));
+    LL_HIP(hipEventRecord(ring.ev[sb], s));
+    timer.mark();
+    slot_pair[sa] = slot_pair[sb] = true;
+    pair_pending = true;
+    pair_P = P + 2;
+    pr1 = r3;
+    pr2 = r4;
+    pset = out_set;
+    prec_set = out_rec;
+    g1p = rec3;
+    g2p = rec4;
+    rho1p = nxt;
+    rho2p = nxt + 1;
+    lag_pending = false;
+    n_pair += 2;
+    n_lagged += 2;  // (the pair form is a one-sweep form: ll_run_stats.lagged_iterations counts it, pair_iterations singles it out)
+    t_enqueue += now_s() - te0;
+    return true;
   }
   bool enqueue_lagged(int64_t k, double offset, int64_t nb_total) {
     constexpr int R = Engine<T>::R;
@@ -792,6 +958,7 @@ template <typename T> struct LoopState {
     }
     const double te0 = now_s();
     const int slot = (int)(k % 4);
+    slot_pair[slot] = false;
     T* y = work[k & 1].p;
     const T* x = lag_pending ? work[(k - 1) & 1].p : U.vec(k - 1);
     timer.mark();
@@ -841,11 +1008,13 @@ template <typename T> struct LoopState {
     return true;
   }
   void enqueue(int64_t k, double offset, const RunList<T>& runs, int mode) {
+    pair_flush();  // (a pending pair is completed first: the forms below start from complete vectors)
     if (mode == LL_ORTH_CGS_DGKS && !pending && enqueue_lagged(k, offset, runs.total())) return;
     flush_lag();  // (leaving the lagged form: u_{k-1} must be complete)
     lag_ok = false;
     const double te0 = now_s();
     const int slot = (int)(k % 4);
+    slot_pair[slot] = false;
     const T* x = U.vec(k - 1);
     T* y = defer ? work[k & 1].p : U.vec(k);
     ScaleIn<T> sc;
@@ -1003,7 +1172,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     d_locked.alloc(ctx, (size_t)P.num_eigs * ld);
   }
   const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
-  ctx->ensure_pinned(16);
+  ctx->ensure_pinned(32);  // 4 ring slots of 4 scalars, then the 4 gate values of the pair form
   EventRing ring;
   PhaseTimer timer(ctx->profiling, s);
 
@@ -1013,12 +1182,16 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   std::multimap<double, std::vector<T>, std::function<bool(double, double)>> kept(cmp);
 
   int64_t passes = 0, total_iters = 0, second_passes = 0;
-  double t_inf_prev = 0.0;  // max over the passes so far of ||T_m||_inf (same numbers on every rank)
+  double t_inf_prev = 0.0;  // max over the passes so far of ||T_m||_inf (same numbers on every rank; between 1 and 3 x ||A + offset||_2)
   double t_tridiag = 0.0, t_wait = 0.0, t_setup = 0.0, t_finish = 0.0;
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
   if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
   if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
+  // two iterations per sweep (single GPU, device operators, streaming vectors; LoopState::enqueue_pair decides per iteration)
+  if (LS.lagged && ctx->tune.pair_gs && ctx->comm == nullptr &&
+      nl * (int64_t)sizeof(T) >= std::min<int64_t>(ctx->tune.blas_small_bytes, (int64_t)1 << 20))
+    LS.enable_pair();
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
   // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
@@ -1096,10 +1269,14 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     RunList<T> locked_runs;
     locked_runs.ld = ld;
     locked_runs.add(d_locked.p, L);  // P5
-    auto enqueue = [&](int64_t k) {
+    // Enqueue the next iteration(s) from k on: two at once where the pair form applies (one sweep over the basis for both),
+    // else one.  Returns how many.
+    auto enqueue = [&](int64_t k) -> int64_t {
+      if (mode == LL_ORTH_CGS_DGKS && !LS.pending && LS.enqueue_pair(k, P.eigenvalue_offset)) return 2;
       RunList<T> runs = locked_runs;
       runs.add_basis(U, k);  // P6
       LS.enqueue(k, P.eigenvalue_offset, runs, mode);
+      return 1;
     };
     // Host half of iteration j, part 1 (this thread): wait for the four scalars, take the DGKS decision, append
     // alpha_j / beta_j and hand T_j to the Ritz tracker.  kRedone: a second Gram-Schmidt pass changed u_j, the
@@ -1158,6 +1335,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
           LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
           LS.pending = false;  // the speculative iteration j+1 was computed from the old u_j: it is enqueued again
           LS.lag_pending = false;
+          LS.pair_pending = false;
           LS.set_beta(j - 1, std::sqrt(beta2_j));
           verdict = kRedone;
         } else {
@@ -1170,6 +1348,23 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
         LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
         verdict = kRedone;  // the speculative iteration j+1 took the one-sweep form: it is enqueued again
       }
+      if (verdict == kContinue && LS.slot_pair[slot] && !(ctx->h_pinned[16 + slot] <= kPairGate)) {
+        // A coefficient of this iteration's raw vector grew beyond what the pair form tracks to first order (beta -> eps: an
+        // exhausted Krylov space, breakdown).  The iteration itself stands — its coefficients were MEASURED, its alpha / beta
+        // are exact — but whatever took the vector as an operator input (the second iteration of its pair, the next pair) is
+        // second-order inaccurate: u_j is completed with its measured coefficients, everything after it is enqueued again, and
+        // the rest of the pass runs in the one-sweep form (exact for coefficients of any size).
+        LS.pair_allowed = false;
+        ++LS.n_gate_trips;
+        LS.make_final(j);
+        LS.pending = false;
+        LS.lag_pending = false;
+        LS.pair_pending = false;
+        double* cj = E.S(kScalNorms + 3 * slot);
+        launch_set_scalar(cj + 1, beta2_j, s);  // what the next three-term update reads as beta_j^2
+        LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+        verdict = kRedone;
+      }
       alpha.push_back(alpha_j);
       beta.push_back(std::sqrt(beta2_j));
       if (trace_file)
@@ -1181,24 +1376,42 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
 
     RitzTracker::Out r;
     if (speculate) {
-      for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
-        enqueue(k);
-        if (k > 1) {
-          if (collect(k - 1) == kRedone) enqueue(k);  // u_{k-1} changed under the speculative iteration: run it again
-          stopped = worker.consume(k - 1, lockstep_lag, kMaxLag, absorb);
+      // One group of iterations (one, or the two of a pair) is enqueued ahead of the group whose scalars are collected.
+      int64_t enq = 0, col = 0;  // iterations enqueued / collected so far
+      int64_t ahead_first = 1, ahead_last = 0;  // the group enqueued last, not yet collected (empty: first > last)
+      while (!stopped && col < P.max_iteration) {
+        const int64_t grp_first = ahead_first, grp_last = ahead_last;
+        if (enq < P.max_iteration) {
+          ahead_first = enq + 1;
+          enq += enqueue(enq + 1);
+          ahead_last = enq;
+        } else {
+          LS.flush();  // nothing follows: the last iteration's normalisation / publish step happens now
+          ahead_first = 1;
+          ahead_last = 0;
         }
-      }
-      if (!stopped) {
-        LS.flush();
-        collect(P.max_iteration);
+        for (int64_t j = grp_first; j <= std::min(grp_last, P.max_iteration) && !stopped; ++j) {
+          const bool redo = collect(j) == kRedone;
+          col = j;
+          if (redo) {  // u_j changed under everything enqueued after it: enqueue again from j + 1
+            enq = j;
+            ahead_first = 1;
+            ahead_last = 0;
+          }
+          stopped = worker.consume(j, lockstep_lag, kMaxLag, absorb);
+          if (redo) break;
+        }
       }
     } else {
       for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
-        enqueue(k);
+        RunList<T> runs = locked_runs;
+        runs.add_basis(U, k);
+        LS.enqueue(k, P.eigenvalue_offset, runs, mode);
         collect(k);  // kRedone: u_k was repaired in place, nothing ran ahead
         while (!stopped && worker.wait_pop(r)) stopped = absorb(r);
       }
     }
+    LS.pair_flush();  // (a pending pair: the Ritz vectors below need every Lanczos vector complete in the basis)
     while (!stopped && worker.wait_pop(r)) stopped = absorb(r);  // the first stop verdict wins; else the last iteration's values
     itern = last.m;  // == max_iteration without a stop (LL:239,312)
     if (trace_file) {
@@ -1369,6 +1582,8 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     stats->seconds_finish = t_finish;
     stats->second_passes = second_passes;
     stats->lagged_iterations = LS.n_lagged;
+    stats->pair_iterations = LS.n_pair;
+    stats->pair_gate_trips = LS.n_gate_trips;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);
     ctx->drain_comm_events(&stats->seconds_comm_gather, &stats->seconds_comm_allreduce);
     stats->seconds_total = now_s() - t_start;

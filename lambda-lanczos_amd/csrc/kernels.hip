@@ -768,6 +768,509 @@ void launch_lagged_fold(double* m, int K, int L, int reals, double* t_out, const
   LL_HIP(hipGetLastError());
 }
 
+// ================================================================= TWO iterations per sweep over the basis ("pair" form)
+// The one-sweep form above reads the basis once per iteration; here the operator is applied TWICE between sweeps and ONE
+// sweep serves both iterations: s n (P + 12) bytes per two iterations instead of 2 s n (P + 4).  Executable specification,
+// kernel by kernel, with the derivation and the numbers: tools/pair_gs_model.py (profiles/r05_pair_gs_model.txt).
+// State between sweeps (P stored, complete, orthonormal vectors S = u_0 .. u_{P-1}; T recorded up to alpha_P, beta_P):
+//   r1 -> u_P      raw, measured g1 = S^H r1,  rho1^2 = |r1|^2 - |g1|^2
+//   r2 -> u_{P+1}  raw, measured g2 = S^H r2,  gam = <u_P, r2>,  rho2^2 = |r2|^2 - |g2|^2 - |gam|^2
+// One pair:
+//   y1 = A (r2 / rho2), e1 = <x2, y1>          operator kernel (scales its input, fused dot)
+//   r3 = y1 - e1 x2 - rho2 x1                   pair_three_term_kernel (raw vectors only: every O(1) coefficient multiplies a
+//   y2 = A (r3 / |r3|), e2                      raw vector; also |r3|^2 and <r1, r3>)
+//   r4 = y2 - e2 x3 - |r3| x2                   pair_three_term_kernel
+//   p4 = predicted S^H r4                       pair_predict_kernel: through the recorded tridiagonal, eps-sized numbers
+//   ONE sweep (pair_sweep_kernel):  u_P = (r1 - S g1) / rho1,  u_{P+1} = (r2 - S g2 - gam u_P) / rho2  written to the basis,
+//       m3 = S^H r3, m4 = S^H r4 measured, r4 -= S p4 (the NEXT operator input carries fresh rounding only along S),
+//       in-strip <u_P, r3>, <u_{P+1}, r3>, <u_P, r4>, <u_{P+1}, r4>, <r3, r4>, |r4|^2
+//   pair_fold_kernel: alpha_{P+1}, beta_{P+1}, alpha_{P+2}, beta_{P+2} and the next pair's (g1, rho1, g2, gam, rho2).
+// Every stored vector is written with MEASURED coefficients, one sweep late; every measured coefficient is eps-sized.  The
+// first-order effects of the perturbed operator inputs are measured and removed like in the one-sweep form; terms of
+// SECOND order in the coefficients are not tracked here, so the form is only used while every coefficient stays below
+// kPairGate relative to its vector (the fold publishes the largest one; near breakdown, where beta -> eps makes them grow,
+// the host falls back to the one-sweep form, which is exact for coefficients of any size).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pair_three_term_kernel(int64_t n, T* __restrict__ y, const T* __restrict__ x,
+                                                                 const T* __restrict__ p, double* __restrict__ e,
+                                                                 const double* __restrict__ e_partials, int e_nparts,
+                                                                 const double* __restrict__ cx2, const double* __restrict__ cp2,
+                                                                 double* __restrict__ partials) {
+  constexpr int EPT = strip<T>::EPT;
+  constexpr int ELEMS = strip<T>::ELEMS;
+  constexpr int R = scalar_traits<T>::reals;
+  __shared__ double red[4][1 + R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double ev;
+  if (e_partials) {  // deferred alpha: every workgroup folds the operator kernel's partials in the same fixed order (ThreeTerm)
+    __shared__ double fold_scratch[5];
+    ev = fold_partials_all(e_partials, e_nparts, fold_scratch);
+    if (blockIdx.x == 0 && tid == 0) *e = ev;
+  } else {
+    ev = *e;
+  }
+  const double nx = sqrt(*cx2);
+  const double ca = ev / nx;            // y - (e / |x|) x_raw - (|x| / |p|) p_raw
+  const double cb = nx / sqrt(*cp2);
+  double nn = 0.0;
+  acc_t<T> dp = zero<acc_t<T>>();
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * ELEMS;
+    T yr[EPT], xr[EPT], pr[EPT];
+    load_strip<T>(y, base, n, yr);
+    load_strip<T>(x, base, n, xr);
+    load_strip<T>(p, base, n, pr);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      yr[i] = sub(sub(yr[i], rmul(ca, xr[i])), rmul(cb, pr[i]));
+      nn += abs2(yr[i]);
+      cfma_acc(dp, pr[i], yr[i]);
+    }
+    store_strip<T>(y, base, n, yr);
+  }
+  nn = wave_sum(nn);
+  const acc_t<T> ds = wave_sum(dp);
+  if (lane == 0) {
+    red[wave][0] = nn;
+    if constexpr (scalar_traits<T>::is_complex) {
+      red[wave][1] = ds.re;
+      red[wave][2] = ds.im;
+    } else {
+      red[wave][1] = ds;
+    }
+  }
+  __syncthreads();
+  if (tid < 1 + R) partials[(size_t)blockIdx.x * (1 + R) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+template <typename T>
+int launch_pair_three_term(int64_t n, T* y, const T* x, const T* p, double* e, const double* e_partials, int e_nparts,
+                           const double* cx2, const double* cp2, double* partials, hipStream_t s) {
+  const int grid = strip_grid(n, strip<T>::ELEMS);
+  hipLaunchKernelGGL((pair_three_term_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, y, x, p, e, e_partials, e_nparts, cx2, cp2,
+                     partials);
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+
+// The stored-basis components of r4, predicted through the recorded tridiagonal (one workgroup; P coefficients each).
+//   c1 = g1 / rho1, c2 = g2 / rho2 (S^H x1, S^H x2), <u_P, x2> = gam / rho2
+//   p3 = T c2 [+ beta_{P-1} <u_P, x2> in the last row] - e1 c2 - rho2 c1                       (predicted S^H r3)
+//   <u_P, r3> ~ (<r1, r3> - g1^H p3) / rho1
+//   p4 = (T p3 [+ beta_{P-1} <u_P, r3> in the last row] - e2 p3) / |r3| - |r3| c2                (predicted S^H r4)
+struct PairScalars {
+  const double* rho1sq;
+  const double* rho2sq;
+  const double* gam;    // reals
+  const double* n3sq;   // |r3|^2, then <r1, r3> (reals) behind it
+  const double* e1;
+  double* e2;
+  const double* e2_partials;  // nullable: the second operator kernel's partial sums of <x3, A x3>, folded here into *e2
+  int e2_nparts;
+};
+__global__ __launch_bounds__(256) void pair_predict_kernel(int P, int reals, const double* __restrict__ g1,
+                                                           const double* __restrict__ g2, PairScalars sc,
+                                                           const double* __restrict__ hist_alpha,
+                                                           const double* __restrict__ hist_beta, double* __restrict__ p3,
+                                                           double* __restrict__ p4) {
+  __shared__ double red[4];
+  __shared__ double sh[2];
+  const int tid = threadIdx.x;
+  const double rho1 = sqrt(*sc.rho1sq), rho2 = sqrt(*sc.rho2sq), n3 = sqrt(sc.n3sq[0]);
+  const double i1 = 1.0 / rho1, i2 = 1.0 / rho2, i3 = 1.0 / n3;
+  double e2;
+  if (sc.e2_partials) {  // (the order of reduce_one_kernel, like every other fold of these partials)
+    __shared__ double fold_scratch[5];
+    e2 = fold_partials_all(sc.e2_partials, sc.e2_nparts, fold_scratch);
+    if (tid == 0) *sc.e2 = e2;
+  } else {
+    e2 = *sc.e2;
+  }
+  const double e1 = *sc.e1;
+  const double bl = hist_beta[P - 1];  // couples u_{P-1} and u_P
+  // p3
+  for (int i = tid; i < reals * P; i += 256) {
+    const int j = i / reals, q = i - j * reals;
+    double t = hist_alpha[j] * g2[i];
+    if (j >= 1) t = fma(hist_beta[j - 1], g2[i - reals], t);
+    if (j + 1 < P) t = fma(hist_beta[j], g2[i + reals], t);
+    else t = fma(bl, sc.gam[q], t);
+    t *= i2;                                     // T c2 (+ the neighbour behind the last stored vector)
+    p3[i] = t - e1 * (g2[i] * i2) - rho2 * (g1[i] * i1);
+  }
+  __syncthreads();
+  // <u_P, r3> = (<r1, r3> - g1^H p3) / rho1      (conj(g1) . p3)
+  double are = 0.0, aim = 0.0;
+  for (int j = tid; j < P; j += 256) {
+    if (reals == 2) {
+      const double gr = g1[2 * j], gi = g1[2 * j + 1], pr = p3[2 * j], pi = p3[2 * j + 1];
+      are += gr * pr + gi * pi;
+      aim += gr * pi - gi * pr;
+    } else {
+      are += g1[j] * p3[j];
+    }
+  }
+  const double sre = block_sum(are, red);
+  if (tid == 0) sh[0] = (sc.n3sq[1] - sre) * i1;
+  if (reals == 2) {
+    const double sim = block_sum(aim, red);
+    if (tid == 0) sh[1] = (sc.n3sq[2] - sim) * i1;
+  } else if (tid == 0) {
+    sh[1] = 0.0;
+  }
+  __syncthreads();
+  for (int i = tid; i < reals * P; i += 256) {
+    const int j = i / reals, q = i - j * reals;
+    double t = hist_alpha[j] * p3[i];
+    if (j >= 1) t = fma(hist_beta[j - 1], p3[i - reals], t);
+    if (j + 1 < P) t = fma(hist_beta[j], p3[i + reals], t);
+    else t = fma(bl, sh[q], t);
+    p4[i] = (t - e2 * p3[i]) * i3 - n3 * (g2[i] * i2);
+  }
+}
+void launch_pair_predict(int P, int reals, const double* g1, const double* g2, const double* rho1sq, const double* rho2sq,
+                         const double* gam, const double* n3sq, const double* e1, double* e2, const double* e2_partials,
+                         int e2_nparts, const double* hist_alpha, const double* hist_beta, double* p3, double* p4, hipStream_t s) {
+  const PairScalars sc{rho1sq, rho2sq, gam, n3sq, e1, e2, e2_partials, e2_nparts};
+  hipLaunchKernelGGL(pair_predict_kernel, dim3(1), dim3(256), 0, s, P, reals, g1, g2, sc, hist_alpha, hist_beta, p3, p4);
+  LL_HIP(hipGetLastError());
+}
+
+// One trip of the pair sweep: NV basis strips; two late updates, the compensation of r4, two measured column sets.
+template <typename T, int NV, int PC>
+__device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
+                                          T (&a1)[lstrip<T, PC>::EPT], T (&a2)[lstrip<T, PC>::EPT],
+                                          const T (&b3)[lstrip<T, PC>::EPT], const T (&b4r)[lstrip<T, PC>::EPT],
+                                          T (&b4)[lstrip<T, PC>::EPT], const double* __restrict__ g1c,
+                                          const double* __restrict__ g2c, const double* __restrict__ p4c, double* mine3,
+                                          double* mine4, int lane) {
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  constexpr int R = scalar_traits<T>::reals;
+  T ur[NV][EPT];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) load_lstrip<T, PC>(u0 + (int64_t)b * ld, base, n, ur[b]);
+  double a[2 * NV * R];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) {
+    acc_t<T> c1, c2, c4;  // wave-uniform addresses in read-only memory: scalar loads
+    if constexpr (scalar_traits<T>::is_complex) {
+      c1 = zc{g1c[2 * b], g1c[2 * b + 1]};
+      c2 = zc{g2c[2 * b], g2c[2 * b + 1]};
+      c4 = zc{p4c[2 * b], p4c[2 * b + 1]};
+    } else {
+      c1 = g1c[b];
+      c2 = g2c[b];
+      c4 = p4c[b];
+    }
+    acc_t<T> s3 = zero<acc_t<T>>(), s4 = zero<acc_t<T>>();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      fnma_acc(a1[e], c1, ur[b][e]);     // late update of u_P
+      fnma_acc(a2[e], c2, ur[b][e]);     // late update of u_{P+1}
+      fnma_acc(b4[e], c4, ur[b][e]);     // compensation of the next operator input
+      cfma_acc(s3, ur[b][e], b3[e]);     // measured coefficients of r3 and of the raw r4
+      cfma_acc(s4, ur[b][e], b4r[e]);
+    }
+    if constexpr (scalar_traits<T>::is_complex) {
+      a[2 * b] = s3.re;
+      a[2 * b + 1] = s3.im;
+      a[NV * R + 2 * b] = s4.re;
+      a[NV * R + 2 * b + 1] = s4.im;
+    } else {
+      a[b] = s3;
+      a[NV * R + b] = s4;
+    }
+  }
+  wave_sum_transposed<2 * NV * R>(a, lane);
+  constexpr int LPI = 64 / (2 * NV * R);  // lanes that end up holding the same sum; sums 0 .. NV*R-1: r3, the rest: r4
+  if ((lane & (LPI - 1)) == 0) {
+    const int c = lane / LPI;
+    if (c < NV * R) mine3[c] += a[0];
+    else mine4[c - NV * R] += a[0];
+  }
+}
+
+// Partial columns per workgroup: [m3: R*P][m4: R*P][<u_P,r3>][<u_{P+1},r3>][<u_P,r4>][<u_{P+1},r4>][<r3,r4>] (R each) [|r4|^2].
+template <typename T, int PC>
+__global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs<T> segs, int P, const T* __restrict__ r1,
+                                                            const T* __restrict__ r2, const T* __restrict__ r3,
+                                                            T* __restrict__ r4, T* __restrict__ uP_out, T* __restrict__ uQ_out,
+                                                            const double* __restrict__ g1, const double* __restrict__ g2,
+                                                            const double* __restrict__ gam, const double* __restrict__ p4,
+                                                            const double* __restrict__ rho1sq, const double* __restrict__ rho2sq,
+                                                            const double* __restrict__ e2, const double* __restrict__ n3sq,
+                                                            double* __restrict__ partials) {
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  constexpr int ELEMS = lstrip<T, PC>::ELEMS;
+  constexpr int JB = kJB;
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = 2 * R * P + 5 * R + 1;
+  extern __shared__ double lds[];  // [4 waves][ncols]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
+  const double s1 = 1.0 / sqrt(*rho1sq), s2 = 1.0 / sqrt(*rho2sq);
+  // the buffer r4 holds y2 = A (r3 / |r3|) on entry: the second three-term update r4 = y2 - (e2 / |r3|) r3 - (|r3| / rho2) r2 is
+  // formed here, from strips this sweep reads anyway (a separate kernel would move 4 more vectors)
+  const double n3 = sqrt(*n3sq);
+  const double ca = *e2 / n3, cb = n3 * s2;
+  acc_t<T> gm;
+  if constexpr (scalar_traits<T>::is_complex) gm = zc{gam[0], gam[1]};
+  else gm = gam[0];
+  __syncthreads();
+  double* mine = lds + (size_t)wave * ncols;
+  double* tail = mine + 2 * R * P;
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * ELEMS;
+    T a1[EPT], a2[EPT], b3[EPT], b4r[EPT], b4[EPT];
+    load_lstrip<T, PC>(r1, base, n, a1);
+    load_lstrip<T, PC>(r2, base, n, a2);
+    load_lstrip<T, PC>(r3, base, n, b3);
+    load_lstrip<T, PC>(r4, base, n, b4r);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      b4r[e] = sub(sub(b4r[e], rmul(ca, b3[e])), rmul(cb, a2[e]));
+      b4[e] = b4r[e];
+    }
+    int col = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+      int j = 0;
+      for (; j + JB <= cnt; j += JB, col += R * JB)
+        pair_trip<T, JB, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, a1, a2, b3, b4r, b4, g1 + col, g2 + col, p4 + col,
+                             mine + col, mine + R * P + col, lane);
+      if (j + 2 <= cnt) {
+        pair_trip<T, 2, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, a1, a2, b3, b4r, b4, g1 + col, g2 + col, p4 + col,
+                            mine + col, mine + R * P + col, lane);
+        j += 2;
+        col += R * 2;
+      }
+      if (j < cnt) {
+        pair_trip<T, 1, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, a1, a2, b3, b4r, b4, g1 + col, g2 + col, p4 + col,
+                            mine + col, mine + R * P + col, lane);
+        j += 1;
+        col += R;
+      }
+    }
+    // u_P and u_{P+1} are complete: normalise, store; the in-strip coefficients and raw dots
+    acc_t<T> t3p = zero<acc_t<T>>(), t3q = zero<acc_t<T>>(), t4p = zero<acc_t<T>>(), t4q = zero<acc_t<T>>(),
+             d34 = zero<acc_t<T>>();
+    double nn = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      a1[e] = rmul(s1, a1[e]);
+      fnma_acc(a2[e], gm, a1[e]);
+      a2[e] = rmul(s2, a2[e]);
+      cfma_acc(t3p, a1[e], b3[e]);
+      cfma_acc(t3q, a2[e], b3[e]);
+      cfma_acc(t4p, a1[e], b4[e]);
+      cfma_acc(t4q, a2[e], b4[e]);
+      cfma_acc(d34, b3[e], b4[e]);
+      nn += abs2(b4[e]);
+    }
+    store_lstrip<T, PC>(uP_out, base, n, a1);
+    store_lstrip<T, PC>(uQ_out, base, n, a2);
+    store_lstrip<T, PC>(r4, base, n, b4);
+    const acc_t<T> sums[5] = {wave_sum(t3p), wave_sum(t3q), wave_sum(t4p), wave_sum(t4q), wave_sum(d34)};
+    nn = wave_sum(nn);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        if constexpr (scalar_traits<T>::is_complex) {
+          tail[2 * c] += sums[c].re;
+          tail[2 * c + 1] += sums[c].im;
+        } else {
+          tail[c] += sums[c];
+        }
+      }
+      tail[5 * R] += nn;
+    }
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < ncols; i += kBlock)
+    out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
+}
+template <typename T>
+int launch_pair_sweep(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
+                      T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
+                      const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces, hipStream_t s) {
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = 2 * R * P + 5 * R + 1;
+  const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
+  const int64_t strips16k = (n * (int64_t)sizeof(T) + 16383) / 16384;
+  int pc = strips16k >= kLaggedFullStrips ? 4 : 2;
+  if (pieces == 2 || pieces == 4) pc = pieces;
+  int grid;
+  if (pc == 4) {
+    grid = strip_grid(n, lstrip<T, 4>::ELEMS);
+    hipLaunchKernelGGL((pair_sweep_kernel<T, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, r1, r2, r3, r4, uP_out, uQ_out,
+                       g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+  } else {
+    grid = strip_grid(n, lstrip<T, 2>::ELEMS);
+    hipLaunchKernelGGL((pair_sweep_kernel<T, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, r1, r2, r3, r4, uP_out, uQ_out,
+                       g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+  }
+  LL_HIP(hipGetLastError());
+  return grid;
+}
+
+// The fold of a pair (one workgroup).  m: the 2 R P + 5 R + 1 folded columns of the sweep.  Outputs:
+//   rec3 = g3 (R (P+2): coefficients of r3 against u_0 .. u_{P+1}),  rec4 = g4 (R (P+2)) followed by gam' = <u_{P+2}, r4>
+//   nxt[0] = rho3^2, nxt[1] = rho4^2 (the next pair's rho1^2, rho2^2)
+//   hist_alpha[P+1], hist_alpha[P+2], hist_beta[P+1] = rho3, hist_beta[P+2] = rho4
+//   host slots of the two iterations (alpha, beta^2, ||w||^2 before, after) and, for each, its gate value: the largest
+//   coefficient of the iteration's raw vector relative to that vector.
+__device__ __forceinline__ double pair_tri_row(const double* __restrict__ ha, const double* __restrict__ hb, const double* v,
+                                               int i, int reals, int m, double alpha_last) {
+  // row j of (T v) for the first m Lanczos vectors; alpha_{m-1} may not be recorded yet: alpha_last
+  const int j = i / reals;
+  double t = (j == m - 1 ? alpha_last : ha[j]) * v[i];
+  if (j >= 1) t = fma(hb[j - 1], v[i - reals], t);
+  if (j + 1 < m) t = fma(hb[j], v[i + reals], t);
+  return t;
+}
+__global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict__ m, int P, int reals,
+                                                        const double* __restrict__ p4, const double* __restrict__ g2,
+                                                        const double* __restrict__ gam, const double* __restrict__ rho2sq,
+                                                        const double* __restrict__ n3sq_p, const double* __restrict__ e1p,
+                                                        const double* __restrict__ e2p, double* __restrict__ rec3,
+                                                        double* __restrict__ rec4, double* __restrict__ nxt,
+                                                        double* __restrict__ hist_alpha, double* __restrict__ hist_beta,
+                                                        double* __restrict__ scratch, double* __restrict__ host_a,
+                                                        double* __restrict__ host_b, double* __restrict__ gate_a,
+                                                        double* __restrict__ gate_b) {
+  __shared__ double red[4];
+  __shared__ double sh[8];
+  const int tid = threadIdx.x;
+  const int RP = reals * P, M = reals * (P + 2);
+  const double* tail = m + 2 * RP;
+  const double n3sq = n3sq_p[0], n4sq = tail[5 * reals];
+  // ---- g3, g4; |g3|^2, |g4|^2, g3^H g4, largest coefficients
+  double s33 = 0.0, s44 = 0.0, s34r = 0.0, s34i = 0.0, mx3 = 0.0, mx4 = 0.0;
+  for (int i = tid; i < M; i += 256) {
+    double a, b;
+    if (i < RP) {
+      a = m[i];
+      b = m[RP + i] - p4[i];
+    } else {
+      a = tail[i - RP];                 // <u_P, r3>, <u_{P+1}, r3>
+      b = tail[2 * reals + (i - RP)];   // <u_P, r4>, <u_{P+1}, r4>
+    }
+    rec3[i] = a;
+    rec4[i] = b;
+    s33 = fma(a, a, s33);
+    s44 = fma(b, b, s44);
+    mx3 = fmax(mx3, fabs(a));
+    mx4 = fmax(mx4, fabs(b));
+  }
+  __syncthreads();
+  for (int j = tid; j < P + 2; j += 256) {  // conj(g3) . g4
+    if (reals == 2) {
+      const double ar = rec3[2 * j], ai = rec3[2 * j + 1], br = rec4[2 * j], bi = rec4[2 * j + 1];
+      s34r += ar * br + ai * bi;
+      s34i += ar * bi - ai * br;
+    } else {
+      s34r += rec3[j] * rec4[j];
+    }
+  }
+  const double t33 = block_sum(s33, red);
+  if (tid == 0) sh[0] = t33;
+  const double t44 = block_sum(s44, red);
+  if (tid == 0) sh[1] = t44;
+  const double t34r = block_sum(s34r, red);
+  if (tid == 0) sh[2] = t34r;
+  const double t34i = block_sum(s34i, red);
+  if (tid == 0) sh[3] = t34i;
+  // block maxima (sums of non-negative numbers are not maxima: fold with fmax through LDS)
+  __syncthreads();
+  {
+    double v3 = mx3, v4 = mx4;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      v3 = fmax(v3, __shfl_down(v3, d, 64));
+      v4 = fmax(v4, __shfl_down(v4, d, 64));
+    }
+    __shared__ double mxs[2][4];
+    if ((tid & 63) == 0) {
+      mxs[0][tid >> 6] = v3;
+      mxs[1][tid >> 6] = v4;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      sh[4] = fmax(fmax(mxs[0][0], mxs[0][1]), fmax(mxs[0][2], mxs[0][3]));
+      sh[5] = fmax(fmax(mxs[1][0], mxs[1][1]), fmax(mxs[1][2], mxs[1][3]));
+    }
+  }
+  __syncthreads();
+  // ---- quadratic terms through the recorded tridiagonal
+  //   alpha_{P+1}: v = [g2 / rho2; gam / rho2] over u_0 .. u_P     (alpha_0 .. alpha_P, beta_0 .. beta_{P-1} recorded)
+  const double rho2 = sqrt(*rho2sq), i2 = 1.0 / rho2;
+  double* v = scratch;  // reals * (P + 1)
+  for (int i = tid; i < reals * (P + 1); i += 256) v[i] = (i < RP ? g2[i] : gam[i - RP]) * i2;
+  __syncthreads();
+  double qa = 0.0;
+  for (int i = tid; i < reals * (P + 1); i += 256) qa = fma(v[i], pair_tri_row(hist_alpha, hist_beta, v, i, reals, P + 1, hist_alpha[P]), qa);
+  const double quad_a = block_sum(qa, red);
+  if (tid == 0) {
+    const double alpha_q = *e1p - 2.0 * gam[0] - quad_a;   // gam[0] = Re <u_P, r2>
+    sh[6] = alpha_q;
+    hist_alpha[P + 1] = alpha_q;
+  }
+  __syncthreads();
+  //   alpha_{P+2}: <r3, A r3> = rho3^2 alpha + 2 rho3^2 Re <u_{P+1}, r3> + <E, A E>, E = sum g3_j u_j over u_0 .. u_{P+1}
+  double qb = 0.0;
+  for (int i = tid; i < M; i += 256) qb = fma(rec3[i], pair_tri_row(hist_alpha, hist_beta, rec3, i, reals, P + 2, sh[6]), qb);
+  const double quad_b = block_sum(qb, red);
+  if (tid == 0) {
+    double rho3sq = n3sq - sh[0];
+    rho3sq = rho3sq > 0.0 ? rho3sq : 0.0;
+    const double rho3 = sqrt(rho3sq), i3 = rho3 > 0.0 ? 1.0 / rho3 : 0.0;
+    const double gre = (tail[4 * reals] - sh[2]) * i3;                      // gam' = (<r3, r4> - g3^H g4) / rho3
+    const double gim = reals == 2 ? (tail[4 * reals + 1] - sh[3]) * i3 : 0.0;
+    double rho4sq = n4sq - sh[1] - (gre * gre + gim * gim);
+    rho4sq = rho4sq > 0.0 ? rho4sq : 0.0;
+    const double alpha_n = rho3sq > 0.0 ? (*e2p * n3sq - 2.0 * rho3sq * rec3[reals * (P + 1)] - quad_b) / rho3sq : 0.0;
+    rec4[M] = gre;
+    if (reals == 2) rec4[M + 1] = gim;
+    nxt[0] = rho3sq;
+    nxt[1] = rho4sq;
+    hist_alpha[P + 2] = alpha_n;
+    hist_beta[P + 1] = rho3;
+    hist_beta[P + 2] = sqrt(rho4sq);
+    // the largest coefficient of each raw vector relative to the vector: what the host's gate (kPairGate) looks at.  r3's decides
+    // whether the SECOND iteration of this pair stands (its operator input was r3), r4's whether the next pair may build on it.
+    const double gate3 = n3sq > 0.0 ? sh[4] / sqrt(n3sq) : 1.0;
+    const double gate4 = n4sq > 0.0 ? fmax(sh[5], sqrt(gre * gre + gim * gim)) / sqrt(n4sq) : 1.0;
+    host_a[0] = sh[6];
+    host_a[1] = rho3sq;
+    host_a[2] = n3sq;
+    host_a[3] = rho3sq;
+    *gate_a = gate3;
+    host_b[0] = alpha_n;
+    host_b[1] = rho4sq;
+    host_b[2] = n4sq;
+    host_b[3] = rho4sq;
+    *gate_b = gate4;
+  }
+}
+void launch_pair_fold(const double* m, int P, int reals, const double* p4, const double* g2, const double* gam,
+                      const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
+                      double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,
+                      double* gate_a, double* gate_b, hipStream_t s) {
+  hipLaunchKernelGGL(pair_fold_kernel, dim3(1), dim3(256), 0, s, m, P, reals, p4, g2, gam, rho2sq, n3sq, e1, e2, rec3, rec4, nxt,
+                     hist_alpha, hist_beta, scratch, host_a, host_b, gate_a, gate_b);
+  LL_HIP(hipGetLastError());
+}
+#define LL_INST_PAIR(T)                                                                                                          \
+  template int launch_pair_three_term<T>(int64_t, T*, const T*, const T*, double*, const double*, int, const double*,           \
+                                         const double*, double*, hipStream_t);                                                   \
+  template int launch_pair_sweep<T>(int64_t, const BasisSegs<T>&, int, const T*, const T*, const T*, T*, T*, T*, const double*, \
+                                    const double*, const double*, const double*, const double*, const double*, const double*,   \
+                                    const double*, double*, int, hipStream_t);
+LL_INST_PAIR(double) LL_INST_PAIR(zc) LL_INST_PAIR(float) LL_INST_PAIR(cf)
+
 // ================================================================= small-vector Gram-Schmidt kernels (vectors < 4 MiB)
 // With few strips the streaming kernels above are a latency / instruction chain: ONE wave walks all k basis vectors of
 // its strip (n = 1e4, k = 100: 28 us for 8 MB that the chip reads in under 7 us, tools/small_strip_probe.hip).  Here a

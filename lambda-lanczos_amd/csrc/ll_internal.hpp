@@ -171,6 +171,7 @@ struct Tuning {
   long long lagged_min_bytes = -1; // test hook LL_TEST_LAGGED_MIN_BYTES: shortest vector of the one-sweep form (-1 = default)
   int lagged_pieces = 0;           // test hook LL_TEST_LAGGED_PIECES: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
+  bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
   // --- test hooks (not for users)
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
   bool tl_force = false;           // LL_TL_FORCE=1: build the tiled image even for matrices that are not eligible (parity tests on small cases)
@@ -458,6 +459,26 @@ constexpr int kLaggedFullStrips = 200;
 template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
                   int pieces, int64_t small_limit, hipStream_t s);  // vectors below small_limit bytes: lagged_small_kernel
+// The pair form (two iterations per sweep; kernels.hip, "pair" section; tools/pair_gs_model.py is the executable specification).
+// Streaming geometry only; 2 * reals * P + 5 * reals + 1 <= kLaggedMaxCols columns per workgroup.
+constexpr double kPairGate = 1e-8;  // largest relative coefficient the pair form accepts (second-order terms stay below 1e-16)
+template <typename T>
+int launch_pair_three_term(int64_t n, T* y, const T* x, const T* p, double* e, const double* e_partials, int e_nparts,
+                           const double* cx2, const double* cp2, double* partials,
+                           hipStream_t s);  // y <- y - (e / sqrt(cx2)) x - sqrt(cx2 / cp2) p; partials [grid][1 + reals]: |y|^2, <p, y>;
+                                            // e_partials (nullable): the operator kernel's partial sums of e, folded here into *e
+void launch_pair_predict(int P, int reals, const double* g1, const double* g2, const double* rho1sq, const double* rho2sq,
+                         const double* gam, const double* n3sq, const double* e1, double* e2, const double* e2_partials,
+                         int e2_nparts, const double* hist_alpha, const double* hist_beta, double* p3, double* p4, hipStream_t s);
+// r4 holds y2 = A (r3 / |r3|) on entry; the sweep forms r4 = y2 - (e2 / |r3|) r3 - (|r3| / rho2) r2 on the fly
+template <typename T>
+int launch_pair_sweep(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
+                      T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
+                      const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces, hipStream_t s);
+void launch_pair_fold(const double* m, int P, int reals, const double* p4, const double* g2, const double* gam,
+                      const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
+                      double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,
+                      double* gate_a, double* gate_b, hipStream_t s);
 // Fold of a lagged iteration (K = L + k columns: L locked eigenvectors with eigenvalues lambda[0..L), then k Lanczos
 // vectors; m: reals * K folded columns, *c0 = ||w||^2, copied to *c0_out): compensated coefficients in place,
 // *c1 = *c0 - |g|^2, t_out (reals * (K + 1) + 1) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha

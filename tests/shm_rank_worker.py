@@ -117,6 +117,18 @@ def main():
     v6, x6 = e6.run()
     res["dense"] = {"vals": v6.tolist(), "vecs": [x6[0].tolist()], "iters": e6.getIterationCounts()}
     dn.close()
+    # the same with shard boundaries on 16-byte pieces of the rows (n = 208: shards of 104 / 70 / 52 rows): the column-split form
+    # (own columns under the all-gather, the rest after it) with vector loads; n = 203 above takes gather-then-multiply
+    n9 = 208
+    rb9, nl9 = ctx.partition(n9)
+    a9 = rng.standard_normal((n9, n9))
+    a9 = a9 + a9.T
+    dn9 = L.DenseOperator(ctx, a9[rb9:rb9 + nl9], row_begin=rb9)
+    e9 = L.LambdaLanczos(dn9, n9, True, 1)
+    e9.init_vector = lambda v, row_begin: np.copyto(v, G.start_vector(v.shape[0], 1, np.float64, row_begin))
+    v9, x9 = e9.run()
+    res["dense_aligned"] = {"vals": v9.tolist(), "vecs": [x9[0].tolist()], "iters": e9.getIterationCounts()}
+    dn9.close()
     # --- fewer rows than ranks: the last shard(s) are empty
     tiny = np.array([[2.0, 1.0], [1.0, 3.0]])
     rb8, nl8 = ctx.partition(2)

@@ -179,7 +179,7 @@ def test_one_sweep_form_to_convergence_matches_the_reference(ctx, name):
     eng.init_vector = fixed_init(G.start_vector(n, gold["seed"]))
     vals, vecs = eng.run()
     itern = eng.getIterationCounts()[0]
-    if n * 8 >= 320 << 10:
+    if n * 8 >= 320 << 10 or os.environ.get("LL_BLAS_SMALL_BYTES") == "0":   # (the suite is also run with the streaming geometry forced)
         assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
     else:
         assert eng.last_stats["lagged_iterations"] == 0, eng.last_stats

@@ -187,6 +187,12 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
     assert abs(ranks[0]["dense"]["vals"][0] - ora6["eigenvalues"][0]) <= 1e-10 * np.max(np.abs(ora6["eigenvalues"]))
     assert abs(ranks[0]["dense"]["iters"][0] - ora6["iter_counts"][0]) <= 2
     assert 1 - overlap(stitch("dense", "vecs", 0), ora6["eigenvectors"][0]) <= 1e-8
+    a9 = rng.standard_normal((208, 208))      # (the worker draws it from the same generator state)
+    a9 = a9 + a9.T
+    ora9 = oracle.lanczos(G.dense_to_csr(a9), G.start_vector(208, 1), True)
+    assert abs(ranks[0]["dense_aligned"]["vals"][0] - ora9["eigenvalues"][0]) <= 1e-10 * np.max(np.abs(ora9["eigenvalues"]))
+    assert abs(ranks[0]["dense_aligned"]["iters"][0] - ora9["iter_counts"][0]) <= 2
+    assert 1 - overlap(stitch("dense_aligned", "vecs", 0), ora9["eigenvectors"][0]) <= 1e-8
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):

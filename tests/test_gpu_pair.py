@@ -1,0 +1,195 @@
+"""The pair form of the Gram-Schmidt step — TWO Lanczos iterations per sweep over the basis (kernels.hip "pair" section,
+LoopState::enqueue_pair; tools/pair_gs_model.py is the executable specification) — against the reference's sequential
+modified Gram-Schmidt (LL:260 -> LA:132-144) through the oracle, and against the two forms it replaces on the same operator:
+    LL_FUSE_LAUNCHES=1   two sweeps per iteration (multi-dot, multi-axpy)
+    LL_PAIR_GS=0         one sweep per iteration (lagged, compensated)
+    default              one sweep per TWO iterations wherever the vectors take the streaming geometry
+Tolerances as everywhere: alpha / beta 1e-10 ||A||_inf against the oracle (1e-11 between the device forms),
+iteration counts equal, eigenvalue 1e-10, eigenvector 1 - overlap <= 1e-8.  The long fixtures from the REAL reference that
+run the pair form in the default geometry are in tests/test_gpu_long_runs.py (laplace400: 1448 iterations, torus300: 524)."""
+import numpy as np
+import pytest
+
+import lambda_lanczos_amd as L
+from lambda_lanczos_amd import generators as G
+from util import inf_norm, overlap
+
+pytestmark = pytest.mark.gpu
+
+
+def fixed_init(v):
+    return lambda out, *_: np.copyto(out, v)
+
+
+def _case(name):
+    if name == "randsym":
+        n = 30011
+        return n, G.randsym_np(n), G.start_vector(n, 1), True, 0.0
+    if name == "laplace":
+        m = 173
+        return m * m, G.laplace2d_np(m), G.start_vector(m * m, 2), True, 0.0
+    N = 160
+    return N * N, G.torus_np(N), G.start_vector(N * N, 3, np.complex128), False, -10.0
+
+
+def _run(ctx, op, n, find_max, offset, init, num_eigs=1, max_iteration=None):
+    eng = L.LambdaLanczos(op, n, find_max, num_eigs)
+    eng.eigenvalue_offset = offset
+    eng.init_vector = fixed_init(init)
+    if max_iteration:
+        eng.max_iteration = max_iteration
+    vals, vecs = eng.run()
+    return dict(vals=vals, vecs=vecs, iters=eng.getIterationCounts(), alpha=eng.last_alpha.copy(), beta=eng.last_beta.copy(),
+                stats=dict(eng.last_stats))
+
+
+@pytest.mark.parametrize("name", ["randsym", "laplace", "torus"])
+def test_pair_form_against_the_oracle_and_the_forms_it_replaces(ctx, oracle, llenv, name):
+    """Whole runs to convergence (245 to several hundred iterations; real and complex), streaming geometry forced on all three
+    forms.  The pair form must take (almost) every iteration, reproduce the oracle's alpha / beta / count / eigenpair, and agree
+    with the one-sweep and the two-sweep form to 1e-11 ||A||."""
+    n, csr, init, find_max, offset = _case(name)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for form, env in (("two_sweep", {"LL_FUSE_LAUNCHES": "1"}), ("one_sweep", {"LL_PAIR_GS": "0"}), ("pair", {})):
+        for k, v in env.items():
+            llenv.setenv(k, v)
+        got[form] = _run(ctx, op, n, find_max, offset, init)
+        for k in env:
+            llenv.delenv(k)
+    pair, one, two = got["pair"], got["one_sweep"], got["two_sweep"]
+    itern = pair["iters"][0]
+    assert two["stats"]["lagged_iterations"] == 0 and two["stats"]["pair_iterations"] == 0
+    assert one["stats"]["pair_iterations"] == 0 and one["stats"]["lagged_iterations"] >= one["iters"][0] - 3
+    # iterations 1 and 2 set the pipeline up; a DGKS repair costs the pair it hits and the two iterations that re-enter
+    assert pair["stats"]["pair_iterations"] >= itern - 3 - 4 * pair["stats"]["second_passes"], pair["stats"]
+    assert pair["iters"] == one["iters"] == two["iters"]
+    scale = inf_norm(csr) + abs(offset)
+    for other in (one, two):
+        assert np.max(np.abs(pair["alpha"] - other["alpha"])) <= 1e-11 * scale
+        assert np.max(np.abs(pair["beta"] - other["beta"])) <= 1e-11 * scale
+        assert abs(pair["vals"][0] - other["vals"][0]) <= 1e-12 * scale
+        assert 1 - overlap(pair["vecs"][0], other["vecs"][0]) <= 1e-10
+    ora = oracle.lanczos(csr, init, find_max, offset=offset)
+    assert pair["iters"] == ora["iter_counts"]
+    m = len(ora["alpha"])
+    assert np.max(np.abs(pair["alpha"][:m] - ora["alpha"])) <= 1e-10 * scale
+    assert np.max(np.abs(pair["beta"][:m - 1] - ora["beta"][:m - 1])) <= 1e-10 * scale
+    assert abs(pair["vals"][0] - ora["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(pair["vals"][0] + offset))
+    assert 1 - overlap(pair["vecs"][0], ora["eigenvectors"][0]) <= 1e-8
+    op.close()
+
+
+@pytest.mark.parametrize("window", [1, 2, 3, 4, 5, 6, 7, 40, 41])
+def test_pair_form_with_every_parity_of_the_iteration_count(ctx, oracle, llenv, window):
+    """max_iteration = 1 .. 7, 40, 41: windows that end on the first or on the second iteration of a pair, windows too short to
+    enter the form at all — the returned pair, the traces and the count against the oracle (the second iteration of a pair that
+    overshoots max_iteration is speculative work nobody reads)."""
+    n = 30011
+    csr, init = G.randsym_np(n), G.start_vector(n, 1)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    r = _run(ctx, op, n, True, 0.0, init, max_iteration=window)
+    ora = oracle.lanczos(csr, init, True, max_iteration=window)
+    assert r["iters"] == ora["iter_counts"] == [window]
+    assert len(r["alpha"]) == window
+    assert np.max(np.abs(r["alpha"] - ora["alpha"][:window])) <= 1e-10 * 30
+    if window > 1:
+        assert np.max(np.abs(r["beta"][:window - 1] - ora["beta"][:window - 1])) <= 1e-10 * 30
+    assert abs(r["vals"][0] - ora["eigenvalues"][0]) <= 1e-10 * abs(r["vals"][0])
+    assert 1 - overlap(r["vecs"][0], ora["eigenvectors"][0]) <= 1e-8
+    assert r["stats"]["pair_iterations"] == (0 if window < 3 else 2 * ((window - 1) // 2))
+    op.close()
+
+
+def test_pair_form_with_a_second_gram_schmidt_pass_in_every_iteration(ctx, oracle, llenv):
+    """LL_DGKS_THRESHOLD=2 makes the host ask for the second pass after EVERY iteration: each pair is cut short by the repair
+    of its first vector (flush of the pending late updates, second pass on the completed vector, re-enqueue from a clean state)
+    — the results must not change."""
+    n = 30011
+    csr, init = G.randsym_np(n), G.start_vector(n, 1)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    llenv.setenv("LL_DGKS_THRESHOLD", "2.0")
+    op = L.CsrOperator(ctx, *csr)
+    r = _run(ctx, op, n, True, 0.0, init, max_iteration=40)
+    ora = oracle.lanczos(csr, init, True, max_iteration=40)
+    assert r["iters"] == ora["iter_counts"] == [40] and r["stats"]["second_passes"] >= 38
+    assert np.max(np.abs(r["alpha"] - ora["alpha"][:40])) <= 1e-10 * 30
+    assert np.max(np.abs(r["beta"][:39] - ora["beta"][:39])) <= 1e-10 * 30
+    assert abs(r["vals"][0] - ora["eigenvalues"][0]) <= 1e-10 * abs(r["vals"][0])
+    assert 1 - overlap(r["vecs"][0], ora["eigenvectors"][0]) <= 1e-8
+    op.close()
+
+
+def test_pair_form_leaves_through_its_gate_when_the_krylov_space_is_exhausted(ctx, oracle, llenv):
+    """An operator with 5 distinct eigenvalues exhausts its Krylov space after 5 iterations: the first vector of the pair (5, 6)
+    is rounding noise (beta ~ 1e-15) whose components along the stored vectors are NOT small against its norm.  The fold's gate
+    (kPairGate) must catch it: iteration 5 stands (its coefficients were measured), iteration 6 — which took the noise vector as
+    its operator input — is done again in the one-sweep form (exact for coefficients of any size), which the rest of the pass
+    keeps.  Same iteration count and eigenpair as the oracle's sequential MGS."""
+    rng = np.random.default_rng(4)
+    n = 300
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.repeat([1.0, 2.0, 3.5, 5.0, 9.0], n // 5)
+    a = (q * lam) @ q.T
+    a = (a + a.T) / 2
+    init = G.start_vector(n, 1)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.DenseOperator(ctx, a)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.init_vector = fixed_init(init)
+    vals, vecs = eng.run()
+    ora = oracle.lanczos(G.dense_to_csr(a), init, True)
+    assert abs(vals[0] - 9.0) <= 1e-10 and abs(ora["eigenvalues"][0] - 9.0) <= 1e-10
+    assert abs(eng.getIterationCounts()[0] - ora["iter_counts"][0]) <= 1
+    assert np.linalg.norm(a @ vecs[0] - vals[0] * vecs[0]) <= 1e-9
+    st = eng.last_stats
+    assert st["pair_iterations"] >= 2 and st["pair_gate_trips"] == 1, st
+    m = 4   # the recurrence up to the exhaustion
+    assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"][:m])) <= 1e-10 * 9 and np.max(np.abs(eng.last_beta[:m] - ora["beta"][:m])) <= 1e-10 * 9
+    op.close()
+
+
+def test_pair_form_on_a_ring_whose_krylov_space_is_exhausted_at_the_end(ctx, oracle, llenv):
+    """A ring of 400 sites has 201 distinct eigenvalues: the run ends where the Krylov space is exhausted (beta collapses to
+    ~1e-13 at m = 201): eigenvalue, iteration count and the traces up to the exhaustion against the oracle, in the pair form."""
+    n = 400
+    csr, init = G.ring_csr(n), G.start_vector(n, 1)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, n, False, 1)
+    eng.eigenvalue_offset = -3.0
+    eng.init_vector = fixed_init(init)
+    vals, vecs = eng.run()
+    ora = oracle.lanczos(csr, init, False, offset=-3.0)
+    assert abs(eng.getIterationCounts()[0] - ora["iter_counts"][0]) <= 2
+    assert abs(vals[0] - ora["eigenvalues"][0]) <= 1e-10 * 5
+    m = min(195, len(ora["alpha"]), len(eng.last_alpha))
+    assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"][:m])) <= 1e-10 * 5
+    assert np.max(np.abs(eng.last_beta[:m] - ora["beta"][:m])) <= 1e-10 * 5
+    assert eng.last_stats["pair_iterations"] >= 190
+    op.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.complex64], ids=["s", "c"])
+def test_pair_form_in_single_precision(ctx, llenv, dtype):
+    """float / complex<float> storage (reductions in double): pair form against the two-sweep form on the same operator."""
+    wide = np.complex128 if dtype == np.complex64 else np.float64
+    n = 30011
+    base = G.randsym_np(n)
+    csr = (base[0], base[1], base[2].astype(dtype))
+    init = G.start_vector(n, 1, wide).astype(dtype)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for fuse in ("1", "2"):
+        llenv.setenv("LL_FUSE_LAUNCHES", fuse)
+        got[fuse] = _run(ctx, op, n, True, 0.0, init, num_eigs=1)
+    two, pair = got["1"], got["2"]
+    assert pair["stats"]["pair_iterations"] >= pair["iters"][0] - 3 - 4 * pair["stats"]["second_passes"]
+    assert abs(pair["iters"][0] - two["iters"][0]) <= 2
+    assert np.max(np.abs(pair["alpha"][:12] - two["alpha"][:12])) <= 2e-4 * 30
+    assert abs(pair["vals"][0] - two["vals"][0]) <= 2e-3 * 30
+    assert 1 - overlap(pair["vecs"][0].astype(wide), two["vecs"][0].astype(wide)) <= 1e-4
+    op.close()

@@ -58,7 +58,9 @@ def main():
         res["window_iterations"] = window_iterations
         orth = [v for k, v in res["kernels"].items() if k.split("<")[0] in ("mdot_kernel", "maxpy_kernel", "scale_kernel", "scale_publish_kernel",
                                                                         "mdot_small_kernel", "maxpy_small_kernel", "lagged_kernel",
-                                                                        "lagged_fold_kernel", "reduce_cols_kernel")]
+                                                                        "lagged_fold_kernel", "reduce_cols_kernel", "pair_sweep_kernel",
+                                                                        "pair_three_term_kernel", "pair_predict_kernel",
+                                                                        "pair_fold_kernel")]
         res["orth_bytes_per_window"] = sum(v["fetch_bytes_sum"] + v["write_bytes_sum"] for v in orth) / windows
     sk = res["kernels"].get("scale_kernel<double>")
     if sk:
@@ -68,7 +70,8 @@ def main():
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["calibration"]))
     for k, v in res["kernels"].items():
-        if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "lagged_kernel<", "stencil", "dense_mv", "gemv_basis")):
+        if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "lagged_kernel<", "stencil", "dense_mv", "gemv_basis",
+                         "tl_spmv_kernel<", "tl_xmax_kernel<", "pair_sweep_kernel<", "pair_three_term_kernel<")):
             print(k, {kk: (round(vv / 1e9, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()})
     if windows:
         print("orth_bytes_per_window_GB", res["orth_bytes_per_window"] / 1e9)
