@@ -36,6 +36,7 @@ Tuning read_tuning() {
   t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : (k == "tiled" ? 3 : 0));
   t.keep_both = flag("LL_SPMV_KEEP_BOTH", false);
   t.tl_force = flag("LL_TL_FORCE", false);
+  t.pb_diag = flag("LL_PB_DIAG", true);
   t.pair_gs = flag("LL_PAIR_GS", true);
   const std::string p2 = str("LL_PB_PHASE2");
   t.pb_phase2 = p2 == "atomic" ? LL_PB_ATOMIC : (p2 == "ordered" ? LL_PB_ORDERED : LL_PB_FIXED);
@@ -204,7 +205,7 @@ void ll_context::drain_comm_events(double* gather_s, double* allreduce_s) {
 ll_operator::~ll_operator() {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* q : {d_row_ptr, (void*)d_tile_rows, d_dense, d_onsite, (void*)d_pb_segq, (void*)d_pb_segdest,
-                  (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp,
+                  (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp, d_pb_diag,
                   (void*)d_pb_blockmax, d_rp_own, d_rp_rem, (void*)d_col_own, (void*)d_col_rem, d_val_own, d_val_rem,
                   (void*)d_tiles_own, (void*)d_tiles_rem, (void*)d_tl_first, (void*)d_tl_col, (void*)d_tl_quad, d_tl_val,
                   (void*)d_tl_idx, (void*)d_tl_rexp, (void*)d_tl_xmax})
@@ -756,6 +757,7 @@ void release_image(ll_operator* op, int keep_kind) {
     drop(op->d_pb_arena);
     drop(op->d_pb_rexp);
     drop(op->d_pb_blockmax);
+    drop(op->d_pb_diag);
     op->d_pb_val = op->d_pb_prod = nullptr;  // interior pointers of the arena
     op->d_pb_col = op->d_pb_row = nullptr;
     op->pb_ncb = op->pb_nrb = 0;
@@ -776,6 +778,7 @@ void release_pb_image(ll_operator* op) {
   drop(op->d_pb_arena);
   drop(op->d_pb_rexp);
   drop(op->d_pb_blockmax);
+  drop(op->d_pb_diag);
   op->d_pb_val = op->d_pb_prod = nullptr;
   op->d_pb_col = op->d_pb_row = nullptr;
   op->pb_ncb = op->pb_nrb = 0;

@@ -814,19 +814,21 @@ template <typename T> struct LoopState {
   }
   // u_j must be complete in its basis slot (second Gram-Schmidt pass on it)
   void make_final(int64_t j) {
-    if (pair_pending && j >= pair_P) pair_flush();
+    if (pair_pending && j >= pair_P) pair_flush(j + 1);
     if (lag_pending && lag_k == j) flush_lag();
   }
   // Leave the pair form: complete the two pending vectors with their measured coefficients (two-sweep kernels).  Afterwards
   // u_0 .. u_{P+1} are complete, nothing is pending, and iteration P + 2 can be enqueued from a clean state.
-  void pair_flush() {
+  // count: only the vectors u_j with j < count are needed (end of a pass: the Ritz vectors use u_0 .. u_{m-1}; a repair of u_j:
+  // nothing behind u_j survives it) — a pending vector beyond that is dropped instead of completed.
+  void pair_flush(int64_t count = std::numeric_limits<int64_t>::max()) {
     if (!pair_pending) return;
     constexpr int R = Engine<T>::R;
     const int64_t P = pair_P;
     const T* src[2] = {pr1, pr2};
     const double* coef[2] = {g1p, g2p};  // g2p: R * P coefficients against the basis, then <u_P, pr2>: one contiguous list
     const double* rho[2] = {rho1p, rho2p};
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 2 && P + v < count; ++v) {
       T* dst = U.vec(P + v);
       if (dst != src[v]) LL_HIP(hipMemcpyAsync(dst, src[v], (size_t)nl * sizeof(T), hipMemcpyDeviceToDevice, s));
       const RunList<T> runs = basis_runs(P + v);
@@ -846,7 +848,7 @@ template <typename T> struct LoopState {
   // coefficients: u_{k-2} plays the part of an already complete first vector, g1 = 0, rho1 = 1) or continued from a pair.
   bool enqueue_pair(int64_t k, double offset) {
     constexpr int R = Engine<T>::R;
-    if (!pair_enabled || !pair_allowed || !lag_ok || n_locked != 0 || E.ctx->comm != nullptr) return false;
+    if (!pair_enabled || !pair_allowed || !lag_ok || n_locked != 0) return false;
     int64_t P;
     const T *r1, *r2;
     const double *g1, *g2, *rho1sq, *rho2sq;
@@ -877,7 +879,8 @@ template <typename T> struct LoopState {
     }
     const int ncols = 2 * R * (int)P + 5 * R + 1;
     const int64_t stream_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);
-    if (ncols > kLaggedMaxCols || nl * (int64_t)sizeof(T) < stream_bytes) return false;
+    const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;  // (sharded: decided on the shard stride, the same on every rank)
+    if (ncols > kLaggedMaxCols || len * (int64_t)sizeof(T) < stream_bytes) return false;
     const RunList<T> stored = basis_runs(P);
     const std::vector<BasisSegs<T>> groups = stored.groups(max_vecs_per_launch<T>());
     if (groups.size() != 1) return false;
@@ -901,6 +904,7 @@ template <typename T> struct LoopState {
     int grid = launch_pair_three_term<T>(nl, r3, r2, r1, e1, da1.nparts > 0 ? da1.partials : nullptr, da1.nparts, rho2sq, rho1sq,
                                          E.ctx->d_partials, s);
     launch_reduce_cols(E.ctx->d_partials, grid, 1 + R, t3, nullptr, s);
+    if (E.ctx->comm != nullptr) E.all_reduce(t3, (size_t)(1 + R));  // |r3|^2 and <r1, r3> over the shards
     timer.mark();
     // ---- iteration k + 1: operator on r3 / |r3|; its three-term update is formed inside the sweep
     timer.mark();
@@ -912,6 +916,8 @@ template <typename T> struct LoopState {
     grid = launch_pair_sweep<T>(nl, groups[0], (int)P, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), g1, g2, gam, pp4, rho1sq, rho2sq,
                                 e2, t3, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
     launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
+    // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits
+    if (E.ctx->comm != nullptr) E.all_reduce(pcols, (size_t)ncols);
     launch_pair_fold(pcols, (int)P, R, pp4, g2, gam, rho2sq, t3, e1, e2, rec3, rec4, nxt, hist_alpha, hist_beta, pfold,
                      E.ctx->h_pinned + 4 * sa, E.ctx->h_pinned + 4 * sb, E.ctx->h_pinned + 16 + sa, E.ctx->h_pinned + 16 + sb, s);
     LL_HIP(hipEventRecord(ring.ev[sa], s));
@@ -1188,9 +1194,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   LS.fuse_launches = fuse_launches;
   if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
   if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
-  // two iterations per sweep (single GPU, device operators, streaming vectors; LoopState::enqueue_pair decides per iteration)
-  if (LS.lagged && ctx->tune.pair_gs && ctx->comm == nullptr &&
-      nl * (int64_t)sizeof(T) >= std::min<int64_t>(ctx->tune.blas_small_bytes, (int64_t)1 << 20))
+  // two iterations per sweep (device operators, streaming vectors, no locked vectors; LoopState::enqueue_pair decides per iteration)
+  if (LS.lagged && ctx->tune.pair_gs &&
+      (ctx->comm != nullptr ? op->n_shard : nl) * (int64_t)sizeof(T) >= std::min<int64_t>(ctx->tune.blas_small_bytes, (int64_t)1 << 20))
     LS.enable_pair();
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
@@ -1309,6 +1315,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       last = std::move(r);
       return last.stop;
     };
+    // the gate of the pair form: what is neglected is the SQUARE of a relative coefficient, which must stay below the rounding
+    // of the storage type (float vectors carry coefficients of ~1e-6 by rounding alone)
+    const double pair_gate = sizeof(typename scalar_traits<T>::real) == 4 ? 2e-4 : kPairGate;
     auto collect = [&](int64_t j) -> int {
       const int slot = (int)(j % 4);
       const double tw0 = now_s();
@@ -1348,7 +1357,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
         LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
         verdict = kRedone;  // the speculative iteration j+1 took the one-sweep form: it is enqueued again
       }
-      if (verdict == kContinue && LS.slot_pair[slot] && !(ctx->h_pinned[16 + slot] <= kPairGate)) {
+      if (verdict == kContinue && LS.slot_pair[slot] && !(ctx->h_pinned[16 + slot] <= pair_gate)) {
         // A coefficient of this iteration's raw vector grew beyond what the pair form tracks to first order (beta -> eps: an
         // exhausted Krylov space, breakdown).  The iteration itself stands — its coefficients were MEASURED, its alpha / beta
         // are exact — but whatever took the vector as an operator input (the second iteration of its pair, the next pair) is
@@ -1411,9 +1420,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
         while (!stopped && worker.wait_pop(r)) stopped = absorb(r);
       }
     }
-    LS.pair_flush();  // (a pending pair: the Ritz vectors below need every Lanczos vector complete in the basis)
     while (!stopped && worker.wait_pop(r)) stopped = absorb(r);  // the first stop verdict wins; else the last iteration's values
     itern = last.m;  // == max_iteration without a stop (LL:239,312)
+    LS.pair_flush(itern);  // (a pending pair: the Ritz vectors below need u_0 .. u_{itern-1} complete in the basis)
     if (trace_file) {
       std::fprintf(trace_file, "stop %lld %lld %d collected %zu\n", (long long)passes, (long long)itern, (int)stopped, alpha.size());
       std::fflush(trace_file);

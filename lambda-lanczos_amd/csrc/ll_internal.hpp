@@ -156,6 +156,7 @@ struct Tuning {
   int pb_col_block = 0;
   int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
   bool pb_xpre = true;             // LL_PB_XPRE=0: phase 2 of the PB SpMV loads x_i in its epilogue (A/B of the early request)
+  bool pb_diag = true;             // LL_PB_DIAG=0: the diagonal entries travel through the PB streams like every other entry (A/B)
   int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
   bool spmv_tile_balance = true;   // LL_SPMV_TILE_BALANCE=0: CSR-stream tiles always hold up to 1024 nonzeros (capi.cpp build_tiles)
   bool csr_split = true;           // LL_CSR_SPLIT=0: sharded CSR-stream / dense operators gather first, then multiply (round-3 form)
@@ -293,6 +294,7 @@ struct ll_operator {
   void* d_pb_prod = nullptr;         // product buffer P (nnz elements of T), row-block order
   int16_t* d_pb_rexp = nullptr;      // LL_PB_PHASE2=fixed: exponent of every local row's absolute sum
   double* d_pb_blockmax = nullptr;   // LL_PB_PHASE2=fixed: max |x| per column block, left by phase 1
+  void* d_pb_diag = nullptr;         // a_ii of every local row (T): the diagonal is kept outside the streams (spmv_pb.hip pb_diag_kernel)
   int64_t pb_entries = 0;            // padded entry count of the image
   int pb_phase2 = 4;                 // form of phase 2 (ll::LL_PB_FIXED / _ORDERED / _ATOMIC): set when the image is built,
                                      // changed by ll_op_set_accuracy (both forms read the same image)
@@ -461,7 +463,8 @@ int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg
                   int pieces, int64_t small_limit, hipStream_t s);  // vectors below small_limit bytes: lagged_small_kernel
 // The pair form (two iterations per sweep; kernels.hip, "pair" section; tools/pair_gs_model.py is the executable specification).
 // Streaming geometry only; 2 * reals * P + 5 * reals + 1 <= kLaggedMaxCols columns per workgroup.
-constexpr double kPairGate = 1e-8;  // largest relative coefficient the pair form accepts (second-order terms stay below 1e-16)
+constexpr double kPairGate = 1e-8;  // largest relative coefficient the pair form accepts in double precision (second-order terms
+                                    // stay below 1e-16; float storage: 2e-4, engine.cpp)
 template <typename T>
 int launch_pair_three_term(int64_t n, T* y, const T* x, const T* p, double* e, const double* e_partials, int e_nparts,
                            const double* cx2, const double* cp2, double* partials,

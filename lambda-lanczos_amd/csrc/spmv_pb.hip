@@ -366,7 +366,8 @@ template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, 
     lds_add(&lds[rl], (double)v);
   }
 }
-// the shared epilogue: value(i) gives row i's sum; y = value + offset x, partial Re<x, y> per workgroup
+// the shared epilogue: value(i, x_i) gives row i's sum (x_i: the row's own input element, for the diagonal term that the
+// PB image keeps outside its streams); y = value + offset x, partial Re<x, y> per workgroup
 template <typename T, typename F>
 __device__ __forceinline__ void pb_phase2_epilogue(int rb, int64_t row0, int rows, const T* __restrict__ xl, T* __restrict__ y,
                                                    double offset, double* __restrict__ dot_partials, double* red,
@@ -386,7 +387,7 @@ __device__ __forceinline__ void pb_phase2_epilogue(int rb, int64_t row0, int row
     for (int u = 0; u < EU; ++u) {
       const int i = i0 + u * kPbThreads;
       if (i < rows) {
-        const T yi = add(narrow<T>(value(i)), rmul(offset, xi[u]));
+        const T yi = add(narrow<T>(value(i, xi[u])), rmul(offset, xi[u]));
         y[row0 + i] = yi;
         dot_acc += re_cmul(xi[u], yi);
       }
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
                                                         const int64_t* __restrict__ rptr,  // [nrb + 1]
                                                         const ushort4* __restrict__ row, const T* __restrict__ P,
                                                         const T* __restrict__ xl, T* __restrict__ y, double offset,
-                                                        double* __restrict__ dot_partials, const double* __restrict__ xnorm2) {
+                                                        double* __restrict__ dot_partials, const double* __restrict__ xnorm2,
+                                                        const T* __restrict__ diag) {
   constexpr int R = scalar_traits<T>::reals;
   constexpr int U = 2;
   extern __shared__ double lds[];  // [rb_rows * R]
@@ -457,10 +459,11 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
     }
   });
   __syncthreads();
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, [&](int i) {
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, [&](int i, const T& xi) {
     acc_t<T> a;
     if constexpr (scalar_traits<T>::is_complex) a = zc{lds[2 * i], lds[2 * i + 1]};
     else a = lds[i];
+    if (diag) a = add(a, to_acc(mul(diag[row0 + i], xi)));  // the diagonal entry, kept outside the streams (pb_diag_kernel)
     return a;
   });
 }
@@ -474,7 +477,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
                                                               const double* __restrict__ blockmax,
                                                               const T* __restrict__ xl, T* __restrict__ y, double offset,
                                                               double* __restrict__ dot_partials,
-                                                              const double* __restrict__ xnorm2, int xprefetch) {
+                                                              const double* __restrict__ xnorm2, int xprefetch,
+                                                              const T* __restrict__ diag) {
   constexpr int R = scalar_traits<T>::reals;
   constexpr int U = 2;
   extern __shared__ double lds_raw[];
@@ -559,12 +563,33 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
     }
   });
   __syncthreads();
-  auto value = [&](int i) {
-    const int k = ex[i];
+  // (the row's diagonal entry is kept outside the streams, pb_diag_kernel: its product joins the row's integers here —
+  // rounded to the same grid, added to the same sum: the same bits as if it had travelled through the product buffer)
+  auto value = [&](int i, const T& xi) {
+    int k = ex[i];
+    long long s[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) s[q] = acc[R * i + q];
+    if (diag != nullptr && k != kBadRow) {
+      const T p = mul(diag[row0 + i], xi);
+      const double sc = pow2(k);
+      long long w[R];
+      if constexpr (scalar_traits<T>::is_complex) {
+        w[0] = pb_to_fixed((double)p.re * sc, 0);
+        w[1] = pb_to_fixed((double)p.im * sc, 0);
+      } else {
+        w[0] = pb_to_fixed((double)p * sc, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        if (w[q] == kPbBadProduct) k = kBadRow;
+        else s[q] = (long long)((unsigned long long)s[q] + (unsigned long long)w[q]);
+      }
+    }
     const double back = k == kBadRow ? __longlong_as_double(0x7ff8000000000000ll) : pow2(-k);  // NaN for unusable rows
     acc_t<T> a;
-    if constexpr (scalar_traits<T>::is_complex) a = zc{(double)acc[2 * i] * back, (double)acc[2 * i + 1] * back};
-    else a = (double)acc[i] * back;
+    if constexpr (scalar_traits<T>::is_complex) a = zc{(double)s[0] * back, (double)s[1] * back};
+    else a = (double)s[0] * back;
     return a;
   };
   if constexpr (sizeof(T) <= 8) {
@@ -576,7 +601,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
         const int i = tid + u * kPbThreads;
         if (i < rows) {
           const T xi = rmul(xs_fac, xpre[u]);
-          const T yi = add(narrow<T>(value(i)), rmul(offset, xi));
+          const T yi = add(narrow<T>(value(i, xi)), rmul(offset, xi));
           y[row0 + i] = yi;
           dot_acc += re_cmul(xi, yi);
         }
@@ -669,15 +694,18 @@ int launch_pb_phase2(const ll_operator& op, const T* x_local, T* y, double offse
     const size_t ldsf = (size_t)op.pb_rb_rows * (sizeof(acc_t<T>) + sizeof(int16_t)) + 16;
     hipLaunchKernelGGL((pb_phase2_fixed<T, D2>), grid, block, ldsf, s, op.pb_rb_rows, op.n_local, op.pb_ncb, op.d_pb_rptr,
                        (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, op.d_pb_rexp, op.d_pb_blockmax, x_local, y,
-                       offset, dot_partials, xnorm2, (op.pb_xpre && op.pb_rb_rows <= kPbXPre * kPbThreads) ? 1 : 0);
+                       offset, dot_partials, xnorm2, (op.pb_xpre && op.pb_rb_rows <= kPbXPre * kPbThreads) ? 1 : 0,
+                       (const T*)op.d_pb_diag);
   } else {
     const size_t lds2 = (size_t)op.pb_rb_rows * sizeof(acc_t<T>);
     if (op.pb_phase2 == LL_PB_ORDERED)
       hipLaunchKernelGGL((pb_phase2<T, true, D2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
-                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, xnorm2);
+                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, xnorm2,
+                         (const T*)op.d_pb_diag);
     else
       hipLaunchKernelGGL((pb_phase2<T, false, D2>), grid, block, lds2, s, op.pb_rb_rows, op.n_local, op.d_pb_rptr,
-                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, xnorm2);
+                         (const ushort4*)op.d_pb_row, (const T*)op.d_pb_prod, x_local, y, offset, dot_partials, xnorm2,
+                         (const T*)op.d_pb_diag);
   }
   LL_HIP(hipGetLastError());
   return op.pb_nrb;
@@ -722,7 +750,8 @@ __host__ __device__ inline int pb_block_of(const PbColMap& m, long long colg, in
 template <typename RP>
 __global__ __launch_bounds__(256) void pb_count_kernel(PbColMap m, int ncb, int nrb, int rb_rows, long long n_local,
                                                        const RP* __restrict__ rp, const int32_t* __restrict__ ci,
-                                                       int32_t* __restrict__ cnt /* [ncb][nrb] */) {
+                                                       int32_t* __restrict__ cnt /* [ncb][nrb] */,
+                                                       const uint32_t* __restrict__ skip = nullptr) {
   extern __shared__ int hist[];
   const int r = blockIdx.x;
   for (int i = threadIdx.x; i < ncb; i += 256) hist[i] = 0;
@@ -730,6 +759,7 @@ __global__ __launch_bounds__(256) void pb_count_kernel(PbColMap m, int ncb, int 
   const long long i0 = (long long)r * rb_rows, i1 = min(n_local, i0 + rb_rows);
   const long long p0 = (long long)rp[i0], p1 = (long long)rp[i1];
   for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+    if (skip != nullptr && ((skip[p >> 5] >> (p & 31)) & 1u)) continue;  // the row's diagonal entry: kept outside the image
     int local;
     atomicAdd(&hist[pb_block_of(m, ci[p], &local)], 1);
   }
@@ -755,7 +785,8 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
                                                         const T* __restrict__ va, const int64_t* __restrict__ segq,
                                                         const int64_t* __restrict__ segdest, T* __restrict__ pval,
                                                         uint16_t* __restrict__ pcol, uint16_t* __restrict__ prow,
-                                                        const int16_t* __restrict__ rexp = nullptr) {
+                                                        const int16_t* __restrict__ rexp = nullptr,
+                                                        const uint32_t* __restrict__ skip = nullptr) {
   extern __shared__ int fill[];  // [ncb]
   const int r = blockIdx.x, lane = threadIdx.x;
   for (int i = lane; i < ncb; i += 64) fill[i] = 0;
@@ -765,10 +796,11 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
   long long row_hint = i0;  // row of the chunk's first entry (monotone over the chunks)
   for (long long base = p0; base < p1; base += 64) {
     const long long p = base + lane;
-    const bool valid = p < p1;
+    const bool in_range = p < p1;
+    const bool valid = in_range && !(skip != nullptr && ((skip[p >> 5] >> (p & 31)) & 1u));  // (the diagonal entry stays outside)
     // row of entry p: the last row i with rp[i] <= p (binary search from the hint; rows of a chunk are few)
     long long lo = row_hint, hi = i1 - 1;
-    if (valid) {
+    if (in_range) {
       while (lo < hi) {
         const long long mid = (lo + hi + 1) >> 1;
         if ((long long)rp[mid] <= p) lo = mid; else hi = mid - 1;
@@ -803,6 +835,28 @@ __global__ __launch_bounds__(64) void pb_scatter_kernel(PbColMap m, int ncb, int
         prow[qd] = (uint16_t)(rowi - i0);
       }
     }
+  }
+}
+
+// The first diagonal entry of every local row leaves the image: it is the one entry whose x element the row's own epilogue
+// holds anyway (offset term, alpha), so its product needs no trip through the product buffer — 28 bytes of traffic per row
+// saved for 8 (the diag array), 1/15 of config 3's entries.  diag[i] = a_ii (0 when the row stores none), skip: one bit
+// per CSR entry, set for the entries taken out (read by the count and scatter kernels).  Further diagonal duplicates of a
+// row stay in the streams.
+template <typename T, typename RP>
+__global__ __launch_bounds__(256) void pb_diag_kernel(long long n_local, long long row_begin, const RP* __restrict__ rp,
+                                                      const int32_t* __restrict__ ci, const T* __restrict__ va,
+                                                      T* __restrict__ diag, uint32_t* __restrict__ skip) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_local; i += (long long)gridDim.x * 256) {
+    T d = zero<T>();
+    const long long g = row_begin + i;
+    for (long long p = (long long)rp[i]; p < (long long)rp[i + 1]; ++p)
+      if ((long long)ci[p] == g) {
+        d = va[p];
+        atomicOr(&skip[p >> 5], 1u << (p & 31));
+        break;
+      }
+    diag[i] = d;
   }
 }
 
@@ -984,6 +1038,28 @@ template <typename T> bool pb_build_device(ll_operator* op) {
       }
   }
 
+  // ---- the diagonal leaves the image (pb_diag_kernel): one bit per CSR entry marks what the passes below skip
+  uint32_t* d_skip = nullptr;
+  struct Free0 {
+    uint32_t*& p;
+    ~Free0() {
+      if (p) (void)hipFree(p);
+    }
+  } free_skip{d_skip};
+  if (tune.pb_diag && nr > 0 && op->nnz > 0) {
+    const size_t words = ((size_t)op->nnz + 31) / 32 + 1;
+    ctx->dev_malloc((void**)&d_skip, words * sizeof(uint32_t), "diagonal marks");
+    ctx->dev_malloc(&op->d_pb_diag, std::max<size_t>((size_t)nr, 2) * sizeof(T), "diagonal of the PB image");
+    LL_HIP(hipMemsetAsync(d_skip, 0, words * sizeof(uint32_t), s));
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (nr + 255) / 256));
+    if (op->rp64)
+      hipLaunchKernelGGL((pb_diag_kernel<T, int64_t>), dim3(g), dim3(256), 0, s, (long long)nr, (long long)op->row_begin,
+                         (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val, (T*)op->d_pb_diag, d_skip);
+    else
+      hipLaunchKernelGGL((pb_diag_kernel<T, int32_t>), dim3(g), dim3(256), 0, s, (long long)nr, (long long)op->row_begin,
+                         (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val, (T*)op->d_pb_diag, d_skip);
+    LL_HIP(hipGetLastError());
+  }
   // ---- pass 1 on the device: segment sizes
   int32_t* d_cnt = nullptr;
   ctx->dev_malloc((void**)&d_cnt, (size_t)ncb * nrb * sizeof(int32_t), "segment counts");
@@ -994,10 +1070,10 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   const size_t hist_bytes = (size_t)ncb * sizeof(int);
   if (op->rp64)
     hipLaunchKernelGGL((pb_count_kernel<int64_t>), dim3((int)nrb), dim3(256), hist_bytes, s, m, (int)ncb, (int)nrb,
-                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, d_cnt);
+                       (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, d_cnt, d_skip);
   else
     hipLaunchKernelGGL((pb_count_kernel<int32_t>), dim3((int)nrb), dim3(256), hist_bytes, s, m, (int)ncb, (int)nrb,
-                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, d_cnt);
+                       (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, d_cnt, d_skip);
   LL_HIP(hipGetLastError());
   std::vector<int32_t> cnt32((size_t)ncb * nrb);
   LL_HIP(hipMemcpyAsync(cnt32.data(), d_cnt, cnt32.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1081,11 +1157,11 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   if (op->rp64)
     hipLaunchKernelGGL((pb_scatter_kernel<T, int64_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
                        (int)rb_rows, (long long)nr, (const int64_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, nullptr, d_skip);
   else
     hipLaunchKernelGGL((pb_scatter_kernel<T, int32_t>), dim3((int)nrb), dim3(64), hist_bytes, s, m, (int)ncb, (int)nrb,
                        (int)rb_rows, (long long)nr, (const int32_t*)op->d_row_ptr, op->d_col, (const T*)op->d_val,
-                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row);
+                       op->d_pb_segq, op->d_pb_segdest, (T*)op->d_pb_val, op->d_pb_col, op->d_pb_row, nullptr, d_skip);
   LL_HIP(hipGetLastError());
   // Fixed-point sums need per-row exponents of the absolute row sums and per-block maxima of |x|.  They are built for EVERY
   // image whose row block leaves room for them (2 bytes per row; the CSR arrays they come from may be released after creation),
@@ -1326,7 +1402,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   }
   __syncthreads();
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
-  auto value = [&](int i) {
+  auto value = [&](int i, const T&) {
     const int er = rexp[row0 + i];
     const bool unusable = er == 32767 || e_x == kPbXInf || ((bad[i >> 5] >> (i & 31)) & 1u);
     const int back = er - kx;  // 2^back restores the row's scale (empty rows: er = -1100, acc = 0)

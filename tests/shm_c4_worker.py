@@ -47,7 +47,8 @@ def main():
         t1 = time.time()
         vals, vecs = eng.run()
         return dict(y=y, dot=dot, vals=vals.copy(), vec=vecs[0].copy(), alpha=eng.last_alpha.copy(), beta=eng.last_beta.copy(),
-                    iters=eng.getIterationCounts(), lagged=int(eng.last_stats["lagged_iterations"]), seconds=time.time() - t1)
+                    iters=eng.getIterationCounts(), lagged=int(eng.last_stats["lagged_iterations"]),
+                    pair=int(eng.last_stats["pair_iterations"]), seconds=time.time() - t1)
 
     # overlapped exchange (production default): all-gather in chunks on the communication stream, own-column blocks under it
     os.environ["LL_COMM_OVERLAP"] = "1"
@@ -61,7 +62,7 @@ def main():
         np.array_equal(a["y"], b["y"]) and a["dot"] == b["dot"] and np.array_equal(a["vals"], b["vals"]) and
         np.array_equal(a["vec"], b["vec"]) and np.array_equal(a["alpha"], b["alpha"]) and np.array_equal(a["beta"], b["beta"]))
     res.update(dot=a["dot"], vals=a["vals"].tolist(), alpha=a["alpha"].tolist(), beta=a["beta"].tolist(), iters=a["iters"],
-               lagged=a["lagged"], seconds_run_overlapped=a["seconds"], seconds_run_serial=b["seconds"])
+               lagged=a["lagged"], pair=a["pair"], seconds_run_overlapped=a["seconds"], seconds_run_serial=b["seconds"])
     np.save(os.path.join(out_dir, "y_rank%d.npy" % rank), a["y"])
     np.save(os.path.join(out_dir, "vec_rank%d.npy" % rank), a["vec"])
     op.close()

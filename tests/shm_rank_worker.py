@@ -37,7 +37,8 @@ def main():
         vals, vecs = eng.run()
         res["randsym_" + label] = {"row_begin": rb, "n_local": nl, "vals": vals.tolist(), "vecs": [v.tolist() for v in vecs],
                                    "iters": eng.getIterationCounts(), "alpha": eng.last_alpha.tolist(),
-                                   "lagged": int(eng.last_stats["lagged_iterations"])}
+                                   "lagged": int(eng.last_stats["lagged_iterations"]),
+                                   "pair": int(eng.last_stats["pair_iterations"])}
         if label == "csr":   # run_iteration with a sharded orthogonalizeTo list: the first eigenvector is locked
             eng.max_iteration = 60
             rv, rx, rit = eng.run_iteration(2, [vecs[0]])

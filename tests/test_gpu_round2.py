@@ -163,6 +163,7 @@ def test_c4_full_size_eight_ranks_match_the_single_gpu_product_and_the_real_refe
     assert np.max(np.abs(np.array(ranks[0]["beta"])[:mb] - ref["beta"][:mb])) <= 1e-10 * anorm
     # the 1.25e6-row shards (10 MB vectors) run the one-sweep Gram-Schmidt form like the single GPU
     assert all(r["lagged"] >= 11 for r in ranks), [r["lagged"] for r in ranks]
+    assert all(r["pair"] >= 10 for r in ranks), [r["pair"] for r in ranks]   # ... two iterations per sweep from iteration 3 on
 
 
 def test_c4_full_size_bench_eight_ranks_on_one_gpu(tmp_path):
