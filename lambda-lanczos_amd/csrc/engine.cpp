@@ -783,6 +783,7 @@ template <typename T> struct LoopState {
   void leave_lagged(int64_t j) {
     make_final(j);
     lag_pending = false;
+    pair_pending = false;
     lag_ok = false;
   }
   // beta_j changed on the host (second Gram-Schmidt pass on u_{j+1})
@@ -848,7 +849,9 @@ template <typename T> struct LoopState {
   // coefficients: u_{k-2} plays the part of an already complete first vector, g1 = 0, rho1 = 1) or continued from a pair.
   bool enqueue_pair(int64_t k, double offset) {
     constexpr int R = Engine<T>::R;
-    if (!pair_enabled || !pair_allowed || !lag_ok || n_locked != 0) return false;
+    // (restart passes: lag_ok already says that the locked vectors are eigenvectors to the one-sweep form's gate, begin_pass)
+    if (!pair_enabled || !pair_allowed || !lag_ok) return false;
+    const int64_t Lk = n_locked;
     int64_t P;
     const T *r1, *r2;
     const double *g1, *g2, *rho1sq, *rho2sq;
@@ -869,7 +872,7 @@ template <typename T> struct LoopState {
       r1 = U.vec(k - 2);
       r2 = work[(k - 1) & 1].p;
       g1 = pzero;
-      g2 = hbuf[(k - 1) & 1];   // k - 1 = P + 1 coefficients: against u_0 .. u_{P-1}, then <u_P, r2>
+      g2 = hbuf[(k - 1) & 1];   // L + k - 1 = K + 1 coefficients: against the locked vectors and u_0 .. u_{P-1}, then <u_P, r2>
       rho1sq = pscal + 0;
       rho2sq = lag_c1;
       out_set = 1;
@@ -877,7 +880,8 @@ template <typename T> struct LoopState {
     } else {
       return false;
     }
-    const int ncols = 2 * R * (int)P + 5 * R + 1;
+    const int64_t K = Lk + P;  // stored columns of the sweep
+    const int ncols = 2 * R * (int)K + 5 * R + 1;
     const int64_t stream_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);
     const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;  // (sharded: decided on the shard stride, the same on every rank)
     if (ncols > kLaggedMaxCols || len * (int64_t)sizeof(T) < stream_bytes) return false;
@@ -891,7 +895,7 @@ template <typename T> struct LoopState {
     double* rec4 = prec[2 * out_rec + 1];
     double* nxt = pscal + 8 + 2 * out_rec;
     double* t3 = pscal + 16;  // |r3|^2, <r1, r3>
-    const double* gam = g2 + R * P;
+    const double* gam = g2 + R * K;
     const int sa = (int)(k % 4), sb = (int)((k + 1) % 4);
     double* e1 = E.S(kScalAlpha + sa);
     double* e2 = E.S(kScalAlpha + sb);
@@ -901,24 +905,39 @@ template <typename T> struct LoopState {
     typename Engine<T>::DeferredAlpha da1, da2;
     E.apply(r2, r3, offset, e1, true, fuse_launches ? &da1 : nullptr, nullptr, rho2sq);
     timer.mark();
+    // Where the second operator kernel reads x itself (CSR-stream, lattice, dense on one GPU) it folds the three-term kernel's
+    // partial sums of |r3|^2 on the fly (ScaleIn, like the deferred normalisation of 3.3) and pair_predict_kernel folds <r1, r3>:
+    // no fold launch in between.  The PB / tiled kernels and sharded contexts want the folded scalar (all-reduced).
+    const bool fold_in_consumers = fuse_launches && E.can_defer_scale();
     int grid = launch_pair_three_term<T>(nl, r3, r2, r1, e1, da1.nparts > 0 ? da1.partials : nullptr, da1.nparts, rho2sq, rho1sq,
-                                         E.ctx->d_partials, s);
-    launch_reduce_cols(E.ctx->d_partials, grid, 1 + R, t3, nullptr, s);
-    if (E.ctx->comm != nullptr) E.all_reduce(t3, (size_t)(1 + R));  // |r3|^2 and <r1, r3> over the shards
+                                         E.ctx->d_partials, fold_in_consumers, s);
+    const int tt_grid = grid;
+    if (!fold_in_consumers) {
+      launch_reduce_cols(E.ctx->d_partials, grid, 1 + R, t3, nullptr, s);
+      if (E.ctx->comm != nullptr) E.all_reduce(t3, (size_t)(1 + R));  // |r3|^2 and <r1, r3> over the shards
+    }
     timer.mark();
     // ---- iteration k + 1: operator on r3 / |r3|; its three-term update is formed inside the sweep
     timer.mark();
-    E.apply(r3, r4, offset, e2, true, fuse_launches ? &da2 : nullptr, nullptr, t3);
+    if (fold_in_consumers) {
+      ScaleIn<T> sc;
+      sc.partials = E.ctx->d_partials;  // column 0: |r3|^2 per workgroup
+      sc.nparts = tt_grid;
+      sc.c1_out = t3;                   // the folded |r3|^2, for the predict / sweep / fold kernels
+      E.apply(r3, r4, offset, e2, true, &da2, &sc, nullptr);
+    } else {
+      E.apply(r3, r4, offset, e2, true, fuse_launches ? &da2 : nullptr, nullptr, t3);
+    }
     timer.mark();
     // ---- one sweep for both
-    launch_pair_predict((int)P, R, g1, g2, rho1sq, rho2sq, gam, t3, e1, e2, da2.nparts > 0 ? da2.partials : nullptr, da2.nparts,
-                        hist_alpha, hist_beta, pp3, pp4, s);
-    grid = launch_pair_sweep<T>(nl, groups[0], (int)P, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), g1, g2, gam, pp4, rho1sq, rho2sq,
+    launch_pair_predict((int)P, (int)Lk, R, g1, g2, rho1sq, rho2sq, gam, t3, fold_in_consumers ? E.ctx->d_partials : nullptr, tt_grid,
+                        e1, e2, da2.nparts > 0 ? da2.partials : nullptr, da2.nparts, hist_alpha, hist_beta, d_lambda, pp3, pp4, s);
+    grid = launch_pair_sweep<T>(nl, groups[0], (int)K, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), g1, g2, gam, pp4, rho1sq, rho2sq,
                                 e2, t3, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
     launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
     // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits
     if (E.ctx->comm != nullptr) E.all_reduce(pcols, (size_t)ncols);
-    launch_pair_fold(pcols, (int)P, R, pp4, g2, gam, rho2sq, t3, e1, e2, rec3, rec4, nxt, hist_alpha, hist_beta, pfold,
+    launch_pair_fold(pcols, (int)P, (int)Lk, R, d_lambda, pp4, g2, gam, rho2sq, t3, e1, e2, rec3, rec4, nxt, hist_alpha, hist_beta, pfold,
                      E.ctx->h_pinned + 4 * sa, E.ctx->h_pinned + 4 * sb, E.ctx->h_pinned + 16 + sa, E.ctx->h_pinned + 16 + sb, s);
     LL_HIP(hipEventRecord(ring.ev[sa], s));
     LL_HIP(hipEventRecord(ring.ev[sb], s));

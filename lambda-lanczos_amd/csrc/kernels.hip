@@ -795,7 +795,7 @@ __global__ __launch_bounds__(kBlock) void pair_three_term_kernel(int64_t n, T* _
                                                                  const T* __restrict__ p, double* __restrict__ e,
                                                                  const double* __restrict__ e_partials, int e_nparts,
                                                                  const double* __restrict__ cx2, const double* __restrict__ cp2,
-                                                                 double* __restrict__ partials) {
+                                                                 double* __restrict__ partials, int colmajor) {
   constexpr int EPT = strip<T>::EPT;
   constexpr int ELEMS = strip<T>::ELEMS;
   constexpr int R = scalar_traits<T>::reals;
@@ -841,14 +841,18 @@ __global__ __launch_bounds__(kBlock) void pair_three_term_kernel(int64_t n, T* _
     }
   }
   __syncthreads();
-  if (tid < 1 + R) partials[(size_t)blockIdx.x * (1 + R) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  // colmajor: column c of every workgroup contiguous (partials[c * grid + b]) — the form in which the next operator kernel
+  // (ScaleIn) and pair_predict_kernel fold the columns themselves; else [b][1 + R] for reduce_cols_kernel
+  if (tid < 1 + R)
+    partials[colmajor ? (size_t)tid * gridDim.x + blockIdx.x : (size_t)blockIdx.x * (1 + R) + tid] =
+        (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 template <typename T>
 int launch_pair_three_term(int64_t n, T* y, const T* x, const T* p, double* e, const double* e_partials, int e_nparts,
-                           const double* cx2, const double* cp2, double* partials, hipStream_t s) {
+                           const double* cx2, const double* cp2, double* partials, bool colmajor, hipStream_t s) {
   const int grid = strip_grid(n, strip<T>::ELEMS);
   hipLaunchKernelGGL((pair_three_term_kernel<T>), dim3(grid), dim3(kBlock), 0, s, n, y, x, p, e, e_partials, e_nparts, cx2, cp2,
-                     partials);
+                     partials, colmajor ? 1 : 0);
   LL_HIP(hipGetLastError());
   return grid;
 }
@@ -862,16 +866,21 @@ struct PairScalars {
   const double* rho1sq;
   const double* rho2sq;
   const double* gam;    // reals
-  const double* n3sq;   // |r3|^2, then <r1, r3> (reals) behind it
+  double* n3sq;         // |r3|^2, then <r1, r3> (reals) behind it
+  const double* d13_partials;  // nullable: column-major partials of the three-term kernel ([1 + reals][nparts]); <r1, r3> is folded
+  int d13_nparts;              // here into n3sq[1 ..] (|r3|^2 was folded by the second operator kernel, ScaleIn::c1_out)
   const double* e1;
   double* e2;
   const double* e2_partials;  // nullable: the second operator kernel's partial sums of <x3, A x3>, folded here into *e2
   int e2_nparts;
 };
-__global__ __launch_bounds__(256) void pair_predict_kernel(int P, int reals, const double* __restrict__ g1,
+// Columns: L locked eigenvectors first (A z_i = lambda_i z_i + r_i: their image is lambda_i times the coefficient, the residual
+// term is what LoopState::begin_pass gates), then the P Lanczos vectors u_0 .. u_{P-1}; K = L + P.
+__global__ __launch_bounds__(256) void pair_predict_kernel(int P, int L, int reals, const double* __restrict__ g1,
                                                            const double* __restrict__ g2, PairScalars sc,
                                                            const double* __restrict__ hist_alpha,
-                                                           const double* __restrict__ hist_beta, double* __restrict__ p3,
+                                                           const double* __restrict__ hist_beta,
+                                                           const double* __restrict__ lambda, double* __restrict__ p3,
                                                            double* __restrict__ p4) {
   __shared__ double red[4];
   __shared__ double sh[2];
@@ -886,22 +895,37 @@ __global__ __launch_bounds__(256) void pair_predict_kernel(int P, int reals, con
   } else {
     e2 = *sc.e2;
   }
+  if (sc.d13_partials) {
+    __shared__ double fold_scratch2[5];
+    for (int q = 0; q < reals; ++q) {
+      const double v = fold_partials_all(sc.d13_partials + (size_t)(1 + q) * sc.d13_nparts, sc.d13_nparts, fold_scratch2);
+      if (tid == 0) sc.n3sq[1 + q] = v;
+      __syncthreads();
+    }
+  }
   const double e1 = *sc.e1;
   const double bl = hist_beta[P - 1];  // couples u_{P-1} and u_P
+  const int K = L + P;
   // p3
-  for (int i = tid; i < reals * P; i += 256) {
-    const int j = i / reals, q = i - j * reals;
-    double t = hist_alpha[j] * g2[i];
-    if (j >= 1) t = fma(hist_beta[j - 1], g2[i - reals], t);
-    if (j + 1 < P) t = fma(hist_beta[j], g2[i + reals], t);
-    else t = fma(bl, sc.gam[q], t);
+  for (int i = tid; i < reals * K; i += 256) {
+    const int col = i / reals, q = i - col * reals;
+    double t;
+    if (col < L) {
+      t = lambda[col] * g2[i];
+    } else {
+      const int j = col - L;
+      t = hist_alpha[j] * g2[i];
+      if (j >= 1) t = fma(hist_beta[j - 1], g2[i - reals], t);
+      if (j + 1 < P) t = fma(hist_beta[j], g2[i + reals], t);
+      else t = fma(bl, sc.gam[q], t);
+    }
     t *= i2;                                     // T c2 (+ the neighbour behind the last stored vector)
     p3[i] = t - e1 * (g2[i] * i2) - rho2 * (g1[i] * i1);
   }
   __syncthreads();
   // <u_P, r3> = (<r1, r3> - g1^H p3) / rho1      (conj(g1) . p3)
   double are = 0.0, aim = 0.0;
-  for (int j = tid; j < P; j += 256) {
+  for (int j = tid; j < K; j += 256) {
     if (reals == 2) {
       const double gr = g1[2 * j], gi = g1[2 * j + 1], pr = p3[2 * j], pi = p3[2 * j + 1];
       are += gr * pr + gi * pi;
@@ -919,20 +943,27 @@ __global__ __launch_bounds__(256) void pair_predict_kernel(int P, int reals, con
     sh[1] = 0.0;
   }
   __syncthreads();
-  for (int i = tid; i < reals * P; i += 256) {
-    const int j = i / reals, q = i - j * reals;
-    double t = hist_alpha[j] * p3[i];
-    if (j >= 1) t = fma(hist_beta[j - 1], p3[i - reals], t);
-    if (j + 1 < P) t = fma(hist_beta[j], p3[i + reals], t);
-    else t = fma(bl, sh[q], t);
+  for (int i = tid; i < reals * K; i += 256) {
+    const int col = i / reals, q = i - col * reals;
+    double t;
+    if (col < L) {
+      t = lambda[col] * p3[i];
+    } else {
+      const int j = col - L;
+      t = hist_alpha[j] * p3[i];
+      if (j >= 1) t = fma(hist_beta[j - 1], p3[i - reals], t);
+      if (j + 1 < P) t = fma(hist_beta[j], p3[i + reals], t);
+      else t = fma(bl, sh[q], t);
+    }
     p4[i] = (t - e2 * p3[i]) * i3 - n3 * (g2[i] * i2);
   }
 }
-void launch_pair_predict(int P, int reals, const double* g1, const double* g2, const double* rho1sq, const double* rho2sq,
-                         const double* gam, const double* n3sq, const double* e1, double* e2, const double* e2_partials,
-                         int e2_nparts, const double* hist_alpha, const double* hist_beta, double* p3, double* p4, hipStream_t s) {
-  const PairScalars sc{rho1sq, rho2sq, gam, n3sq, e1, e2, e2_partials, e2_nparts};
-  hipLaunchKernelGGL(pair_predict_kernel, dim3(1), dim3(256), 0, s, P, reals, g1, g2, sc, hist_alpha, hist_beta, p3, p4);
+void launch_pair_predict(int P, int L, int reals, const double* g1, const double* g2, const double* rho1sq, const double* rho2sq,
+                         const double* gam, double* n3sq, const double* d13_partials, int d13_nparts, const double* e1, double* e2,
+                         const double* e2_partials, int e2_nparts, const double* hist_alpha, const double* hist_beta,
+                         const double* lambda, double* p3, double* p4, hipStream_t s) {
+  const PairScalars sc{rho1sq, rho2sq, gam, n3sq, d13_partials, d13_nparts, e1, e2, e2_partials, e2_nparts};
+  hipLaunchKernelGGL(pair_predict_kernel, dim3(1), dim3(256), 0, s, P, L, reals, g1, g2, sc, hist_alpha, hist_beta, lambda, p3, p4);
   LL_HIP(hipGetLastError());
 }
 
@@ -1117,21 +1148,27 @@ int launch_pair_sweep(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, c
 }
 
 // The fold of a pair (one workgroup).  m: the 2 R P + 5 R + 1 folded columns of the sweep.  Outputs:
-//   rec3 = g3 (R (P+2): coefficients of r3 against u_0 .. u_{P+1}),  rec4 = g4 (R (P+2)) followed by gam' = <u_{P+2}, r4>
+//   rec3 = g3 (R (K+2): coefficients of r3 against the K = L + P stored columns, u_P, u_{P+1}),  rec4 = g4 (R (K+2)) followed by
+//   gam' = <u_{P+2}, r4>
 //   nxt[0] = rho3^2, nxt[1] = rho4^2 (the next pair's rho1^2, rho2^2)
 //   hist_alpha[P+1], hist_alpha[P+2], hist_beta[P+1] = rho3, hist_beta[P+2] = rho4
 //   host slots of the two iterations (alpha, beta^2, ||w||^2 before, after) and, for each, its gate value: the largest
 //   coefficient of the iteration's raw vector relative to that vector.
-__device__ __forceinline__ double pair_tri_row(const double* __restrict__ ha, const double* __restrict__ hb, const double* v,
-                                               int i, int reals, int m, double alpha_last) {
-  // row j of (T v) for the first m Lanczos vectors; alpha_{m-1} may not be recorded yet: alpha_last
-  const int j = i / reals;
+__device__ __forceinline__ double pair_tri_row(const double* __restrict__ ha, const double* __restrict__ hb,
+                                               const double* __restrict__ lambda, const double* v, int i, int reals, int L, int m,
+                                               double alpha_last) {
+  // entry i of the image of E = sum v_col (vector col) under the operator, expressed in the same columns: lambda_col v for a
+  // locked eigenvector, row j of (T v) for the first m Lanczos vectors behind them; alpha_{m-1} may not be recorded yet
+  const int col = i / reals;
+  if (col < L) return lambda[col] * v[i];
+  const int j = col - L;
   double t = (j == m - 1 ? alpha_last : ha[j]) * v[i];
   if (j >= 1) t = fma(hb[j - 1], v[i - reals], t);
   if (j + 1 < m) t = fma(hb[j], v[i + reals], t);
   return t;
 }
-__global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict__ m, int P, int reals,
+__global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict__ m, int P, int L, int reals,
+                                                        const double* __restrict__ lambda,
                                                         const double* __restrict__ p4, const double* __restrict__ g2,
                                                         const double* __restrict__ gam, const double* __restrict__ rho2sq,
                                                         const double* __restrict__ n3sq_p, const double* __restrict__ e1p,
@@ -1144,7 +1181,8 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
   __shared__ double red[4];
   __shared__ double sh[8];
   const int tid = threadIdx.x;
-  const int RP = reals * P, M = reals * (P + 2);
+  const int K = L + P;  // stored columns: L locked eigenvectors, then u_0 .. u_{P-1}
+  const int RP = reals * K, M = reals * (K + 2);
   const double* tail = m + 2 * RP;
   const double n3sq = n3sq_p[0], n4sq = tail[5 * reals];
   // ---- g3, g4; |g3|^2, |g4|^2, g3^H g4, largest coefficients
@@ -1166,7 +1204,7 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
     mx4 = fmax(mx4, fabs(b));
   }
   __syncthreads();
-  for (int j = tid; j < P + 2; j += 256) {  // conj(g3) . g4
+  for (int j = tid; j < K + 2; j += 256) {  // conj(g3) . g4
     if (reals == 2) {
       const double ar = rec3[2 * j], ai = rec3[2 * j + 1], br = rec4[2 * j], bi = rec4[2 * j + 1];
       s34r += ar * br + ai * bi;
@@ -1207,11 +1245,12 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
   // ---- quadratic terms through the recorded tridiagonal
   //   alpha_{P+1}: v = [g2 / rho2; gam / rho2] over u_0 .. u_P     (alpha_0 .. alpha_P, beta_0 .. beta_{P-1} recorded)
   const double rho2 = sqrt(*rho2sq), i2 = 1.0 / rho2;
-  double* v = scratch;  // reals * (P + 1)
-  for (int i = tid; i < reals * (P + 1); i += 256) v[i] = (i < RP ? g2[i] : gam[i - RP]) * i2;
+  double* v = scratch;  // reals * (K + 1)
+  for (int i = tid; i < reals * (K + 1); i += 256) v[i] = (i < RP ? g2[i] : gam[i - RP]) * i2;
   __syncthreads();
   double qa = 0.0;
-  for (int i = tid; i < reals * (P + 1); i += 256) qa = fma(v[i], pair_tri_row(hist_alpha, hist_beta, v, i, reals, P + 1, hist_alpha[P]), qa);
+  for (int i = tid; i < reals * (K + 1); i += 256)
+    qa = fma(v[i], pair_tri_row(hist_alpha, hist_beta, lambda, v, i, reals, L, P + 1, hist_alpha[P]), qa);
   const double quad_a = block_sum(qa, red);
   if (tid == 0) {
     const double alpha_q = *e1p - 2.0 * gam[0] - quad_a;   // gam[0] = Re <u_P, r2>
@@ -1221,7 +1260,7 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
   __syncthreads();
   //   alpha_{P+2}: <r3, A r3> = rho3^2 alpha + 2 rho3^2 Re <u_{P+1}, r3> + <E, A E>, E = sum g3_j u_j over u_0 .. u_{P+1}
   double qb = 0.0;
-  for (int i = tid; i < M; i += 256) qb = fma(rec3[i], pair_tri_row(hist_alpha, hist_beta, rec3, i, reals, P + 2, sh[6]), qb);
+  for (int i = tid; i < M; i += 256) qb = fma(rec3[i], pair_tri_row(hist_alpha, hist_beta, lambda, rec3, i, reals, L, P + 2, sh[6]), qb);
   const double quad_b = block_sum(qb, red);
   if (tid == 0) {
     double rho3sq = n3sq - sh[0];
@@ -1231,7 +1270,7 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
     const double gim = reals == 2 ? (tail[4 * reals + 1] - sh[3]) * i3 : 0.0;
     double rho4sq = n4sq - sh[1] - (gre * gre + gim * gim);
     rho4sq = rho4sq > 0.0 ? rho4sq : 0.0;
-    const double alpha_n = rho3sq > 0.0 ? (*e2p * n3sq - 2.0 * rho3sq * rec3[reals * (P + 1)] - quad_b) / rho3sq : 0.0;
+    const double alpha_n = rho3sq > 0.0 ? (*e2p * n3sq - 2.0 * rho3sq * rec3[reals * (K + 1)] - quad_b) / rho3sq : 0.0;
     rec4[M] = gre;
     if (reals == 2) rec4[M + 1] = gim;
     nxt[0] = rho3sq;
@@ -1255,17 +1294,17 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
     *gate_b = gate4;
   }
 }
-void launch_pair_fold(const double* m, int P, int reals, const double* p4, const double* g2, const double* gam,
+void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,
                       const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
                       double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,
                       double* gate_a, double* gate_b, hipStream_t s) {
-  hipLaunchKernelGGL(pair_fold_kernel, dim3(1), dim3(256), 0, s, m, P, reals, p4, g2, gam, rho2sq, n3sq, e1, e2, rec3, rec4, nxt,
+  hipLaunchKernelGGL(pair_fold_kernel, dim3(1), dim3(256), 0, s, m, P, L, reals, lambda, p4, g2, gam, rho2sq, n3sq, e1, e2, rec3, rec4, nxt,
                      hist_alpha, hist_beta, scratch, host_a, host_b, gate_a, gate_b);
   LL_HIP(hipGetLastError());
 }
 #define LL_INST_PAIR(T)                                                                                                          \
   template int launch_pair_three_term<T>(int64_t, T*, const T*, const T*, double*, const double*, int, const double*,           \
-                                         const double*, double*, hipStream_t);                                                   \
+                                         const double*, double*, bool, hipStream_t);                                             \
   template int launch_pair_sweep<T>(int64_t, const BasisSegs<T>&, int, const T*, const T*, const T*, T*, T*, T*, const double*, \
                                     const double*, const double*, const double*, const double*, const double*, const double*,   \
                                     const double*, double*, int, hipStream_t);

@@ -462,23 +462,26 @@ template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
                   int pieces, int64_t small_limit, hipStream_t s);  // vectors below small_limit bytes: lagged_small_kernel
 // The pair form (two iterations per sweep; kernels.hip, "pair" section; tools/pair_gs_model.py is the executable specification).
-// Streaming geometry only; 2 * reals * P + 5 * reals + 1 <= kLaggedMaxCols columns per workgroup.
+// Streaming geometry only; 2 * reals * K + 5 * reals + 1 <= kLaggedMaxCols columns per workgroup (K stored columns).
 constexpr double kPairGate = 1e-8;  // largest relative coefficient the pair form accepts in double precision (second-order terms
                                     // stay below 1e-16; float storage: 2e-4, engine.cpp)
 template <typename T>
 int launch_pair_three_term(int64_t n, T* y, const T* x, const T* p, double* e, const double* e_partials, int e_nparts,
-                           const double* cx2, const double* cp2, double* partials,
-                           hipStream_t s);  // y <- y - (e / sqrt(cx2)) x - sqrt(cx2 / cp2) p; partials [grid][1 + reals]: |y|^2, <p, y>;
-                                            // e_partials (nullable): the operator kernel's partial sums of e, folded here into *e
-void launch_pair_predict(int P, int reals, const double* g1, const double* g2, const double* rho1sq, const double* rho2sq,
-                         const double* gam, const double* n3sq, const double* e1, double* e2, const double* e2_partials,
-                         int e2_nparts, const double* hist_alpha, const double* hist_beta, double* p3, double* p4, hipStream_t s);
+                           const double* cx2, const double* cp2, double* partials, bool colmajor,
+                           hipStream_t s);  // y <- y - (e / sqrt(cx2)) x - sqrt(cx2 / cp2) p; partials [grid][1 + reals] (colmajor:
+                                            // [1 + reals][grid]): |y|^2, <p, y>; e_partials (nullable): the operator kernel's
+                                            // partial sums of e, folded here into *e
+// P Lanczos vectors behind L locked eigenvectors (eigenvalues lambda[0..L) of the operator the loop applies): K = L + P columns
+void launch_pair_predict(int P, int L, int reals, const double* g1, const double* g2, const double* rho1sq, const double* rho2sq,
+                         const double* gam, double* n3sq, const double* d13_partials, int d13_nparts, const double* e1, double* e2,
+                         const double* e2_partials, int e2_nparts, const double* hist_alpha, const double* hist_beta,
+                         const double* lambda, double* p3, double* p4, hipStream_t s);
 // r4 holds y2 = A (r3 / |r3|) on entry; the sweep forms r4 = y2 - (e2 / |r3|) r3 - (|r3| / rho2) r2 on the fly
 template <typename T>
 int launch_pair_sweep(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
                       T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
                       const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces, hipStream_t s);
-void launch_pair_fold(const double* m, int P, int reals, const double* p4, const double* g2, const double* gam,
+void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,
                       const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
                       double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,
                       double* gate_a, double* gate_b, hipStream_t s);

@@ -1210,10 +1210,30 @@ constexpr int kTlXmaxParts = 512;
 constexpr int kTlDepth = 3;
 
 template <typename T>
-__global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ parts) {
+__global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ parts, int aligned) {
   __shared__ double red[4];
+  constexpr int V = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  constexpr int U = 4;                     // pieces per lane and trip, all requested before the first is used
   double m = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmax(m, abs1(x[i]));
+  const long long nv = aligned ? n / V : 0;  // whole pieces (the vector is 16-byte aligned)
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += U * stride) {
+    uint4 piece[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = i0 + u * stride;
+      piece[u] = x4[i < nv ? i : nv - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      T el[V];
+      __builtin_memcpy(el, &piece[u], sizeof(uint4));
+#pragma unroll
+      for (int q = 0; q < V; ++q) m = fmax(m, abs1(el[q]));
+    }
+  }
+  for (long long i = nv * V + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmax(m, abs1(x[i]));
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1439,7 +1459,8 @@ int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, do
   if (op.tl_nrb <= 0) return 0;
   tl_opt_in_lds<T>();
   const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>(kTlXmaxParts, (op.n + 255) / 256));
-  hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(xgrid), dim3(256), 0, s, (long long)op.n, x, op.d_tl_xmax);
+  hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(xgrid), dim3(256), 0, s, (long long)op.n, x, op.d_tl_xmax,
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0);
   // 16-byte pieces of x: the fast form needs an aligned vector of at least one piece
   const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && op.n >= (int64_t)(16 / sizeof(T));
   if (aligned)

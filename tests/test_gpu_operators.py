@@ -11,6 +11,7 @@ import pytest
 
 import cases
 import lambda_lanczos_amd as L
+from lambda_lanczos_amd import _capi as capi
 from lambda_lanczos_amd import generators as G
 from util import overlap
 
@@ -284,3 +285,71 @@ def test_dense_known_answers(ctx, name):
         assert abs(vals[r] - want) <= max(abs(want) * eng.eps, 1e-8 if eng.eps > 1e-8 else 0.0)
         assert 1 - overlap(vecs[r], case["vectors"][r]) <= max(100 * eng.eps, 1e-12)
     op.close()
+
+
+# ------------------------------------------------------------------ the 2-D tiled SpMV kernel inside the loops
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["d", "s"])
+def test_lanczos_on_the_tiled_kernel_matches_the_oracle(ctx, oracle, dtype):
+    """A banded matrix (n = 2e5, columns within +-300: eligible for the tiled kernel on its own, no test hook), the kernel
+    chosen through ll_csr_options.kernel: a 60-iteration LambdaLanczos window in the default geometry — 1.6 MB vectors, i.e. the
+    two-iterations-per-sweep form, whose operator inputs are UNNORMALISED vectors the kernel scales while it stages its x tiles —
+    against the oracle (alpha / beta, Ritz pair), plus ll_spmv on an unaligned x pointer (the scalar staging path)."""
+    n = 200_000
+    rp, ci, va = G.randsym(n, band=300)
+    va = va.astype(dtype)
+    csr = (rp, ci, va)
+    op = L.CsrOperator(ctx, *csr, kernel=capi.SPMV_TILED)
+    assert op.selected_spmv() == capi.SPMV_TILED and op.accuracy() == capi.ACCURACY_NORMWISE
+    init = G.start_vector(n, 1).astype(dtype)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.max_iteration = 60
+    eng.init_vector = lambda v, *_: np.copyto(v, init)
+    vals, vecs = eng.run()
+    wide = (rp, ci, va.astype(np.float64))
+    ora = oracle.lanczos(wide, init.astype(np.float64), True, max_iteration=60)
+    single = dtype == np.float32
+    tol = 2e-4 if single else 1e-10
+    m = 12 if single else 60
+    assert eng.getIterationCounts() == [60]
+    assert np.max(np.abs(eng.last_alpha[:m] - ora["alpha"][:m])) <= tol * 30
+    assert np.max(np.abs(eng.last_beta[:m - 1] - ora["beta"][:m - 1])) <= tol * 30
+    assert abs(vals[0] - ora["eigenvalues"][0]) <= (2e-3 if single else 1e-10) * abs(vals[0])
+    assert 1 - overlap(vecs[0].astype(np.float64), ora["eigenvectors"][0]) <= (1e-4 if single else 1e-8)
+    if not single:
+        assert eng.last_stats["pair_iterations"] >= 56
+    # unaligned input pointer: x one element into a buffer
+    x = G.start_vector(n + 1, 5).astype(dtype)
+    xd, yd = ctx.to_device(x), ctx.empty(n, dtype)
+    import types
+    dot = L.spmv(op, types.SimpleNamespace(ptr=xd.at(1).value), yd, offset=-0.75, want_dot=True)
+    y_ref = oracle.spmv(wide, x[1:].astype(np.float64)) - 0.75 * x[1:].astype(np.float64)
+    assert np.max(np.abs(yd.get().astype(np.float64) - y_ref)) <= (3e-6 if single else 1e-13) * 40
+    assert abs(dot - float(x[1:].astype(np.float64) @ y_ref)) <= (1e-5 if single else 1e-11) * n
+    op.close()
+
+
+def test_exponentiator_on_the_tiled_kernel_matches_the_oracle(ctx, oracle, llenv):
+    """Complex Hermitian torus 200 x 200 (config 5's matrix in small) through the tiled kernel (forced for this small matrix:
+    LL_TL_FORCE): exp(-iH) v against the oracle's Exponentiator::run."""
+    llenv.setenv("LL_TL_FORCE", "1")
+    N = 200
+    csr = G.torus(N)
+    op = L.CsrOperator(ctx, *csr, kernel=capi.SPMV_TILED)
+    assert op.selected_spmv() == capi.SPMV_TILED
+    inp = G.start_vector(N * N, 1, np.complex128)
+    out, it = L.Exponentiator(op, N * N).run(-1j, inp)
+    o_out, o_it, _ = oracle.expo(csr, -1j, inp)
+    assert abs(it - o_it) <= 1
+    assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(inp)
+    op.close()
+
+
+def test_a_matrix_without_column_locality_is_not_eligible_for_the_tiled_kernel(ctx):
+    """The random matrix of config 3 in small: its row blocks touch every column tile — the creation-time timing must not even
+    consider the tiled kernel, and asking for it by name is an error, not a silent fallback."""
+    csr = G.randsym(400_000)
+    op = L.CsrOperator(ctx, *csr)
+    assert op.selected_spmv() in (capi.SPMV_CSR_STREAM, capi.SPMV_PB) and op.autotune_ms_of(capi.SPMV_TILED) < 0
+    op.close()
+    with pytest.raises(L.LanczosHipError):
+        L.CsrOperator(ctx, *csr, kernel=capi.SPMV_TILED)
