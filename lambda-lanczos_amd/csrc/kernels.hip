@@ -976,11 +976,10 @@ __device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, 
                                           const double* __restrict__ g2c, const double* __restrict__ p4c, double* mine3,
                                           double* mine4, int lane) {
   constexpr int EPT = lstrip<T, PC>::EPT;
-  constexpr int R = scalar_traits<T>::reals;
   T ur[NV][EPT];
 #pragma unroll
   for (int b = 0; b < NV; ++b) load_lstrip<T, PC>(u0 + (int64_t)b * ld, base, n, ur[b]);
-  double a[2 * NV * R];
+  double a3[NV], a4[NV], a3i[NV], a4i[NV];  // (imaginary parts: complex types only)
 #pragma unroll
   for (int b = 0; b < NV; ++b) {
     acc_t<T> c1, c2, c4;  // wave-uniform addresses in read-only memory: scalar loads
@@ -1003,21 +1002,36 @@ __device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, 
       cfma_acc(s4, ur[b][e], b4r[e]);
     }
     if constexpr (scalar_traits<T>::is_complex) {
-      a[2 * b] = s3.re;
-      a[2 * b + 1] = s3.im;
-      a[NV * R + 2 * b] = s4.re;
-      a[NV * R + 2 * b + 1] = s4.im;
+      a3[b] = s3.re;
+      a3i[b] = s3.im;
+      a4[b] = s4.re;
+      a4i[b] = s4.im;
     } else {
-      a[b] = s3;
-      a[NV * R + b] = s4;
+      a3[b] = s3;
+      a4[b] = s4;
+      a3i[b] = a4i[b] = 0.0;
     }
   }
-  wave_sum_transposed<2 * NV * R>(a, lane);
-  constexpr int LPI = 64 / (2 * NV * R);  // lanes that end up holding the same sum; sums 0 .. NV*R-1: r3, the rest: r4
-  if ((lane & (LPI - 1)) == 0) {
-    const int c = lane / LPI;
-    if (c < NV * R) mine3[c] += a[0];
-    else mine4[c - NV * R] += a[0];
+  // (transposed reductions of at most NV = 4 sums each: with 8 or 16 sums at once the compiler sends part of the array through
+  // scratch memory — a round trip with a full drain of the memory pipeline in every trip; checked in the ISA)
+  wave_sum_transposed<NV>(a3, lane);
+  wave_sum_transposed<NV>(a4, lane);
+  constexpr int LPI = 64 / NV;  // lanes that end up holding the same sum
+  if constexpr (scalar_traits<T>::is_complex) {
+    wave_sum_transposed<NV>(a3i, lane);
+    wave_sum_transposed<NV>(a4i, lane);
+    if ((lane & (LPI - 1)) == 0) {
+      const int b = lane / LPI;
+      mine3[2 * b] += a3[0];
+      mine3[2 * b + 1] += a3i[0];
+      mine4[2 * b] += a4[0];
+      mine4[2 * b + 1] += a4i[0];
+    }
+  } else {
+    if ((lane & (LPI - 1)) == 0) {
+      mine3[lane / LPI] += a3[0];
+      mine4[lane / LPI] += a4[0];
+    }
   }
 }
 

@@ -42,3 +42,12 @@ def test_beyond_the_gate_one_beta_carries_a_second_order_term_but_the_basis_stay
     r = model.measure(False, 1e-3, n=1500, K=120)
     assert 1e-8 <= r["dbeta"] <= 1e-3
     assert r["dvec"] <= 1e-12 and r["orth"] <= 1e-14 and r["fold_rho"] <= 1e-13
+
+
+@pytest.mark.parametrize("complex_,locked", [(False, 3), (True, 2)], ids=["real-3-locked", "complex-2-locked"])
+def test_pair_form_behind_locked_eigenvectors(model, complex_, locked):
+    """A restart pass (LL:233,259): the locked eigenvectors are the first stored columns of every sweep; their image under the
+    operator is lambda_i times the coefficient — in the prediction and in the quadratic forms of the alphas."""
+    r = model.measure(complex_, 0.0, n=1200, K=100, locked=locked)
+    assert r["dalpha"] <= 1e-12 and r["dbeta"] <= 1e-12 and r["dvec"] <= 1e-12 and r["orth"] <= 1e-13
+    assert r["maxcoef"] <= 1e-12

@@ -8,12 +8,12 @@ State between sweeps (P stored, complete, orthonormal vectors S = u_0 .. u_{P-1}
     r1 -> u_P      raw, with measured g1 = S^H r1, rho1 = sqrt(|r1|^2 - |g1|^2)
     r2 -> u_{P+1}  raw, with measured g2 = S^H r2, gam = <u_P, r2> = (<r1, r2> - g1^H g2) / rho1,
                    rho2 = sqrt(|r2|^2 - |g2|^2 - |gam|^2)
-One pair = two operator applications on RAW vectors, two three-term kernels over raw vectors, one small predict kernel, ONE
-sweep over S and one fold:
+One pair = two operator applications on RAW vectors, one three-term kernel over raw vectors (the second three-term update is
+formed inside the sweep, from strips it reads anyway), one small predict kernel, ONE sweep over S and one fold:
     y1 = A x2,  x2 = r2 / rho2                 e1 = <x2, y1>            (operator kernel, fused dot)
     r3 = y1 - e1 x2 - rho2 x1,  x1 = r1 / rho1                          (pair_three_term; also |r3|^2)
     y2 = A x3,  x3 = r3 / n3,  n3 = |r3|       e2 = <x3, y2>
-    r4 = y2 - e2 x3 - n3 x2                                             (pair_three_term)
+    r4 = y2 - e2 x3 - n3 x2                                             (inside the sweep)
     predict S^H r3, S^H r4 through the recorded tridiagonal                (pair_predict: eps-sized numbers)
     sweep: u_P = (r1 - S g1) / rho1, u_{P+1} = (r2 - S g2 - gam u_P) / rho2   -> stored
            m3 = S^H r3, m4 = S^H r4 (raw), r4 -= S pred4 (compensation of the NEXT operator input)
@@ -40,8 +40,8 @@ def make_problem(n, complex_, seed=3):
     return A, v0 / np.linalg.norm(v0)
 
 
-def reference(A, v0, K):
-    """Full re-orthogonalisation, sequential (the reference's loop, LL:216-322)."""
+def reference(A, v0, K, Z=None):
+    """Full re-orthogonalisation, sequential (the reference's loop, LL:216-322; Z: locked eigenvectors, LL:259)."""
     n = v0.shape[0]
     U = np.zeros((K + 1, n), dtype=v0.dtype)
     U[0] = v0
@@ -52,6 +52,8 @@ def reference(A, v0, K):
         w = w - a * U[k - 1]
         if k > 1:
             w = w - be[-1] * U[k - 2]
+        for z in (Z if Z is not None else ()):
+            w = w - np.vdot(z, w) * z
         for j in range(k):
             w = w - np.vdot(U[j], w) * U[j]
         b = np.linalg.norm(w)
@@ -61,32 +63,46 @@ def reference(A, v0, K):
     return np.array(al), np.array(be), U
 
 
-def tri_apply(al, be, v, extra=None):
-    """(T v) for the recorded tridiagonal on len(v) vectors; extra = (coefficient on the vector BEHIND the last one, its
-    coupling beta) adds that neighbour's contribution to the last row."""
-    m = len(v)
-    out = np.asarray(al[:m]) * v
+def tri_apply(al, be, v, extra=None, lam=()):
+    """The image of E = sum v_col (stored column col) under the operator, in the same columns: lam_i v_i for the len(lam) locked
+    EIGENvectors in front (A z_i = lam_i z_i up to their residual), (T v) through the recorded tridiagonal for the Lanczos vectors
+    behind them; extra = (coefficient on the vector BEHIND the last one, its coupling beta) adds that neighbour's contribution to
+    the last row."""
+    L = len(lam)
+    out = np.empty_like(v)
+    out[:L] = np.asarray(lam) * v[:L]
+    w = v[L:]
+    m = len(w)
+    t = np.asarray(al[:m]) * w
     if m > 1:
-        out[1:] += np.asarray(be[:m - 1]) * v[:-1]
-        out[:-1] += np.asarray(be[:m - 1]) * v[1:]
+        t[1:] += np.asarray(be[:m - 1]) * w[:-1]
+        t[:-1] += np.asarray(be[:m - 1]) * w[1:]
     if extra is not None:
-        out[m - 1] += extra[1] * extra[0]
+        t[m - 1] += extra[1] * extra[0]
+    out[L:] = t
     return out
 
 
-def quad(al, be, v):
-    """Re <E, A E> for E = sum_j v_j u_j over the first len(v) Lanczos vectors (through T: second order in eps)."""
-    return np.vdot(v, tri_apply(al, be, v)).real
+def quad(al, be, v, lam=()):
+    """Re <E, A E> for E = sum v_col (stored column col): locked eigenvectors, then the first Lanczos vectors (through T: second
+    order in eps)."""
+    return np.vdot(v, tri_apply(al, be, v, lam=lam)).real
 
 
 class PairLoop:
     """The device loop.  Vectors are numpy arrays here; every method below is one kernel launch (or one fold) of the device code."""
 
-    def __init__(self, A, v0, K, plant=0.0):
+    def __init__(self, A, v0, K, plant=0.0, Z=None, lam=()):
+        """Z (L x n), lam: locked eigenpairs of a restart pass (LL:233,259): the start vector is orthogonal to them, every Lanczos
+        vector is kept orthogonal to them; they are the first L stored columns of every sweep."""
         self.A, self.K, self.plant = A, K, plant
         n = v0.shape[0]
-        self.S = np.zeros((K + 6, n), dtype=v0.dtype)
-        self.S[0] = v0
+        self.L = 0 if Z is None else len(Z)
+        self.lam = tuple(lam)
+        self.S = np.zeros((self.L + K + 6, n), dtype=v0.dtype)
+        if self.L:
+            self.S[:self.L] = Z
+        self.S[self.L] = v0
         self.P = 1
         self.al, self.be = [], []
         self.maxcoef = 0.0
@@ -94,11 +110,12 @@ class PairLoop:
 
     # ---- entry: two clean iterations (device: the clean / one-sweep iterations that precede the first pair leave the same state)
     def start(self):
-        A, S = self.A, self.S
-        y = A @ S[0]
-        a0 = np.vdot(S[0], y).real
-        w = y - a0 * S[0]
-        w = w - np.vdot(S[0], w) * S[0]
+        A, S, L = self.A, self.S, self.L
+        K1 = L + 1                                   # stored columns: the locked vectors and u_0
+        y = A @ S[L]
+        a0 = np.vdot(S[L], y).real
+        w = y - a0 * S[L]
+        w = w - (S[:K1].conj() @ w) @ S[:K1]
         b0 = np.linalg.norm(w)
         u1 = w / b0
         self.al.append(a0)
@@ -106,20 +123,21 @@ class PairLoop:
         # pending raw pair: r1 = u1 (already complete: g1 = 0 up to rounding, rho1 = 1), r2 = raw w of iteration 2
         y = A @ u1
         e = np.vdot(u1, y).real
-        r2 = y - e * u1 - b0 * S[0]
+        r2 = y - e * u1 - b0 * S[L]
         self.r1, self.r2 = u1.copy(), r2
-        self.g1 = S[:1].conj() @ self.r1
-        self.g2 = S[:1].conj() @ self.r2
+        self.g1 = S[:K1].conj() @ self.r1
+        self.g2 = S[:K1].conj() @ self.r2
         self.rho1 = np.sqrt(np.vdot(self.r1, self.r1).real - np.vdot(self.g1, self.g1).real)
         self.gam = (np.vdot(self.r1, self.r2) - np.vdot(self.g1, self.g2)) / self.rho1
         self.rho2 = np.sqrt(np.vdot(self.r2, self.r2).real - np.vdot(self.g2, self.g2).real - abs(self.gam) ** 2)
         # alpha of u_1: e = <u1, A u1> exactly (u1 complete)
         self.al.append(e)
         self.be.append(self.rho2)
-        # now: P = 1 stored; al = [alpha_0, alpha_1], be = [beta_0 (u0-u1), beta_1 = rho2 (u1-u2)]
+        # now: P = 1 stored Lanczos vector; al = [alpha_0, alpha_1], be = [beta_0 (u0-u1), beta_1 = rho2 (u1-u2)]
 
     def pair(self):
-        A, S, P = self.A, self.S, self.P
+        A, S, P, L, lam = self.A, self.S, self.P, self.L, self.lam
+        Kc = L + P                                   # stored columns of this sweep
         al, be = self.al, self.be
         r1, r2, g1, g2, rho1, rho2, gam = self.r1, self.r2, self.g1, self.g2, self.rho1, self.rho2, self.gam
         # ---- operator 1 (input r2 / rho2, fused dot) + three-term 1
@@ -131,30 +149,30 @@ class PairLoop:
         n3sq = np.vdot(r3, r3).real                 # (partial sums of the three-term kernel)
         d13 = np.vdot(r1, r3)                       # <r1, r3>: the same kernel reads r1 anyway
         n3 = np.sqrt(n3sq)
-        # ---- operator 2 (input r3 / n3) + three-term 2
+        # ---- operator 2 (input r3 / n3); its three-term update is formed inside the sweep on the device
         x3 = r3 / n3
         y2 = A @ x3
         e2 = np.vdot(x3, y2).real
         r4 = y2 - e2 * x3 - n3 * x2
-        # ---- predict (small kernel): stored-basis components of r3 and r4 from those of r1, r2 through T
+        # ---- predict (small kernel): stored-column components of r3 and r4 from those of r1, r2 through T (and lam)
         c1, c2 = g1 / rho1, g2 / rho2               # S^H x1, S^H x2
         uP_x2 = gam / rho2                          # <u_P, x2>
-        Sy1 = tri_apply(al, be, c2, extra=(uP_x2, be[P - 1]))      # S^H A x2 (only S and u_P reach back into S)
+        Sy1 = tri_apply(al, be, c2, extra=(uP_x2, be[P - 1]), lam=lam)   # S^H A x2 (only S and u_P reach back into S)
         p3 = Sy1 - e1 * c2 - rho2 * c1              # predicted S^H r3
         uP_r3 = (d13 - np.vdot(g1, p3)) / rho1      # predicted <u_P, r3>
-        Sy2 = tri_apply(al, be, p3 / n3, extra=(uP_r3 / n3, be[P - 1]))
+        Sy2 = tri_apply(al, be, p3 / n3, extra=(uP_r3 / n3, be[P - 1]), lam=lam)
         p4 = Sy2 - e2 * p3 / n3 - n3 * c2           # predicted S^H r4
         # ---- ONE sweep over S
-        uP = (r1 - g1 @ S[:P]) / rho1
-        uQ = (r2 - g2 @ S[:P] - gam * uP) / rho2
-        m3 = S[:P].conj() @ r3
-        m4 = S[:P].conj() @ r4
+        uP = (r1 - g1 @ S[:Kc]) / rho1
+        uQ = (r2 - g2 @ S[:Kc] - gam * uP) / rho2
+        m3 = S[:Kc].conj() @ r3
+        m4 = S[:Kc].conj() @ r4
         if self.plant and P == 21:                  # test: a known perturbation along stored vectors in the next operator input
-            pert = self.plant * np.linalg.norm(r4) * (S[3] - S[7] + 0.5 * S[P - 1])
+            pert = self.plant * np.linalg.norm(r4) * (S[L + 3] - S[L + 7] + 0.5 * S[Kc - 1])
             r4 = r4 + pert
-            m4 = m4 + S[:P].conj() @ pert
-        r4 = r4 - p4 @ S[:P]                        # compensation: the next operator input carries fresh rounding only
-        S[P], S[P + 1] = uP, uQ
+            m4 = m4 + S[:Kc].conj() @ pert
+        r4 = r4 - p4 @ S[:Kc]                       # compensation: the next operator input carries fresh rounding only
+        S[Kc], S[Kc + 1] = uP, uQ
         tail3 = np.array([np.vdot(uP, r3), np.vdot(uQ, r3)])
         tail4 = np.array([np.vdot(uP, r4), np.vdot(uQ, r4)])
         n4sq = np.vdot(r4, r4).real
@@ -165,38 +183,46 @@ class PairLoop:
         self.maxcoef = max(self.maxcoef, np.abs(g4).max() / np.sqrt(n4sq), np.abs(g3).max() / n3)
         #   alpha of u_{P+1}: e1 = alpha + 2 Re <eps, A u_{P+1}> + <eps, A eps>, eps = (S g2 + gam u_P) / rho2
         v = np.concatenate([c2, [uP_x2]])
-        alpha_q = e1 - 2.0 * gam.real - quad(al, be, v)
+        alpha_q = e1 - 2.0 * gam.real - quad(al, be, v, lam)
         al.append(alpha_q)
         rho3 = np.sqrt(n3sq - np.vdot(g3, g3).real)
         be.append(rho3)                             # couples u_{P+1} and u_{P+2}
         #   alpha of u_{P+2}: <r3, A r3> = rho3^2 alpha + 2 rho3^2 Re <u_{P+1}, r3> + <E, A E>, E = S_new g3
-        alpha_n = (e2 * n3sq - 2.0 * rho3 * rho3 * g3[-1].real - quad(al, be, g3)) / (rho3 * rho3)
+        alpha_n = (e2 * n3sq - 2.0 * rho3 * rho3 * g3[-1].real - quad(al, be, g3, lam)) / (rho3 * rho3)
         al.append(alpha_n)
         gam_n = (d34 - np.vdot(g3, g4)) / rho3
         rho4 = np.sqrt(n4sq - np.vdot(g4, g4).real - abs(gam_n) ** 2)
         be.append(rho4)
         # ---- self-check of the folded quantities against the directly computed truth (model only)
-        Pn = P + 2
-        proj = lambda w: w - (S[:Pn].conj() @ w) @ S[:Pn]
+        Kn = Kc + 2
+        proj = lambda w: w - (S[:Kn].conj() @ w) @ S[:Kn]
         t3 = proj(r3)
         self.checks.append((abs(np.linalg.norm(t3) - rho3), abs(np.vdot(t3 / np.linalg.norm(t3), r4) - gam_n)))
-        self.P = Pn
+        self.P = P + 2
         self.r1, self.r2, self.g1, self.g2, self.rho1, self.rho2, self.gam = r3, r4, g3, g4, rho3, rho4, gam_n
 
     def flush(self):
         """Leave the pair form: complete the two pending vectors with their measured coefficients (device: two multi-axpys)."""
-        S, P = self.S, self.P
-        uP = (self.r1 - self.g1 @ S[:P]) / self.rho1
-        uQ = (self.r2 - self.g2 @ S[:P] - self.gam * uP) / self.rho2
-        S[P], S[P + 1] = uP, uQ
+        S, P, Kc = self.S, self.P, self.L + self.P
+        uP = (self.r1 - self.g1 @ S[:Kc]) / self.rho1
+        uQ = (self.r2 - self.g2 @ S[:Kc] - self.gam * uP) / self.rho2
+        S[Kc], S[Kc + 1] = uP, uQ
         self.P = P + 2
 
 
-def measure(complex_, plant, n=4000, K=260):
-    """Run the pair loop and the reference on the same problem; the numbers the statements of DESIGN.md 3.2 rest on."""
+def measure(complex_, plant, n=4000, K=260, locked=0):
+    """Run the pair loop and the reference on the same problem; the numbers the statements of DESIGN.md 3.2 rest on.
+    locked: that many converged eigenpairs (the largest) are locked like in a restart pass."""
     A, v0 = make_problem(n, complex_)
-    ra, rb, RU = reference(A, v0, K)
-    L = PairLoop(A, v0, K, plant)
+    Z, lam = None, ()
+    if locked:
+        w, V = np.linalg.eigh(A.toarray())
+        Z = np.ascontiguousarray(V[:, -locked:].T).astype(v0.dtype)
+        lam = tuple(w[-locked:])
+        v0 = v0 - (Z.conj() @ v0) @ Z
+        v0 = v0 / np.linalg.norm(v0)
+    ra, rb, RU = reference(A, v0, K, Z)
+    L = PairLoop(A, v0, K, plant, Z, lam)
     L.start()
     while len(L.al) + 2 <= K:
         L.pair()
@@ -204,16 +230,16 @@ def measure(complex_, plant, n=4000, K=260):
     a, b = np.array(L.al), np.array(L.be)
     m = min(len(a), K)
     mb = m - 1
-    S = L.S[:L.P]
+    S = L.S[:L.L + L.P]
     chk = np.array(L.checks)
     return dict(iterations=m, dalpha=np.abs(a[:m] - ra[:m]).max(), dbeta=np.abs(b[:mb] - rb[:mb]).max(),
                 orth=np.abs(S.conj() @ S.T - np.eye(len(S))).max(),
-                dvec=max(np.linalg.norm(S[j] - RU[j]) for j in range(min(len(S), K))),   # same sign convention: positive beta
+                dvec=max(np.linalg.norm(S[L.L + j] - RU[j]) for j in range(min(L.P, K))),   # same sign convention: positive beta
                 maxcoef=L.maxcoef, fold_rho=chk[:, 0].max(), fold_gam=chk[:, 1].max())
 
 
-def run(label, complex_, plant, n=4000, K=260):
-    r = measure(complex_, plant, n, K)
+def run(label, complex_, plant, n=4000, K=260, locked=0):
+    r = measure(complex_, plant, n, K, locked)
     return ["%s: %d iterations" % (label, r["iterations"]),
             "  max|dalpha| %.2e  max|dbeta| %.2e  (tolerance 1e-10 ||A|| = 1.2e-09);  max|S^H S - I| %.2e;  max|u_j - u_j(ref)| %.2e" % (
                 r["dalpha"], r["dbeta"], r["orth"], r["dvec"]),
@@ -223,6 +249,8 @@ def run(label, complex_, plant, n=4000, K=260):
 
 def main():
     out = ["two-iterations-per-sweep Gram-Schmidt, kernel-structured model (tools/pair_gs_model.py); n = 4000, 260 iterations"]
+    out += run("real symmetric, restart pass with 3 locked eigenvectors (n = 1500, 160 iterations)", False, 0.0, 1500, 160, 3)
+    out += run("complex Hermitian, 2 locked eigenvectors (n = 1500, 160 iterations)", True, 0.0, 1500, 160, 2)
     for label, cplx, plant in (("real symmetric", False, 0.0), ("complex Hermitian", True, 0.0),
                                ("real, components of relative size 1e-8 planted in one operator input", False, 1e-8),
                                ("real, 1e-6 planted", False, 1e-6), ("real, 1e-3 planted", False, 1e-3),
