@@ -122,6 +122,10 @@ template <typename T, int D> struct ColStream {  // phase 1: (4 values, 4 local 
     consume(v[PH], c[PH], cur + (threadIdx.x & 63));
     return true;
   }
+  // (Measured and rejected in round 5: TWO rounds of the ring per loop iteration.  The waitcnt pass merges the pending loads of
+  // the loop's two entries conservatively at its header, which costs a full drain in the first trip behind it — once per D
+  // trips; with two rounds per iteration it is once per 2 D, yet config 3's SpMV came out 1 % slower on the same box,
+  // 0.911 against 0.899 ms, profiles/r05_pb_ring_two_rounds_ab.txt: the other 15 waves of the workgroup cover the drain.)
   template <typename F> __device__ __forceinline__ void run(F&& consume) {
     static_assert(D >= 2 && D <= 4, "pipeline depth");
     for (;;) {
@@ -1208,6 +1212,9 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 constexpr int kTlTileBytes = 16 * 1024;  // one x tile: one 16-byte piece per lane of the workgroup
 constexpr int kTlXmaxParts = 512;
 constexpr int kTlDepth = 3;
+#ifndef LL_TL_ROUNDS
+#define LL_TL_ROUNDS 2  // rounds of the ring per loop iteration of tl_spmv_kernel (A/B builds: -DLL_TL_ROUNDS=1)
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ parts, int aligned) {
@@ -1410,6 +1417,8 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     tile_start = cur.t != t_before;
     return true;
   };
+  // (Two rounds of the ring per loop iteration: the waitcnt pass merges the pending loads of the prologue and of the back edge
+  // conservatively at the loop header, which costs a full drain in the FIRST trip behind it — once per 2 D trips this way.)
   for (;;) {
     if (!step(std::integral_constant<int, 0>{})) break;
     if (!step(std::integral_constant<int, 1>{})) break;
@@ -1418,6 +1427,16 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     }
     if constexpr (D > 3) {
       if (!step(std::integral_constant<int, 3>{})) break;
+    }
+    if constexpr (sizeof(T) <= 8 && LL_TL_ROUNDS > 1) {  // (16-byte values: the second copy of the ring's code spills registers)
+      if (!step(std::integral_constant<int, 0>{})) break;
+      if (!step(std::integral_constant<int, 1>{})) break;
+      if constexpr (D > 2) {
+        if (!step(std::integral_constant<int, 2>{})) break;
+      }
+      if constexpr (D > 3) {
+        if (!step(std::integral_constant<int, 3>{})) break;
+      }
     }
   }
   __syncthreads();

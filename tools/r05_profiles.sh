@@ -35,7 +35,8 @@ if has pmc; then
       mkdir -p "$OUT/pmc_$name"
       [ -n "$f" ] && cp "$f" "$OUT/pmc_$name/${tag}_counter_collection.csv"
     done
-    python3 tools/pmc_summary.py "$OUT/pmc_$name" "$OUT/r05_${name}_pmc_traffic.json" 10000000 3 | tail -14
+    # windows of 100 iterations the profiled command runs: warmup 1 + steps 2, and the same three through the other I/O boundary
+    python3 tools/pmc_summary.py "$OUT/pmc_$name" "$OUT/r05_${name}_pmc_traffic.json" 10000000 6 | tail -14
   done
 fi
 rm -rf "$OUT"/raw_* "$OUT"/pmc_*/pmc_*_counter_collection.csv   # keep the summaries only (gpurun_out is capped)
