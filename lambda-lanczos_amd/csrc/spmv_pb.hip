@@ -1212,9 +1212,6 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 constexpr int kTlTileBytes = 16 * 1024;  // one x tile: one 16-byte piece per lane of the workgroup
 constexpr int kTlXmaxParts = 512;
 constexpr int kTlDepth = 3;
-#ifndef LL_TL_ROUNDS
-#define LL_TL_ROUNDS 2  // rounds of the ring per loop iteration of tl_spmv_kernel (A/B builds: -DLL_TL_ROUNDS=1)
-#endif
 
 template <typename T>
 __global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ parts, int aligned) {
@@ -1417,8 +1414,10 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     tile_start = cur.t != t_before;
     return true;
   };
-  // (Two rounds of the ring per loop iteration: the waitcnt pass merges the pending loads of the prologue and of the back edge
-  // conservatively at the loop header, which costs a full drain in the FIRST trip behind it — once per 2 D trips this way.)
+  // (The waitcnt pass merges the pending loads of the prologue and of the back edge conservatively at the loop header: the FIRST
+  // trip behind it drains the memory pipeline, one trip in D.  Two rounds of the ring per loop iteration halve that and change
+  // nothing measurable — 0.548 against 0.550 ms on the banded config 3, profiles/r05_tl_ring_two_rounds_ab.txt: the other waves
+  // of the workgroup cover the drain — so the loop keeps one round.)
   for (;;) {
     if (!step(std::integral_constant<int, 0>{})) break;
     if (!step(std::integral_constant<int, 1>{})) break;
@@ -1427,16 +1426,6 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     }
     if constexpr (D > 3) {
       if (!step(std::integral_constant<int, 3>{})) break;
-    }
-    if constexpr (sizeof(T) <= 8 && LL_TL_ROUNDS > 1) {  // (16-byte values: the second copy of the ring's code spills registers)
-      if (!step(std::integral_constant<int, 0>{})) break;
-      if (!step(std::integral_constant<int, 1>{})) break;
-      if constexpr (D > 2) {
-        if (!step(std::integral_constant<int, 2>{})) break;
-      }
-      if constexpr (D > 3) {
-        if (!step(std::integral_constant<int, 3>{})) break;
-      }
     }
   }
   __syncthreads();

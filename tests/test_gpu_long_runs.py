@@ -229,14 +229,19 @@ def test_one_sweep_form_in_restart_passes_matches_the_reference(ctx):
 
 
 # ------------------------------------------------------------------ the STREAMING one-sweep kernel over whole runs (round 5)
+@pytest.mark.parametrize("form", ["pair", "one_sweep"])
 @pytest.mark.parametrize("name", ["laplace400_converge", "torus300_converge"])
-def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, name):
-    """lagged_kernel (the streaming geometry of the one-sweep Gram-Schmidt form, vectors >= 1 MiB — what configs 2 and 3 run for
-    thousands / hundreds of iterations) against the reference's sequential MGS (LL:260 -> LA:132-144) over WHOLE runs to
-    convergence, default geometry, no environment overrides: the 400 x 400 Laplacian (smallest pair, offset -8, 1.28 MB vectors,
-    1448 reference iterations) and the complex torus 300 x 300 (config 5's matrix in small, smallest pair, offset -10, 1.44 MB
-    vectors).  EVERY alpha / beta of the run to 1e-10 ||A||_inf (an error of the compensation that grew slowly with k would show
-    here), iteration count +-2, eigenvalue, sampled eigenvector entries, residual, and the run really took that kernel."""
+def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, llenv, name, form):
+    """The streaming geometry of the Gram-Schmidt step (vectors >= 1 MiB — what configs 2 and 3 run for thousands / hundreds of
+    iterations) against the reference's sequential MGS (LL:260 -> LA:132-144) over WHOLE runs to convergence, default geometry:
+    the 400 x 400 Laplacian (smallest pair, offset -8, 1.28 MB vectors, 1448 reference iterations) and the complex torus 300 x 300
+    (config 5's matrix in small, smallest pair, offset -10, 1.44 MB vectors, 524 iterations), in both forms these vectors can take:
+    `pair` — the default: two iterations per sweep (pair_sweep_kernel) — and `one_sweep` — LL_PAIR_GS=0: one sweep per iteration
+    (lagged_kernel), the form the pair form falls back to.  EVERY alpha / beta of the run to 1e-10 ||A||_inf (an error of a
+    compensation that grew slowly with k would show here), iteration count +-2, eigenvalue, sampled eigenvector entries, residual,
+    and the run really took that kernel."""
+    if form == "one_sweep":
+        llenv.setenv("LL_PAIR_GS", "0")
     gold = GOLD[name]
     csr = MG.long_run_matrix(gold)
     n = gold["n"]
@@ -249,6 +254,10 @@ def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, 
     vals, vecs = eng.run()
     itern = eng.getIterationCounts()[0]
     assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
+    if form == "pair":
+        assert eng.last_stats["pair_iterations"] >= itern - 3 - 4 * eng.last_stats["second_passes"], eng.last_stats
+    else:
+        assert eng.last_stats["pair_iterations"] == 0
     check_counts(eng.getIterationCounts(), gold)
     da, db = check_trace(eng, gold, csr, upto=10 ** 9)    # the whole run
     check_values(vals, gold)

@@ -13,8 +13,8 @@ if has tests; then
   LL_BLAS_SMALL_BYTES=0 timeout 1200 python -m pytest tests/test_gpu_engines.py tests/test_gpu_round3.py tests/test_gpu_fuzz.py tests/test_gpu_float.py \
       tests/test_gpu_long_runs.py tests/test_gpu_pair.py -m gpu -x -q -p no:cacheprovider > gpurun_out/r05_tests_final_streaming.log 2>&1 < /dev/null
   echo "streaming-geometry tests rc=$?"; tail -4 gpurun_out/r05_tests_final_streaming.log
-  LL_PAIR_GS=0 timeout 900 python -m pytest tests/test_gpu_long_runs.py tests/test_gpu_round2.py -m gpu -x -q -p no:cacheprovider \
-      -k "streaming or c3_full or c2_full or one_sweep" > gpurun_out/r05_tests_final_pair_off.log 2>&1 < /dev/null
+  LL_PAIR_GS=0 timeout 900 python -m pytest tests/test_gpu_round2.py tests/test_gpu_round3.py -m gpu -x -q -p no:cacheprovider \
+      -k "c3_full or c2_full or lagged" > gpurun_out/r05_tests_final_pair_off.log 2>&1 < /dev/null
   echo "LL_PAIR_GS=0 tests rc=$?"; tail -3 gpurun_out/r05_tests_final_pair_off.log
 fi
 line() {
