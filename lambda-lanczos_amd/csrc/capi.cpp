@@ -36,6 +36,8 @@ Tuning read_tuning() {
   t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : (k == "tiled" ? 3 : 0));
   t.keep_both = flag("LL_SPMV_KEEP_BOTH", false);
   t.tl_force = flag("LL_TL_FORCE", false);
+  t.tl_xcd_order = flag("LL_TL_XCD", true);
+  t.tl_walk_modulo = flag("LL_TL_WALK", true);
   t.pb_diag = flag("LL_PB_DIAG", true);
   t.pair_gs = flag("LL_PAIR_GS", true);
   const std::string p2 = str("LL_PB_PHASE2");

@@ -317,22 +317,35 @@ __device__ __forceinline__ void mdot_trip(const T* __restrict__ u0, int64_t ld, 
   T ur[NV][EPT];
 #pragma unroll
   for (int b = 0; b < NV; ++b) load_strip<T>(u0 + (int64_t)b * ld, base, n, ur[b]);
-  double a[NV * R];
+  // (complex types: real and imaginary parts in transposed reductions of their own, at most NV = 4 sums each — with all 2 NV
+  // sums in one reduction the compiler sends part of the array through scratch memory, a round trip with a full drain of the
+  // memory pipeline in every trip; checked in the ISA, round 5)
+  double a[NV], ai[NV];
 #pragma unroll
   for (int b = 0; b < NV; ++b) {
     acc_t<T> acc = zero<acc_t<T>>();
 #pragma unroll
     for (int e = 0; e < EPT; ++e) cfma_acc(acc, ur[b][e], wr[e]);
     if constexpr (scalar_traits<T>::is_complex) {
-      a[2 * b] = acc.re;
-      a[2 * b + 1] = acc.im;
+      a[b] = acc.re;
+      ai[b] = acc.im;
     } else {
       a[b] = acc;
+      ai[b] = 0.0;
     }
   }
-  wave_sum_transposed<NV * R>(a, lane);
-  constexpr int LPI = 64 / (NV * R);  // lanes that end up holding the same sum
-  if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
+  wave_sum_transposed<NV>(a, lane);
+  constexpr int LPI = 64 / NV;  // lanes that end up holding the same sum
+  if constexpr (scalar_traits<T>::is_complex) {
+    wave_sum_transposed<NV>(ai, lane);
+    if ((lane & (LPI - 1)) == 0) {
+      mine_col[2 * (lane / LPI)] += a[0];
+      mine_col[2 * (lane / LPI) + 1] += ai[0];
+    }
+  } else {
+    if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
+  }
+  (void)R;
 }
 
 // One trip of the multi-axpy: w -= sum_b h_b u_b for NV basis strips, coefficients from LDS.
@@ -518,7 +531,7 @@ __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld
   T ur[NV][EPT];
 #pragma unroll
   for (int b = 0; b < NV; ++b) load_lstrip<T, PC>(u0 + (int64_t)b * ld, base, n, ur[b]);
-  double a[NV * R];
+  double a[NV], ai[NV];  // (complex: real and imaginary parts reduced separately, see mdot_trip)
 #pragma unroll
   for (int b = 0; b < NV; ++b) {
     // g_j and d_j = t_j - (alpha / beta) g_j: wave-uniform addresses in read-only memory (scalar loads, no LDS copy, so
@@ -539,15 +552,25 @@ __device__ __forceinline__ void lagged_trip(const T* __restrict__ u0, int64_t ld
       cfma_acc(acc, ur[b][e], wr[e]);  // this iteration's (raw) coefficient
     }
     if constexpr (scalar_traits<T>::is_complex) {
-      a[2 * b] = acc.re;
-      a[2 * b + 1] = acc.im;
+      a[b] = acc.re;
+      ai[b] = acc.im;
     } else {
       a[b] = acc;
+      ai[b] = 0.0;
     }
   }
-  wave_sum_transposed<NV * R>(a, lane);
-  constexpr int LPI = 64 / (NV * R);
-  if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
+  wave_sum_transposed<NV>(a, lane);
+  constexpr int LPI = 64 / NV;
+  if constexpr (scalar_traits<T>::is_complex) {
+    wave_sum_transposed<NV>(ai, lane);
+    if ((lane & (LPI - 1)) == 0) {
+      mine_col[2 * (lane / LPI)] += a[0];
+      mine_col[2 * (lane / LPI) + 1] += ai[0];
+    }
+  } else {
+    if ((lane & (LPI - 1)) == 0) mine_col[lane / LPI] += a[0];
+  }
+  (void)R;
 }
 
 template <typename T, int PC>

@@ -175,6 +175,8 @@ struct Tuning {
   bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
   // --- test hooks (not for users)
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
+  bool tl_xcd_order = true;        // LL_TL_XCD=0: row blocks of the tiled kernel in launch order instead of one contiguous eighth per XCD (A/B)
+  bool tl_walk_modulo = true;      // LL_TL_WALK=0: a row block's tiles in ascending column order instead of by column index modulo the longest tile list (A/B; read at creation)
   bool tl_force = false;           // LL_TL_FORCE=1: build the tiled image even for matrices that are not eligible (parity tests on small cases)
   bool pb_test_all_remote = false; // LL_PB_TEST_ALL_REMOTE=1: own columns are read from the gathered buffer too
   int tridiag_test_jitter_us = 0;  // LL_TRIDIAG_TEST_JITTER_US: random delay of every helper-thread verdict

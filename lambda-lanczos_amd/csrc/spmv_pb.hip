@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
                                                              const T* __restrict__ x, const T* __restrict__ xl,
                                                              T* __restrict__ y, double offset,
                                                              double* __restrict__ dot_partials,
-                                                             const double* __restrict__ xnorm2) {
+                                                             const double* __restrict__ xnorm2, int xcd_order) {
   constexpr int R = scalar_traits<T>::reals;
   constexpr int C = kTlTileBytes / (int)sizeof(T);  // columns per tile
   constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte piece
@@ -1267,7 +1267,15 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   unsigned* bad = reinterpret_cast<unsigned*>(xs + 2 * C);                       // [(rb_rows + 31) / 32] rows that met Inf / NaN
   __shared__ double red[kPbWaves + 1];
   const int tid = threadIdx.x;
-  const int rb = blockIdx.x;
+  // XCD-aware row-block order: workgroups with equal blockIdx % 8 share an XCD and its L2, and neighbouring row blocks share
+  // most of their x tiles (94 % for the banded config 3) — so every XCD takes a CONTIGUOUS eighth of the row blocks: the
+  // 32 blocks it runs at a time then stage their tiles out of its own L2 instead of each fetching them through the fabric.
+  int rb = blockIdx.x;
+  if (xcd_order) {
+    const int nb = gridDim.x, q = nb / kXcds, r = nb % kXcds;
+    const int x = blockIdx.x % kXcds, l = blockIdx.x / kXcds;
+    rb = x * q + min(x, r) + l;  // XCD x owns q + (x < r) consecutive blocks; a bijection on [0, nb)
+  }
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const int t0 = tfirst[rb], t1 = tfirst[rb + 1];
@@ -1475,12 +1483,12 @@ int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, do
     hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, true>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,
                        op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,
                        (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset,
-                       dot_partials, xnorm2);
+                       dot_partials, xnorm2, op.ctx->tune.tl_xcd_order ? 1 : 0);
   else
     hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, false>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,
                        op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,
                        (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset,
-                       dot_partials, xnorm2);
+                       dot_partials, xnorm2, op.ctx->tune.tl_xcd_order ? 1 : 0);
   LL_HIP(hipGetLastError());
   return op.tl_nrb;
 }
@@ -1544,14 +1552,30 @@ template <typename T> bool tl_build_device(ll_operator* op) {
   const int64_t pad = 16;
   std::vector<int32_t> tfirst((size_t)nrb + 1), tcol;
   std::vector<int64_t> tquad, segq((size_t)ncb * (nrb + 1), 0);
+  // Order of a row block's tiles (the sums are integers: any order gives the same bits).  Neighbouring row blocks of a banded
+  // matrix share most of their column tiles, and with one contiguous eighth of the row blocks per XCD (tl_xcd_order) they
+  // run at the same time behind the same L2: walking the tiles by column index MODULO the longest tile list makes every
+  // row block reach the tile of residue t at about step t, so a staged x slice is fetched from the fabric once per group of
+  // row blocks that share it rather than once per row block (LL_TL_WALK=0: ascending column index; A/B in DESIGN.md §3.1).
+  int64_t period = 1;
+  for (int64_t r = 0; r < nrb; ++r) {
+    int64_t k = 0;
+    for (int64_t c = 0; c < ncb; ++c) k += cnt32[(size_t)c * nrb + r] != 0;
+    period = std::max(period, k);
+  }
+  if (!tune.tl_walk_modulo) period = ncb;
+  std::vector<int32_t> order;
+  order.reserve((size_t)ncb);
+  for (int64_t c0 = 0; c0 < std::min(period, ncb); ++c0)
+    for (int64_t c = c0; c < ncb; c += period) order.push_back((int32_t)c);
   int64_t q = 0;
   for (int64_t r = 0; r < nrb; ++r) {
     tfirst[(size_t)r] = (int32_t)tcol.size();
-    for (int64_t c = 0; c < ncb; ++c) {
+    for (const int32_t c : order) {
       const int64_t k = cnt32[(size_t)c * nrb + r];
       segq[(size_t)c * (nrb + 1) + r] = q;
       if (k == 0) continue;
-      tcol.push_back((int32_t)c);
+      tcol.push_back(c);
       tquad.push_back(q >> 2);
       q += (k + pad - 1) / pad * pad;
     }

@@ -362,10 +362,12 @@ def test_one_sweep_form_in_the_small_vector_geometry(ctx, llenv, dtype):
 
 @pytest.mark.parametrize("name", ["randsym", "laplace", "torus", "laplace_long"])
 def test_lagged_gram_schmidt_keeps_the_recurrence_of_the_two_sweep_form(ctx, llenv, name):
-    """The one-sweep (lagged, compensated) Gram-Schmidt form against the two-sweep kernels on the same operator and
-    start vector, streaming geometry forced on both: same iteration count, alpha / beta traces equal to 1e-11 ||A||
-    over the whole run (an uncompensated lag loses them after ~40 iterations), same eigenpair, residual at the level the
-    Ritz estimate promises.  LL_FUSE_LAUNCHES=1 is the two-sweep comparator."""
+    """The one-sweep Gram-Schmidt forms (since round 5 the default in the streaming geometry is TWO iterations per sweep, the pair
+    form; LL_PAIR_GS=0 — set by the suite's pair-off leg, tools/r05_gpu_batch.sh — gives one sweep per iteration) against the
+    two-sweep kernels on the same operator and start vector, streaming geometry forced on both: same iteration count, alpha /
+    beta traces equal to 1e-11 ||A|| over the whole run (an uncompensated lag loses them after ~40 iterations), same eigenpair,
+    residual at the level the Ritz estimate promises.  LL_FUSE_LAUNCHES=1 is the two-sweep comparator.  (tests/test_gpu_pair.py
+    compares all three forms with each other and with the oracle.)"""
     n, csr, init, find_max, offset = _lagged_case(name)
     llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
     op = L.CsrOperator(ctx, *csr)
