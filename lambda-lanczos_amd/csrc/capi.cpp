@@ -45,6 +45,10 @@ Tuning read_tuning() {
   t.pb_block = (int)std::max<long long>(0, num("LL_PB_BLOCK", 0));
   t.pb_row_block = (int)std::max<long long>(0, num("LL_PB_ROW_BLOCK", 0));
   t.pb_col_block = (int)std::max<long long>(0, num("LL_PB_COL_BLOCK", 0));
+  t.pb_threads1 = (int)num("LL_PB_THREADS1", 0);
+  if (t.pb_threads1 != 256 && t.pb_threads1 != 512 && t.pb_threads1 != 1024) t.pb_threads1 = 0;
+  t.pb_pad = (int)num("LL_PB_PAD", 0);
+  if (t.pb_pad != 4 && t.pb_pad != 16) t.pb_pad = 0;
   t.pb_placements = (int)std::max<long long>(1, std::min<long long>(8, num("LL_PB_PLACEMENTS", 4)));
   t.pb_xpre = flag("LL_PB_XPRE", true);
   t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));

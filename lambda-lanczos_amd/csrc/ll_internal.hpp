@@ -154,6 +154,8 @@ struct Tuning {
   int pb_block = 0;                // LL_PB_BLOCK: rows AND columns per block (0: automatic); tests force ragged blocks
   int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
   int pb_col_block = 0;
+  int pb_threads1 = 0;             // LL_PB_THREADS1 = 256 | 512 | 1024: lanes per workgroup of PB phase 1 (0: automatic — 512 for the thin column blocks of a sharded image, 1024 on one GPU); read at creation
+  int pb_pad = 0;                  // LL_PB_PAD = 4 | 16: entries every segment of the PB image is padded to (0: automatic — 4 sharded, 16 on one GPU); read at creation
   int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
   bool pb_xpre = true;             // LL_PB_XPRE=0: phase 2 of the PB SpMV loads x_i in its epilogue (A/B of the early request)
   bool pb_diag = true;             // LL_PB_DIAG=0: the diagonal entries travel through the PB streams like every other entry (A/B)
@@ -315,6 +317,7 @@ struct ll_operator {
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
+  int pb_threads1 = 1024;                      // lanes per workgroup of phase 1 (1024; 512 for the thin column blocks of a sharded image)
   bool pb_xpre = true;                         // fixed-point phase 2 requests the epilogue's x_i before its stream (LL_PB_XPRE)
   int pb_own_count = 0;                        // table range [0, own_count)
   int pb_chunk_first[ll::kMaxGatherChunks] = {0};  // remote blocks of gather chunk c: [first, first + count)

@@ -32,6 +32,7 @@
 #include <string>
 
 #include "dev_helpers.hpp"
+#include "fixed_round.hpp"
 #include "ll_internal.hpp"
 
 namespace ll {
@@ -81,11 +82,11 @@ template <typename T> __device__ __forceinline__ void store_quad(T* __restrict__
 // by a fixed stride: the hardware favours a workgroup's oldest waves, so with a fixed partition wave 0 is done long
 // before wave 15 (measured: 94 us against 160 us in phase 1) and the tail of every workgroup runs with a fraction of its
 // loads in flight.  The first D - 1 chunks of every wave are fixed (they are requested before the counter is live).
-template <int U> struct WaveChunks {
+template <int U, int W = kPbWaves> struct WaveChunks {  // W: waves of the workgroup
   static constexpr int kQuads = 64 * U;  // quads per chunk
-  unsigned* ctr;                         // LDS: chunks handed out so far (starts at (D - 1) * kPbWaves)
+  unsigned* ctr;                         // LDS: chunks handed out so far (starts at (D - 1) * W)
   long long g0;
-  __device__ __forceinline__ long long fixed(int d) const { return g0 + (long long)((threadIdx.x >> 6) + d * kPbWaves) * kQuads; }
+  __device__ __forceinline__ long long fixed(int d) const { return g0 + (long long)((threadIdx.x >> 6) + d * W) * kQuads; }
   __device__ __forceinline__ long long grab() const {
     unsigned c = 0;
     if ((threadIdx.x & 63) == 0) c = atomicAdd(ctr, 1u);
@@ -93,14 +94,14 @@ template <int U> struct WaveChunks {
     return g0 + (long long)c * kQuads;
   }
 };
-template <typename T, int D> struct ColStream {  // phase 1: (4 values, 4 local columns) per lane per trip
+template <typename T, int D, int TH = kPbThreads> struct ColStream {  // phase 1: (4 values, 4 local columns) per lane per trip; TH lanes
   quad<T> v[D];
   ushort4 c[D];
   long long base[D];  // first quad of the chunk held in each slot
   const T* val;
   const ushort4* col;
   long long g1, glast;  // end of the range; last valid quad (>= its first quad; the image is padded behind its end)
-  WaveChunks<1> chunks;
+  WaveChunks<1, TH / 64> chunks;
   __device__ __forceinline__ void issue(int slot, long long cbase) {
     base[slot] = cbase;
     const long long g = cbase + (threadIdx.x & 63);
@@ -227,24 +228,28 @@ constexpr long long kPbBadProduct = (long long)0x8000000000000000ull;  // "not a
 constexpr int kPbXPre = 16;      // rows per lane whose x_i the fixed-point phase 2 holds in registers (row blocks of <= 16 384 rows)
 constexpr int kPbXInf = 20000;   // e_x when max|x| is not finite: every row is reported as NaN
 
-__device__ __forceinline__ long long pb_to_fixed(double p, int k) {
-  const double sc = ldexp(p, k);  // v_ldexp_f64: one instruction, no range restrictions
+// (fixed_round.hpp: rint() to a 64-bit integer in four full-rate additions instead of the six-instruction, mostly quarter-rate
+// f64 -> i64 conversion sequence — the same integers, checked value by value on the host in tests/cpp/fixed_round_test.cpp)
+__device__ __forceinline__ long long pb_to_fixed(double sc) {
   if (!(fabs(sc) < 9.0e18)) return kPbBadProduct;
-  return (long long)rint(sc);
+  return fixed_round(sc);
+}
+__device__ __forceinline__ long long pb_to_fixed(double p, int k) {
+  return pb_to_fixed(ldexp(p, k));  // v_ldexp_f64: one instruction, no range restrictions
 }
 // maximum over the workgroup of a per-lane value (result in every lane); scratch: kPbWaves doubles + 1
-__device__ __forceinline__ double pb_block_max(double m, double* scratch) {
+template <int W = kPbWaves> __device__ __forceinline__ double pb_block_max(double m, double* scratch) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
   if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = scratch[0];
-    for (int w = 1; w < kPbWaves; ++w) t = fmax(t, scratch[w]);
-    scratch[kPbWaves] = t;
+    for (int w = 1; w < W; ++w) t = fmax(t, scratch[w]);
+    scratch[W] = t;
   }
   __syncthreads();
-  return scratch[kPbWaves];
+  return scratch[W];
 }
 
 // ================================================================= phase 1
@@ -252,8 +257,8 @@ __device__ __forceinline__ double pb_block_max(double m, double* scratch) {
 // stream in, ordered by destination row block; product = value * x_lds[col] goes to the product buffer P at its position
 // in row-block order.  The first D - 1 trips are requested before the x slice is staged.
 // blockmax (nullable; fixed-point phase 2) receives the maximum of |x| over the slice.
-template <typename T, int D>
-__global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, const int64_t* __restrict__ xoff,
+template <typename T, int D, int TH>
+__global__ __launch_bounds__(TH) void pb_phase1(int nrb, int blk_first, const int64_t* __restrict__ xoff,
                                                         const int32_t* __restrict__ ncols_tab,
                                                         const int64_t* __restrict__ seg_q,     // [ncb][nrb+1]
                                                         const int64_t* __restrict__ seg_dest,  // [ncb][nrb]
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
   // xnorm2 (nullable): the input is an UNNORMALISED vector w with ||w||^2 = *xnorm2 (lagged Gram-Schmidt, kernels.hip): the
   // slice is scaled by 1 / ||w|| while it is staged
   const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;
-  __shared__ double bm_red[kPbWaves + 1];
+  __shared__ double bm_red[TH / 64 + 1];
   __shared__ unsigned chunk_ctr;
   T* xs = reinterpret_cast<T*>(lds);                                               // [cb_cols]
   long long* qs = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds) +
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
   const int64_t* sq = seg_q + (size_t)c * (nrb + 1);
   const long long g0 = sq[0] >> 2, g1 = sq[nrb] >> 2;
 
-  ColStream<T, D> st;
+  ColStream<T, D, TH> st;
   st.val = val;
   st.col = col;
   st.g1 = g1;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
   st.chunks.ctr = &chunk_ctr;
   st.chunks.g0 = g0;
   st.prologue();
-  if (tid == 0) chunk_ctr = (D - 1) * kPbWaves;  // (published by the barriers below)
+  if (tid == 0) chunk_ctr = (D - 1) * (TH / 64);  // (published by the barriers below)
   {  // stage the x slice (16-byte loads when the slice is 16-byte aligned) and the segment tables.  All loads of a batch are
     // requested before the first LDS store (clamped addresses, no load under a divergent branch): a load -> store loop
     // per piece is a chain of memory latencies — 9-17 us per workgroup with nothing else running on the CU.
@@ -295,17 +300,17 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
       const int nv = ncols / V;
       const uint4* s4 = reinterpret_cast<const uint4*>(src);
       uint4* d4 = reinterpret_cast<uint4*>(xs);
-      constexpr int SB = 7;  // 7 x 1024 x 16 B = 112 KiB: every slice in one batch
-      for (int i0 = 0; i0 < nv; i0 += SB * kPbThreads) {
+      constexpr int SB = 7;  // 7 x 1024 x 16 B = 112 KiB: every slice in one batch (256 lanes: 28 KiB, more than their slices)
+      for (int i0 = 0; i0 < nv; i0 += SB * TH) {
         uint4 piece[SB];
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
-          const int i = i0 + b * kPbThreads + tid;
+          const int i = i0 + b * TH + tid;
           piece[b] = s4[i < nv ? i : nv - 1];
         }
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
-          const int i = i0 + b * kPbThreads + tid;
+          const int i = i0 + b * TH + tid;
           if (xnorm2) {
             T el[V];
             __builtin_memcpy(el, &piece[b], sizeof(uint4));
@@ -316,22 +321,22 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
           if (i < nv) d4[i] = piece[b];
         }
       }
-      for (int i = nv * V + tid; i < ncols; i += kPbThreads) xs[i] = rmul(xs_fac, src[i]);
+      for (int i = nv * V + tid; i < ncols; i += TH) xs[i] = rmul(xs_fac, src[i]);
     } else {
-      for (int i = tid; i < ncols; i += kPbThreads) xs[i] = rmul(xs_fac, src[i]);
+      for (int i = tid; i < ncols; i += TH) xs[i] = rmul(xs_fac, src[i]);
     }
     const int64_t* sd = seg_dest + (size_t)c * nrb;
-    for (int i0 = 0; i0 <= nrb; i0 += 2 * kPbThreads) {
+    for (int i0 = 0; i0 <= nrb; i0 += 2 * TH) {
       long long tq[2], td[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int i = i0 + b * kPbThreads + tid;
+        const int i = i0 + b * TH + tid;
         tq[b] = sq[i <= nrb ? i : nrb];
         td[b] = sd[i < nrb ? i : (nrb > 0 ? nrb - 1 : 0)];
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int i = i0 + b * kPbThreads + tid;
+        const int i = i0 + b * TH + tid;
         if (i <= nrb) qs[i] = tq[b];
         if (i < nrb) db[i] = td[b];
       }
@@ -341,8 +346,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase1(int nrb, int blk_first, 
   if (blockmax != nullptr) {  // the largest |x| of the slice (phase 2 needs max |x| over all columns)
     double m = 0.0;
     const int ncols = ncols_tab[c];
-    for (int i = tid; i < ncols; i += kPbThreads) m = fmax(m, abs1(xs[i]));
-    m = pb_block_max(m, bm_red);
+    for (int i = tid; i < ncols; i += TH) m = fmax(m, abs1(xs[i]));
+    m = pb_block_max<TH / 64>(m, bm_red);
     if (tid == 0) blockmax[c] = m;  // NaN in the slice: fmax drops it; the products carry it into P and phase 2 reports it
   }
   int r = 0;
@@ -550,10 +555,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
           const double sc = pow2(k == kBadRow ? 0 : k);
           long long w[R];
           if constexpr (scalar_traits<T>::is_complex) {
-            w[0] = pb_to_fixed((double)p[u].e[e].re * sc, 0);
-            w[1] = pb_to_fixed((double)p[u].e[e].im * sc, 0);
+            w[0] = pb_to_fixed((double)p[u].e[e].re * sc);
+            w[1] = pb_to_fixed((double)p[u].e[e].im * sc);
           } else {
-            w[0] = pb_to_fixed((double)p[u].e[e] * sc, 0);
+            w[0] = pb_to_fixed((double)p[u].e[e] * sc);
           }
           bool ok = true;
 #pragma unroll
@@ -579,10 +584,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
       const double sc = pow2(k);
       long long w[R];
       if constexpr (scalar_traits<T>::is_complex) {
-        w[0] = pb_to_fixed((double)p.re * sc, 0);
-        w[1] = pb_to_fixed((double)p.im * sc, 0);
+        w[0] = pb_to_fixed((double)p.re * sc);
+        w[1] = pb_to_fixed((double)p.im * sc);
       } else {
-        w[0] = pb_to_fixed((double)p * sc, 0);
+        w[0] = pb_to_fixed((double)p * sc);
       }
 #pragma unroll
       for (int q = 0; q < R; ++q) {
@@ -662,7 +667,9 @@ template <typename T> void pb_opt_in_lds() {
   const unsigned long long bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
   constexpr int D2 = pb_depth2<T>();
-  pb_opt_in(&pb_phase1<T, kPbDepth1>);
+  pb_opt_in(&pb_phase1<T, kPbDepth1, kPbThreads>);
+  pb_opt_in(&pb_phase1<T, kPbDepth1, 256>);
+  pb_opt_in(&pb_phase1<T, kPbDepth1, 512>);
   pb_opt_in(&pb_phase2<T, false, D2>);
   pb_opt_in(&pb_phase2<T, true, D2>);
   pb_opt_in(&pb_phase2_fixed<T, D2>);
@@ -673,9 +680,22 @@ template <typename T>
 void phase1_launch(const ll_operator& op, int blk_first, int blk_count, const T* xsrc, const double* xnorm2, hipStream_t s) {
   const size_t lds1 = (((size_t)op.pb_cb_cols * sizeof(T) + 15) & ~(size_t)15) + (size_t)(2 * op.pb_nrb + 1) * sizeof(long long);
   double* bm = op.pb_phase2 == LL_PB_FIXED ? op.d_pb_blockmax : nullptr;
-  hipLaunchKernelGGL((pb_phase1<T, kPbDepth1>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
-                     op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, xsrc,
-                     (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries, xnorm2);
+  // Fewer lanes per workgroup for the thin column blocks of a sharded image: at N = 8 a block holds 16 K entries — four trips of
+  // 1024 lanes, two of them requested by the prologue: the ring never reaches its steady state — but 8 trips of 512 lanes
+  // (measured on config 4's shards through the stand-in transport, profiles/r05_shard_phase1_lanes.txt: 60.8 -> 41.9 us per
+  // launch at N = 8 with the same 68 KB slices; smaller slices with more workgroups per CU lose to their segment count)
+  if (op.pb_threads1 == 256)
+    hipLaunchKernelGGL((pb_phase1<T, kPbDepth1, 256>), dim3(blk_count), dim3(256), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
+                       op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, xsrc,
+                       (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries, xnorm2);
+  else if (op.pb_threads1 == 512)
+    hipLaunchKernelGGL((pb_phase1<T, kPbDepth1, 512>), dim3(blk_count), dim3(512), lds1, s, op.pb_nrb, blk_first, op.d_pb_xoff,
+                       op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val, (const ushort4*)op.d_pb_col, xsrc,
+                       (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries, xnorm2);
+  else
+    hipLaunchKernelGGL((pb_phase1<T, kPbDepth1, kPbThreads>), dim3(blk_count), dim3(kPbThreads), lds1, s, op.pb_nrb, blk_first,
+                       op.d_pb_xoff, op.d_pb_ncols, op.d_pb_segq, op.d_pb_segdest, (const T*)op.d_pb_val,
+                       (const ushort4*)op.d_pb_col, xsrc, (T*)op.d_pb_prod, op.pb_cb_cols, bm, (long long)op.pb_entries, xnorm2);
   LL_HIP(hipGetLastError());
 }
 }  // namespace
@@ -1084,7 +1104,9 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   LL_HIP(hipStreamSynchronize(s));
   // every segment is padded to 16 entries: kernels move quads (4 entries per lane, 16-byte accesses) and every run of
   // products written by phase 1 starts and ends on a 128-byte line (measured 3.5 % faster than quad padding)
-  const int64_t pad = 16;
+  // (sharded images: quad padding.  Their segments hold 105 entries at N = 8 instead of 840, the 16-entry padding costs 8 % of both
+  // streams there, and phase 2 measured 54.9 -> 47.8 us without it)
+  const int64_t pad = tune.pb_pad > 0 ? tune.pb_pad : (P > 1 ? 4 : 16);
   // column-block order: segments (c, r) with r fastest; row-block order: (r, c) with c fastest
   std::vector<int64_t> segq((size_t)ncb * (nrb + 1)), segdest((size_t)ncb * nrb), rptr((size_t)nrb + 1);
   {
@@ -1114,6 +1136,7 @@ template <typename T> bool pb_build_device(ll_operator* op) {
   op->pb_own_count = own_total;
   op->pb_entries = (int64_t)entries;
   op->pb_xpre = tune.pb_xpre;
+  op->pb_threads1 = tune.pb_threads1 > 0 ? tune.pb_threads1 : (P > 1 ? 512 : kPbThreads);
   op->gather = gp;
   // Phase 2 form, fixed per operator at creation (LL_PB_PHASE2).  Default "fixed": order-independent fixed-point sums
   // (integer LDS adds, all waves at once) — bit-reproducible for every launch, kernel geometry and partition, and 2-5 %
@@ -1324,6 +1347,12 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
       __builtin_memcpy(&xp[slot], el, sizeof(uint4));
     }
   };
+  // (double / complex<double>: the scale 2^kx of the fixed-point grid rides on the staged x elements — one exact scaling per
+  // element and tile instead of one v_ldexp_f64 per entry; |kx| <= 1000 and every product below 2^-1022 rounds to the integer 0
+  // either way, so the integers are the same.  The float types keep the scaling behind their float product, whose underflow
+  // threshold is within reach of the scale.)
+  constexpr bool kFoldScale = sizeof(typename scalar_traits<T>::real) == 8;
+  int kx = 0;  // set below, before the first tile is staged
   auto store_piece = [&](int buf, int ct, uint4 piece) {
     T el[V];
     __builtin_memcpy(el, &piece, sizeof(uint4));
@@ -1345,6 +1374,10 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
 #pragma unroll
       for (int q = 0; q < V; ++q) el[q] = rmul(xs_fac, el[q]);
     }
+    if constexpr (kFoldScale) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) el[q] = scale_pow2(el[q], kx);
+    }
     uint4 out;
     __builtin_memcpy(&out, el, sizeof(uint4));
     reinterpret_cast<uint4*>(xs + (size_t)buf * C)[tid] = out;
@@ -1361,31 +1394,48 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     else if (!(t == 0.0)) e_x = kPbXInf;
   }
   // integer = (PRE-SCALED value * x) * 2^kx; row i's sum is acc_i * 2^(er_i - kx)   (pb_phase2_fixed: k = 62 - (er + e_x + 1))
-  const int kx = e_x == kPbXInf ? 0 : max(-1000, min(1000, 61 - e_x));
+  kx = e_x == kPbXInf ? 0 : max(-1000, min(1000, 61 - e_x));
 
   // (No branch on `valid`: a lane beyond the end of its tile holds a re-read of a valid quad and adds ZERO to that quad's
   // rows — every trip then waits for and uses its loads on every path, which keeps the wait counts of the ring exact.)
   auto consume = [&](const quad<T>& vv, const uint4& ii, bool valid, int buf) {
     const T* xb = xs + (size_t)buf * C;
     const unsigned w4[4] = {ii.x, ii.y, ii.z, ii.w};
+    // the four x elements first, in one batch of LDS reads: behind the first atomic the compiler may not move a read of the
+    // same LDS array forward (it cannot prove that xs and acc do not overlap), and entry by entry every read's latency is exposed
+    T xe[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xe[e] = xb[w4[e] & 0xffffu];
+    unsigned badmask = 0u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const unsigned lc = w4[e] & 0xffffu, lr = w4[e] >> 16;
-      const T p = mul(vv.e[e], xb[lc]);
-      long long w[R];
+      const unsigned lr = w4[e] >> 16;
+      const T p = mul(vv.e[e], xe[e]);
+      double pr[R];
       if constexpr (scalar_traits<T>::is_complex) {
-        w[0] = pb_to_fixed((double)p.re, kx);
-        w[1] = pb_to_fixed((double)p.im, kx);
+        pr[0] = (double)p.re;
+        pr[1] = (double)p.im;
       } else {
-        w[0] = pb_to_fixed((double)p, kx);
+        pr[0] = (double)p;
       }
-      bool ok = true;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        if (w[q] == kPbBadProduct) ok = false;
-        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[R * lr + q]), (valid && w[q] != kPbBadProduct) ? (unsigned long long)w[q] : 0ull);
+        const double sc = kFoldScale ? pr[q] : ldexp(pr[q], kx);
+        const bool good = fabs(sc) < 9.0e18;  // false for Inf / NaN too; fixed_round's value is not used then
+        if (!good) badmask |= 1u << e;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[R * lr + q]), (valid && good) ? (unsigned long long)fixed_round(sc) : 0ull);
       }
-      if (!ok && valid) atomicOr(&bad[lr >> 5], 1u << (lr & 31));
+    }
+    // rows that met an Inf / NaN (rare: one wave-uniform branch per trip instead of a masked LDS OR per entry)
+    if (__builtin_expect(__any(valid && badmask != 0u), 0)) {
+      if (valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((badmask >> e) & 1u) {
+            const unsigned lr = w4[e] >> 16;
+            atomicOr(&bad[lr >> 5], 1u << (lr & 31));
+          }
+      }
     }
   };
   // one trip.  The FIRST trip of a tile parks the tile's x pieces in the buffer the tile before the previous one used

@@ -193,3 +193,35 @@ def test_pair_form_in_single_precision(ctx, llenv, dtype):
     assert abs(pair["vals"][0] - two["vals"][0]) <= 2e-3 * 30
     assert 1 - overlap(pair["vecs"][0].astype(wide), two["vecs"][0].astype(wide)) <= 1e-4
     op.close()
+
+
+@pytest.mark.parametrize("name", ["randsym", "laplace"])
+def test_pair_form_in_restart_passes_with_locked_eigenvectors(ctx, oracle, llenv, name):
+    """Three eigenpairs (LL:334-354): every pass after the first orthogonalises against the locked eigenvectors (LL:233,259).
+    Their columns take lambda_i c_i in the pair form's prediction and quadratic forms (tools/pair_gs_model.py, locked > 0), so
+    the restart passes run two iterations per sweep too wherever the locked residuals pass the one-sweep form's gate (the well
+    separated top of the random matrix's spectrum).  Same passes, counts and eigenpairs as the one-sweep form and the oracle."""
+    n, csr, init, find_max, offset = _case(name)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    llenv.setenv("LL_PAIR_GS", "0")
+    one = _run(ctx, op, n, find_max, offset, init, num_eigs=3)
+    llenv.delenv("LL_PAIR_GS")
+    pair = _run(ctx, op, n, find_max, offset, init, num_eigs=3)
+    assert len(pair["iters"]) >= 2 and pair["iters"] == one["iters"]      # at least one pass behind locked vectors
+    assert one["stats"]["pair_iterations"] == 0
+    if name == "randsym":   # every pass in the pair form (set-up iterations and DGKS repairs aside)
+        assert pair["stats"]["pair_iterations"] >= sum(pair["iters"]) - 3 * len(pair["iters"]) - 4 * pair["stats"]["second_passes"], \
+            pair["stats"]
+    else:                   # at least the first pass
+        assert pair["stats"]["pair_iterations"] >= pair["iters"][0] - 3 - 4 * pair["stats"]["second_passes"], pair["stats"]
+    scale = inf_norm(csr) + abs(offset)
+    ora = oracle.lanczos(csr, init, find_max, num_eigs=3, offset=offset)
+    assert pair["iters"] == ora["iter_counts"]
+    assert np.max(np.abs(pair["vals"] - one["vals"])) <= 1e-11 * scale
+    assert np.max(np.abs(pair["vals"] - ora["eigenvalues"])) <= 1e-10 * scale
+    for i in range(3):
+        assert 1 - overlap(pair["vecs"][i], ora["eigenvectors"][i]) <= 1e-8
+        for j in range(i):
+            assert abs(np.vdot(pair["vecs"][i], pair["vecs"][j])) <= 1e-9
+    op.close()
