@@ -1235,6 +1235,8 @@ template <typename T> bool pb_build_device(ll_operator* op) {
 constexpr int kTlTileBytes = 16 * 1024;  // one x tile: one 16-byte piece per lane of the workgroup
 constexpr int kTlXmaxParts = 512;
 constexpr int kTlDepth = 3;
+constexpr int kTlSlots = 4;       // x tiles resident in LDS (a ring; power of two)
+constexpr int kTlNewPerTrip = 2;  // x tiles a trip may bring in
 
 template <typename T>
 __global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __restrict__ x, double* __restrict__ parts, int aligned) {
@@ -1286,8 +1288,8 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte piece
   extern __shared__ double lds_raw[];
   long long* acc = reinterpret_cast<long long*>(lds_raw);                        // [rb_rows * R]
-  T* xs = reinterpret_cast<T*>(acc + (size_t)rb_rows * R);                       // [2][C]
-  unsigned* bad = reinterpret_cast<unsigned*>(xs + 2 * C);                       // [(rb_rows + 31) / 32] rows that met Inf / NaN
+  T* xs = reinterpret_cast<T*>(acc + (size_t)rb_rows * R);                       // [kTlSlots][C]
+  unsigned* bad = reinterpret_cast<unsigned*>(xs + kTlSlots * C);                       // [(rb_rows + 31) / 32] rows that met Inf / NaN
   __shared__ double red[kPbWaves + 1];
   const int tid = threadIdx.x;
   // XCD-aware row-block order: workgroups with equal blockIdx % 8 share an XCD and its L2, and neighbouring row blocks share
@@ -1303,48 +1305,97 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const int t0 = tfirst[rb], t1 = tfirst[rb + 1];
   const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;  // unnormalised input (see pb_phase1)
-  const long long q_end = tquad[t1];
-  const long long q_last = q_end > tquad[t0] ? q_end - 1 : tquad[t0];  // (the image is padded by one quad behind its end)
+  const long long q_begin = tquad[t0], q_end = tquad[t1];
+  const long long q_last = q_end > q_begin ? q_end - 1 : q_begin;  // (the image is padded by one quad behind its end)
 
-  // ---- the stream: a cursor over (tile, trip) pairs; D - 1 trips are requested ahead of the one being consumed.
-  // Every trip requests the SAME four loads, unconditionally and in straight-line code — the lane's quad of values (2), its
-  // packed indices (1) and its 16-byte piece of the trip's x tile (1; requested again by every trip of a tile that spans
-  // several trips: an L2 hit) — so the compiler can wait for exactly the oldest trip (s_waitcnt vmcnt(N), see above).
-  struct Cursor {
-    int t;            // tile (index into the tile list)
-    long long q, q1;  // first quad of this trip, end of the tile
+  // ---- trips.  A trip is kPbThreads consecutive quads of the row block's stream, WHEREVER the tile boundaries fall: a lane's
+  // quad belongs to one tile (tiles are whole quads), the lanes of a trip to up to three consecutive tiles of the block's list.
+  // (Round 5's first form ended every trip at the end of its tile: the tiles of the banded config 3 hold 0.75 trips, a quarter of
+  // the lane slots of every trip carried no entry.)  Tile number tau of the list lives in slot (tau - t0) % kTlSlots of the x ring
+  // in LDS.  A trip brings in at most kTlNewPerTrip new tiles — one 16-byte piece per lane and new tile, requested with the trip's
+  // entries and parked in registers until the trip is consumed — and never more than the ring has room for next to the tiles of the
+  // trip before it (which slower waves may still be reading): span(k) + new(k + 1) <= kTlSlots consecutive tiles, hence distinct
+  // slots; a trip that would need more ends early, at a tile boundary.  ONE barrier per trip (new tiles visible; every wave has left
+  // the trip before the previous one).  The planner below is uniform over the workgroup and runs at REQUEST time, D - 1 trips ahead.
+  struct Plan {
+    long long q0, q1;  // quads [q0, q1) of the stream
+    long long e1, e2;  // ends of tiles a and a + 1: a lane's tile is a + (g >= e1) + (g >= e2)
+    int a;             // tile of the trip's first quad
+    int first_new, n_new;
   };
-  auto advance = [&](Cursor& c) {
-    c.q += kPbThreads;
-    if (c.q >= c.q1 && c.t < t1) {  // next tile (the tiles of a row block are consecutive in the stream)
-      ++c.t;
-      c.q = c.q1;
-      c.q1 = c.t < t1 ? tquad[c.t + 1] : c.q1;
+  long long pq = q_begin;  // next quad to plan
+  int pcur = t0;           // tile that holds pq
+  int pb = t0 - 1;         // last tile some earlier trip brought in
+  int pspan = 0;           // tiles of the trip before
+  auto plan = [&]() {
+    Plan p;
+    p.q0 = pq;
+    p.a = pcur;
+    p.first_new = pb + 1;
+    if (pq >= q_end) {  // beyond the row block: nothing valid (q0 >= q_end ends the loop when it is consumed)
+      p.q1 = pq;
+      p.e1 = p.e2 = pq;
+      p.n_new = 0;
+      return p;
     }
+    const int cap = min(kTlNewPerTrip, kTlSlots - pspan);  // >= 1: a trip spans at most three tiles
+    const int bmax = min(t1 - 1, pb + cap);
+    const long long end = min(pq + (long long)kPbThreads, q_end);
+    const long long e1 = tquad[min(pcur + 1, t1)], e2 = tquad[min(pcur + 2, t1)], e3 = tquad[min(pcur + 3, t1)];
+    int b = pcur;
+    long long eb = e1;
+    if (b < bmax && eb < end) {
+      ++b;
+      eb = e2;
+      if (b < bmax && eb < end) {
+        ++b;
+        eb = e3;
+      }
+    }
+    p.e1 = e1;
+    p.e2 = e2;
+    p.q1 = min(end, eb);
+    p.n_new = max(0, b - pb);
+    pspan = b - pcur + 1;
+    pb = max(pb, b);
+    pq = p.q1;
+    pcur = p.q1 == eb ? b + 1 : b;
+    return p;
   };
   quad<T> v[D];
-  uint4 ix[D], xp[D];
-  long long gq[D], gend[D];
-  auto issue = [&](int slot, const Cursor& c) {
-    const long long g = c.q + tid;
+  uint4 ix[D], xp[D][kTlNewPerTrip];
+  long long gq[D];
+  Plan pl[D];
+  int ctn[D][kTlNewPerTrip];  // column tiles of the (up to) two new tiles of the trip
+  // Every trip requests the SAME loads, unconditionally and in straight-line code — the lane's quad of values (2 x 16 B), its packed
+  // indices (16 B) and its 16-byte piece of each of the trip's new x tiles (a trip with fewer new tiles requests its last one again:
+  // a cache hit) — so the compiler can wait for exactly the oldest trip (s_waitcnt vmcnt(N), see above).
+  auto issue = [&](int slot) {
+    const Plan p = plan();
+    pl[slot] = p;
+    const long long g = p.q0 + tid;
     const long long gc = g < q_last ? g : q_last;
     gq[slot] = g;
-    gend[slot] = c.t < t1 ? c.q1 : g;  // beyond the row block: nothing valid
     v[slot] = load_quad<T>(val + 4 * gc);
     ix[slot] = idx[gc];
-    // the lane's piece of x tile tcol[c.t]; elements beyond the vector's end are never referenced by an entry
-    const int ct = tcol[c.t < t1 ? c.t : (t1 > t0 ? t1 - 1 : t0)];
-    const long long off = (long long)ct * C + (long long)tid * V;
-    if constexpr (ALIGNED) {
-      // a piece that would reach beyond the end is read V-aligned from the last whole piece position that is still inside
-      // (n_cols >= V is guaranteed by the launcher) and shifted into place below (store_piece)
-      const long long lim = n_cols - V;
-      xp[slot] = *reinterpret_cast<const uint4*>(x + (off <= lim ? off : lim));
-    } else {
-      T el[V];
 #pragma unroll
-      for (int q = 0; q < V; ++q) el[q] = x[off + q < n_cols ? off + q : n_cols - 1];
-      __builtin_memcpy(&xp[slot], el, sizeof(uint4));
+    for (int j = 0; j < kTlNewPerTrip; ++j) {
+      // (a row block without tiles reads the table's padding entry; elements beyond the vector's end are never referenced)
+      const int tj = max(t0, min(p.first_new + min(j, max(p.n_new - 1, 0)), t1 - 1));
+      const int ct = tcol[tj];
+      ctn[slot][j] = ct;
+      const long long off = (long long)ct * C + (long long)tid * V;
+      if constexpr (ALIGNED) {
+        // a piece that would reach beyond the end is read V-aligned from the last whole piece position that is still inside
+        // (n_cols >= V is guaranteed by the launcher) and shifted into place below (store_piece)
+        const long long lim = n_cols - V;
+        xp[slot][j] = *reinterpret_cast<const uint4*>(x + (off <= lim ? off : lim));
+      } else {
+        T el[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) el[q] = x[off + q < n_cols ? off + q : n_cols - 1];
+        __builtin_memcpy(&xp[slot][j], el, sizeof(uint4));
+      }
     }
   };
   // (double / complex<double>: the scale 2^kx of the fixed-point grid rides on the staged x elements — one exact scaling per
@@ -1353,7 +1404,8 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   // threshold is within reach of the scale.)
   constexpr bool kFoldScale = sizeof(typename scalar_traits<T>::real) == 8;
   int kx = 0;  // set below, before the first tile is staged
-  auto store_piece = [&](int buf, int ct, uint4 piece) {
+  auto store_piece = [&](int tile, int ct, uint4 piece) {
+    const int buf = (tile - t0) & (kTlSlots - 1);
     T el[V];
     __builtin_memcpy(el, &piece, sizeof(uint4));
     if constexpr (ALIGNED) {
@@ -1396,7 +1448,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   // integer = (PRE-SCALED value * x) * 2^kx; row i's sum is acc_i * 2^(er_i - kx)   (pb_phase2_fixed: k = 62 - (er + e_x + 1))
   kx = e_x == kPbXInf ? 0 : max(-1000, min(1000, 61 - e_x));
 
-  // (No branch on `valid`: a lane beyond the end of its tile holds a re-read of a valid quad and adds ZERO to that quad's
+  // (No branch on `valid`: a lane beyond the end of its trip holds a re-read of a valid quad and adds ZERO to that quad's
   // rows — every trip then waits for and uses its loads on every path, which keeps the wait counts of the ring exact.)
   auto consume = [&](const quad<T>& vv, const uint4& ii, bool valid, int buf) {
     const T* xb = xs + (size_t)buf * C;
@@ -1438,38 +1490,29 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
       }
     }
   };
-  // one trip.  The FIRST trip of a tile parks the tile's x pieces in the buffer the tile before the previous one used
-  // (every wave has left that tile: it has passed the barrier of the previous tile's first trip) and meets the others.
   // (The first D - 1 trips are requested HERE, right in front of the loop and after everything else of the prologue has
   // drained: the loop is then entered with exactly the pending loads its back edge carries, and the compiler's wait counts
   // stay exact in every phase; requested earlier, the merge of the two paths costs a full drain in the loop's first phase.)
-  Cursor cur{t0, tquad[t0], t0 < t1 ? tquad[t0 + 1] : tquad[t0]};
-  Cursor nxt = cur;
 #pragma unroll
   for (int d = 0; d < D - 1; ++d) {
     __builtin_amdgcn_sched_barrier(0);  // keep the trips' loads in trip order (the wait counts of the loop assume it)
-    issue(d, nxt);
-    advance(nxt);
+    issue(d);
   }
   __builtin_amdgcn_sched_barrier(0);
-  bool tile_start = true;
   auto step = [&](auto ph) -> bool {
     constexpr int PH = decltype(ph)::value;
-    if (cur.t >= t1) return false;  // uniform over the workgroup
-    const int buf = (cur.t - t0) & 1;
-    if (tile_start) {
-      store_piece(buf, tcol[cur.t], xp[PH]);
-      __syncthreads();
-    }
-    const bool valid = gq[PH] < gend[PH];
+    const Plan p = pl[PH];
+    if (p.q0 >= q_end) return false;  // uniform over the workgroup
+    if (p.n_new > 0) store_piece(p.first_new, ctn[PH][0], xp[PH][0]);
+    if (p.n_new > 1) store_piece(p.first_new + 1, ctn[PH][1], xp[PH][1]);
+    __syncthreads();
+    const long long g = gq[PH];
+    const bool valid = g < p.q1;
+    const int buf = (p.a - t0 + (g >= p.e1 ? 1 : 0) + (g >= p.e2 ? 1 : 0)) & (kTlSlots - 1);
     const quad<T> vv = v[PH];
     const uint4 ii = ix[PH];
-    issue((PH + D - 1) % D, nxt);
-    advance(nxt);
+    issue((PH + D - 1) % D);
     consume(vv, ii, valid, buf);
-    const int t_before = cur.t;
-    advance(cur);
-    tile_start = cur.t != t_before;
     return true;
   };
   // (The waitcnt pass merges the pending loads of the prologue and of the back edge conservatively at the loop header: the FIRST
@@ -1505,7 +1548,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
 namespace {
 template <typename T> constexpr int tl_cols() { return kTlTileBytes / (int)sizeof(T); }
 template <typename T> size_t tl_lds_bytes(int rb_rows) {
-  return (size_t)rb_rows * sizeof(acc_t<T>) + 2 * (size_t)kTlTileBytes + (size_t)((rb_rows + 31) / 32) * sizeof(unsigned) + 16;
+  return (size_t)rb_rows * sizeof(acc_t<T>) + (size_t)kTlSlots * kTlTileBytes + (size_t)((rb_rows + 31) / 32) * sizeof(unsigned) + 16;
 }
 template <typename T> void tl_opt_in_lds() {
   static std::atomic<unsigned long long> mask{0};
@@ -1555,7 +1598,7 @@ template <typename T> bool tl_build_device(ll_operator* op) {
   constexpr int C = tl_cols<T>();
   // ---- row blocks: as long as the LDS allows (the longer the block, the smaller the share of re-staged x per entry),
   //      in whole rounds of 256 workgroups
-  const int64_t row_max = std::min<int64_t>(65536, ((int64_t)kPbLdsCap - 2 * kTlTileBytes - 2048 - 64) / (int64_t)sizeof(acc_t<T>) / 256 * 256);
+  const int64_t row_max = std::min<int64_t>(65536, ((int64_t)kPbLdsCap - kTlSlots * kTlTileBytes - 2048 - 64) / (int64_t)sizeof(acc_t<T>) / 256 * 256);
   int64_t rounds = std::max<int64_t>(1, (nr + 256 * row_max - 1) / (256 * row_max));
   int64_t rb_rows = std::min<int64_t>(row_max, std::max<int64_t>(16, (nr + 256 * rounds - 1) / (256 * rounds)));
   if (tune.pb_block > 0) rb_rows = std::min<int64_t>(row_max, std::max(4, tune.pb_block));
@@ -1634,6 +1677,7 @@ template <typename T> bool tl_build_device(ll_operator* op) {
   tquad.push_back(q >> 2);
   const int64_t entries = q;
   const int64_t ntiles = (int64_t)tcol.size();
+  tcol.push_back(tcol.empty() ? 0 : tcol.back());  // padding entry: what a row block without tiles reads (and ignores)
   // ---- eligibility: the re-staged x slices must cost less than the matrix stream, and the padding must stay small
   const double staged = (double)ntiles * kTlTileBytes, stream = (double)entries * (sizeof(T) + 4);
   const bool eligible = staged <= stream && (double)entries <= 1.25 * (double)op->nnz + 16.0 * (double)nrb;
