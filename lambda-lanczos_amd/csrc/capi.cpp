@@ -63,6 +63,7 @@ Tuning read_tuning() {
   }
   t.sharded_norm_measured = str("LL_SHARDED_NORM") == "measured";
   t.slab_bytes = std::max<long long>(1, num("LL_SLAB_BYTES", (long long)4 << 30));
+  t.slab_prefetch = flag("LL_SLAB_PREFETCH", true);
   t.blas_small_bytes = num("LL_BLAS_SMALL_BYTES", (long long)4 << 20);
   {
     const long long level = num("LL_FUSE_LAUNCHES", 2);

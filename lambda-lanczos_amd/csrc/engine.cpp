@@ -64,42 +64,70 @@ template <typename T> Basis<T>::~Basis() {
   // slabs go back to the context's cache: the next run() on this context reuses them instead of paying
   // hipMalloc/hipFree of tens of GB per call (ll_ctx_release_cache or ll_ctx_destroy frees them)
   const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
+  if (next.valid()) {  // a slab that was allocated ahead and never needed
+    const auto r = next.get();
+    if (r.second == (int)hipSuccess && r.first) ctx->cache_put(r.first, bytes);
+  }
   for (T* p : chunks) ctx->cache_put((void*)p, bytes);
 }
-template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_) {
+template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_, int64_t max_vecs_) {
   ctx = c;
   n_local = n_local_;
   ld = ld_;
   chunk_vecs = chunk_vecs_;
+  max_vecs = max_vecs_;
+}
+template <typename T> T* Basis<T>::take_cached(size_t bytes) {
+  for (size_t i = 0; i < ctx->slab_cache.size(); ++i)
+    if (ctx->slab_cache[i].second == bytes) {
+      T* p = (T*)ctx->slab_cache[i].first;
+      ctx->slab_cache.erase(ctx->slab_cache.begin() + (long)i);
+      return p;
+    }
+  return nullptr;
+}
+template <typename T> void Basis<T>::prefetch() {
+  if (next.valid() || !ctx->tune.slab_prefetch) return;
+  if (max_vecs > 0 && (int64_t)chunks.size() * chunk_vecs >= max_vecs) return;  // the run cannot reach another slab
+  const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
+  for (auto& c : ctx->slab_cache)
+    if (c.second == bytes) return;  // the cache serves the next one
+  const int dev = ctx->device;
+  // (only hipSetDevice + hipMalloc run on the helper; the cache and the slab list belong to the calling thread)
+  next = std::async(std::launch::async, [dev, bytes]() {
+    void* p = nullptr;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipMalloc(&p, bytes);
+    return std::make_pair(p, (int)e);
+  });
 }
 template <typename T> T* Basis<T>::vec(int64_t k) {
   const int64_t ci = k / chunk_vecs;
   while ((int64_t)chunks.size() <= ci) {
-    T* p = nullptr;
     const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
-    for (size_t i = 0; i < ctx->slab_cache.size(); ++i)
-      if (ctx->slab_cache[i].second == bytes) {
-        p = (T*)ctx->slab_cache[i].first;
-        ctx->slab_cache.erase(ctx->slab_cache.begin() + (long)i);
-        break;
+    T* p = nullptr;
+    if (next.valid()) {  // allocated ahead (a failure there falls through to the synchronous path and its retry)
+      const auto r = next.get();
+      if (r.second == (int)hipSuccess) p = (T*)r.first;
+      else (void)hipGetLastError();
+    }
+    if (!p) p = take_cached(bytes);
+    if (!p) {
+      hipError_t e = hipMalloc((void**)&p, bytes);
+      if (e != hipSuccess && !ctx->slab_cache.empty()) {  // make room: drop cached slabs of other shapes and retry
+        (void)hipGetLastError();
+        for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
+        ctx->slab_cache.clear();
+        e = hipMalloc((void**)&p, bytes);
       }
-    if (p) {
-      chunks.push_back(p);
-      continue;
-    }
-    hipError_t e = hipMalloc((void**)&p, bytes);
-    if (e != hipSuccess && !ctx->slab_cache.empty()) {  // make room: drop cached slabs of other shapes and retry
-      (void)hipGetLastError();
-      for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
-      ctx->slab_cache.clear();
-      e = hipMalloc((void**)&p, bytes);
-    }
-    if (e != hipSuccess) {
-      set_error("out of device memory growing the Krylov basis to " + std::to_string((chunks.size() + 1) * chunk_vecs) +
-                " vectors of " + std::to_string(ld * sizeof(T)) + " bytes: " + hipGetErrorString(e));
-      throw Failure{LL_ERR_ALLOC};
+      if (e != hipSuccess) {
+        set_error("out of device memory growing the Krylov basis to " + std::to_string((chunks.size() + 1) * chunk_vecs) +
+                  " vectors of " + std::to_string(ld * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+        throw Failure{LL_ERR_ALLOC};
+      }
     }
     chunks.push_back(p);
+    prefetch();
   }
   return chunks[ci] + (k % chunk_vecs) * ld;
 }
@@ -1188,7 +1216,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   constexpr int R = scalar_traits<T>::reals;
 
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes), P.max_iteration + 2);
   DevBuf<T> d_locked, d_ritz;
   int64_t d_ritz_cap = 0;
   if (spec) {
@@ -1662,7 +1690,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
   const bool fuse_launches = ctx->tune.fuse_launches;
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes), P.max_iteration + 2);
   st.at("basis");
   ctx->ensure_pinned(16);
   EventRing ring;

@@ -169,6 +169,7 @@ struct Tuning {
   double dgks_threshold = 0.5;     // LL_DGKS_THRESHOLD: second Gram-Schmidt pass when ||w'||^2 < thr * ||w||^2
   bool sharded_norm_measured = false;  // LL_SHARDED_NORM=measured: all-reduce the post-pass norm instead of deriving it
   int64_t slab_bytes = (int64_t)4 << 30;       // LL_SLAB_BYTES: cap of one Krylov-basis slab
+  bool slab_prefetch = true;                   // LL_SLAB_PREFETCH=0: allocate every slab when it is needed (A/B of the helper-thread allocation)
   int64_t blas_small_bytes = (int64_t)4 << 20;  // LL_BLAS_SMALL_BYTES: vectors below this use the small-vector kernels
   bool fuse_launches = true;       // LL_FUSE_LAUNCHES=0: separate fold / publish kernels (A/B of the launch fusion)
   long long lagged_min_bytes = -1; // test hook LL_TEST_LAGGED_MIN_BYTES: shortest vector of the one-sweep form (-1 = default)

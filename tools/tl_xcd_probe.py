@@ -30,7 +30,7 @@ for walk in ("1", "0"):
     ys[walk] = ctx.empty(n)
 combos = [only] if only is not None else ["11", "01", "10", "00"]
 res = {c: [] for c in combos}
-for rnd in range(1 if only is not None else 5):
+for rnd in range(int(os.environ.get("LL_TL_PROBE_ROUNDS", "1" if only is not None else "5"))):
     for c in combos:
         os.environ["LL_TL_XCD"] = c[0]
         ctx.reload_env()
