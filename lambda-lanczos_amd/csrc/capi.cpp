@@ -49,7 +49,7 @@ Tuning read_tuning() {
   if (t.pb_threads1 != 256 && t.pb_threads1 != 512 && t.pb_threads1 != 1024) t.pb_threads1 = 0;
   t.pb_pad = (int)num("LL_PB_PAD", 0);
   if (t.pb_pad != 4 && t.pb_pad != 16) t.pb_pad = 0;
-  t.pb_placements = (int)std::max<long long>(1, std::min<long long>(8, num("LL_PB_PLACEMENTS", 4)));
+  t.pb_placements = (int)std::max<long long>(1, std::min<long long>(16, num("LL_PB_PLACEMENTS", 8)));
   t.pb_xpre = flag("LL_PB_XPRE", true);
   t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
   t.comm_overlap = flag("LL_COMM_OVERLAP", true);
@@ -841,6 +841,7 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
   // Every candidate stays allocated until all have been timed (an allocation freed at once would simply be handed out
   // again for the next one); then all but the fastest are freed.
   double best = time_pb();
+  if (std::getenv("LL_PB_PLACEMENT_TRACE")) std::fprintf(stderr, "[ll placement] draw 0 at %p: %.4f ms\n", op->d_pb_arena, best);
   void* best_arena = op->d_pb_arena;
   std::vector<void*> losers;
   // Unwinding (a failed copy or launch, thrown through LL_HIP): the operator goes back to the best image found so far and
@@ -869,6 +870,7 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
     LL_HIP(hipMemcpyAsync(cand, best_arena, op->pb_arena_static_bytes, hipMemcpyDeviceToDevice, s));
     rebase(cand);
     const double ms = time_pb();
+    if (std::getenv("LL_PB_PLACEMENT_TRACE")) std::fprintf(stderr, "[ll placement] draw %d at %p: %.4f ms (best so far %.4f)\n", t, cand, ms, best);
     if (ms < best) {
       best = ms;
       losers.back() = best_arena;  // the previous best becomes a loser

@@ -94,10 +94,13 @@ template <typename T> void Basis<T>::prefetch() {
     if (c.second == bytes) return;  // the cache serves the next one
   const int dev = ctx->device;
   // (only hipSetDevice + hipMalloc run on the helper; the cache and the slab list belong to the calling thread)
-  next = std::async(std::launch::async, [dev, bytes]() {
+  const bool trace = std::getenv("LL_SLAB_TRACE") != nullptr;
+  next = std::async(std::launch::async, [dev, bytes, trace]() {
     void* p = nullptr;
+    const double t0 = now_s();
     hipError_t e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipMalloc(&p, bytes);
+    if (trace) std::fprintf(stderr, "[ll slab] helper: hipMalloc of %.2f GiB took %.1f ms\n", (double)bytes / 1073741824.0, (now_s() - t0) * 1e3);
     return std::make_pair(p, (int)e);
   });
 }
@@ -107,13 +110,17 @@ template <typename T> T* Basis<T>::vec(int64_t k) {
     const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
     T* p = nullptr;
     if (next.valid()) {  // allocated ahead (a failure there falls through to the synchronous path and its retry)
+      const double t0 = now_s();
       const auto r = next.get();
+      if (std::getenv("LL_SLAB_TRACE")) std::fprintf(stderr, "[ll slab] slab %zu: waited %.1f ms for the helper\n", chunks.size(), (now_s() - t0) * 1e3);
       if (r.second == (int)hipSuccess) p = (T*)r.first;
       else (void)hipGetLastError();
     }
     if (!p) p = take_cached(bytes);
     if (!p) {
+      const double t0 = now_s();
       hipError_t e = hipMalloc((void**)&p, bytes);
+      if (std::getenv("LL_SLAB_TRACE")) std::fprintf(stderr, "[ll slab] slab %zu: synchronous hipMalloc of %.2f GiB took %.1f ms\n", chunks.size(), (double)bytes / 1073741824.0, (now_s() - t0) * 1e3);
       if (e != hipSuccess && !ctx->slab_cache.empty()) {  // make room: drop cached slabs of other shapes and retry
         (void)hipGetLastError();
         for (auto& c : ctx->slab_cache) (void)hipFree(c.first);

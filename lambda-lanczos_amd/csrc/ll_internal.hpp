@@ -156,7 +156,7 @@ struct Tuning {
   int pb_col_block = 0;
   int pb_threads1 = 0;             // LL_PB_THREADS1 = 256 | 512 | 1024: lanes per workgroup of PB phase 1 (0: automatic — 512 for the thin column blocks of a sharded image, 1024 on one GPU); read at creation
   int pb_pad = 0;                  // LL_PB_PAD = 4 | 16: entries every segment of the PB image is padded to (0: automatic — 4 sharded, 16 on one GPU); read at creation
-  int pb_placements = 4;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first); capi.cpp
+  int pb_placements = 8;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first; LL_PB_PLACEMENT_TRACE=1 prints every draw); capi.cpp
   bool pb_xpre = true;             // LL_PB_XPRE=0: phase 2 of the PB SpMV loads x_i in its epilogue (A/B of the early request)
   bool pb_diag = true;             // LL_PB_DIAG=0: the diagonal entries travel through the PB streams like every other entry (A/B)
   int gather_chunks = 0;           // LL_GATHER_CHUNKS: pieces of the all-gather (0: 4 on two ranks, 2 on more)
