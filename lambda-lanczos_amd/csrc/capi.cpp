@@ -63,7 +63,6 @@ Tuning read_tuning() {
   }
   t.sharded_norm_measured = str("LL_SHARDED_NORM") == "measured";
   t.slab_bytes = std::max<long long>(1, num("LL_SLAB_BYTES", (long long)4 << 30));
-  t.slab_prefetch = flag("LL_SLAB_PREFETCH", true);
   t.blas_small_bytes = num("LL_BLAS_SMALL_BYTES", (long long)4 << 20);
   {
     const long long level = num("LL_FUSE_LAUNCHES", 2);
@@ -317,6 +316,7 @@ int ll_ctx_destroy(ll_context* ctx) {
     if (ctx->d_xfull) (void)hipFree(ctx->d_xfull);
     if (ctx->d_halo) (void)hipFree(ctx->d_halo);
     for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
+    for (auto e : ctx->timer_events) (void)hipEventDestroy(e);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

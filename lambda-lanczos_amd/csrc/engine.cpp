@@ -64,77 +64,44 @@ template <typename T> Basis<T>::~Basis() {
   // slabs go back to the context's cache: the next run() on this context reuses them instead of paying
   // hipMalloc/hipFree of tens of GB per call (ll_ctx_release_cache or ll_ctx_destroy frees them)
   const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
-  if (next.valid()) {  // a slab that was allocated ahead and never needed
-    const auto r = next.get();
-    if (r.second == (int)hipSuccess && r.first) ctx->cache_put(r.first, bytes);
-  }
   for (T* p : chunks) ctx->cache_put((void*)p, bytes);
 }
-template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_, int64_t max_vecs_) {
+template <typename T> void Basis<T>::init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_) {
   ctx = c;
   n_local = n_local_;
   ld = ld_;
   chunk_vecs = chunk_vecs_;
-  max_vecs = max_vecs_;
-}
-template <typename T> T* Basis<T>::take_cached(size_t bytes) {
-  for (size_t i = 0; i < ctx->slab_cache.size(); ++i)
-    if (ctx->slab_cache[i].second == bytes) {
-      T* p = (T*)ctx->slab_cache[i].first;
-      ctx->slab_cache.erase(ctx->slab_cache.begin() + (long)i);
-      return p;
-    }
-  return nullptr;
-}
-template <typename T> void Basis<T>::prefetch() {
-  if (next.valid() || !ctx->tune.slab_prefetch) return;
-  if (max_vecs > 0 && (int64_t)chunks.size() * chunk_vecs >= max_vecs) return;  // the run cannot reach another slab
-  const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
-  for (auto& c : ctx->slab_cache)
-    if (c.second == bytes) return;  // the cache serves the next one
-  const int dev = ctx->device;
-  // (only hipSetDevice + hipMalloc run on the helper; the cache and the slab list belong to the calling thread)
-  const bool trace = std::getenv("LL_SLAB_TRACE") != nullptr;
-  next = std::async(std::launch::async, [dev, bytes, trace]() {
-    void* p = nullptr;
-    const double t0 = now_s();
-    hipError_t e = hipSetDevice(dev);
-    if (e == hipSuccess) e = hipMalloc(&p, bytes);
-    if (trace) std::fprintf(stderr, "[ll slab] helper: hipMalloc of %.2f GiB took %.1f ms\n", (double)bytes / 1073741824.0, (now_s() - t0) * 1e3);
-    return std::make_pair(p, (int)e);
-  });
 }
 template <typename T> T* Basis<T>::vec(int64_t k) {
   const int64_t ci = k / chunk_vecs;
   while ((int64_t)chunks.size() <= ci) {
-    const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
     T* p = nullptr;
-    if (next.valid()) {  // allocated ahead (a failure there falls through to the synchronous path and its retry)
-      const double t0 = now_s();
-      const auto r = next.get();
-      if (std::getenv("LL_SLAB_TRACE")) std::fprintf(stderr, "[ll slab] slab %zu: waited %.1f ms for the helper\n", chunks.size(), (now_s() - t0) * 1e3);
-      if (r.second == (int)hipSuccess) p = (T*)r.first;
-      else (void)hipGetLastError();
+    const size_t bytes = (size_t)chunk_vecs * (size_t)ld * sizeof(T);
+    for (size_t i = 0; i < ctx->slab_cache.size(); ++i)
+      if (ctx->slab_cache[i].second == bytes) {
+        p = (T*)ctx->slab_cache[i].first;
+        ctx->slab_cache.erase(ctx->slab_cache.begin() + (long)i);
+        break;
+      }
+    if (p) {
+      chunks.push_back(p);
+      continue;
     }
-    if (!p) p = take_cached(bytes);
-    if (!p) {
-      const double t0 = now_s();
-      hipError_t e = hipMalloc((void**)&p, bytes);
-      if (std::getenv("LL_SLAB_TRACE")) std::fprintf(stderr, "[ll slab] slab %zu: synchronous hipMalloc of %.2f GiB took %.1f ms\n", chunks.size(), (double)bytes / 1073741824.0, (now_s() - t0) * 1e3);
-      if (e != hipSuccess && !ctx->slab_cache.empty()) {  // make room: drop cached slabs of other shapes and retry
-        (void)hipGetLastError();
-        for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
-        ctx->slab_cache.clear();
-        e = hipMalloc((void**)&p, bytes);
-      }
-      if (e != hipSuccess) {
-        set_error("out of device memory growing the Krylov basis to " + std::to_string((chunks.size() + 1) * chunk_vecs) +
-                  " vectors of " + std::to_string(ld * sizeof(T)) + " bytes: " + hipGetErrorString(e));
-        throw Failure{LL_ERR_ALLOC};
-      }
+    // (a 4 GiB hipMalloc was measured at 0.3-0.5 ms on every box of round 5: allocating the next slab ahead of need on a helper
+    // thread changed nothing and was removed again — what does stall the loop is a hipFREE, see LoopState::begin_pass)
+    hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e != hipSuccess && !ctx->slab_cache.empty()) {  // make room: drop cached slabs of other shapes and retry
+      (void)hipGetLastError();
+      for (auto& c : ctx->slab_cache) (void)hipFree(c.first);
+      ctx->slab_cache.clear();
+      e = hipMalloc((void**)&p, bytes);
+    }
+    if (e != hipSuccess) {
+      set_error("out of device memory growing the Krylov basis to " + std::to_string((chunks.size() + 1) * chunk_vecs) +
+                " vectors of " + std::to_string(ld * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+      throw Failure{LL_ERR_ALLOC};
     }
     chunks.push_back(p);
-    prefetch();
   }
   return chunks[ci] + (k % chunk_vecs) * ld;
 }
@@ -619,27 +586,44 @@ struct EventRing {
 };
 
 struct PhaseTimer {  // optional per-phase device timing (HIP events on the context's stream)
+  // Marks come in triples — start, after the operator, end of the iteration (or pair) — and are recorded into a RING of events
+  // that the context keeps between runs: a triple is read back (its events completed long ago: the host runs a group or two ahead
+  // of the device) when its slot comes round again.  (One fresh event per mark — 900 for config 3's run to convergence, 10 000 for
+  // config 2's — cost the first profiled run of a process up to 0.5 s of host time in hipEventCreate on some boxes.)
+  static constexpr size_t kTriples = 128;
   bool on;
   hipStream_t s;
-  std::vector<hipEvent_t> evs;  // triples: start, after operator, end
-  PhaseTimer(bool enabled, hipStream_t st) : on(enabled), s(st) {}
-  ~PhaseTimer() {
-    for (auto e : evs) (void)hipEventDestroy(e);
+  std::vector<hipEvent_t>& evs;
+  size_t n = 0;  // marks so far
+  double acc_op = 0.0, acc_rest = 0.0;
+  PhaseTimer(ll_context* ctx, hipStream_t st) : on(ctx->profiling), s(st), evs(ctx->timer_events) {}
+  void read(size_t first) {
+    float a = 0, b = 0;
+    if (hipEventSynchronize(evs[first + 2]) != hipSuccess) return;
+    if (hipEventElapsedTime(&a, evs[first], evs[first + 1]) == hipSuccess) acc_op += a * 1e-3;
+    if (hipEventElapsedTime(&b, evs[first + 1], evs[first + 2]) == hipSuccess) acc_rest += b * 1e-3;
   }
   void mark() {
     if (!on) return;
-    hipEvent_t e;
-    LL_HIP(hipEventCreate(&e));
-    LL_HIP(hipEventRecord(e, s));
-    evs.push_back(e);
+    const size_t slot = n % (3 * kTriples);
+    if (slot % 3 == 0 && n >= 3 * kTriples) read(slot);  // the triple that used these events
+    if (slot >= evs.size()) {
+      hipEvent_t e;
+      LL_HIP(hipEventCreate(&e));
+      evs.push_back(e);
+    }
+    LL_HIP(hipEventRecord(evs[slot], s));
+    ++n;
   }
   void collect(double& t_op, double& t_rest) {
     if (!on) return;
-    for (size_t i = 0; i + 3 <= evs.size(); i += 3) {
-      float a = 0, b = 0;
-      if (hipEventElapsedTime(&a, evs[i], evs[i + 1]) == hipSuccess) t_op += a * 1e-3;
-      if (hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]) == hipSuccess) t_rest += b * 1e-3;
-    }
+    // complete triples still in the ring: the last min(n / 3, kTriples) ones, minus those already read when their slot was reused
+    const size_t triples = n / 3, done = n >= 3 * kTriples ? (n - 3 * kTriples) / 3 + ((n % 3) ? 1 : 0) : 0;
+    for (size_t t = done; t < triples; ++t) read((t % kTriples) * 3);
+    t_op += acc_op;
+    t_rest += acc_rest;
+    acc_op = acc_rest = 0.0;
+    n = 0;
   }
 };
 
@@ -688,6 +672,7 @@ template <typename T> struct LoopState {
   // Pair form (kernels.hip, "pair" section; tools/pair_gs_model.py): TWO iterations per sweep over the basis.  State between
   // sweeps: u_0 .. u_{pair_P-1} complete in the basis; two raw vectors pending, pr1 -> u_P and pr2 -> u_{P+1}, with their
   // measured coefficients (g1p; g2p followed by <u_P, pr2>) and the squared norms of their orthogonal parts (rho1p, rho2p).
+  int64_t max_k_hint = 0;     // the loop's max_iteration (sizes the sweeps' partial sums up front, begin_pass)
   bool pair_enabled = false;
   bool pair_allowed = true;   // this pass: a coefficient above kPairGate switches the form off for the rest of the pass
   bool pair_pending = false;
@@ -779,7 +764,18 @@ template <typename T> struct LoopState {
     for (auto& b : slot_pair) b = false;
     lag_ok = lagged && (n_lock == 0 || (lambda_shifted != nullptr && n_lock <= kLaggedMaxLocked));
     lag_beta2_min = 0.0;
-    if (lagged) bind_buffers();
+    if (lagged) {
+      bind_buffers();
+      // The partial sums of the sweeps — one column per coefficient, kMaxGrid rows — are sized HERE for the longest basis this pass can
+      // reach (max_k_hint: max_iteration; the column limits of the one-sweep forms bound it): growing them in the loop means a
+      // hipFree, i.e. a device synchronisation, plus a hipMalloc a dozen times in a run's first call on a context (geometric growth
+      // up to 600 columns for config 3's 301 iterations) — 0.5-0.7 s of the 1.15-1.37 s that call took on some boxes of round 5,
+      // against 0.62 s for the second call.
+      constexpr size_t R = (size_t)Engine<T>::R;
+      const size_t reach = (size_t)std::max<int64_t>(0, std::min<int64_t>(max_k_hint, (int64_t)kLaggedMaxCols)) + (size_t)n_lock + 2;
+      const size_t cols = std::min<size_t>((size_t)kLaggedMaxCols + 8, 2 * R * reach + 5 * R + 1);
+      E.ctx->ensure_partials((size_t)kMaxGrid * cols);
+    }
     if (!lag_ok || n_lock == 0) return;
     LL_HIP(hipMemcpyAsync(d_lambda, lambda_shifted, (size_t)n_lock * sizeof(double), hipMemcpyHostToDevice, s));
     LL_HIP(hipStreamSynchronize(s));  // (pageable source: the caller's array may go away)
@@ -1223,7 +1219,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   constexpr int R = scalar_traits<T>::reals;
 
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes), P.max_iteration + 2);
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
   DevBuf<T> d_locked, d_ritz;
   int64_t d_ritz_cap = 0;
   if (spec) {
@@ -1234,7 +1230,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   const int64_t nroot_max = std::min<int64_t>(P.num_eigs_per_iteration, n);
   ctx->ensure_pinned(32);  // 4 ring slots of 4 scalars, then the 4 gate values of the pair form
   EventRing ring;
-  PhaseTimer timer(ctx->profiling, s);
+  PhaseTimer timer(ctx, s);
 
   // EigenPairManager (EPM:21-80): best num_eigs pairs, ordered by the comparator
   std::function<bool(double, double)> cmp;
@@ -1247,6 +1243,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
   if (E.can_defer_scale() && fuse_launches && mode == LL_ORTH_CGS_DGKS) LS.enable_defer(ld);
+  LS.max_k_hint = P.max_iteration;
   if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
   // two iterations per sweep (device operators, streaming vectors, no locked vectors; LoopState::enqueue_pair decides per iteration)
   if (LS.lagged && ctx->tune.pair_gs &&
@@ -1697,11 +1694,11 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   // the post-pass norm + the publish step ride in the normalisation kernel.  LL_FUSE_LAUNCHES=0: separate kernels (A/B).
   const bool fuse_launches = ctx->tune.fuse_launches;
   Basis<T> U;
-  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes), P.max_iteration + 2);
+  U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
   st.at("basis");
   ctx->ensure_pinned(16);
   EventRing ring;
-  PhaseTimer timer(ctx->profiling, s);
+  PhaseTimer timer(ctx, s);
   double t_tridiag = 0.0;
   st.at("events");
 
@@ -1726,6 +1723,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   LoopState<T> LS(E, U, ring, timer, nl, s);
   LS.fuse_launches = fuse_launches;
   LS.refs_prev = refs_prev;
+  LS.max_k_hint = P.max_iteration;
   if (E.can_defer_scale() && fuse_launches && (!P.full_orthogonalize || P.orth_mode == LL_ORTH_CGS_DGKS)) LS.enable_defer(ld);
   if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS)
     LS.enable_lagged(ld);

@@ -2,7 +2,6 @@
 // complex<double> in engine.cpp).  See DESIGN.md for the data flow.
 #pragma once
 
-#include <future>
 #include <complex>
 #include <functional>
 #include <map>
@@ -29,18 +28,9 @@ template <typename T> struct Basis {
   int64_t n_local = 0, ld = 0;
   int64_t chunk_vecs = 0;
   std::vector<T*> chunks;
-  // The NEXT slab is allocated ahead of need on a helper thread: a 4 GiB hipMalloc takes 30-70 ms on the boxes of this pool, the
-  // host runs one group of launches (1-3 ms) ahead of the device, so an allocation in the loop's way idles the GPU for all
-  // of its duration — 0.17-0.41 s of config 3's 0.75-0.99 s to convergence (six slabs) before this.  max_vecs bounds the
-  // prefetch (max_iteration + 2: a run that cannot use another slab does not ask for one).
-  int64_t max_vecs = 0;
-  std::future<std::pair<void*, int>> next;  // (pointer, hipError_t) of slab number chunks.size(), when valid()
   ~Basis();
-  void init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_, int64_t max_vecs_ = 0);
+  void init(ll_context* c, int64_t n_local_, int64_t ld_, int64_t chunk_vecs_);
   T* vec(int64_t k);  // pointer to vector k, growing the slab list if needed
- private:
-  void prefetch();    // start allocating the slab after the last one, unless the cache has one or the run cannot reach it
-  T* take_cached(size_t bytes);
 };
 
 // A list of (base, count) runs with a common ld, packed into kernel-argument groups.

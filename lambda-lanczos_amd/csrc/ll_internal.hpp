@@ -169,7 +169,6 @@ struct Tuning {
   double dgks_threshold = 0.5;     // LL_DGKS_THRESHOLD: second Gram-Schmidt pass when ||w'||^2 < thr * ||w||^2
   bool sharded_norm_measured = false;  // LL_SHARDED_NORM=measured: all-reduce the post-pass norm instead of deriving it
   int64_t slab_bytes = (int64_t)4 << 30;       // LL_SLAB_BYTES: cap of one Krylov-basis slab
-  bool slab_prefetch = true;                   // LL_SLAB_PREFETCH=0: allocate every slab when it is needed (A/B of the helper-thread allocation)
   int64_t blas_small_bytes = (int64_t)4 << 20;  // LL_BLAS_SMALL_BYTES: vectors below this use the small-vector kernels
   bool fuse_launches = true;       // LL_FUSE_LAUNCHES=0: separate fold / publish kernels (A/B of the launch fusion)
   long long lagged_min_bytes = -1; // test hook LL_TEST_LAGGED_MIN_BYTES: shortest vector of the one-sweep form (-1 = default)
@@ -222,6 +221,7 @@ struct ll_context {
   size_t pinned_cap = 0;         // doubles
   void* d_coeff = nullptr;       // coefficient upload area for gemv_basis
   size_t coeff_cap = 0;          // bytes
+  std::vector<hipEvent_t> timer_events;  // PhaseTimer's ring of timing events (profiling mode), created once and kept between runs
   std::vector<std::pair<void*, size_t>> slab_cache;  // Krylov-basis slabs kept between runs (ptr, bytes), oldest first
   // Return a buffer to the cache.  The cache is bounded (kSlabCacheMaxEntries): a long-lived context that solves problems
   // of many different shapes frees its oldest cached buffers instead of accumulating them (hipFree synchronises the device;

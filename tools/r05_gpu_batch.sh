@@ -37,8 +37,7 @@ if has final; then
 fi
 if has conv; then
   for wl in c3 c2; do
-    LL_SLAB_TRACE=1 timeout 600 python3 tests/convergence_run.py $wl > gpurun_out/r05_convergence_${wl}_defaults.json 2> gpurun_out/r05_convergence_$wl.err < /dev/null
-    grep -c 'll slab' gpurun_out/r05_convergence_$wl.err; grep 'll slab' gpurun_out/r05_convergence_$wl.err | sort -t' ' -k9 -n | tail -3
+    timeout 600 python3 tests/convergence_run.py $wl > gpurun_out/r05_convergence_${wl}_defaults.json 2> gpurun_out/r05_convergence_$wl.err < /dev/null
     echo "convergence $wl rc=$?"; tail -c 600 gpurun_out/r05_convergence_${wl}_defaults.json
   done
 fi
