@@ -637,3 +637,39 @@ def test_coo_operator_sample2_and_inf_norm_offset(ctx):
     assert abs(v2[0] - G.laplace2d_lambda_min(30)) <= 1e-10 * 8
     assert e2.getIterationCounts()[0] < 900          # converged, did not run to max_iteration
     lap.close()
+
+
+@pytest.mark.parametrize("geometry", ["default", "streaming"])
+def test_profiled_runs_longer_than_the_timing_event_ring(geometry, llenv):
+    """ll_ctx_set_profiling: the per-phase device times come from a ring of 128 event triples that the context keeps between
+    runs (a triple is read back when its slot comes round again).  A run with several hundred iterations — more triples than
+    the ring holds, in the pair form two per sweep — must report device times that add up (below the wall time of the call,
+    above the bulk of it for a device-bound problem), the same figures for a second call on the same context, and the same
+    Lanczos results as an unprofiled run."""
+    if geometry == "streaming":
+        llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    c = L.Context(0)
+    m = 300
+    csr = G.laplace2d_np(m)
+    init = G.start_vector(m * m, 2)
+    op = L.CsrOperator(c, *csr)
+
+    def run():
+        eng = L.LambdaLanczos(op, m * m, True, 1)
+        eng.init_vector = fixed_init(init)
+        vals, _ = eng.run()
+        return vals[0], eng.getIterationCounts()[0], dict(eng.last_stats)
+
+    plain = run()
+    c.set_profiling(True)
+    a, b = run(), run()
+    c.set_profiling(False)
+    assert plain[0] == a[0] == b[0] and plain[1] == a[1] == b[1] and a[1] > 3 * 128
+    for st in (a[2], b[2]):
+        dev = st["seconds_spmv"] + st["seconds_orth"]
+        assert 0.0 < dev <= st["seconds_total"] * 1.02, st
+        assert st["seconds_spmv"] > 0.0 and st["seconds_orth"] > 0.0
+    da, db = a[2]["seconds_spmv"] + a[2]["seconds_orth"], b[2]["seconds_spmv"] + b[2]["seconds_orth"]
+    assert abs(da - db) <= 0.35 * max(da, db), (a[2], b[2])
+    op.close()
+    c.close()
