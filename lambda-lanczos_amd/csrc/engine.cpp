@@ -680,6 +680,8 @@ template <typename T> struct LoopState {
   int64_t n_pair = 0;         // iterations enqueued in the pair form (statistics; includes speculative ones that were dropped)
   int64_t n_gate_trips = 0;   // passes that left the pair form through the coefficient gate
   DevBuf<T> pwork[2];         // with work[0..1]: the four raw vectors of a pair
+  DevBuf<T> psplit;           // hand-over vector of a split sweep (more stored vectors than one launch sums columns for)
+  static constexpr size_t kPresizeCols = 4096;  // columns the sweeps' partial sums are sized for at pass start
   DevBuf<double> pbuf;        // coefficient records, predictions, scalars (its own allocation: ctx->d_h may move)
   const T *pr1 = nullptr, *pr2 = nullptr;
   int pset = 0;               // which pair of buffers holds pr1 / pr2: 0 = work, 1 = pwork
@@ -697,8 +699,8 @@ template <typename T> struct LoopState {
     pair_enabled = true;
     for (auto& w : pwork)
       if (!w.p) w.alloc(E.ctx, (size_t)ld);
-    // 4 records + zero record + p3 + p4 + fold scratch + folded columns + 64 scalars
-    pbuf.alloc(E.ctx, 9 * kPairRec + 64);
+    // 4 records + zero record + p3 + p4 + fold scratch + folded columns (two per stored vector: twice a record) + 64 scalars
+    pbuf.alloc(E.ctx, 10 * kPairRec + 64);
     double* b = pbuf.p;
     for (int i = 0; i < 4; ++i) prec[i] = b + (size_t)i * kPairRec;
     pzero = b + 4 * kPairRec;
@@ -706,10 +708,20 @@ template <typename T> struct LoopState {
     pp4 = b + 6 * kPairRec;
     pfold = b + 7 * kPairRec;
     pcols = b + 8 * kPairRec;
-    pscal = b + 9 * kPairRec;
+    pscal = b + 10 * kPairRec;
     LL_HIP(hipMemsetAsync(pzero, 0, kPairRec * sizeof(double), s));
     launch_set_scalar(pscal + 0, 1.0, s);  // pscal[0] = 1 (rho1^2 of a vector that is already complete)
     // pscal[8 + 2 i], [9 + 2 i]: rho^2 pair i (alternating); pscal[16 ..]: |r3|^2, <r1, r3>
+  }
+  // partial sums of the sweeps: sized at pass start for up to kPresizeCols columns (begin_pass); beyond that in powers of two —
+  // every growth is a hipFree, i.e. a device synchronisation
+  void want_partial_cols(size_t cols) {
+    if (cols > kPresizeCols) {
+      size_t p2 = kPresizeCols;
+      while (p2 < cols) p2 *= 2;
+      cols = p2;
+    }
+    E.ctx->ensure_partials((size_t)kMaxGrid * cols);
   }
   void enable_defer(int64_t ld_) {
     defer = true;
@@ -773,7 +785,7 @@ template <typename T> struct LoopState {
       // against 0.62 s for the second call.
       constexpr size_t R = (size_t)Engine<T>::R;
       const size_t reach = (size_t)std::max<int64_t>(0, std::min<int64_t>(max_k_hint, (int64_t)kLaggedMaxCols)) + (size_t)n_lock + 2;
-      const size_t cols = std::min<size_t>((size_t)kLaggedMaxCols + 8, 2 * R * reach + 5 * R + 1);
+      const size_t cols = std::min<size_t>(kPresizeCols, 2 * R * reach + 5 * R + 1);  // (longer runs: powers of two, enqueue_pair)
       E.ctx->ensure_partials((size_t)kMaxGrid * cols);
     }
     if (!lag_ok || n_lock == 0) return;
@@ -915,10 +927,14 @@ template <typename T> struct LoopState {
     const int ncols = 2 * R * (int)K + 5 * R + 1;
     const int64_t stream_bytes = std::min<int64_t>(small_bytes, (int64_t)1 << 20);
     const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;  // (sharded: decided on the shard stride, the same on every rank)
-    if (ncols > kLaggedMaxCols || len * (int64_t)sizeof(T) < stream_bytes) return false;
+    // the coefficient records hold reals * (K + 2) (+ reals) numbers, the recorded tridiagonal kLaggedMaxCols + 8 entries; the
+    // sweep's 2 reals K + 5 reals + 1 columns are summed in as many launches as one workgroup's LDS asks for (pair_sweep_max_vecs)
+    if ((int64_t)R * (K + 8) > kLaggedMaxCols || len * (int64_t)sizeof(T) < stream_bytes) return false;
     const RunList<T> stored = basis_runs(P);
-    const std::vector<BasisSegs<T>> groups = stored.groups(max_vecs_per_launch<T>());
-    if (groups.size() != 1) return false;
+    int per_launch = pair_sweep_max_vecs<T>();
+    if (E.ctx->tune.pair_split_vecs > 0) per_launch = std::min(per_launch, std::max(1, E.ctx->tune.pair_split_vecs));
+    const std::vector<BasisSegs<T>> groups = stored.groups(per_launch);
+    if (groups.size() > 1 && !psplit.p) psplit.alloc(E.ctx, (size_t)ld);
     const double te0 = now_s();
     T* r3 = out_set ? pwork[0].p : work[0].p;
     T* r4 = out_set ? pwork[1].p : work[1].p;
@@ -930,7 +946,7 @@ template <typename T> struct LoopState {
     const int sa = (int)(k % 4), sb = (int)((k + 1) % 4);
     double* e1 = E.S(kScalAlpha + sa);
     double* e2 = E.S(kScalAlpha + sb);
-    E.ctx->ensure_partials((size_t)kMaxGrid * (size_t)std::max(ncols, 1 + R));
+    want_partial_cols((size_t)std::max(ncols, 1 + R));
     // ---- iteration k: operator on r2 / rho2, three-term with raw vectors
     timer.mark();
     typename Engine<T>::DeferredAlpha da1, da2;
@@ -963,7 +979,7 @@ template <typename T> struct LoopState {
     // ---- one sweep for both
     launch_pair_predict((int)P, (int)Lk, R, g1, g2, rho1sq, rho2sq, gam, t3, fold_in_consumers ? E.ctx->d_partials : nullptr, tt_grid,
                         e1, e2, da2.nparts > 0 ? da2.partials : nullptr, da2.nparts, hist_alpha, hist_beta, d_lambda, pp3, pp4, s);
-    grid = launch_pair_sweep<T>(nl, groups[0], (int)K, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), g1, g2, gam, pp4, rho1sq, rho2sq,
+    grid = launch_pair_sweep<T>(nl, groups, (int)K, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), psplit.p, g1, g2, gam, pp4, rho1sq, rho2sq,
                                 e2, t3, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
     launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
     // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits
@@ -1028,7 +1044,7 @@ template <typename T> struct LoopState {
       tt.alpha_out = E.S(kScalAlpha + slot);
     }
     const int ncols = R * (int)nb_total + 1;
-    E.ctx->ensure_partials((size_t)kMaxGrid * (size_t)ncols);
+    want_partial_cols((size_t)ncols);
     BasisSegs<T> none;
     none.nseg = 0;
     none.ld = ld;

@@ -1060,22 +1060,30 @@ __device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, 
 
 // Partial columns per workgroup: [m3: R*P][m4: R*P][<u_P,r3>][<u_{P+1},r3>][<u_P,r4>][<u_{P+1},r4>][<r3,r4>] (R each) [|r4|^2].
 template <typename T, int PC>
-__global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs<T> segs, int P, const T* __restrict__ r1,
-                                                            const T* __restrict__ r2, const T* __restrict__ r3,
-                                                            T* __restrict__ r4, T* __restrict__ uP_out, T* __restrict__ uQ_out,
+__global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs<T> segs, int P, int col0, int Pl, int flags,
+                                                            const T* __restrict__ r1, const T* __restrict__ r2,
+                                                            const T* __restrict__ r3, T* __restrict__ r4, T* __restrict__ uP_out,
+                                                            T* __restrict__ uQ_out, T* __restrict__ part4,
                                                             const double* __restrict__ g1, const double* __restrict__ g2,
                                                             const double* __restrict__ gam, const double* __restrict__ p4,
                                                             const double* __restrict__ rho1sq, const double* __restrict__ rho2sq,
                                                             const double* __restrict__ e2, const double* __restrict__ n3sq,
                                                             double* __restrict__ partials) {
+  // A sweep over more stored vectors than one workgroup's LDS holds columns for is SPLIT into launches over consecutive ranges of
+  // the stored vectors (segs = vectors [col0, col0 + Pl) of the P stored ones; flags: kPairFirst / kPairLast).  Between launches the
+  // two late updates travel through their basis slots (uP_out, uQ_out: unnormalised) and the partly compensated r4 through part4;
+  // r4 itself keeps y2 until the last launch, which finishes everything.  Every coefficient column is summed in exactly one launch,
+  // over the same strips by the same waves, and a strip written and read back is the same bits: the split changes no result.
   constexpr int EPT = lstrip<T, PC>::EPT;
   constexpr int ELEMS = lstrip<T, PC>::ELEMS;
   constexpr int JB = kJB;
   constexpr int R = scalar_traits<T>::reals;
-  const int ncols = 2 * R * P + 5 * R + 1;
-  extern __shared__ double lds[];  // [4 waves][ncols]
+  const bool first = (flags & kPairFirst) != 0, last = (flags & kPairLast) != 0;
+  const int ncols = 2 * R * P + 5 * R + 1;               // columns of the whole sweep (layout of `partials`)
+  const int lcols = 2 * R * Pl + (last ? 5 * R + 1 : 0);  // columns this launch sums
+  extern __shared__ double lds[];  // [4 waves][lcols]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
+  for (int i = tid; i < 4 * lcols; i += kBlock) lds[i] = 0.0;
   const double s1 = 1.0 / sqrt(*rho1sq), s2 = 1.0 / sqrt(*rho2sq);
   // the buffer r4 holds y2 = A (r3 / |r3|) on entry: the second three-term update r4 = y2 - (e2 / |r3|) r3 - (|r3| / rho2) r2 is
   // formed here, from strips this sweep reads anyway (a separate kernel would move 4 more vectors)
@@ -1085,13 +1093,13 @@ __global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs
   if constexpr (scalar_traits<T>::is_complex) gm = zc{gam[0], gam[1]};
   else gm = gam[0];
   __syncthreads();
-  double* mine = lds + (size_t)wave * ncols;
-  double* tail = mine + 2 * R * P;
+  double* mine = lds + (size_t)wave * lcols;
+  double* tail = mine + 2 * R * Pl;
   const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
   for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int64_t base = sidx * ELEMS;
     T a1[EPT], a2[EPT], b3[EPT], b4r[EPT], b4[EPT];
-    load_lstrip<T, PC>(r1, base, n, a1);
+    load_lstrip<T, PC>(first ? r1 : uP_out, base, n, a1);
     load_lstrip<T, PC>(r2, base, n, a2);
     load_lstrip<T, PC>(r3, base, n, b3);
     load_lstrip<T, PC>(r4, base, n, b4r);
@@ -1100,26 +1108,36 @@ __global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs
       b4r[e] = sub(sub(b4r[e], rmul(ca, b3[e])), rmul(cb, a2[e]));
       b4[e] = b4r[e];
     }
-    int col = 0;
+    if (!first) {  // (uniform) the late update of r2 and the compensated r4 as the launch before left them
+      load_lstrip<T, PC>(uQ_out, base, n, a2);
+      load_lstrip<T, PC>(part4, base, n, b4);
+    }
+    int col = R * col0;
     for (int sg = 0; sg < segs.nseg; ++sg) {
       const T* ub = segs.base[sg];
       const int cnt = segs.count[sg];
       int j = 0;
       for (; j + JB <= cnt; j += JB, col += R * JB)
         pair_trip<T, JB, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, a1, a2, b3, b4r, b4, g1 + col, g2 + col, p4 + col,
-                             mine + col, mine + R * P + col, lane);
+                             mine + (col - R * col0), mine + R * Pl + (col - R * col0), lane);
       if (j + 2 <= cnt) {
         pair_trip<T, 2, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, a1, a2, b3, b4r, b4, g1 + col, g2 + col, p4 + col,
-                            mine + col, mine + R * P + col, lane);
+                            mine + (col - R * col0), mine + R * Pl + (col - R * col0), lane);
         j += 2;
         col += R * 2;
       }
       if (j < cnt) {
         pair_trip<T, 1, PC>(ub + (int64_t)j * segs.ld, segs.ld, base, n, a1, a2, b3, b4r, b4, g1 + col, g2 + col, p4 + col,
-                            mine + col, mine + R * P + col, lane);
+                            mine + (col - R * col0), mine + R * Pl + (col - R * col0), lane);
         j += 1;
         col += R;
       }
+    }
+    if (!last) {  // (uniform) hand the three running strips to the next launch
+      store_lstrip<T, PC>(uP_out, base, n, a1);
+      store_lstrip<T, PC>(uQ_out, base, n, a2);
+      store_lstrip<T, PC>(part4, base, n, b4);
+      continue;
     }
     // u_P and u_{P+1} are complete: normalise, store; the in-strip coefficients and raw dots
     acc_t<T> t3p = zero<acc_t<T>>(), t3q = zero<acc_t<T>>(), t4p = zero<acc_t<T>>(), t4q = zero<acc_t<T>>(),
@@ -1156,31 +1174,46 @@ __global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs
     }
   }
   __syncthreads();
+  // this launch's columns into the sweep's layout: <u_j, r3> at R col0.., <u_j, r4> at R P + R col0.., the tail at 2 R P
   double* out = partials + (size_t)blockIdx.x * ncols;
-  for (int i = tid; i < ncols; i += kBlock)
-    out[i] = (lds[i] + lds[ncols + i]) + (lds[2 * ncols + i] + lds[3 * ncols + i]);
+  for (int i = tid; i < lcols; i += kBlock) {
+    const double v = (lds[i] + lds[lcols + i]) + (lds[2 * lcols + i] + lds[3 * lcols + i]);
+    const int g = i < R * Pl ? R * col0 + i : (i < 2 * R * Pl ? R * P + R * col0 + (i - R * Pl) : 2 * R * P + (i - 2 * R * Pl));
+    out[g] = v;
+  }
 }
+// groups: the stored vectors in launch order (every group within pair_sweep_max_vecs<T>() vectors and kMaxSegs segments);
+// part4: an n-vector of scratch, needed (and touched) only when there is more than one group.
 template <typename T>
-int launch_pair_sweep(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
-                      T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
-                      const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces, hipStream_t s) {
+int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P, const T* r1, const T* r2, const T* r3, T* r4,
+                      T* uP_out, T* uQ_out, T* part4, const double* g1, const double* g2, const double* gam, const double* p4,
+                      const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
+                      hipStream_t s) {
   constexpr int R = scalar_traits<T>::reals;
-  const int ncols = 2 * R * P + 5 * R + 1;
-  const size_t lds_bytes = (size_t)4 * ncols * sizeof(double);
   const int64_t strips16k = (n * (int64_t)sizeof(T) + 16383) / 16384;
   int pc = strips16k >= kLaggedFullStrips ? 4 : 2;
   if (pieces == 2 || pieces == 4) pc = pieces;
-  int grid;
-  if (pc == 4) {
-    grid = strip_grid(n, lstrip<T, 4>::ELEMS);
-    hipLaunchKernelGGL((pair_sweep_kernel<T, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, r1, r2, r3, r4, uP_out, uQ_out,
-                       g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
-  } else {
-    grid = strip_grid(n, lstrip<T, 2>::ELEMS);
-    hipLaunchKernelGGL((pair_sweep_kernel<T, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, r1, r2, r3, r4, uP_out, uQ_out,
-                       g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+  const int grid = pc == 4 ? strip_grid(n, lstrip<T, 4>::ELEMS) : strip_grid(n, lstrip<T, 2>::ELEMS);
+  BasisSegs<T> none;
+  none.nseg = 0;
+  none.ld = groups.empty() ? 0 : groups[0].ld;
+  const size_t ng = std::max<size_t>(groups.size(), 1);
+  int col0 = 0;
+  for (size_t gi = 0; gi < ng; ++gi) {
+    const BasisSegs<T>& segs = groups.empty() ? none : groups[gi];
+    int Pl = 0;
+    for (int i = 0; i < segs.nseg; ++i) Pl += segs.count[i];
+    const int flags = (gi == 0 ? kPairFirst : 0) | (gi + 1 == ng ? kPairLast : 0);
+    const size_t lds_bytes = (size_t)4 * (size_t)(2 * R * Pl + ((flags & kPairLast) ? 5 * R + 1 : 0)) * sizeof(double);
+    if (pc == 4)
+      hipLaunchKernelGGL((pair_sweep_kernel<T, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, col0, Pl, flags, r1, r2, r3, r4,
+                         uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+    else
+      hipLaunchKernelGGL((pair_sweep_kernel<T, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, col0, Pl, flags, r1, r2, r3, r4,
+                         uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+    LL_HIP(hipGetLastError());
+    col0 += Pl;
   }
-  LL_HIP(hipGetLastError());
   return grid;
 }
 
@@ -1342,9 +1375,9 @@ void launch_pair_fold(const double* m, int P, int L, int reals, const double* la
 #define LL_INST_PAIR(T)                                                                                                          \
   template int launch_pair_three_term<T>(int64_t, T*, const T*, const T*, double*, const double*, int, const double*,           \
                                          const double*, double*, bool, hipStream_t);                                             \
-  template int launch_pair_sweep<T>(int64_t, const BasisSegs<T>&, int, const T*, const T*, const T*, T*, T*, T*, const double*, \
-                                    const double*, const double*, const double*, const double*, const double*, const double*,   \
-                                    const double*, double*, int, hipStream_t);
+  template int launch_pair_sweep<T>(int64_t, const std::vector<BasisSegs<T>>&, int, const T*, const T*, const T*, T*, T*, T*, T*, \
+                                    const double*, const double*, const double*, const double*, const double*, const double*,    \
+                                    const double*, const double*, double*, int, hipStream_t);
 LL_INST_PAIR(double) LL_INST_PAIR(zc) LL_INST_PAIR(float) LL_INST_PAIR(cf)
 
 // ================================================================= small-vector Gram-Schmidt kernels (vectors < 4 MiB)

@@ -154,6 +154,7 @@ struct Tuning {
   int pb_block = 0;                // LL_PB_BLOCK: rows AND columns per block (0: automatic); tests force ragged blocks
   int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
   int pb_col_block = 0;
+  int pair_split_vecs = 0;         // LL_TEST_PAIR_SPLIT=n: at most n stored vectors per launch of the pair sweep (test hook: split sweeps on small problems)
   int pb_threads1 = 0;             // LL_PB_THREADS1 = 256 | 512 | 1024: lanes per workgroup of PB phase 1 (0: automatic — 512 for the thin column blocks of a sharded image, 1024 on one GPU); read at creation
   int pb_pad = 0;                  // LL_PB_PAD = 4 | 16: entries every segment of the PB image is padded to (0: automatic — 4 sharded, 16 on one GPU); read at creation
   int pb_placements = 8;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first; LL_PB_PLACEMENT_TRACE=1 prints every draw); capi.cpp
@@ -483,10 +484,18 @@ void launch_pair_predict(int P, int L, int reals, const double* g1, const double
                          const double* e2_partials, int e2_nparts, const double* hist_alpha, const double* hist_beta,
                          const double* lambda, double* p3, double* p4, hipStream_t s);
 // r4 holds y2 = A (r3 / |r3|) on entry; the sweep forms r4 = y2 - (e2 / |r3|) r3 - (|r3| / rho2) r2 on the fly
+// One workgroup keeps 4 x (2 reals Pl + 5 reals + 1) columns in LDS: a sweep over more stored vectors than that is split into
+// launches over consecutive groups of them (same results bit for bit, kernels.hip); part4: scratch n-vector for the hand-over
+// (touched only when there is more than one group).
+constexpr int kPairFirst = 1, kPairLast = 2;
+template <typename T> constexpr int pair_sweep_max_vecs() {
+  return (kLaggedMaxCols - 5 * scalar_traits<T>::reals - 1) / (2 * scalar_traits<T>::reals);
+}
 template <typename T>
-int launch_pair_sweep(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
-                      T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
-                      const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces, hipStream_t s);
+int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P, const T* r1, const T* r2, const T* r3, T* r4,
+                      T* uP_out, T* uQ_out, T* part4, const double* g1, const double* g2, const double* gam, const double* p4,
+                      const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
+                      hipStream_t s);
 void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,
                       const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
                       double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,

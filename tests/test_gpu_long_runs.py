@@ -229,7 +229,7 @@ def test_one_sweep_form_in_restart_passes_matches_the_reference(ctx):
 
 
 # ------------------------------------------------------------------ the STREAMING one-sweep kernel over whole runs (round 5)
-@pytest.mark.parametrize("form", ["pair", "one_sweep"])
+@pytest.mark.parametrize("form", ["pair", "pair_split", "one_sweep"])
 @pytest.mark.parametrize("name", ["laplace400_converge", "torus300_converge"])
 def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, llenv, name, form):
     """The streaming geometry of the Gram-Schmidt step (vectors >= 1 MiB — what configs 2 and 3 run for thousands / hundreds of
@@ -237,11 +237,15 @@ def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, 
     the 400 x 400 Laplacian (smallest pair, offset -8, 1.28 MB vectors, 1448 reference iterations) and the complex torus 300 x 300
     (config 5's matrix in small, smallest pair, offset -10, 1.44 MB vectors, 524 iterations), in both forms these vectors can take:
     `pair` — the default: two iterations per sweep (pair_sweep_kernel) — and `one_sweep` — LL_PAIR_GS=0: one sweep per iteration
-    (lagged_kernel), the form the pair form falls back to.  EVERY alpha / beta of the run to 1e-10 ||A||_inf (an error of a
+    (lagged_kernel), the form the pair form falls back to; `pair_split` — the pair form with its sweep split into launches of at most
+    300 stored vectors each (LL_TEST_PAIR_SPLIT: what happens by itself beyond 2 497 real / 1 247 complex stored vectors, where one
+    workgroup's LDS no longer holds a column per coefficient).  EVERY alpha / beta of the run to 1e-10 ||A||_inf (an error of a
     compensation that grew slowly with k would show here), iteration count +-2, eigenvalue, sampled eigenvector entries, residual,
     and the run really took that kernel."""
     if form == "one_sweep":
         llenv.setenv("LL_PAIR_GS", "0")
+    if form == "pair_split":
+        llenv.setenv("LL_TEST_PAIR_SPLIT", "300")
     gold = GOLD[name]
     csr = MG.long_run_matrix(gold)
     n = gold["n"]
@@ -254,7 +258,7 @@ def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, 
     vals, vecs = eng.run()
     itern = eng.getIterationCounts()[0]
     assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
-    if form == "pair":
+    if form in ("pair", "pair_split"):
         assert eng.last_stats["pair_iterations"] >= itern - 3 - 4 * eng.last_stats["second_passes"], eng.last_stats
     else:
         assert eng.last_stats["pair_iterations"] == 0
