@@ -46,6 +46,7 @@ Tuning read_tuning() {
   t.pb_row_block = (int)std::max<long long>(0, num("LL_PB_ROW_BLOCK", 0));
   t.pb_col_block = (int)std::max<long long>(0, num("LL_PB_COL_BLOCK", 0));
   t.pair_split_vecs = (int)std::max<long long>(0, num("LL_TEST_PAIR_SPLIT", 0));
+  t.pair_max_stored = (int)std::max<long long>(0, num("LL_TEST_PAIR_MAX_STORED", 0));
   t.pb_threads1 = (int)num("LL_PB_THREADS1", 0);
   if (t.pb_threads1 != 256 && t.pb_threads1 != 512 && t.pb_threads1 != 1024) t.pb_threads1 = 0;
   t.pb_pad = (int)num("LL_PB_PAD", 0);

@@ -930,6 +930,7 @@ template <typename T> struct LoopState {
     // the coefficient records hold reals * (K + 2) (+ reals) numbers, the recorded tridiagonal kLaggedMaxCols + 8 entries; the
     // sweep's 2 reals K + 5 reals + 1 columns are summed in as many launches as one workgroup's LDS asks for (pair_sweep_max_vecs)
     if ((int64_t)R * (K + 8) > kLaggedMaxCols || len * (int64_t)sizeof(T) < stream_bytes) return false;
+    if (E.ctx->tune.pair_max_stored > 0 && K > E.ctx->tune.pair_max_stored) return false;  // (test hook: the hand-over to the one-sweep form)
     const RunList<T> stored = basis_runs(P);
     int per_launch = pair_sweep_max_vecs<T>();
     if (E.ctx->tune.pair_split_vecs > 0) per_launch = std::min(per_launch, std::max(1, E.ctx->tune.pair_split_vecs));

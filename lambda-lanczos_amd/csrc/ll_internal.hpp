@@ -154,6 +154,7 @@ struct Tuning {
   int pb_block = 0;                // LL_PB_BLOCK: rows AND columns per block (0: automatic); tests force ragged blocks
   int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
   int pb_col_block = 0;
+  int pair_max_stored = 0;         // LL_TEST_PAIR_MAX_STORED=n: the pair form hands over to the one-sweep form beyond n stored vectors (test hook; by itself at 4 992 real / 2 492 complex)
   int pair_split_vecs = 0;         // LL_TEST_PAIR_SPLIT=n: at most n stored vectors per launch of the pair sweep (test hook: split sweeps on small problems)
   int pb_threads1 = 0;             // LL_PB_THREADS1 = 256 | 512 | 1024: lanes per workgroup of PB phase 1 (0: automatic — 512 for the thin column blocks of a sharded image, 1024 on one GPU); read at creation
   int pb_pad = 0;                  // LL_PB_PAD = 4 | 16: entries every segment of the PB image is padded to (0: automatic — 4 sharded, 16 on one GPU); read at creation

@@ -252,3 +252,32 @@ def test_split_sweeps_change_no_bit(ctx, llenv, name, split):
     for a, b in zip(whole["vecs"], parts["vecs"]):
         assert np.array_equal(a, b)
     op.close()
+
+
+@pytest.mark.parametrize("name,limit", [("laplace", 100), ("laplace", 101), ("torus", 77)])
+def test_pair_form_hands_over_to_the_one_sweep_form_at_its_column_limit(ctx, oracle, llenv, name, limit):
+    """The coefficient records of the pair form end at 4 992 real (2 492 complex) stored vectors; beyond that the loop completes the
+    pending pair and continues with one sweep per iteration.  No test problem runs that long, so LL_TEST_PAIR_MAX_STORED moves the
+    hand-over into reach (even and odd limits: either vector of a pair can be the last one): same run as the pair form alone to
+    1e-11 ||A||, the oracle's counts and eigenpair, and both forms really ran."""
+    n, csr, init, find_max, offset = _case(name)
+    llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
+    op = L.CsrOperator(ctx, *csr)
+    pair = _run(ctx, op, n, find_max, offset, init)
+    llenv.setenv("LL_TEST_PAIR_MAX_STORED", str(limit))
+    both = _run(ctx, op, n, find_max, offset, init)
+    llenv.delenv("LL_TEST_PAIR_MAX_STORED")
+    itern = both["iters"][0]
+    assert both["iters"] == pair["iters"] and itern > limit + 50
+    assert limit - 4 <= both["stats"]["pair_iterations"] <= limit + 6, both["stats"]
+    assert both["stats"]["lagged_iterations"] >= itern - 3 - 4 * both["stats"]["second_passes"], both["stats"]
+    scale = inf_norm(csr) + abs(offset)
+    assert np.max(np.abs(both["alpha"] - pair["alpha"])) <= 1e-11 * scale
+    assert np.max(np.abs(both["beta"] - pair["beta"])) <= 1e-11 * scale
+    assert abs(both["vals"][0] - pair["vals"][0]) <= 1e-12 * scale
+    assert 1 - overlap(both["vecs"][0], pair["vecs"][0]) <= 1e-10
+    ora = oracle.lanczos(csr, init, find_max, offset=offset)
+    assert both["iters"] == ora["iter_counts"]
+    assert abs(both["vals"][0] - ora["eigenvalues"][0]) <= 1e-10 * max(1.0, abs(both["vals"][0] + offset))
+    assert 1 - overlap(both["vecs"][0], ora["eigenvectors"][0]) <= 1e-8
+    op.close()
