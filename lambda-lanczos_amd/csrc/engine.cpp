@@ -13,6 +13,7 @@
 #include <limits>
 #include <random>
 #include <string>
+#include <thread>
 
 namespace ll {
 
@@ -37,6 +38,27 @@ static bool is_device_ptr(const void* p) {
     return false;
   }
   return a.type == hipMemoryTypeDevice;
+}
+// n-sized copies between two HOST buffers at the reference's std::vector boundary (pinned staging buffer -> the caller's vector):
+// one thread moves 8-10 GB/s, which made this copy the longest single item of a run's epilogue (80 MB: 9 ms); four threads
+// share it from 8 MiB up.
+void host_copy(void* dst, const void* src, size_t bytes) {
+  constexpr size_t kParallelFrom = (size_t)8 << 20;
+  constexpr int kThreads = 4;
+  if (bytes < kParallelFrom) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t piece = ((bytes / kThreads) + 4095) & ~(size_t)4095;
+  std::thread th[kThreads - 1];
+  for (int t = 1; t < kThreads; ++t) {
+    const size_t off = std::min(bytes, (size_t)t * piece), len = std::min(bytes, (size_t)(t + 1) * piece) - off;
+    th[t - 1] = std::thread([=] {
+      if (len) std::memcpy((char*)dst + off, (const char*)src + off, len);
+    });
+  }
+  std::memcpy(dst, src, std::min(bytes, piece));
+  for (auto& t : th) t.join();
 }
 // LL_STALL_TRACE=ms: a whole-loop call that takes longer than that prints where its time went (host timestamps at
 // the phase boundaries) — for hunting one-off runtime stalls in launch-bound runs.
@@ -1276,7 +1298,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   const bool out_dev = is_device_ptr(eigvecs);
   auto to_caller = [&](T* dst, const T* src_host) {  // host -> the caller's buffer, wherever it lives
     if (out_dev) LL_HIP(hipMemcpy(dst, src_host, (size_t)nl * sizeof(T), hipMemcpyHostToDevice));
-    else std::memcpy(dst, src_host, (size_t)nl * sizeof(T));
+    else host_copy(dst, src_host, (size_t)nl * sizeof(T));
   };
 
   struct TraceFile {  // LL_ITER_TRACE
