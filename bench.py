@@ -87,7 +87,7 @@ def kernel_sources_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("kernels.hip", "spmv_pb.hip", "dev_helpers.hpp"):
+    for name in ("kernels.hip", "spmv_pb.hip", "dev_helpers.hpp", "fixed_round.hpp"):
         with open(os.path.join(ROOT, "lambda-lanczos_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

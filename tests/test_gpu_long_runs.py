@@ -267,3 +267,38 @@ def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, 
     check_values(vals, gold)
     check_vectors(vecs, vals, gold, csr)
     op.close()
+
+
+@pytest.mark.parametrize("form", ["pair", "one_sweep"])
+def test_run_beyond_the_column_capacity_of_one_sweep_launch_matches_the_reference(ctx, llenv, form):
+    """800 x 800 Laplacian, smallest pair, offset -8 (5.12 MB vectors): the REAL reference needs about 2 900 iterations — more
+    stored vectors than one workgroup of the pair sweep holds coefficient columns for (2 497), so from there on every sweep of the
+    default form is two launches (kernels.hip pair_sweep_kernel; bit-identical to an unsplit sweep by construction,
+    test_split_sweeps_change_no_bit) — nothing forced, nothing hooked.  Every alpha / beta of the run, count, eigenvalue, sampled
+    eigenvector entries and the residual against the fixture; `one_sweep` (LL_PAIR_GS=0) runs the same length in the form the
+    pair form hands over to at 4 992 stored vectors."""
+    name = "laplace800_converge"
+    if name not in GOLD:
+        pytest.skip("fixture not generated (tests/golden/make_golden.py long_runs laplace800_converge)")
+    if form == "one_sweep":
+        llenv.setenv("LL_PAIR_GS", "0")
+    gold = GOLD[name]
+    csr = MG.long_run_matrix(gold)
+    n = gold["n"]
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.LambdaLanczos(op, n, gold["find_max"], 1)
+    eng.eigenvalue_offset = gold["offset"]
+    eng.init_vector = fixed_init(G.start_vector(n, gold["seed"]))
+    vals, vecs = eng.run()
+    itern = eng.getIterationCounts()[0]
+    assert itern > 2497 + 100
+    assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
+    if form == "pair":
+        assert eng.last_stats["pair_iterations"] >= itern - 3 - 4 * eng.last_stats["second_passes"], eng.last_stats
+    else:
+        assert eng.last_stats["pair_iterations"] == 0
+    check_counts(eng.getIterationCounts(), gold)
+    check_trace(eng, gold, csr, upto=10 ** 9)
+    check_values(vals, gold)
+    check_vectors(vecs, vals, gold, csr)
+    op.close()

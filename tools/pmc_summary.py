@@ -38,7 +38,7 @@ def main():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for name in ("kernels.hip", "spmv_pb.hip", "dev_helpers.hpp"):
+    for name in ("kernels.hip", "spmv_pb.hip", "dev_helpers.hpp", "fixed_round.hpp"):
         with open(os.path.join(root, "lambda-lanczos_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     res = {"kernel_sources_sha16": h.hexdigest()[:16],  # bench.py compares it with the sources it runs (roofline.traffic_age)
