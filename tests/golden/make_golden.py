@@ -114,8 +114,8 @@ def long_run_specs():
         "laplace400_converge": dict(gen="laplace2d", args=[400], find_max=False, offset=-8.0, num_eigs=1, seed=1),
         "torus300_converge": dict(gen="torus", args=[300], find_max=False, offset=-10.0, num_eigs=1, seed=1, complex=True),
         # Round 5: a run LONGER than one workgroup of the pair sweep holds coefficient columns for (2 497 stored vectors): the sweep
-        # splits into two launches by itself.  800 x 800 Laplacian, smallest pair, offset -8: 5.12 MB vectors, ~2 900 iterations
-        # (the reference takes about half an hour on one core for this one).
+        # splits into two launches by itself.  800 x 800 Laplacian, smallest pair, offset -8: 5.12 MB vectors, 2 557 iterations
+        # (the reference takes 85 minutes on one core for this one).
         "laplace800_converge": dict(gen="laplace2d", args=[800], find_max=False, offset=-8.0, num_eigs=1, seed=1),
     }
 

@@ -271,7 +271,7 @@ def test_streaming_one_sweep_kernel_over_a_whole_run_matches_the_reference(ctx, 
 
 @pytest.mark.parametrize("form", ["pair", "one_sweep"])
 def test_run_beyond_the_column_capacity_of_one_sweep_launch_matches_the_reference(ctx, llenv, form):
-    """800 x 800 Laplacian, smallest pair, offset -8 (5.12 MB vectors): the REAL reference needs about 2 900 iterations — more
+    """800 x 800 Laplacian, smallest pair, offset -8 (5.12 MB vectors): the REAL reference needs 2 557 iterations (85 minutes on one core) — more
     stored vectors than one workgroup of the pair sweep holds coefficient columns for (2 497), so from there on every sweep of the
     default form is two launches (kernels.hip pair_sweep_kernel; bit-identical to an unsplit sweep by construction,
     test_split_sweeps_change_no_bit) — nothing forced, nothing hooked.  Every alpha / beta of the run, count, eigenvalue, sampled
@@ -291,7 +291,7 @@ def test_run_beyond_the_column_capacity_of_one_sweep_launch_matches_the_referenc
     eng.init_vector = fixed_init(G.start_vector(n, gold["seed"]))
     vals, vecs = eng.run()
     itern = eng.getIterationCounts()[0]
-    assert itern > 2497 + 100
+    assert itern > 2497 + 40        # the last ~30 sweeps of the pair form are two launches each
     assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
     if form == "pair":
         assert eng.last_stats["pair_iterations"] >= itern - 3 - 4 * eng.last_stats["second_passes"], eng.last_stats
