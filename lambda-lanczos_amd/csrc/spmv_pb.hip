@@ -377,26 +377,33 @@ template <typename T> __device__ __forceinline__ void lds_add_elem(double* lds, 
 }
 // the shared epilogue: value(i, x_i) gives row i's sum (x_i: the row's own input element, for the diagonal term that the
 // PB image keeps outside its streams); y = value + offset x, partial Re<x, y> per workgroup
-template <typename T, typename F>
+template <typename T, typename F, typename G>
 __device__ __forceinline__ void pb_phase2_epilogue(int rb, int64_t row0, int rows, const T* __restrict__ xl, T* __restrict__ y,
                                                    double offset, double* __restrict__ dot_partials, double* red,
-                                                   const double* __restrict__ xnorm2, F&& value) {
+                                                   const double* __restrict__ xnorm2, F&& value, G&& pre) {
+  // value(i, x_i, pre(i)): pre(i) is what row i's value needs from GLOBAL memory besides x_i (its diagonal entry, its exponent).
+  // All loads of a round — x_i and pre(i) of EU rows per lane, clamped addresses, no load under a divergent branch — are requested
+  // before the first is used: requested inside the per-row `if (i < rows)` they form a chain of one memory latency per row, which
+  // made this epilogue 12-17 us per workgroup with nothing else running on the CU.
   const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;  // unnormalised input (see pb_phase1)
   const int tid = threadIdx.x;
-  constexpr int EU = 4;  // rows per lane per round: the loads of a round are all requested before the first is used
+  constexpr int EU = 8;  // rows per lane per round
   double dot_acc = 0.0;
   for (int i0 = tid; i0 < rows; i0 += EU * kPbThreads) {
     T xi[EU];
+    decltype(pre(0)) pl[EU];
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int i = i0 + u * kPbThreads;
-      if (i < rows) xi[u] = rmul(xs_fac, xl[row0 + i]);
+      const int ic = i < rows ? i : rows - 1;
+      xi[u] = rmul(xs_fac, xl[row0 + ic]);
+      pl[u] = pre(ic);
     }
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
       const int i = i0 + u * kPbThreads;
       if (i < rows) {
-        const T yi = add(narrow<T>(value(i, xi[u])), rmul(offset, xi[u]));
+        const T yi = add(narrow<T>(value(i, xi[u], pl[u])), rmul(offset, xi[u]));
         y[row0 + i] = yi;
         dot_acc += re_cmul(xi[u], yi);
       }
@@ -468,13 +475,16 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2(int rb_rows, int64_t n_l
     }
   });
   __syncthreads();
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, [&](int i, const T& xi) {
-    acc_t<T> a;
-    if constexpr (scalar_traits<T>::is_complex) a = zc{lds[2 * i], lds[2 * i + 1]};
-    else a = lds[i];
-    if (diag) a = add(a, to_acc(mul(diag[row0 + i], xi)));  // the diagonal entry, kept outside the streams (pb_diag_kernel)
-    return a;
-  });
+  pb_phase2_epilogue<T>(
+      rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2,
+      [&](int i, const T& xi, const T& dg) {
+        acc_t<T> a;
+        if constexpr (scalar_traits<T>::is_complex) a = zc{lds[2 * i], lds[2 * i + 1]};
+        else a = lds[i];
+        if (diag) a = add(a, to_acc(mul(dg, xi)));  // the diagonal entry, kept outside the streams (pb_diag_kernel)
+        return a;
+      },
+      [&](int i) { return diag ? diag[row0 + i] : zero<T>(); });
 }
 
 // Fixed-point sums (see above): P holds fl(a_ij x_j) in the storage type.
@@ -574,13 +584,13 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
   __syncthreads();
   // (the row's diagonal entry is kept outside the streams, pb_diag_kernel: its product joins the row's integers here —
   // rounded to the same grid, added to the same sum: the same bits as if it had travelled through the product buffer)
-  auto value = [&](int i, const T& xi) {
+  auto value = [&](int i, const T& xi, const T& dg) {  // dg: the row's diagonal entry (requested ahead, see the epilogue)
     int k = ex[i];
     long long s[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) s[q] = acc[R * i + q];
     if (diag != nullptr && k != kBadRow) {
-      const T p = mul(diag[row0 + i], xi);
+      const T p = mul(dg, xi);
       const double sc = pow2(k);
       long long w[R];
       if constexpr (scalar_traits<T>::is_complex) {
@@ -605,12 +615,20 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
     if (xprefetch) {  // same arithmetic, same order of the per-lane dot sum (rows tid, tid + 1024, ...) as the loading form
       const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;
       double dot_acc = 0.0;
+      // the diagonal entries of the lane's rows in one batch (clamped addresses, no load under the per-row branch): the ring's
+      // registers are free here; requested row by row they were a chain of up to 13 memory latencies — the 17 us of this epilogue
+      T dgs[kPbXPre];
+#pragma unroll
+      for (int u = 0; u < kPbXPre; ++u) {
+        const int i = tid + u * kPbThreads;
+        dgs[u] = diag ? diag[row0 + (i < rows ? i : rows - 1)] : zero<T>();
+      }
 #pragma unroll
       for (int u = 0; u < kPbXPre; ++u) {
         const int i = tid + u * kPbThreads;
         if (i < rows) {
           const T xi = rmul(xs_fac, xpre[u]);
-          const T yi = add(narrow<T>(value(i, xi)), rmul(offset, xi));
+          const T yi = add(narrow<T>(value(i, xi, dgs[u])), rmul(offset, xi));
           y[row0 + i] = yi;
           dot_acc += re_cmul(xi, yi);
         }
@@ -629,7 +647,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_phase2_fixed(int rb_rows, int64
       return;
     }
   }
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, value);
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, value,
+                        [&](int i) { return diag ? diag[row0 + i] : zero<T>(); });
 }
 
 // exponent of every local row's absolute sum: sum_j |a_ij| < 2^rexp[i]  (32767: the row holds Inf / NaN)
@@ -1531,8 +1550,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   }
   __syncthreads();
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
-  auto value = [&](int i, const T&) {
-    const int er = rexp[row0 + i];
+  auto value = [&](int i, const T&, int er) {  // er: the row's exponent (requested ahead, see the epilogue)
     const bool unusable = er == 32767 || e_x == kPbXInf || ((bad[i >> 5] >> (i & 31)) & 1u);
     const int back = er - kx;  // 2^back restores the row's scale (empty rows: er = -1100, acc = 0)
     acc_t<T> a;
@@ -1542,7 +1560,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
       a = unusable ? nan : ldexp((double)acc[i], back);
     return a;
   };
-  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, value);
+  pb_phase2_epilogue<T>(rb, row0, rows, xl, y, offset, dot_partials, red, xnorm2, value, [&](int i) { return (int)rexp[row0 + i]; });
 }
 
 namespace {
