@@ -49,7 +49,12 @@ def parse_args():
     ap.add_argument("--size", dest="n", type=int, default=0, help="override the problem size (grid side for c2/c5)")
     ap.add_argument("--window", type=int, default=100, help="Lanczos iterations per step (max_iteration)")
     ap.add_argument("--spmv-reps", type=int, default=20)
-    ap.add_argument("--cpu-window", type=int, default=14, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-window", type=int, default=-1,
+                    help="iterations of the CPU baseline sample (default -1: the headline window itself, so that cpu_baseline.value "
+                         "is like-for-like with `value` — about 105 s of one host core for config 3 at window 100; 0 = skip).  A "
+                         "second, short sample (--cpu-short-window) is reported as cpu_baseline_short")
+    ap.add_argument("--cpu-short-window", type=int, default=14,
+                    help="iterations of the short CPU sample (cpu_baseline_short; also the window of the all-cores and host-callback legs)")
     ap.add_argument("--eps", type=float, default=None,
                     help="override the engine's eps (0 = never converge: every run does exactly --window iterations)")
     ap.add_argument("--orth-mode", type=int, default=0)
@@ -65,6 +70,8 @@ def parse_args():
                     help="skip the instrumented steps after the timed region (no per-phase split, no roofline_orth)")
     ap.add_argument("--phase-timers-inline", action="store_true",
                     help="record the per-phase HIP events inside the timed steps instead of in separate steps after them")
+    ap.add_argument("--no-exchange-tuning", action="store_true",
+                    help="N > 1: skip the pre-pass that times LL_GATHER_CHUNKS x LL_COMM_OVERLAP on the actual shards and keeps the fastest")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short config-2 / config-5 / host-callback legs that follow the headline run at N = 1")
     ap.add_argument("--watchdog", type=float, default=1500.0,
@@ -348,6 +355,8 @@ def main():
             dist.broadcast_object_list(box, src=0)
             ctx.init_comm(box[0], rank, world)   # fails loudly unless all `world` ranks answer in rank order
     ranks_seen = 1 if args.dry_run_dist else ctx.ranks_seen()
+    # which transport answers the collectives: "rccl" | "plugin:<path>" (LL_COMM_PLUGIN: the host-staged test transport) | "none"
+    transport = "none" if args.dry_run_dist else ctx.transport()
 
     # ------------------------------------------------------------ synthetic input, resident in HBM
     STAGE[0] = "matrix generation + upload"
@@ -465,6 +474,42 @@ def main():
             rounds.append(max_over_ranks(ctx.timer_stop() / args.spmv_reps))
         return sorted(rounds)[len(rounds) // 2]
 
+    # ------------------------------------------------------------ N > 1: how the exchange is cut and issued, timed on the actual shards
+    # LL_GATHER_CHUNKS in {1, 2, 4} (pieces of the all-gather: fixed in the PB image's column-block table, so one operator per
+    # value) x LL_COMM_OVERLAP in {0, 1} (own-column work under the gather or everything on one stream: read per launch), three
+    # SpMVs each behind one warm-up, max over ranks; the fastest combination is what the timed steps run.  Every rank sees the same
+    # maxima and takes the same pick.
+    exchange_tuning = None
+    if world > 1 and selected == L.capi.SPMV_PB and not args.no_exchange_tuning:
+        STAGE[0] = "exchange tuning pre-pass"
+        table, ops_by_chunks = {}, {}
+        ctx.set_tuning("spmv_kernel", "pb")
+        for chunks in (1, 2, 4):
+            ctx.set_tuning("gather_chunks", chunks)
+            cand = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
+            ops_by_chunks[chunks] = cand
+            for overlap in (1, 0):
+                ctx.set_tuning("comm_overlap", overlap)
+                L.spmv(cand, xd, yd)
+                barrier()
+                ctx.timer_start()
+                for _ in range(3):
+                    L.spmv(cand, xd, yd)
+                table["chunks=%d,overlap=%d" % (chunks, overlap)] = max_over_ranks(ctx.timer_stop() / 3)
+        best = min(table, key=lambda k: (table[k], k))
+        pick_chunks, pick_overlap = int(best.split(",")[0].split("=")[1]), int(best.split(",")[1].split("=")[1])
+        ctx.set_tuning("gather_chunks", pick_chunks)
+        ctx.set_tuning("comm_overlap", pick_overlap)
+        ctx.set_tuning("spmv_kernel", None)
+        for chunks, cand in ops_by_chunks.items():
+            if chunks != pick_chunks:
+                cand.close()
+        op.close()
+        op = ops_by_chunks[pick_chunks]
+        exchange_tuning = {"ms_per_spmv_max_over_ranks": table, "pick": {"LL_GATHER_CHUNKS": pick_chunks, "LL_COMM_OVERLAP": pick_overlap},
+                           "how": "3 SpMVs per combination behind one warm-up, HIP events on the library stream, max over ranks; "
+                                  "the operator of the timed steps is the picked one"}
+
     spmv_ms = time_spmv(op)
     spmv_variants = {"%s [%s]" % (kernel_names[selected], phase2_form) if selected == L.capi.SPMV_PB else kernel_names[selected]: spmv_ms}
     spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
@@ -491,6 +536,15 @@ def main():
                     os.environ[k] = v
             ctx.reload_env()
         spmv_variants["%s [%s] again, after the others" % (kernel_names[selected], phase2_form)] = time_spmv(op)
+
+    # ------------------------------------------------------------ measured streaming ceilings of THIS device, same process (SURVEY 8d "Bound")
+    STAGE[0] = "bandwidth ceilings"
+    probe_bytes = 2 << 30
+    read_ceiling, copy_ceiling = ctx.bandwidth_probe(probe_bytes)
+    ceiling = {"read_GBps": read_ceiling, "copy_GBps": copy_ceiling, "bytes": probe_bytes,
+               "how": "ll_bandwidth_probe: a read-only sum and a copy kernel over 2 GiB, 16-byte accesses, best grid of four, three "
+                      "launches each by HIP events on the library stream, in this process right after the SpMV timing; copy = bytes read + "
+                      "bytes written per second"}
 
     # ------------------------------------------------------------ timed steps
     STAGE[0] = "timed Lanczos windows"
@@ -636,18 +690,20 @@ def main():
     comm_allreduce_s = max_over_ranks(stats_acc["seconds_comm_allreduce"])
     setup_by_rank = [t_gen]
     upload_by_rank = [t_up]
+    gather_by_rank = [stats_acc["seconds_comm_gather"]]
     if dist is not None:
         import torch
 
-        tt = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(tt, torch.tensor([t_gen, t_up], dtype=torch.float64))
+        tt = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tt, torch.tensor([t_gen, t_up, stats_acc["seconds_comm_gather"]], dtype=torch.float64))
         setup_by_rank = [float(t[0]) for t in tt]
         upload_by_rank = [float(t[1]) for t in tt]
+        gather_by_rank = [float(t[2]) for t in tt]
 
     # ------------------------------------------------------------ CPU baseline (rank 0, N = 1 only; bounded sample)
     STAGE[0] = "CPU baseline"
     cpu = None
-    if world == 1 and args.cpu_window > 0 and wl == "c5":
+    if world == 1 and args.cpu_window != 0 and wl == "c5":
         # config 5 runs fully on the CPU in seconds: the real Exponentiator<T>::run (EX:87-173) through
         # oracle/_ref, same matrix, same input, same a = -5i; the whole run is the sample
         import oracle_lib
@@ -678,43 +734,58 @@ def main():
                                    "ok": bool(err <= 1e-10 and 1.0 - ovl <= 10 * 2.3e-16 + 1e-15 and abs(int(o_it) - int(g_it)) <= 1)},
             "host_cores_available": os.cpu_count(),
         }
-    if world == 1 and args.cpu_window > 0 and wl != "c5":
+    cpu_short = None
+    if world == 1 and args.cpu_window != 0 and wl != "c5":
         import oracle_lib
 
         kind = "reference" if oracle_lib.have_reference() else "port"
         chk = oracle_lib.reference() if kind == "reference" else oracle_lib.oracle()
         full = (csr[0], csr[1], csr[2])
-        r = chk.lanczos(full, init, find_max, max_iteration=args.cpu_window, offset=offset, trace=False)
-        cpu_its = r["iter_counts"][0]
-        # the same window on the GPU, for a like-for-like ratio
-        eng.max_iteration = args.cpu_window
-        step()
-        barrier()
-        tg = time.perf_counter()
-        vals_g, vecs_g = eng.run()
-        barrier()
-        tg = time.perf_counter() - tg
-        d_lam = float(abs(vals_g[0] - r["eigenvalues"][0]))
-        vecs_g = vecs_g if isinstance(vecs_g, np.ndarray) else vecs_g.get()
-        defect = float(1.0 - abs(np.vdot(r["eigenvectors"][0], vecs_g[0])))
-        cpu = {
-            "value": cpu_its / r["t_total"],
-            "unit": "Lanczos iterations/s",
-            "cores": 1,
-            "kind": kind,
-            "sample": "same matrix and start vector, LambdaLanczos::run with max_iteration=%d (mean k=%.1f), "
-                      "single thread like the reference" % (args.cpu_window, (args.cpu_window + 1) / 2),
-            "seconds": r["t_total"],
-            "note": "the cost of an iteration grows with k: compare `value` (window of %d iterations) with "
-                    "`gpu_same_window_value`, NOT with the headline value (window of %d)" % (args.cpu_window, args.window),
-            "spmv_GBps": b_spmv * cpu_its / max(r["t_mv"], 1e-12) / 1e9,
-            "gpu_same_window_value": cpu_its / tg,
-            "parity_same_window": {"eigenvalue_cpu": float(r["eigenvalues"][0]), "eigenvalue_gpu": float(vals_g[0]),
-                                   "abs_diff": d_lam, "eigenvector_one_minus_overlap": defect,
-                                   "tolerance": "|dlambda| <= 1e-10*max(1,|lambda|), 1-|<v_cpu,v_gpu>| <= 1e-8",
-                                   "ok": bool(d_lam <= 1e-10 * max(1.0, abs(vals_g[0])) and defect <= 1e-8)},
-            "host_cores_available": os.cpu_count(),
-        }
+
+        def cpu_leg(w):
+            """LambdaLanczos::run of the real reference (or the oracle port) with max_iteration = w on the host, then the same window
+            on the GPU: like-for-like rate and eigenpair parity."""
+            r = chk.lanczos(full, init, find_max, max_iteration=w, offset=offset, trace=False)
+            cpu_its = r["iter_counts"][0]
+            eng.max_iteration = w
+            step()
+            barrier()
+            tg = time.perf_counter()
+            vals_g, vecs_g = eng.run()
+            barrier()
+            tg = time.perf_counter() - tg
+            d_lam = float(abs(vals_g[0] - r["eigenvalues"][0]))
+            vecs_g = vecs_g if isinstance(vecs_g, np.ndarray) else vecs_g.get()
+            defect = float(1.0 - abs(np.vdot(r["eigenvectors"][0], vecs_g[0])))
+            return {
+                "value": cpu_its / r["t_total"],
+                "unit": "Lanczos iterations/s",
+                "cores": 1,
+                "kind": kind,
+                "sample": "same matrix and start vector, LambdaLanczos::run with max_iteration=%d (mean k=%.1f), "
+                          "single thread like the reference" % (w, (w + 1) / 2),
+                "seconds": r["t_total"],
+                "note": ("the cost of an iteration grows with k: this sample IS the headline window, `value` and "
+                         "`gpu_same_window_value` are like-for-like with the line's `value`" if w == args.window else
+                         "the cost of an iteration grows with k: compare `value` (window of %d iterations) with "
+                         "`gpu_same_window_value`, NOT with the headline value (window of %d)" % (w, args.window)),
+                "spmv_GBps": b_spmv * cpu_its / max(r["t_mv"], 1e-12) / 1e9,
+                "gpu_same_window_value": cpu_its / tg,
+                "parity_same_window": {"eigenvalue_cpu": float(r["eigenvalues"][0]), "eigenvalue_gpu": float(vals_g[0]),
+                                       "abs_diff": d_lam, "eigenvector_one_minus_overlap": defect,
+                                       "tolerance": "|dlambda| <= 1e-10*max(1,|lambda|), 1-|<v_cpu,v_gpu>| <= 1e-8",
+                                       "ok": bool(d_lam <= 1e-10 * max(1.0, abs(vals_g[0])) and defect <= 1e-8)},
+                "host_cores_available": os.cpu_count(),
+            }
+
+        w_main = args.window if args.cpu_window < 0 else args.cpu_window
+        if args.cpu_short_window > 0 and args.cpu_short_window != w_main:
+            STAGE[0] = "CPU baseline (short sample)"
+            cpu_short = cpu_leg(args.cpu_short_window)
+        STAGE[0] = "CPU baseline (headline window)"
+        cpu = cpu_leg(w_main)
+        eng.max_iteration = args.window
+    short_w = args.cpu_short_window if args.cpu_short_window > 0 else 14
 
     traffic, traffic_src, traffic_age = (None, None, None)
     orth_traffic, orth_traffic_src = (None, None)
@@ -735,7 +806,7 @@ def main():
                 if want > (os.cpu_count() or 1):
                     break
                 threads = orc.set_threads(want)
-                r2 = orc.lanczos((csr[0], csr[1], csr[2]), init, find_max, max_iteration=args.cpu_window, offset=offset,
+                r2 = orc.lanczos((csr[0], csr[1], csr[2]), init, find_max, max_iteration=short_w, offset=offset,
                                  trace=False)
                 if best is None or r2["t_total"] < best[1]["t_total"]:
                     best = (threads, r2)
@@ -745,8 +816,8 @@ def main():
             threads, r2 = best
             cpu_all = {"value": r2["iter_counts"][0] / r2["t_total"], "unit": "Lanczos iterations/s", "cores": threads,
                        "kind": "port", "seconds": r2["t_total"],
-                       "sample": cpu["sample"].replace("single thread like the reference",
-                                                       "OpenMP threads (best of 16/32/64; not how the reference runs)"),
+                       "sample": (cpu_short or cpu)["sample"].replace("single thread like the reference",
+                                                                      "OpenMP threads (best of 16/32/64; not how the reference runs)"),
                        "spmv_GBps": b_spmv * r2["iter_counts"][0] / max(r2["t_mv"], 1e-12) / 1e9}
 
     # ------------------------------------------------------------ the other single-GPU configs and the callback path
@@ -754,8 +825,8 @@ def main():
     if world == 1 and wl == "c3" and not args.n and not args.no_other_configs:
         STAGE[0] = "host-callback leg"
         try:
-            cb_leg = callback_leg(ctx, L, csr, n, init, find_max, offset, max(args.cpu_window, 8),
-                                  cpu["gpu_same_window_value"] if cpu else None)
+            cb_leg = callback_leg(ctx, L, csr, n, init, find_max, offset, max(short_w, 8),
+                                  (cpu_short or cpu)["gpu_same_window_value"] if (cpu_short or cpu) else None)
         except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
             cb_leg = {"error": repr(e)}
         other = {}
@@ -815,7 +886,11 @@ def main():
                        "start vector / input and eigenvector / output in device buffers (resident in HBM before the timed "
                        "region; --host-io times the std::vector boundary instead)"),
             },
-            "rccl_ranks_seen": ranks_seen,
+            # ranks that answered the communicator self-check — counted as RCCL's only when RCCL is the transport that ran
+            "rccl_ranks_seen": ranks_seen if (transport == "rccl" or world == 1) else 0,
+            "comm_ranks_seen": ranks_seen,
+            "transport": transport,
+            "exchange_tuning": exchange_tuning,
             "spmv": {"GBps": spmv_gbs, "ms": spmv_ms, "algorithmic_bytes": b_spmv, "frac_of_8TBps": spmv_gbs / HBM_PEAK_GBS,
                      "kernel": kernel_names[selected] + " (picked by timing the candidates at upload; the other images are released)",
                      "ms_by_kernel": spmv_variants, "creation_time_autotune_ms": tune,
@@ -829,6 +904,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": spmv_gbs / HBM_PEAK_GBS,
+                "measured_ceiling": ceiling,
+                "frac_of_measured": spmv_gbs / read_ceiling,        # against the read-only stream (96 % of the algorithmic bytes are reads)
+                "frac_of_measured_copy": spmv_gbs / copy_ceiling,   # against the copy stream (read + write mix)
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "traffic_age": traffic_age,
@@ -843,6 +921,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (orth_bytes / orth_s / 1e9 / HBM_PEAK_GBS) if orth_s > 0 else None,
+                "frac_of_measured": (orth_bytes / orth_s / 1e9 / read_ceiling) if orth_s > 0 else None,
                 "traffic": orth_traffic,
                 "traffic_source": orth_traffic_src,
                 "traffic_note": "measured HBM bytes of the Gram-Schmidt kernels (one-sweep form: lagged sweep + folds; two-sweep "
@@ -868,12 +947,16 @@ def main():
                 "library_s_total": stats_acc["seconds_total"],
                 "wall_s": elapsed,
                 "device_s_comm_gather": comm_gather_s,
+                "device_s_comm_gather_min_over_ranks": min(gather_by_rank),
+                "device_s_comm_gather_max_over_ranks": max(gather_by_rank),
+                "device_s_comm_gather_by_rank": gather_by_rank,
                 "device_s_comm_allreduce": comm_allreduce_s,
                 "setup_s_generate_upload": max(setup_by_rank),
                 "setup_s_generate_upload_by_rank": setup_by_rank,
                 "setup_s_operator_create_by_rank": upload_by_rank,
             },
             "cpu_baseline": cpu,
+            "cpu_baseline_short": cpu_short,
             "cpu_baseline_all_cores": cpu_all,
             "callback_path": cb_leg,
             "other_configs": other,

@@ -44,11 +44,13 @@ extern "C" {
 #endif
 
 #define LL_VERSION_MAJOR 0
-#define LL_VERSION_MINOR 4  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers
+#define LL_VERSION_MINOR 5  /* 2: ll_lanczos_params.init_vector_dev, device pointers accepted for n-sized buffers
                              * 3: ll_run_stats.lagged_iterations + reserved tail (the struct grew: code compiled against a
                              *    minor-2 header must be rebuilt — ll_abi_check refuses it), ll_ctx_reload_env, ll_abi_check
                              * 4: additive — ll_csr_options / ll_op_create_csr_opt_*, ll_op_set_accuracy, ll_op_accuracy, the tiled
-                             *    SpMV kernel id; no struct changed, callers built against minor 3 keep working */
+                             *    SpMV kernel id; no struct changed, callers built against minor 3 keep working
+                             * 5: additive — ll_ctx_set_tuning (the test hooks and geometry overrides left the environment),
+                             *    ll_comm_transport, ll_bandwidth_probe; no struct changed */
 
 enum {
   LL_OK = 0,
@@ -88,6 +90,14 @@ int ll_ctx_destroy(ll_context* ctx);
  * copied into the operators created on it — never on a launch path.  This reads them again into an existing context
  * (test suites and tuning scripts that flip a switch inside one process); operators that already exist keep theirs. */
 int ll_ctx_reload_env(ll_context* ctx);
+/* UNSTABLE (tests, probes and A/B measurements; keys may change between minors): set one tuning field of THIS context by key,
+ * on top of what the environment said.  The environment carries only the user-facing switches of INTEGRATION.md section 8; block
+ * geometries, forced code paths and the hooks of the test suite ("pb_block", "pair_split", "lagged_min_bytes", "tl_force",
+ * "force_rp64", ... — the list is INTEGRATION.md section 8, second table) exist only here, so that a stray variable in a user's
+ * environment can never change the numerics path.  Every user-facing switch is also a key (its name in lower case without the
+ * LL_ prefix: "spmv_kernel", "pair_gs", ...).  value NULL removes the setting again; an unknown key is LL_ERR_INVALID.  Like the
+ * environment switches it takes effect for operators / runs created afterwards. */
+int ll_ctx_set_tuning(ll_context* ctx, const char* key, const char* value);
 /* hipStream_t of the context (for callers that enqueue their own work in between). */
 int ll_ctx_stream(ll_context* ctx, void** hip_stream_out);
 /* Block until the context's stream is idle. */
@@ -100,6 +110,10 @@ int ll_ctx_release_cache(ll_context* ctx);
  * stream it is launched on).  ll_timer_stop waits for the stream and returns the milliseconds since ll_timer_start. */
 int ll_timer_start(ll_context* ctx);
 int ll_timer_stop(ll_context* ctx, double* ms_out);
+/* Streaming ceilings of the device at hand, measured now on the context's stream with two plain kernels over `bytes` (>= 1 MiB;
+ * two scratch buffers of that size are allocated and freed): a read-only stream (GB/s of bytes read) and a copy (GB/s of bytes
+ * read + written).  bench.py reports its roofline fractions against these next to the 8 TB/s spec peak (SURVEY 8d "Bound"). */
+int ll_bandwidth_probe(ll_context* ctx, size_t bytes, double* read_GBps, double* copy_GBps);
 
 /* ------------------------------------------------------------------ multi-GPU
  * One process per GPU.  Rows of A and every n-vector are partitioned 1-D and contiguously:
@@ -118,6 +132,10 @@ int ll_comm_rank(ll_context* ctx, int* rank, int* n_ranks);
  * n_ranks ranks in rank order.  This returns how many rank tags arrived (== n_ranks after a successful init; 1 without
  * a communicator) so that a launcher can print it next to its results. */
 int ll_comm_ranks_seen(ll_context* ctx, int* out);
+/* Which transport answers this context's collectives, as text: "rccl" (the communicator ll_comm_init created with librccl),
+ * "plugin:<path>" (the shared object LL_COMM_PLUGIN named), "attached" (ll_comm_attach) or "none" (no communicator).  A launcher
+ * prints it next to ll_comm_ranks_seen: a rank count alone does not say that RCCL ran. */
+int ll_comm_transport(ll_context* ctx, char* out, size_t cap);
 /* The contiguous row range of `rank`: shards of ceil(n / n_ranks) rows (the last ones may be shorter or empty).
  * Sharded operators and vectors must use exactly these ranges (the all-gather relies on equal shard strides). */
 int ll_partition(int64_t n, int n_ranks, int rank, int64_t* row_begin, int64_t* n_local);

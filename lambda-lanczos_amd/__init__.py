@@ -27,6 +27,7 @@ from .engine import (  # noqa: F401
     LambdaLanczos,
     default_context,
     live_contexts,
+    CONTEXT_CREATED_HOOKS,
     dot,
     gemv_basis,
     normalize,

@@ -19,7 +19,7 @@ ACCURACY_DEFAULT, ACCURACY_NORMWISE, ACCURACY_COMPONENTWISE = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 
-ABI_VERSION = (0, 4)  # LL_VERSION_MAJOR, LL_VERSION_MINOR of the include/lanczos_hip.h these mirrors were written against
+ABI_VERSION = (0, 5)  # LL_VERSION_MAJOR, LL_VERSION_MINOR of the include/lanczos_hip.h these mirrors were written against
 
 
 class LanczosHipError(RuntimeError):
@@ -121,13 +121,16 @@ PROTOTYPES = {
     "ll_ctx_synchronize": (C.c_int, [vp]),
     "ll_ctx_release_cache": (C.c_int, [vp]),
     "ll_ctx_reload_env": (C.c_int, [vp]),
+    "ll_ctx_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
     "ll_ctx_set_profiling": (C.c_int, [vp, C.c_int]),
     "ll_timer_start": (C.c_int, [vp]),
     "ll_timer_stop": (C.c_int, [vp, P(f64)]),
+    "ll_bandwidth_probe": (C.c_int, [vp, C.c_size_t, P(f64), P(f64)]),
     "ll_comm_unique_id": (C.c_int, [vp]),
     "ll_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "ll_comm_rank": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
     "ll_comm_ranks_seen": (C.c_int, [vp, P(C.c_int)]),
+    "ll_comm_transport": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "ll_comm_attach": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "ll_partition": (C.c_int, [i64, C.c_int, C.c_int, P(i64), P(i64)]),
     "ll_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),

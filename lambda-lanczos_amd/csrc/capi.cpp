@@ -16,72 +16,87 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 using namespace ll;
 
-// ---------------------------------------------------------------- environment switches (ll_internal.hpp: ll::Tuning)
+// ---------------------------------------------------------------- tuning (ll_internal.hpp: ll::Tuning)
+// ONE parser for every setting, by key.  The library reads the USER-FACING switches from the environment (kEnvSwitches:
+// the list of INTEGRATION.md section 8) when a context is created; everything else — block geometries, forced code paths, the
+// hooks the test suite needs — is reachable only through ll_ctx_set_tuning(ctx, key, value), an explicit call on one context
+// that is documented as unstable: a stray variable in a user's environment cannot change the numerics path of a drop-in.
 namespace ll {
-Tuning read_tuning() {
-  Tuning t;
-  auto str = [](const char* name) -> std::string {
-    const char* e = std::getenv(name);
-    return e ? std::string(e) : std::string();
-  };
-  auto flag = [&](const char* name, bool dflt) {
-    const std::string v = str(name);
-    return v.empty() ? dflt : std::atoi(v.c_str()) != 0;
-  };
-  auto num = [&](const char* name, long long dflt) {
-    const std::string v = str(name);
-    return v.empty() ? dflt : std::atoll(v.c_str());
-  };
-  const std::string k = str("LL_SPMV_KERNEL");
-  t.spmv_kernel = k == "csr" ? 1 : (k == "pb" ? 2 : (k == "tiled" ? 3 : 0));
-  t.keep_both = flag("LL_SPMV_KEEP_BOTH", false);
-  t.tl_force = flag("LL_TL_FORCE", false);
-  t.tl_xcd_order = flag("LL_TL_XCD", true);
-  t.tl_walk_modulo = flag("LL_TL_WALK", true);
-  t.pb_diag = flag("LL_PB_DIAG", true);
-  t.pair_gs = flag("LL_PAIR_GS", true);
-  const std::string p2 = str("LL_PB_PHASE2");
-  t.pb_phase2 = p2 == "atomic" ? LL_PB_ATOMIC : (p2 == "ordered" ? LL_PB_ORDERED : LL_PB_FIXED);
-  t.pb_block = (int)std::max<long long>(0, num("LL_PB_BLOCK", 0));
-  t.pb_row_block = (int)std::max<long long>(0, num("LL_PB_ROW_BLOCK", 0));
-  t.pb_col_block = (int)std::max<long long>(0, num("LL_PB_COL_BLOCK", 0));
-  t.pair_split_vecs = (int)std::max<long long>(0, num("LL_TEST_PAIR_SPLIT", 0));
-  t.pair_max_stored = (int)std::max<long long>(0, num("LL_TEST_PAIR_MAX_STORED", 0));
-  t.pb_threads1 = (int)num("LL_PB_THREADS1", 0);
-  if (t.pb_threads1 != 256 && t.pb_threads1 != 512 && t.pb_threads1 != 1024) t.pb_threads1 = 0;
-  t.pb_pad = (int)num("LL_PB_PAD", 0);
-  if (t.pb_pad != 4 && t.pb_pad != 16) t.pb_pad = 0;
-  t.pb_placements = (int)std::max<long long>(1, std::min<long long>(16, num("LL_PB_PLACEMENTS", 8)));
-  t.pb_xpre = flag("LL_PB_XPRE", true);
-  t.gather_chunks = (int)std::max<long long>(0, num("LL_GATHER_CHUNKS", 0));
-  t.comm_overlap = flag("LL_COMM_OVERLAP", true);
-  t.csr_split = flag("LL_CSR_SPLIT", true);
-  t.spmv_tile_balance = flag("LL_SPMV_TILE_BALANCE", true);
-  t.tridiag_thread = flag("LL_TRIDIAG_THREAD", true);
-  t.tridiag_lag = (int)num("LL_TRIDIAG_LAG", 3);
-  {
-    const std::string v = str("LL_DGKS_THRESHOLD");
-    if (!v.empty()) t.dgks_threshold = std::atof(v.c_str());
-  }
-  t.sharded_norm_measured = str("LL_SHARDED_NORM") == "measured";
-  t.slab_bytes = std::max<long long>(1, num("LL_SLAB_BYTES", (long long)4 << 30));
-  t.blas_small_bytes = num("LL_BLAS_SMALL_BYTES", (long long)4 << 20);
-  {
-    const long long level = num("LL_FUSE_LAUNCHES", 2);
+namespace {
+long long to_ll(const std::string& v) { return std::atoll(v.c_str()); }
+bool to_flag(const std::string& v) { return std::atoi(v.c_str()) != 0; }
+}  // namespace
+bool tuning_apply(Tuning& t, const std::string& key, const std::string& v) {
+  const Tuning d;  // defaults (an empty value restores the default of its key)
+  const bool e = v.empty();
+  // ---- user-facing (also read from the environment, kEnvSwitches below)
+  if (key == "spmv_kernel") t.spmv_kernel = v == "csr" ? 1 : (v == "pb" ? 2 : (v == "tiled" ? 3 : 0));
+  else if (key == "spmv_keep_both") t.keep_both = e ? d.keep_both : to_flag(v);
+  else if (key == "pb_phase2") t.pb_phase2 = v == "atomic" ? LL_PB_ATOMIC : (v == "ordered" ? LL_PB_ORDERED : LL_PB_FIXED);
+  else if (key == "pb_placements") t.pb_placements = e ? d.pb_placements : (int)std::max<long long>(1, std::min<long long>(16, to_ll(v)));
+  else if (key == "pb_placement_trace") t.pb_placement_trace = e ? false : to_flag(v);
+  else if (key == "comm_overlap") t.comm_overlap = e ? d.comm_overlap : to_flag(v);
+  else if (key == "gather_chunks") t.gather_chunks = e ? 0 : (int)std::max<long long>(0, to_ll(v));
+  else if (key == "csr_split") t.csr_split = e ? d.csr_split : to_flag(v);
+  else if (key == "iter_trace") t.iter_trace = v;
+  else if (key == "sharded_norm") t.sharded_norm_measured = v == "measured";
+  else if (key == "pair_gs") t.pair_gs = e ? d.pair_gs : to_flag(v);
+  else if (key == "pb_diag") t.pb_diag = e ? d.pb_diag : to_flag(v);
+  else if (key == "fuse_launches") {
+    const long long level = e ? 2 : to_ll(v);
     t.fuse_launches = level >= 1;
     t.lagged_gs = level >= 2;
+  } else if (key == "blas_small_bytes") t.blas_small_bytes = e ? d.blas_small_bytes : to_ll(v);
+  else if (key == "tridiag_thread") t.tridiag_thread = e ? d.tridiag_thread : to_flag(v);
+  else if (key == "tridiag_lag") t.tridiag_lag = e ? d.tridiag_lag : (int)to_ll(v);
+  else if (key == "dgks_threshold") t.dgks_threshold = e ? d.dgks_threshold : std::atof(v.c_str());
+  else if (key == "slab_bytes") t.slab_bytes = e ? d.slab_bytes : std::max<long long>(1, to_ll(v));
+  // ---- unstable: ll_ctx_set_tuning only (tests, tools/ probes, A/B measurements)
+  else if (key == "pb_block") t.pb_block = e ? 0 : (int)std::max<long long>(0, to_ll(v));
+  else if (key == "pb_row_block") t.pb_row_block = e ? 0 : (int)std::max<long long>(0, to_ll(v));
+  else if (key == "pb_col_block") t.pb_col_block = e ? 0 : (int)std::max<long long>(0, to_ll(v));
+  else if (key == "pb_threads1") {
+    t.pb_threads1 = e ? 0 : (int)to_ll(v);
+    if (t.pb_threads1 != 256 && t.pb_threads1 != 512 && t.pb_threads1 != 1024) t.pb_threads1 = 0;
+  } else if (key == "pb_pad") {
+    t.pb_pad = e ? 0 : (int)to_ll(v);
+    if (t.pb_pad != 4 && t.pb_pad != 16) t.pb_pad = 0;
+  } else if (key == "pb_xpre") t.pb_xpre = e ? d.pb_xpre : to_flag(v);
+  else if (key == "pb_test_all_remote") t.pb_test_all_remote = e ? false : to_flag(v);
+  else if (key == "force_rp64") t.force_rp64 = e ? false : to_flag(v);
+  else if (key == "spmv_tile_balance") t.spmv_tile_balance = e ? d.spmv_tile_balance : to_flag(v);
+  else if (key == "stencil_vec") t.stencil_vec = e ? d.stencil_vec : to_flag(v);
+  else if (key == "tl_force") t.tl_force = e ? false : to_flag(v);
+  else if (key == "tl_xcd") t.tl_xcd_order = e ? d.tl_xcd_order : to_flag(v);
+  else if (key == "tl_walk") t.tl_walk_modulo = e ? d.tl_walk_modulo : to_flag(v);
+  else if (key == "pair_split") t.pair_split_vecs = e ? 0 : (int)std::max<long long>(0, to_ll(v));
+  else if (key == "pair_max_stored") t.pair_max_stored = e ? 0 : (int)std::max<long long>(0, to_ll(v));
+  else if (key == "lagged_pieces") t.lagged_pieces = e ? 0 : (int)to_ll(v);
+  else if (key == "lagged_min_bytes") t.lagged_min_bytes = e ? -1 : to_ll(v);
+  else if (key == "tridiag_test_jitter_us") t.tridiag_test_jitter_us = e ? 0 : (int)to_ll(v);
+  else if (key == "stall_trace") t.stall_trace_ms = e ? -1.0 : std::atof(v.c_str());
+  else return false;
+  return true;
+}
+// environment variable -> key: the switches a user may set.  LL_COMM_PLUGIN and LL_ROCTX are read
+// where they are used (comm.cpp, trace.hpp), once per communicator / process.
+static const char* const kEnvSwitches[][2] = {
+    {"LL_SPMV_KERNEL", "spmv_kernel"},       {"LL_SPMV_KEEP_BOTH", "spmv_keep_both"}, {"LL_PB_PHASE2", "pb_phase2"},
+    {"LL_PB_PLACEMENTS", "pb_placements"},   {"LL_PB_PLACEMENT_TRACE", "pb_placement_trace"},
+    {"LL_COMM_OVERLAP", "comm_overlap"},     {"LL_GATHER_CHUNKS", "gather_chunks"},   {"LL_CSR_SPLIT", "csr_split"},
+    {"LL_ITER_TRACE", "iter_trace"},         {"LL_SHARDED_NORM", "sharded_norm"},     {"LL_PAIR_GS", "pair_gs"},
+    {"LL_PB_DIAG", "pb_diag"},               {"LL_FUSE_LAUNCHES", "fuse_launches"},   {"LL_BLAS_SMALL_BYTES", "blas_small_bytes"},
+    {"LL_TRIDIAG_THREAD", "tridiag_thread"}, {"LL_TRIDIAG_LAG", "tridiag_lag"},       {"LL_DGKS_THRESHOLD", "dgks_threshold"},
+    {"LL_SLAB_BYTES", "slab_bytes"},
+};
+Tuning read_tuning(const std::map<std::string, std::string>* overrides) {
+  Tuning t;
+  for (auto& sw : kEnvSwitches) {
+    const char* e = std::getenv(sw[0]);
+    if (e && *e) (void)tuning_apply(t, sw[1], e);
   }
-  t.lagged_pieces = (int)num("LL_TEST_LAGGED_PIECES", 0);
-  t.lagged_min_bytes = num("LL_TEST_LAGGED_MIN_BYTES", -1);
-  t.force_rp64 = flag("LL_FORCE_RP64", false);
-  t.pb_test_all_remote = flag("LL_PB_TEST_ALL_REMOTE", false);
-  t.tridiag_test_jitter_us = (int)num("LL_TRIDIAG_TEST_JITTER_US", 0);
-  t.stencil_vec = flag("LL_STENCIL_VEC", true);
-  {
-    const std::string v = str("LL_STALL_TRACE");
-    if (!v.empty()) t.stall_trace_ms = std::atof(v.c_str());
-  }
-  t.iter_trace = str("LL_ITER_TRACE");
+  if (overrides)
+    for (auto& kv : *overrides) (void)tuning_apply(t, kv.first, kv.second);
   return t;
 }
 }  // namespace ll
@@ -277,7 +292,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ll_context** out)
     LL_HIP(hipSetDevice(device));
     std::unique_ptr<ll_context> c(new ll_context);
     c->device = device;
-    c->tune = read_tuning();
+    c->tune = read_tuning(nullptr);
     if (own) {
       LL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
       c->own_stream = true;
@@ -328,7 +343,17 @@ int ll_ctx_destroy(ll_context* ctx) {
 int ll_ctx_reload_env(ll_context* ctx) {
   return guarded([&] {
     LL_REQUIRE(ctx != nullptr, "null context");
-    ctx->tune = read_tuning();
+    ctx->tune = read_tuning(&ctx->tuning_overrides);
+  });
+}
+int ll_ctx_set_tuning(ll_context* ctx, const char* key, const char* value) {
+  return guarded([&] {
+    LL_REQUIRE(ctx != nullptr && key != nullptr, "null argument");
+    Tuning probe;
+    LL_REQUIRE(tuning_apply(probe, key, value ? value : ""), std::string("ll_ctx_set_tuning: unknown key '") + key + "'");
+    if (value) ctx->tuning_overrides[key] = value;
+    else ctx->tuning_overrides.erase(key);
+    ctx->tune = read_tuning(&ctx->tuning_overrides);
   });
 }
 int ll_ctx_stream(ll_context* ctx, void** out) {
@@ -379,6 +404,51 @@ int ll_timer_stop(ll_context* ctx, double* ms_out) {
     float ms = 0.f;
     LL_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
     *ms_out = (double)ms;
+  });
+}
+int ll_bandwidth_probe(ll_context* ctx, size_t bytes, double* read_GBps, double* copy_GBps) {
+  return guarded([&] {
+    use(ctx);
+    LL_REQUIRE(bytes >= ((size_t)1 << 20) && read_GBps && copy_GBps, "ll_bandwidth_probe: at least 1 MiB and two outputs");
+    bytes &= ~(size_t)4095;
+    struct Buf {
+      void *a = nullptr, *b = nullptr;
+      double* out = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      ~Buf() {
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        if (out) (void)hipFree(out);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+      }
+    } w;
+    hipStream_t s = ctx->stream;
+    ctx->dev_malloc(&w.a, bytes, "bandwidth probe (source)");
+    ctx->dev_malloc(&w.b, bytes, "bandwidth probe (destination)");
+    ctx->dev_malloc((void**)&w.out, 16, "bandwidth probe (sink)");
+    LL_HIP(hipMemsetAsync(w.a, 0, bytes, s));
+    LL_HIP(hipMemsetAsync(w.b, 0, bytes, s));
+    LL_HIP(hipEventCreate(&w.e0));
+    LL_HIP(hipEventCreate(&w.e1));
+    auto timed = [&](auto launch) {  // best grid of a few, three launches each behind one warm-up
+      double best = 1e30;
+      for (int grid : {512, 1024, 2048, 8192}) {
+        launch(grid);
+        LL_HIP(hipEventRecord(w.e0, s));
+        for (int r = 0; r < 3; ++r) launch(grid);
+        LL_HIP(hipEventRecord(w.e1, s));
+        LL_HIP(hipEventSynchronize(w.e1));
+        float ms = 0.f;
+        LL_HIP(hipEventElapsedTime(&ms, w.e0, w.e1));
+        best = std::min(best, (double)ms / 3.0);
+      }
+      return best;
+    };
+    const double ms_r = timed([&](int g) { launch_bw_read(w.a, bytes, w.out, g, s); });
+    const double ms_c = timed([&](int g) { launch_bw_copy(w.a, w.b, bytes, g, s); });
+    *read_GBps = (double)bytes / (ms_r * 1e-3) / 1e9;
+    *copy_GBps = 2.0 * (double)bytes / (ms_c * 1e-3) / 1e9;  // bytes read + bytes written
   });
 }
 
@@ -487,6 +557,13 @@ int ll_comm_ranks_seen(ll_context* ctx, int* out) {
   return guarded([&] {
     LL_REQUIRE(ctx != nullptr && out != nullptr, "null argument");
     *out = ctx->comm ? ctx->ranks_seen : 1;
+  });
+}
+int ll_comm_transport(ll_context* ctx, char* out, size_t cap) {
+  return guarded([&] {
+    LL_REQUIRE(ctx != nullptr && out != nullptr && cap > 0, "null argument");
+    const std::string name = comm_transport_name(ctx->comm);
+    std::snprintf(out, cap, "%s", name.c_str());
   });
 }
 int ll_comm_rank(ll_context* ctx, int* rank, int* n_ranks) {
@@ -843,7 +920,7 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
   // Every candidate stays allocated until all have been timed (an allocation freed at once would simply be handed out
   // again for the next one); then all but the fastest are freed.
   double best = time_pb();
-  if (std::getenv("LL_PB_PLACEMENT_TRACE")) std::fprintf(stderr, "[ll placement] draw 0 at %p: %.4f ms\n", op->d_pb_arena, best);
+  if (op->ctx->tune.pb_placement_trace) std::fprintf(stderr, "[ll placement] draw 0 at %p: %.4f ms\n", op->d_pb_arena, best);
   void* best_arena = op->d_pb_arena;
   std::vector<void*> losers;
   // Unwinding (a failed copy or launch, thrown through LL_HIP): the operator goes back to the best image found so far and
@@ -872,7 +949,7 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
     LL_HIP(hipMemcpyAsync(cand, best_arena, op->pb_arena_static_bytes, hipMemcpyDeviceToDevice, s));
     rebase(cand);
     const double ms = time_pb();
-    if (std::getenv("LL_PB_PLACEMENT_TRACE")) std::fprintf(stderr, "[ll placement] draw %d at %p: %.4f ms (best so far %.4f)\n", t, cand, ms, best);
+    if (op->ctx->tune.pb_placement_trace) std::fprintf(stderr, "[ll placement] draw %d at %p: %.4f ms (best so far %.4f)\n", t, cand, ms, best);
     if (ms < best) {
       best = ms;
       losers.back() = best_arena;  // the previous best becomes a loser
@@ -1046,8 +1123,11 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     }
     LL_REQUIRE(!(want == 3 && !tl_ok), "this matrix is not eligible for the tiled SpMV kernel (its row blocks touch too many column tiles)");
   }
+  // Asked for by name, the tiled kernel is an error where no tiled image exists (a matrix without entries) — never a silent
+  // fallback, and never a kernel selected without its image (launch_spmv_tiled would write nothing).
+  LL_REQUIRE(!(want == 3 && !tl_ok), "the tiled SpMV kernel was asked for by name but no tiled image was built (matrix without entries)");
   if (want == 2 && pb_ok) op->spmv_kind = LL_SPMV_PB;
-  else if (want == 3) op->spmv_kind = LL_SPMV_TILED;
+  else if (want == 3 && tl_ok) op->spmv_kind = LL_SPMV_TILED;
   else if (want == 0 && (pb_ok || tl_ok)) autotune_spmv<T>(op.get());
   if (op->spmv_kind == LL_SPMV_PB && ctx->tune.pb_placements > 1) {
     const double ms = tune_pb_placement<T>(op.get());

@@ -92,6 +92,7 @@ struct Comm {
   bool external = false;
   ll_transport ext = {};
   void* plugin = nullptr;  // dlopen handle when the transport came from LL_COMM_PLUGIN
+  std::string plugin_name; // ... and the path it was loaded from
 };
 
 namespace {
@@ -144,6 +145,7 @@ Comm* comm_create(const void* id128, int rank, int nranks, int device) {
   try {
     if (plugin_path()) {
       c->plugin = plugin_open();
+      c->plugin_name = plugin_path();
       auto fn = (int (*)(const void*, int, int, int, ll_transport*))plugin_sym(c->plugin, "ll_transport_open");
       ext_check(fn(id128, rank, nranks, device, &c->ext), "ll_transport_open");
       c->external = true;
@@ -169,6 +171,13 @@ Comm* comm_attach(const ll_transport* t, int rank, int nranks) {
   c->external = true;
   c->ext = *t;
   return c;
+}
+
+// Which transport answers this communicator's collectives: "rccl", "plugin:<path>" (LL_COMM_PLUGIN) or "attached" (ll_comm_attach).
+std::string comm_transport_name(const Comm* c) {
+  if (!c) return "none";
+  if (!c->external) return "rccl";
+  return c->plugin ? "plugin:" + c->plugin_name : std::string("attached");
 }
 
 void comm_destroy(Comm* c) {

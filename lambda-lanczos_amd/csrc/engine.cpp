@@ -13,6 +13,7 @@
 #include <limits>
 #include <random>
 #include <string>
+#include <system_error>
 #include <thread>
 
 namespace ll {
@@ -51,14 +52,24 @@ void host_copy(void* dst, const void* src, size_t bytes) {
   }
   const size_t piece = ((bytes / kThreads) + 4095) & ~(size_t)4095;
   std::thread th[kThreads - 1];
+  int started = 0;
   for (int t = 1; t < kThreads; ++t) {
     const size_t off = std::min(bytes, (size_t)t * piece), len = std::min(bytes, (size_t)(t + 1) * piece) - off;
-    th[t - 1] = std::thread([=] {
-      if (len) std::memcpy((char*)dst + off, (const char*)src + off, len);
-    });
+    try {
+      th[t - 1] = std::thread([=] {
+        if (len) std::memcpy((char*)dst + off, (const char*)src + off, len);
+      });
+      ++started;
+    } catch (const std::system_error&) {
+      // no thread to be had (thread limit, cgroup pids): this and the remaining ranges are copied here — never std::terminate
+      // out of a joinable thread's destructor, never an error for what is only a slower copy
+      const size_t rest = std::min(bytes, (size_t)t * piece);
+      std::memcpy((char*)dst + rest, (const char*)src + rest, bytes - rest);
+      break;
+    }
   }
   std::memcpy(dst, src, std::min(bytes, piece));
-  for (auto& t : th) t.join();
+  for (int t = 0; t < started; ++t) th[t].join();
 }
 // LL_STALL_TRACE=ms: a whole-loop call that takes longer than that prints where its time went (host timestamps at
 // the phase boundaries) — for hunting one-off runtime stalls in launch-bound runs.
@@ -916,6 +927,9 @@ template <typename T> struct LoopState {
     constexpr int R = Engine<T>::R;
     // (restart passes: lag_ok already says that the locked vectors are eigenvectors to the one-sweep form's gate, begin_pass)
     if (!pair_enabled || !pair_allowed || !lag_ok) return false;
+    // never beyond the loop's max_iteration: iteration k + 1 would be an operator application the caller did not ask for, and with
+    // max_iteration == n its input is the normalised remainder of a vanishing vector; the last odd iteration runs in the one-sweep form
+    if (max_k_hint > 0 && k + 1 > max_k_hint) return false;
     const int64_t Lk = n_locked;
     int64_t P;
     const T *r1, *r2;

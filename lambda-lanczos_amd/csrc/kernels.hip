@@ -2839,4 +2839,39 @@ void launch_publish(double* out_mapped, const double* alpha, const NormRefs& nor
   LL_HIP(hipGetLastError());
 }
 
+// ================================================================= streaming ceilings of the device at hand (ll_bandwidth_probe)
+// SURVEY 8d "Bound": the roofline fraction is also reported against a MEASURED ceiling taken in the same process: a read-only
+// stream (sum of a buffer) and a copy (read + write), 16-byte accesses per lane, U loads in flight per lane.
+template <int U> __global__ __launch_bounds__(256) void bw_read_kernel(const double2* __restrict__ a, size_t n2, double* out) {
+  double acc = 0.0;
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < n2; i += stride) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = i + (size_t)u * 256 < n2 ? a[i + (size_t)u * 256] : double2{0, 0};
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u].x + v[u].y;
+  }
+  if (acc == 1.2345e-300) out[0] = acc;  // keeps the loads alive
+}
+template <int U> __global__ __launch_bounds__(256) void bw_copy_kernel(const double2* __restrict__ a, double2* __restrict__ b, size_t n2) {
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < n2; i += stride) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = i + (size_t)u * 256 < n2 ? a[i + (size_t)u * 256] : double2{0, 0};
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i + (size_t)u * 256 < n2) b[i + (size_t)u * 256] = v[u];
+  }
+}
+void launch_bw_read(const void* a, size_t bytes, double* out, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(bw_read_kernel<8>, dim3(grid), dim3(256), 0, s, (const double2*)a, bytes / sizeof(double2), out);
+  LL_HIP(hipGetLastError());
+}
+void launch_bw_copy(const void* a, void* b, size_t bytes, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(bw_copy_kernel<4>, dim3(grid), dim3(256), 0, s, (const double2*)a, (double2*)b, bytes / sizeof(double2));
+  LL_HIP(hipGetLastError());
+}
+
 }  // namespace ll

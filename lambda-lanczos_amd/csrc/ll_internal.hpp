@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -116,6 +117,7 @@ struct Comm;
 Comm* comm_attach(const struct ::ll_transport* t, int rank, int nranks);
 Comm* comm_create(const void* id128, int rank, int nranks, int device);
 void comm_destroy(Comm*);
+std::string comm_transport_name(const Comm*);  // "none" | "rccl" | "plugin:<path>" | "attached"
 void comm_unique_id(void* id128);
 void comm_allgather(Comm*, const void* send, void* recv, size_t bytes, hipStream_t s);
 void comm_allreduce_sum(Comm*, double* buf, size_t n_doubles, hipStream_t s);
@@ -140,11 +142,12 @@ struct GatherPlan {
 };
 }  // namespace ll
 
-// ---------------------------------------------------------------- environment switches
-// Every LL_* switch of the library (INTEGRATION.md section 8 is the user-facing list).  They are read ONCE, when a
-// context is created (ll_ctx_create*), into the context; operators copy what shapes their image when THEY are created.
-// Nothing on a launch path calls getenv.  ll_ctx_reload_env() reads them again (tests and tuning scripts that flip a
-// switch inside one process).
+// ---------------------------------------------------------------- tuning: environment switches and per-context settings
+// The USER-FACING LL_* switches are read from the environment ONCE, when a context is created
+// (ll_ctx_create*), into the context; operators copy what shapes their image when THEY are created.  Nothing on a launch path
+// calls getenv.  ll_ctx_reload_env() reads them again.  Every other field below — geometry overrides, forced code paths, the
+// hooks of the test suite — is NOT read from the environment: it is set per context through ll_ctx_set_tuning(ctx, key, value)
+// (capi.cpp tuning_apply holds the one parser; the comments below name the key).
 namespace ll {
 struct Tuning {
   // --- operator creation
@@ -154,8 +157,8 @@ struct Tuning {
   int pb_block = 0;                // LL_PB_BLOCK: rows AND columns per block (0: automatic); tests force ragged blocks
   int pb_row_block = 0;            // LL_PB_ROW_BLOCK / LL_PB_COL_BLOCK: one of the two only
   int pb_col_block = 0;
-  int pair_max_stored = 0;         // LL_TEST_PAIR_MAX_STORED=n: the pair form hands over to the one-sweep form beyond n stored vectors (test hook; by itself at 4 992 real / 2 492 complex)
-  int pair_split_vecs = 0;         // LL_TEST_PAIR_SPLIT=n: at most n stored vectors per launch of the pair sweep (test hook: split sweeps on small problems)
+  int pair_max_stored = 0;         // key pair_max_stored = n: the pair form hands over to the one-sweep form beyond n stored vectors (test hook; by itself at 4 992 real / 2 492 complex)
+  int pair_split_vecs = 0;         // key pair_split = n: at most n stored vectors per launch of the pair sweep (test hook: split sweeps on small problems)
   int pb_threads1 = 0;             // LL_PB_THREADS1 = 256 | 512 | 1024: lanes per workgroup of PB phase 1 (0: automatic — 512 for the thin column blocks of a sharded image, 1024 on one GPU); read at creation
   int pb_pad = 0;                  // LL_PB_PAD = 4 | 16: entries every segment of the PB image is padded to (0: automatic — 4 sharded, 16 on one GPU); read at creation
   int pb_placements = 8;           // LL_PB_PLACEMENTS: arena placements timed at creation (1: keep the first; LL_PB_PLACEMENT_TRACE=1 prints every draw); capi.cpp
@@ -173,8 +176,8 @@ struct Tuning {
   int64_t slab_bytes = (int64_t)4 << 30;       // LL_SLAB_BYTES: cap of one Krylov-basis slab
   int64_t blas_small_bytes = (int64_t)4 << 20;  // LL_BLAS_SMALL_BYTES: vectors below this use the small-vector kernels
   bool fuse_launches = true;       // LL_FUSE_LAUNCHES=0: separate fold / publish kernels (A/B of the launch fusion)
-  long long lagged_min_bytes = -1; // test hook LL_TEST_LAGGED_MIN_BYTES: shortest vector of the one-sweep form (-1 = default)
-  int lagged_pieces = 0;           // test hook LL_TEST_LAGGED_PIECES: strip geometry of the one-sweep kernel (0 = by length)
+  long long lagged_min_bytes = -1; // key lagged_min_bytes: shortest vector of the one-sweep form (-1 = default)
+  int lagged_pieces = 0;           // key lagged_pieces: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
   bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
   // --- test hooks (not for users)
@@ -188,13 +191,18 @@ struct Tuning {
   double stall_trace_ms = -1.0;    // LL_STALL_TRACE: print where a whole-loop call longer than this spent its time
   std::string iter_trace;          // LL_ITER_TRACE=path: the eigen-solver loop appends one line per collected iteration
                                    // (pass k alpha beta^2 c0 c1 second-pass) and one per stop verdict — for parity hunts
+  bool pb_placement_trace = false; // LL_PB_PLACEMENT_TRACE=1: print every placement draw of the PB image (capi.cpp)
 };
-Tuning read_tuning();  // capi.cpp
+// capi.cpp: defaults <- the user-facing environment switches <- the context's overrides (ll_ctx_set_tuning), in that order
+Tuning read_tuning(const std::map<std::string, std::string>* overrides);
+bool tuning_apply(Tuning& t, const std::string& key, const std::string& value);  // false: unknown key
+
 }  // namespace ll
 
 // ---------------------------------------------------------------- context
 struct ll_context {
   ll::Tuning tune;
+  std::map<std::string, std::string> tuning_overrides;  // ll_ctx_set_tuning: key -> value, applied on top of the environment
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -464,7 +472,7 @@ template <typename T> struct Lagged {
   const double* beta2;
 };
 // pieces: 0 = pick the strip geometry from the vector length (16-byte pieces per lane: 4 from kLaggedFullStrips 16 KiB
-// strips up, else 2); 2 / 4 force it (test hook LL_TEST_LAGGED_PIECES).
+// strips up, else 2); 2 / 4 force it (key lagged_pieces).
 constexpr int kLaggedFullStrips = 200;
 template <typename T>
 int launch_lagged(int64_t n, T* w, const BasisSegs<T>& segs, const Lagged<T>& lg, const ThreeTerm<T>& tt, double* partials,
@@ -546,6 +554,10 @@ void launch_gemv_basis(int64_t n, int64_t m, const BasisSegs<T>* segs, int nlaun
 void launch_accumulate_h(double* h_acc, const double* h_add, int count, const NormRefs* pred, hipStream_t s);
 // out_host_visible[0] = *alpha (0 if null), [1] = final norm^2, [2] = c0, [3] = c1  (pinned, device-mapped memory)
 void launch_publish(double* out_mapped, const double* alpha, const NormRefs& norms, hipStream_t s);
+
+// streaming kernels of ll_bandwidth_probe (kernels.hip): a read-only sum and a copy, 16-byte accesses
+void launch_bw_read(const void* a, size_t bytes, double* out, int grid, hipStream_t s);
+void launch_bw_copy(const void* a, void* b, size_t bytes, int grid, hipStream_t s);
 
 // ---------------------------------------------------------------- host tridiagonal solver (tridiag_host.cpp)
 // Flat-array implicit-shift QR; same arithmetic as the reference's (TRI:151-343) so that

@@ -76,6 +76,10 @@ def live_contexts():
     return [c for c in list(_LIVE_CONTEXTS) if c.handle]
 
 
+# callables(context) run at the end of Context.__init__ (the test harness applies its per-context tuning through them)
+CONTEXT_CREATED_HOOKS = []
+
+
 class Context:
     """Device + HIP stream + workspace (+ RCCL communicator): ll_context."""
 
@@ -89,6 +93,8 @@ class Context:
         self.device = int(device)
         self.rank, self.n_ranks = 0, 1
         _LIVE_CONTEXTS.add(self)
+        for hook in list(CONTEXT_CREATED_HOOKS):
+            hook(self)
 
     # ---- multi-GPU
     @staticmethod
@@ -107,6 +113,12 @@ class Context:
         out = C.c_int()
         check(lib().ll_comm_ranks_seen(self.handle, C.byref(out)))
         return out.value
+
+    def transport(self):
+        """Which transport answers the collectives: "rccl", "plugin:<path>", "attached" or "none" (ll_comm_transport)."""
+        buf = C.create_string_buffer(512)
+        check(lib().ll_comm_transport(self.handle, buf, len(buf)))
+        return buf.value.decode()
 
     def partition(self, n):
         return partition(n, self.n_ranks, self.rank)
@@ -136,12 +148,23 @@ class Context:
         check(lib().ll_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
+    def bandwidth_probe(self, nbytes=2 << 30):
+        """(read-only GB/s, copy GB/s) of two plain streaming kernels over nbytes, measured now (ll_bandwidth_probe)."""
+        r, c = C.c_double(), C.c_double()
+        check(lib().ll_bandwidth_probe(self.handle, int(nbytes), C.byref(r), C.byref(c)))
+        return r.value, c.value
+
     def release_cache(self):
         check(lib().ll_ctx_release_cache(self.handle))
 
     def reload_env(self):
         """Read the LL_* environment switches again (they are read once, when the context is created)."""
         check(lib().ll_ctx_reload_env(self.handle))
+
+    def set_tuning(self, key, value):
+        """ll_ctx_set_tuning (UNSTABLE; tests and probes): one tuning field of this context by key, on top of the environment;
+        value None removes the setting again."""
+        check(lib().ll_ctx_set_tuning(self.handle, str(key).encode(), None if value is None else str(value).encode()))
 
     def set_profiling(self, on):
         check(lib().ll_ctx_set_profiling(self.handle, 1 if on else 0))

@@ -17,6 +17,9 @@ SHM_TRANSPORT = os.path.join(ROOT, "tests", "transport", "_build", "libll_shm_tr
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from util import install_hook_sync
+
+    install_hook_sync()   # every Context of this process takes the harness's hook settings (util.HOOK_KEYS)
 
 
 def _have_gpu():
@@ -30,9 +33,10 @@ def _have_gpu():
 
 
 class _LLEnv:
-    """Set / delete LL_* environment switches for one test.  The library reads them once per context (ll_ctx_create),
-    so every change is followed by ll_ctx_reload_env on all live contexts; the old values come back (and are reloaded)
-    when the test ends."""
+    """Set / delete LL_* switches for one test.  The library reads the user-facing ones once per context (ll_ctx_create), so
+    every change is followed by ll_ctx_reload_env on all live contexts; the test hooks (util.HOOK_KEYS) are not environment
+    switches of the library at all — the harness carries them in os.environ (worker processes inherit them) and applies them
+    to every context through ll_ctx_set_tuning.  The old values come back when the test ends."""
 
     def __init__(self):
         self._saved = {}
@@ -40,9 +44,11 @@ class _LLEnv:
     @staticmethod
     def _reload():
         import lambda_lanczos_amd as L
+        from util import sync_hooks
 
         for c in L.live_contexts():
-            c.reload_env()
+            c.reload_env()   # the user-facing switches: the library reads them from the environment
+            sync_hooks(c)    # the test hooks and geometry overrides: per-context settings (ll_ctx_set_tuning)
 
     def setenv(self, name, value):
         self._saved.setdefault(name, os.environ.get(name))

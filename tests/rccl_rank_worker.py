@@ -9,8 +9,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lambda_lanczos_amd as L  # noqa: E402
+from util import install_hook_sync  # noqa: E402
 from lambda_lanczos_amd import generators as G  # noqa: E402
+
+
+install_hook_sync()   # the harness's hook settings (util.HOOK_KEYS in os.environ) -> every context of this process
 
 
 def main():

@@ -17,7 +17,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 import lambda_lanczos_amd as L  # noqa: E402
+from util import install_hook_sync  # noqa: E402
 from lambda_lanczos_amd import generators as G  # noqa: E402
+
+
+install_hook_sync()   # the harness's hook settings (util.HOOK_KEYS in os.environ) -> every context of this process
 
 
 def main():

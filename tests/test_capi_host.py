@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # and the ctypes table binds exactly that set
     assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
-    assert lib.ll_version() == capi.ABI_VERSION[0] * 1000 + capi.ABI_VERSION[1] == 4
+    assert lib.ll_version() == capi.ABI_VERSION[0] * 1000 + capi.ABI_VERSION[1] == 5
 
 
 def test_abi_handshake_refuses_a_caller_built_against_another_header():
@@ -45,13 +45,38 @@ def test_abi_handshake_refuses_a_caller_built_against_another_header():
     import ctypes as C
 
     lib = capi.lib()
-    # minor 4 only added entry points: callers built against minor 3 (same structs) and against minor 4 are both accepted,
+    # minors 4 and 5 only added entry points: callers built against minor 3 (same structs), 4 and 5 are all accepted,
     # a caller built against a NEWER header than the loaded library is not
     assert lib.ll_abi_check(0, 3, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_OK
     assert lib.ll_abi_check(0, 4, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_OK
-    assert lib.ll_abi_check(0, 5, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_ERR_INVALID
+    assert lib.ll_abi_check(0, 5, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_OK
+    assert lib.ll_abi_check(0, 6, C.sizeof(capi.RunStats), C.sizeof(capi.LanczosParams)) == capi.LL_ERR_INVALID
     assert lib.ll_abi_check(0, 2, C.sizeof(capi.RunStats) - 72, C.sizeof(capi.LanczosParams)) == capi.LL_ERR_INVALID
     assert b"rebuild the caller" in lib.ll_last_error()
+
+
+def test_the_library_reads_only_the_documented_environment_switches():
+    """A drop-in must not change its numerics path because a stray variable is set: the shipped library names only the
+    user-facing switches of INTEGRATION.md section 8 (first table) — the test hooks and geometry overrides are per-context
+    settings behind ll_ctx_set_tuning, and no LL_TEST_* name exists in the binary at all."""
+    with open(capi.LIB_PATH, "rb") as f:
+        blob = f.read()
+    assert b"LL_TEST" not in blob
+    named = set(m.decode() for m in re.findall(rb"\bLL_[A-Z][A-Z0-9_]{2,}\b", blob))
+    root = os.path.dirname(os.path.dirname(capi.HEADER_PATH))
+    with open(os.path.join(root, "INTEGRATION.md")) as f:
+        text = f.read()
+    table = text[text.index("## 8. Environment switches"):]
+    table = table[:table.index("Per-context settings")]
+    documented = set(re.findall(r"`(LL_[A-Z0-9_]+)", table))
+    from util import HOOK_KEYS
+
+    assert not (named & set(HOOK_KEYS)), named & set(HOOK_KEYS)   # none of the harness's hook names is an environment switch
+    env_like = {n for n in named if not n.startswith(("LL_ERR", "LL_OK", "LL_SPMV_CSR", "LL_SPMV_PB", "LL_SPMV_TILED", "LL_ORTH",
+                                                      "LL_TRIDIAG_QR", "LL_TRIDIAG_BISECT", "LL_TRIDIAG_AUTO", "LL_ACCURACY",
+                                                      "LL_VERSION", "LL_ABI", "LL_UNIQUE", "LL_HIP", "LL_REQUIRE", "LL_PB_FIXED",
+                                                      "LL_PB_ORDERED", "LL_PB_ATOMIC", "LL_INST"))}
+    assert env_like <= documented, env_like - documented
 
 
 def test_header_cites_the_reference_interface():

@@ -121,7 +121,7 @@ def _apply_all_vec_cases(ctx):
 
 def test_vectorised_lattice_kernel_equals_scalar_kernel(ctx, tmp_path):
     """The vectorised kernel adds every site's terms in the order of the one-site-per-lane kernel: identical bits for
-    every storage type.  (LL_STENCIL_VEC is read once per process, so the scalar run happens in one child process.)"""
+    every storage type.  (The scalar run happens in a child process whose context takes the stencil_vec = 0 hook.)"""
     import os
     import subprocess
     import sys
@@ -129,7 +129,7 @@ def test_vectorised_lattice_kernel_equals_scalar_kernel(ctx, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = str(tmp_path / "scalar.npz")
     code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import lambda_lanczos_amd as L; import test_gpu_operators as t\n"
+            "import lambda_lanczos_amd as L; import test_gpu_operators as t; import util; util.install_hook_sync()\n"
             "np.savez(%r, **t._apply_all_vec_cases(L.Context(0)))\n") % (root, os.path.join(root, "tests"), path)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LL_STENCIL_VEC="0"), capture_output=True, text=True,
                        timeout=200)

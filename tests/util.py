@@ -45,3 +45,35 @@ def residual(csr, lam, v):
 def inf_norm(csr):
     rp, ci, va = csr
     return np.max(np.add.reduceat(np.abs(va), rp[:-1]))
+
+
+# ------------------------------------------------------------------ tuning hooks of the harness
+# The library reads only the user-facing LL_* switches from the environment.  The test hooks and
+# geometry overrides are per-context settings (ll_ctx_set_tuning); the harness keeps NAMING them like environment variables —
+# so that a test can hand them to a worker process in its environment — and applies them itself, to every context it creates.
+HOOK_KEYS = {
+    "LL_PB_BLOCK": "pb_block", "LL_PB_ROW_BLOCK": "pb_row_block", "LL_PB_COL_BLOCK": "pb_col_block",
+    "LL_PB_THREADS1": "pb_threads1", "LL_PB_PAD": "pb_pad", "LL_PB_XPRE": "pb_xpre",
+    "LL_PB_TEST_ALL_REMOTE": "pb_test_all_remote", "LL_FORCE_RP64": "force_rp64",
+    "LL_SPMV_TILE_BALANCE": "spmv_tile_balance", "LL_STENCIL_VEC": "stencil_vec",
+    "LL_TL_FORCE": "tl_force", "LL_TL_XCD": "tl_xcd", "LL_TL_WALK": "tl_walk",
+    "LL_TEST_PAIR_SPLIT": "pair_split", "LL_TEST_PAIR_MAX_STORED": "pair_max_stored",
+    "LL_TEST_LAGGED_PIECES": "lagged_pieces", "LL_TEST_LAGGED_MIN_BYTES": "lagged_min_bytes",
+    "LL_TRIDIAG_TEST_JITTER_US": "tridiag_test_jitter_us", "LL_STALL_TRACE": "stall_trace",
+}
+
+
+def sync_hooks(ctx):
+    """Make the context's hook settings equal to what os.environ says under the harness names above."""
+    for name, key in HOOK_KEYS.items():
+        v = os.environ.get(name)
+        ctx.set_tuning(key, v if v else None)
+
+
+def install_hook_sync():
+    """Every Context created from now on (this process) takes the hook settings of os.environ: call once in conftest.py and at
+    the top of every worker script."""
+    import lambda_lanczos_amd as L
+
+    if sync_hooks not in L.CONTEXT_CREATED_HOOKS:
+        L.CONTEXT_CREATED_HOOKS.append(sync_hooks)

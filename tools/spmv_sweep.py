@@ -18,6 +18,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import lambda_lanczos_amd as L  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import sync_hooks  # noqa: E402
 from lambda_lanczos_amd import generators as G  # noqa: E402
 
 DEFAULT = ";".join([
@@ -58,7 +60,8 @@ for spec in a.variants.split(";"):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        ctx.reload_env()   # the switches are read once per context
+        ctx.reload_env()   # the user-facing switches are read once per context ...
+        sync_hooks(ctx)    # ... the geometry overrides / hooks are per-context settings (tests/util.py HOOK_KEYS)
         variants[name] = L.CsrOperator(ctx, *csr)
     finally:
         for k, v in saved.items():
@@ -67,6 +70,7 @@ for spec in a.variants.split(";"):
             else:
                 os.environ[k] = v
         ctx.reload_env()
+        sync_hooks(ctx)
     envs[name] = env
 
 ref = None

@@ -1,5 +1,5 @@
 """A/B of the tiled SpMV kernel's two locality switches on the banded config 3, same process, interleaved rounds of 20 launches
-by HIP events: LL_TL_XCD (one contiguous eighth of the row blocks per XCD against launch order; read per launch) and LL_TL_WALK
+by HIP events: the per-context settings tl_xcd (one contiguous eighth of the row blocks per XCD against launch order; read per launch) and tl_walk
 (a row block's tiles by column index modulo the longest tile list against ascending order; read at operator creation).
     python tools/tl_xcd_probe.py
     LL_TL_PROBE_ONLY=<xcd><walk> (e.g. 11, 10, 01, 00) under rocprofv3 --pmc FETCH_SIZE: one combination, for its traffic"""
@@ -24,16 +24,14 @@ ops, ys = {}, {}
 for walk in ("1", "0"):
     if only is not None and only[1] != walk:
         continue
-    os.environ["LL_TL_WALK"] = walk
-    ctx.reload_env()
+    ctx.set_tuning("tl_walk", walk)
     ops[walk] = L.CsrOperator(ctx, *csr, kernel=L.capi.SPMV_TILED)
     ys[walk] = ctx.empty(n)
 combos = [only] if only is not None else ["11", "01", "10", "00"]
 res = {c: [] for c in combos}
 for rnd in range(int(os.environ.get("LL_TL_PROBE_ROUNDS", "1" if only is not None else "5"))):
     for c in combos:
-        os.environ["LL_TL_XCD"] = c[0]
-        ctx.reload_env()
+        ctx.set_tuning("tl_xcd", c[0])
         op, yd = ops[c[1]], ys[c[1]]
         L.spmv(op, xd, yd)
         ctx.synchronize()
