@@ -74,6 +74,9 @@ def parse_args():
                     help="N > 1: skip the pre-pass that times LL_GATHER_CHUNKS x LL_COMM_OVERLAP on the actual shards and keeps the fastest")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short config-2 / config-5 / host-callback legs that follow the headline run at N = 1")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="per-context setting for this run (ll_ctx_set_tuning; UNSTABLE keys, INTEGRATION.md section 8): A/B "
+                         "measurements such as --tuning sweep_pipeline=0; may be given several times; echoed in config.tuning")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a job that has not finished prints a diagnostic and exits with code 3 "
                          "(a hung collective must not look like a slow run); 0 = off")
@@ -354,6 +357,9 @@ def main():
             box = [L.Context.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             ctx.init_comm(box[0], rank, world)   # fails loudly unless all `world` ranks answer in rank order
+    for kv in args.tuning:
+        if not args.dry_run_dist:
+            ctx.set_tuning(*kv.split("=", 1))
     ranks_seen = 1 if args.dry_run_dist else ctx.ranks_seen()
     # which transport answers the collectives: "rccl" | "plugin:<path>" (LL_COMM_PLUGIN: the host-staged test transport) | "none"
     transport = "none" if args.dry_run_dist else ctx.transport()
@@ -882,6 +888,7 @@ def main():
                                    if lagged_gs else "two sweeps over the basis per iteration (multi-dot, multi-axpy)"))),
                 "tridiag_mode": int(eng.tridiag_mode) if hasattr(eng, "tridiag_mode") else None,
                 "eps": "engine default" if args.eps is None else args.eps,
+                "tuning": args.tuning or None,
                 "io": ("host buffers at the boundary (PCIe copies inside the timed region)" if args.host_io else
                        "start vector / input and eigenvector / output in device buffers (resident in HBM before the timed "
                        "region; --host-io times the std::vector boundary instead)"),

@@ -724,6 +724,26 @@ template <typename T> struct LoopState {
   int prec_set = 0;           // records prec[2 * prec_set], prec[2 * prec_set + 1] hold the pending pair's coefficients
   bool slot_pair[4] = {false, false, false, false};  // the scalars of this ring slot came from a pair fold (its gate is valid)
   static constexpr size_t kPairRec = (size_t)kLaggedMaxCols + 32;
+  // Pointer table of the software-pipelined sweep (kernels.hip, pair_sweep_pipe_kernel): entry c = stored column c of this pass —
+  // the locked eigenvectors, then u_0, u_1, ... — written on the device, slab by slab (launch_fill_ptrs), when a pass starts and
+  // whenever the basis has grown by a slab.
+  DevBuf<const T*> vtab;
+  static constexpr size_t kVtabCap = (size_t)kLaggedMaxCols + (size_t)kLaggedMaxLocked + 64;
+  size_t vtab_chunks = 0;     // slabs of U whose slots are in the table
+  void vtab_begin_pass() {
+    if (!vtab.p) return;
+    launch_fill_ptrs<T>(vtab.p, 0, (int)std::min<int64_t>(n_locked, (int64_t)kVtabCap), locked, ld, s);
+    vtab_chunks = 0;
+  }
+  const T* const* vtab_sync() {
+    if (!vtab.p) return nullptr;
+    for (; vtab_chunks < U.chunks.size(); ++vtab_chunks) {
+      const int64_t start = n_locked + (int64_t)vtab_chunks * U.chunk_vecs;
+      const int64_t count = std::min<int64_t>(U.chunk_vecs, (int64_t)kVtabCap - start);
+      launch_fill_ptrs<T>(vtab.p, (int)start, (int)count, U.chunks[vtab_chunks], ld, s);
+    }
+    return vtab.p;
+  }
 
   LoopState(Engine<T>& e, Basis<T>& u, EventRing& r, PhaseTimer& t, int64_t n_local, hipStream_t st)
       : E(e), U(u), ring(r), timer(t), nl(n_local), s(st) {}
@@ -734,6 +754,7 @@ template <typename T> struct LoopState {
       if (!w.p) w.alloc(E.ctx, (size_t)ld);
     // 4 records + zero record + p3 + p4 + fold scratch + folded columns (two per stored vector: twice a record) + 64 scalars
     pbuf.alloc(E.ctx, 10 * kPairRec + 64);
+    if (E.ctx->tune.sweep_pipeline) vtab.alloc(E.ctx, kVtabCap);
     double* b = pbuf.p;
     for (int i = 0; i < 4; ++i) prec[i] = b + (size_t)i * kPairRec;
     pzero = b + 4 * kPairRec;
@@ -809,6 +830,7 @@ template <typename T> struct LoopState {
     for (auto& b : slot_pair) b = false;
     lag_ok = lagged && (n_lock == 0 || (lambda_shifted != nullptr && n_lock <= kLaggedMaxLocked));
     lag_beta2_min = 0.0;
+    if (lag_ok) vtab_begin_pass();
     if (lagged) {
       bind_buffers();
       // The partial sums of the sweeps — one column per coefficient, kMaxGrid rows — are sized HERE for the longest basis this pass can
@@ -1016,8 +1038,10 @@ template <typename T> struct LoopState {
     // ---- one sweep for both
     launch_pair_predict((int)P, (int)Lk, R, g1, g2, rho1sq, rho2sq, gam, t3, fold_in_consumers ? E.ctx->d_partials : nullptr, tt_grid,
                         e1, e2, da2.nparts > 0 ? da2.partials : nullptr, da2.nparts, hist_alpha, hist_beta, d_lambda, pp3, pp4, s);
-    grid = launch_pair_sweep<T>(nl, groups, (int)K, r1, r2, r3, r4, U.vec(P), U.vec(P + 1), psplit.p, g1, g2, gam, pp4, rho1sq, rho2sq,
-                                e2, t3, E.ctx->d_partials, E.ctx->tune.lagged_pieces, s);
+    T* const uP = U.vec(P);
+    T* const uQ = U.vec(P + 1);  // (may add a slab: the pointer table is brought up to date after it)
+    grid = launch_pair_sweep<T>(nl, groups, (int)K, r1, r2, r3, r4, uP, uQ, psplit.p, g1, g2, gam, pp4, rho1sq, rho2sq, e2, t3,
+                                E.ctx->d_partials, E.ctx->tune.lagged_pieces, s, vtab_sync());
     launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
     // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits
     if (E.ctx->comm != nullptr) E.all_reduce(pcols, (size_t)ncols);

@@ -990,30 +990,63 @@ void launch_pair_predict(int P, int L, int reals, const double* g1, const double
   LL_HIP(hipGetLastError());
 }
 
+// Address-space casts for the pipelined sweeps.  A pointer that reaches a load through a table or a lambda has lost what lets
+// the compiler pick the cheap instruction: uniform reads of data no kernel writes while it runs (coefficients, the pointer table)
+// go through the CONSTANT address space (s_load: scalar cache, no vmcnt slot — a vector load in the middle of a trip would be
+// younger than the prefetched strips and turn the trip's wait into a full drain), strips through the GLOBAL one (global_load with
+// an SGPR base instead of flat_load, which also occupies the LDS counter).
+__device__ __forceinline__ double ld_const(const double* p, int i) {
+  return reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<uintptr_t>(p))[i];
+}
+template <typename T> __device__ __forceinline__ const T* ld_const_ptr(const T* const* tab, int i) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const __attribute__((address_space(4))) uintptr_t*>(reinterpret_cast<uintptr_t>(tab))[i]);
+}
+typedef unsigned int ll_u4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char* ll_gcp;
+typedef __attribute__((address_space(1))) char* ll_gp;
+__device__ __forceinline__ uint4 ld_global16(const char* uniform_base, unsigned lane_off) {
+  const ll_gcp g = (ll_gcp)uniform_base;  // generic -> global
+  const ll_u4v v = *(const __attribute__((address_space(1))) ll_u4v*)(g + lane_off);
+  uint4 r;
+  __builtin_memcpy(&r, &v, sizeof(r));
+  return r;
+}
+__device__ __forceinline__ void st_global16(char* uniform_base, unsigned lane_off, uint4 x) {
+  const ll_gp g = (ll_gp)uniform_base;
+  ll_u4v v;
+  __builtin_memcpy(&v, &x, sizeof(v));
+  *(__attribute__((address_space(1))) ll_u4v*)(g + lane_off) = v;
+}
 // One trip of the pair sweep: NV basis strips; two late updates, the compensation of r4, two measured column sets.
+// nv <= NV of the strips are real (a prefix): the others are re-reads of the last real vector that the pipelined loop below issues
+// to keep every trip's loads unconditional — their coefficients are zero (x - 0 u = x exactly) and their column sums are dropped.
 template <typename T, int NV, int PC>
-__device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
-                                          T (&a1)[lstrip<T, PC>::EPT], T (&a2)[lstrip<T, PC>::EPT],
-                                          const T (&b3)[lstrip<T, PC>::EPT], const T (&b4r)[lstrip<T, PC>::EPT],
-                                          T (&b4)[lstrip<T, PC>::EPT], const double* __restrict__ g1c,
-                                          const double* __restrict__ g2c, const double* __restrict__ p4c, double* mine3,
-                                          double* mine4, int lane) {
+__device__ __forceinline__ void pair_trip_compute(const T (&ur)[NV][lstrip<T, PC>::EPT], int nv,
+                                                  T (&a1)[lstrip<T, PC>::EPT], T (&a2)[lstrip<T, PC>::EPT],
+                                                  const T (&b3)[lstrip<T, PC>::EPT], const T (&b4r)[lstrip<T, PC>::EPT],
+                                                  T (&b4)[lstrip<T, PC>::EPT], const double* __restrict__ g1c,
+                                                  const double* __restrict__ g2c, const double* __restrict__ p4c, double* mine3,
+                                                  double* mine4, int lane) {
   constexpr int EPT = lstrip<T, PC>::EPT;
-  T ur[NV][EPT];
-#pragma unroll
-  for (int b = 0; b < NV; ++b) load_lstrip<T, PC>(u0 + (int64_t)b * ld, base, n, ur[b]);
   double a3[NV], a4[NV], a3i[NV], a4i[NV];  // (imaginary parts: complex types only)
 #pragma unroll
   for (int b = 0; b < NV; ++b) {
-    acc_t<T> c1, c2, c4;  // wave-uniform addresses in read-only memory: scalar loads
+    // wave-uniform addresses in read-only memory: scalar loads, unconditional (a column beyond the real ones reads the last real
+    // one's coefficients and zeroes them)
+    acc_t<T> c1, c2, c4;
+    const int bb = b < nv ? b : nv - 1;
+    const bool real = b < nv;  // (uniform: scalar selects, the coefficients stay in SGPRs)
     if constexpr (scalar_traits<T>::is_complex) {
-      c1 = zc{g1c[2 * b], g1c[2 * b + 1]};
-      c2 = zc{g2c[2 * b], g2c[2 * b + 1]};
-      c4 = zc{p4c[2 * b], p4c[2 * b + 1]};
+      const double x1 = ld_const(g1c, 2 * bb), y1 = ld_const(g1c, 2 * bb + 1), x2 = ld_const(g2c, 2 * bb), y2 = ld_const(g2c, 2 * bb + 1),
+                   x4 = ld_const(p4c, 2 * bb), y4 = ld_const(p4c, 2 * bb + 1);
+      c1 = zc{real ? x1 : 0.0, real ? y1 : 0.0};
+      c2 = zc{real ? x2 : 0.0, real ? y2 : 0.0};
+      c4 = zc{real ? x4 : 0.0, real ? y4 : 0.0};
     } else {
-      c1 = g1c[b];
-      c2 = g2c[b];
-      c4 = p4c[b];
+      const double x1 = ld_const(g1c, bb), x2 = ld_const(g2c, bb), x4 = ld_const(p4c, bb);
+      c1 = real ? x1 : 0.0;
+      c2 = real ? x2 : 0.0;
+      c4 = real ? x4 : 0.0;
     }
     acc_t<T> s3 = zero<acc_t<T>>(), s4 = zero<acc_t<T>>();
 #pragma unroll
@@ -1036,14 +1069,16 @@ __device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, 
     }
   }
   // (transposed reductions of at most NV = 4 sums each: with 8 or 16 sums at once the compiler sends part of the array through
-  // scratch memory — a round trip with a full drain of the memory pipeline in every trip; checked in the ISA)
+  // scratch memory — a round trip with a full drain of the memory pipeline in every trip; checked in the ISA.  The butterfly adds
+  // the lanes in the same order whatever NV and whatever the column's position in the trip: a column's bits do not depend on how
+  // the stored vectors are cut into trips.)
   wave_sum_transposed<NV>(a3, lane);
   wave_sum_transposed<NV>(a4, lane);
   constexpr int LPI = 64 / NV;  // lanes that end up holding the same sum
   if constexpr (scalar_traits<T>::is_complex) {
     wave_sum_transposed<NV>(a3i, lane);
     wave_sum_transposed<NV>(a4i, lane);
-    if ((lane & (LPI - 1)) == 0) {
+    if ((lane & (LPI - 1)) == 0 && lane / LPI < nv) {
       const int b = lane / LPI;
       mine3[2 * b] += a3[0];
       mine3[2 * b + 1] += a3i[0];
@@ -1051,18 +1086,31 @@ __device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, 
       mine4[2 * b + 1] += a4i[0];
     }
   } else {
-    if ((lane & (LPI - 1)) == 0) {
+    if ((lane & (LPI - 1)) == 0 && lane / LPI < nv) {
       mine3[lane / LPI] += a3[0];
       mine4[lane / LPI] += a4[0];
     }
   }
 }
+template <typename T, int NV, int PC>
+__device__ __forceinline__ void pair_trip(const T* __restrict__ u0, int64_t ld, int64_t base, int64_t n,
+                                          T (&a1)[lstrip<T, PC>::EPT], T (&a2)[lstrip<T, PC>::EPT],
+                                          const T (&b3)[lstrip<T, PC>::EPT], const T (&b4r)[lstrip<T, PC>::EPT],
+                                          T (&b4)[lstrip<T, PC>::EPT], const double* __restrict__ g1c,
+                                          const double* __restrict__ g2c, const double* __restrict__ p4c, double* mine3,
+                                          double* mine4, int lane) {
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  T ur[NV][EPT];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) load_lstrip<T, PC>(u0 + (int64_t)b * ld, base, n, ur[b]);
+  pair_trip_compute<T, NV, PC>(ur, NV, a1, a2, b3, b4r, b4, g1c, g2c, p4c, mine3, mine4, lane);
+}
 
 // Partial columns per workgroup: [m3: R*P][m4: R*P][<u_P,r3>][<u_{P+1},r3>][<u_P,r4>][<u_{P+1},r4>][<r3,r4>] (R each) [|r4|^2].
 template <typename T, int PC>
 __global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs<T> segs, int P, int col0, int Pl, int flags,
-                                                            const T* __restrict__ r1, const T* __restrict__ r2,
-                                                            const T* __restrict__ r3, T* __restrict__ r4, T* __restrict__ uP_out,
+                                                            const T* r1, const T* __restrict__ r2,   // (r1 may alias uP_out, see the
+                                                            const T* __restrict__ r3, T* __restrict__ r4, T* uP_out,  // pipelined kernel)
                                                             T* __restrict__ uQ_out, T* __restrict__ part4,
                                                             const double* __restrict__ g1, const double* __restrict__ g2,
                                                             const double* __restrict__ gam, const double* __restrict__ p4,
@@ -1182,13 +1230,197 @@ __global__ __launch_bounds__(kBlock) void pair_sweep_kernel(int64_t n, BasisSegs
     out[g] = v;
   }
 }
+// ---- the same sweep, software-pipelined (the production form; the kernel above is its A/B reference, key sweep_pipeline = 0)
+// Unpipelined, every wave alternates between waiting for the 4 strips of its trip and 0.3 us of arithmetic on them, and the
+// prologue / epilogue of every strip (4 raw strips in, 3 out, six wave reductions) is exposed in full: 5.26 TB/s where the chip
+// streams 6.3.  Here the NEXT trip's strips are requested before the current trip is consumed — two register buffers with
+// compile-time roles — so a wave always has a trip in flight while it computes.  What that takes:
+//   * every trip requests the same JB loads, UNCONDITIONALLY and in straight-line code (the consuming trip's s_waitcnt then names
+//     exactly the older trip; a load under a branch, divergent or not, makes the compiler drain the memory pipeline): whole
+//     strips take this path (a uniform branch per strip; the vector's ragged last strip takes the guarded loads of the
+//     reference kernel inside the same loop structure);
+//   * the stored vectors are addressed through a device table of pointers (vtab[c] = column c: the locked eigenvectors, then
+//     u_0, u_1, ...; written by fill_ptrs_kernel when a slab is added) instead of a walk over the segment list: one scalar load
+//     per vector, trips run across slab boundaries, and a trip beyond the last stored vector re-reads the last one (a cache hit)
+//     with zero coefficients and its column sums dropped (pair_trip_compute);
+//   * a lane's address is a uniform base plus a 32-bit lane offset (global_load with an SGPR base): no 64-bit address
+//     arithmetic per load.
+// Same additions in the same order as the kernel above: identical bits (tests/test_gpu_pair.py compares the two).
+template <typename T, int PC, bool FULL>
+__device__ __forceinline__ void load_lstrip_u(const T* __restrict__ v, int64_t base, int64_t n, T (&r)[lstrip<T, PC>::EPT]) {
+  if constexpr (FULL) {
+    constexpr int EPT = lstrip<T, PC>::EPT;
+    const char* sb = reinterpret_cast<const char*>(v + base);  // uniform
+    const unsigned off = threadIdx.x * (unsigned)(EPT * sizeof(T));
+    uint4 c[PC];
+#pragma unroll
+    for (int e = 0; e < PC; ++e) c[e] = ld_global16(sb, off + 16u * e);
+    __builtin_memcpy(&r[0], c, sizeof(c));
+  } else {
+    load_lstrip<T, PC>(v, base, n, r);
+  }
+}
+template <typename T, int PC, bool FULL>
+__device__ __forceinline__ void store_lstrip_u(T* __restrict__ v, int64_t base, int64_t n, const T (&r)[lstrip<T, PC>::EPT]) {
+  if constexpr (FULL) {
+    constexpr int EPT = lstrip<T, PC>::EPT;
+    char* sb = reinterpret_cast<char*>(v + base);
+    const unsigned off = threadIdx.x * (unsigned)(EPT * sizeof(T));
+    uint4 c[PC];
+    __builtin_memcpy(c, &r[0], sizeof(c));
+#pragma unroll
+    for (int e = 0; e < PC; ++e) st_global16(sb, off + 16u * e, c[e]);
+  } else {
+    store_lstrip<T, PC>(v, base, n, r);
+  }
+}
+template <typename T>
+__global__ void fill_ptrs_kernel(const T** tab, int start, int count, const T* base, long long ld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) tab[start + i] = base + (long long)i * ld;
+}
+template <typename T> void launch_fill_ptrs(const T** tab, int start, int count, const T* base, int64_t ld, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL((fill_ptrs_kernel<T>), dim3((count + 255) / 256), dim3(256), 0, s, tab, start, count, base, (long long)ld);
+  LL_HIP(hipGetLastError());
+}
+constexpr int kPipeJB = 2;  // stored vectors per trip of the pipelined sweep (two trips resident: see the register budget in DESIGN.md 3.2)
+template <typename T, int PC, int JB>
+__global__ __launch_bounds__(kBlock) void pair_sweep_pipe_kernel(int64_t n, const T* const* __restrict__ vtab, int P, int col0, int Pl,
+                                                                 int flags, const T* r1, const T* __restrict__ r2,
+                                                                 const T* __restrict__ r3, T* __restrict__ r4, T* uP_out,
+                                                                 T* __restrict__ uQ_out, T* __restrict__ part4,
+                                                                 const double* __restrict__ g1, const double* __restrict__ g2,
+                                                                 const double* __restrict__ gam, const double* __restrict__ p4,
+                                                                 const double* __restrict__ rho1sq, const double* __restrict__ rho2sq,
+                                                                 const double* __restrict__ e2, const double* __restrict__ n3sq,
+                                                                 double* __restrict__ partials) {
+  // (r1 and uP_out may be the SAME buffer — entering the pair form from the one-sweep state, u_{k-2} is already complete in its
+  // slot and is "updated" with zero coefficients: every lane reads its strip before it writes it; neither is __restrict__)
+  constexpr int EPT = lstrip<T, PC>::EPT;
+  constexpr int ELEMS = lstrip<T, PC>::ELEMS;
+  constexpr int R = scalar_traits<T>::reals;
+  const bool first = (flags & kPairFirst) != 0, last = (flags & kPairLast) != 0;
+  const int ncols = 2 * R * P + 5 * R + 1;               // columns of the whole sweep (layout of `partials`)
+  const int lcols = 2 * R * Pl + (last ? 5 * R + 1 : 0);  // columns this launch sums
+  extern __shared__ double lds[];  // [4 waves][lcols]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 4 * lcols; i += kBlock) lds[i] = 0.0;
+  const double s1 = 1.0 / sqrt(*rho1sq), s2 = 1.0 / sqrt(*rho2sq);
+  const double n3 = sqrt(*n3sq);
+  const double ca = *e2 / n3, cb = n3 * s2;
+  acc_t<T> gm;
+  if constexpr (scalar_traits<T>::is_complex) gm = zc{gam[0], gam[1]};
+  else gm = gam[0];
+  __syncthreads();
+  double* mine = lds + (size_t)wave * lcols;
+  double* tail = mine + 2 * R * Pl;
+  const T* const* tab = vtab + col0;
+  const double *g1c = g1 + R * col0, *g2c = g2 + R * col0, *p4c = p4 + R * col0;
+  const int ntrips = (Pl + JB - 1) / JB;
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+
+  auto do_strip = [&](auto full_c, const int64_t base) {
+    constexpr bool FULL = decltype(full_c)::value;
+    T a1[EPT], a2[EPT], b3[EPT], b4r[EPT], b4[EPT];
+    load_lstrip_u<T, PC, FULL>(first ? r1 : uP_out, base, n, a1);
+    load_lstrip_u<T, PC, FULL>(r2, base, n, a2);
+    load_lstrip_u<T, PC, FULL>(r3, base, n, b3);
+    load_lstrip_u<T, PC, FULL>(r4, base, n, b4r);
+    auto issue = [&](T (&buf)[JB][EPT], int t) {
+      const T* ptr[JB];
+#pragma unroll
+      for (int b = 0; b < JB; ++b) ptr[b] = ld_const_ptr<T>(tab, min(JB * t + b, Pl - 1));  // uniform; beyond the end: the last stored vector again
+#pragma unroll
+      for (int b = 0; b < JB; ++b) load_lstrip_u<T, PC, FULL>(ptr[b], base, n, buf[b]);
+    };
+    T ua[JB][EPT], ub[JB][EPT];
+    if (ntrips > 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue(ua, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      b4r[e] = sub(sub(b4r[e], rmul(ca, b3[e])), rmul(cb, a2[e]));
+      b4[e] = b4r[e];
+    }
+    if (!first) {  // (uniform) the late update of r2 and the compensated r4 as the launch before left them
+      load_lstrip_u<T, PC, FULL>(uQ_out, base, n, a2);
+      load_lstrip_u<T, PC, FULL>(part4, base, n, b4);
+    }
+    for (int t = 0; t < ntrips; t += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue(ub, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      pair_trip_compute<T, JB, PC>(ua, min(JB, Pl - JB * t), a1, a2, b3, b4r, b4, g1c + R * JB * t, g2c + R * JB * t, p4c + R * JB * t,
+                                   mine + R * JB * t, mine + R * Pl + R * JB * t, lane);
+      if (t + 1 >= ntrips) break;
+      __builtin_amdgcn_sched_barrier(0);
+      issue(ua, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      pair_trip_compute<T, JB, PC>(ub, min(JB, Pl - JB * (t + 1)), a1, a2, b3, b4r, b4, g1c + R * JB * (t + 1), g2c + R * JB * (t + 1),
+                                   p4c + R * JB * (t + 1), mine + R * JB * (t + 1), mine + R * Pl + R * JB * (t + 1), lane);
+    }
+    if (!last) {  // (uniform) hand the three running strips to the next launch
+      store_lstrip_u<T, PC, FULL>(uP_out, base, n, a1);
+      store_lstrip_u<T, PC, FULL>(uQ_out, base, n, a2);
+      store_lstrip_u<T, PC, FULL>(part4, base, n, b4);
+      return;
+    }
+    acc_t<T> t3p = zero<acc_t<T>>(), t3q = zero<acc_t<T>>(), t4p = zero<acc_t<T>>(), t4q = zero<acc_t<T>>(),
+             d34 = zero<acc_t<T>>();
+    double nn = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      a1[e] = rmul(s1, a1[e]);
+      fnma_acc(a2[e], gm, a1[e]);
+      a2[e] = rmul(s2, a2[e]);
+      cfma_acc(t3p, a1[e], b3[e]);
+      cfma_acc(t3q, a2[e], b3[e]);
+      cfma_acc(t4p, a1[e], b4[e]);
+      cfma_acc(t4q, a2[e], b4[e]);
+      cfma_acc(d34, b3[e], b4[e]);
+      nn += abs2(b4[e]);
+    }
+    store_lstrip_u<T, PC, FULL>(uP_out, base, n, a1);
+    store_lstrip_u<T, PC, FULL>(uQ_out, base, n, a2);
+    store_lstrip_u<T, PC, FULL>(r4, base, n, b4);
+    const acc_t<T> sums[5] = {wave_sum(t3p), wave_sum(t3q), wave_sum(t4p), wave_sum(t4q), wave_sum(d34)};
+    nn = wave_sum(nn);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        if constexpr (scalar_traits<T>::is_complex) {
+          tail[2 * c] += sums[c].re;
+          tail[2 * c + 1] += sums[c].im;
+        } else {
+          tail[c] += sums[c];
+        }
+      }
+      tail[5 * R] += nn;
+    }
+  };
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t base = sidx * ELEMS;
+    if (base + ELEMS <= n) do_strip(std::true_type{}, base);
+    else do_strip(std::false_type{}, base);
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < lcols; i += kBlock) {
+    const double v = (lds[i] + lds[lcols + i]) + (lds[2 * lcols + i] + lds[3 * lcols + i]);
+    const int g = i < R * Pl ? R * col0 + i : (i < 2 * R * Pl ? R * P + R * col0 + (i - R * Pl) : 2 * R * P + (i - 2 * R * Pl));
+    out[g] = v;
+  }
+}
 // groups: the stored vectors in launch order (every group within pair_sweep_max_vecs<T>() vectors and kMaxSegs segments);
 // part4: an n-vector of scratch, needed (and touched) only when there is more than one group.
 template <typename T>
 int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P, const T* r1, const T* r2, const T* r3, T* r4,
                       T* uP_out, T* uQ_out, T* part4, const double* g1, const double* g2, const double* gam, const double* p4,
                       const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
-                      hipStream_t s) {
+                      hipStream_t s, const T* const* vtab) {
   constexpr int R = scalar_traits<T>::reals;
   const int64_t strips16k = (n * (int64_t)sizeof(T) + 16383) / 16384;
   int pc = strips16k >= kLaggedFullStrips ? 4 : 2;
@@ -1205,12 +1437,20 @@ int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P,
     for (int i = 0; i < segs.nseg; ++i) Pl += segs.count[i];
     const int flags = (gi == 0 ? kPairFirst : 0) | (gi + 1 == ng ? kPairLast : 0);
     const size_t lds_bytes = (size_t)4 * (size_t)(2 * R * Pl + ((flags & kPairLast) ? 5 * R + 1 : 0)) * sizeof(double);
-    if (pc == 4)
+    if (vtab != nullptr) {  // software-pipelined form: the stored vectors through the pointer table (columns [col0, col0 + Pl))
+      if (pc == 4)
+        hipLaunchKernelGGL((pair_sweep_pipe_kernel<T, 4, kPipeJB>), dim3(grid), dim3(kBlock), lds_bytes, s, n, vtab, P, col0, Pl, flags, r1, r2, r3,
+                           r4, uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+      else
+        hipLaunchKernelGGL((pair_sweep_pipe_kernel<T, 2, kPipeJB>), dim3(grid), dim3(kBlock), lds_bytes, s, n, vtab, P, col0, Pl, flags, r1, r2, r3,
+                           r4, uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+    } else if (pc == 4) {
       hipLaunchKernelGGL((pair_sweep_kernel<T, 4>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, col0, Pl, flags, r1, r2, r3, r4,
                          uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
-    else
+    } else {
       hipLaunchKernelGGL((pair_sweep_kernel<T, 2>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, col0, Pl, flags, r1, r2, r3, r4,
                          uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+    }
     LL_HIP(hipGetLastError());
     col0 += Pl;
   }
@@ -1377,7 +1617,8 @@ void launch_pair_fold(const double* m, int P, int L, int reals, const double* la
                                          const double*, double*, bool, hipStream_t);                                             \
   template int launch_pair_sweep<T>(int64_t, const std::vector<BasisSegs<T>>&, int, const T*, const T*, const T*, T*, T*, T*, T*, \
                                     const double*, const double*, const double*, const double*, const double*, const double*,    \
-                                    const double*, const double*, double*, int, hipStream_t);
+                                    const double*, const double*, double*, int, hipStream_t, const T* const*);                    \
+  template void launch_fill_ptrs<T>(const T**, int, int, const T*, int64_t, hipStream_t);
 LL_INST_PAIR(double) LL_INST_PAIR(zc) LL_INST_PAIR(float) LL_INST_PAIR(cf)
 
 // ================================================================= small-vector Gram-Schmidt kernels (vectors < 4 MiB)

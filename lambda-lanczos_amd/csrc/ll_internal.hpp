@@ -179,6 +179,7 @@ struct Tuning {
   long long lagged_min_bytes = -1; // key lagged_min_bytes: shortest vector of the one-sweep form (-1 = default)
   int lagged_pieces = 0;           // key lagged_pieces: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
+  bool sweep_pipeline = true;      // key sweep_pipeline = 0: the Gram-Schmidt sweeps request a trip's strips only when they consume it (A/B of the software pipeline; same bits)
   bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
   // --- test hooks (not for users)
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
@@ -504,7 +505,10 @@ template <typename T>
 int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P, const T* r1, const T* r2, const T* r3, T* r4,
                       T* uP_out, T* uQ_out, T* part4, const double* g1, const double* g2, const double* gam, const double* p4,
                       const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
-                      hipStream_t s);
+                      hipStream_t s, const T* const* vtab = nullptr);  // vtab (device; column c -> pointer of stored vector c): the software-
+                                                                       // pipelined kernel; null: the reference kernel over the segment lists
+// tab[start + i] = base + i * ld, i < count (the pointer table of the pipelined sweeps; one launch per slab)
+template <typename T> void launch_fill_ptrs(const T** tab, int start, int count, const T* base, int64_t ld, hipStream_t s);
 void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,
                       const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
                       double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,

@@ -84,8 +84,8 @@ def test_pair_form_against_the_oracle_and_the_forms_it_replaces(ctx, oracle, lle
 @pytest.mark.parametrize("window", [1, 2, 3, 4, 5, 6, 7, 40, 41])
 def test_pair_form_with_every_parity_of_the_iteration_count(ctx, oracle, llenv, window):
     """max_iteration = 1 .. 7, 40, 41: windows that end on the first or on the second iteration of a pair, windows too short to
-    enter the form at all — the returned pair, the traces and the count against the oracle (the second iteration of a pair that
-    overshoots max_iteration is speculative work nobody reads)."""
+    enter the form at all — the returned pair, the traces and the count against the oracle.  A pair never runs past
+    max_iteration (round 6: an odd last iteration takes the one-sweep form instead of a pair whose second half nobody asked for)."""
     n = 30011
     csr, init = G.randsym_np(n), G.start_vector(n, 1)
     llenv.setenv("LL_BLAS_SMALL_BYTES", "0")
@@ -99,7 +99,7 @@ def test_pair_form_with_every_parity_of_the_iteration_count(ctx, oracle, llenv, 
         assert np.max(np.abs(r["beta"][:window - 1] - ora["beta"][:window - 1])) <= 1e-10 * 30
     assert abs(r["vals"][0] - ora["eigenvalues"][0]) <= 1e-10 * abs(r["vals"][0])
     assert 1 - overlap(r["vecs"][0], ora["eigenvectors"][0]) <= 1e-8
-    assert r["stats"]["pair_iterations"] == (0 if window < 3 else 2 * ((window - 1) // 2))
+    assert r["stats"]["pair_iterations"] == (0 if window < 3 else 2 * ((window - 2) // 2))
     op.close()
 
 
@@ -251,6 +251,35 @@ def test_split_sweeps_change_no_bit(ctx, llenv, name, split):
     assert np.array_equal(whole["alpha"], parts["alpha"]) and np.array_equal(whole["beta"], parts["beta"])
     assert np.array_equal(whole["vals"], parts["vals"])
     for a, b in zip(whole["vecs"], parts["vecs"]):
+        assert np.array_equal(a, b)
+    op.close()
+
+
+@pytest.mark.parametrize("name,split", [("randsym", None), ("laplace", 37), ("torus", None), ("torus", 51)])
+def test_software_pipelined_sweep_changes_no_bit(ctx, name, split):
+    """The production sweep (pair_sweep_pipe_kernel: the next trip's strips requested before the current trip is consumed, stored
+    vectors addressed through a device pointer table, two vectors per trip, trips across slab boundaries, dummy columns with zero
+    coefficients behind the last stored vector) performs the additions of the reference kernel (pair_sweep_kernel, setting
+    sweep_pipeline = 0: four vectors per trip over the segment lists) in the same order: whole runs — restart passes behind locked
+    vectors, ragged last strips, split sweeps included — agree bit for bit: alpha, beta, counts, eigenvalues, eigenvectors."""
+    n, csr, init, find_max, offset = _case(name)
+    ctx.set_tuning("blas_small_bytes", "0")
+    if split:
+        ctx.set_tuning("pair_split", str(split))
+    try:
+        op = L.CsrOperator(ctx, *csr)
+        num_eigs = 2 if name == "randsym" else 1
+        piped = _run(ctx, op, n, find_max, offset, init, num_eigs=num_eigs)
+        ctx.set_tuning("sweep_pipeline", "0")
+        plain = _run(ctx, op, n, find_max, offset, init, num_eigs=num_eigs)
+    finally:
+        for key in ("sweep_pipeline", "pair_split", "blas_small_bytes"):
+            ctx.set_tuning(key, None)
+    assert piped["iters"] == plain["iters"]
+    assert piped["stats"]["pair_iterations"] > 0 and plain["stats"]["pair_iterations"] > 0
+    assert np.array_equal(piped["alpha"], plain["alpha"]) and np.array_equal(piped["beta"], plain["beta"])
+    assert np.array_equal(piped["vals"], plain["vals"])
+    for a, b in zip(piped["vecs"], plain["vecs"]):
         assert np.array_equal(a, b)
     op.close()
 
