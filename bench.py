@@ -241,6 +241,32 @@ def other_config_c5(ctx, L, G):
         its += eng.run(-5.0j, d_in, out=d_out)[1]
     ctx.synchronize()
     dt = time.perf_counter() - t0
+    # the same run with full_orthogonalize (EX:63,120-122): Gram-Schmidt against the whole basis in every iteration, two iterations
+    # per sweep (pair form) — and with LL_PAIR_GS=0 one sweep per iteration, for the A/B
+    full = {}
+    eng.full_orthogonalize = True
+    for label, key in (("pair_form", None), ("one_sweep_form", "0")):
+        ctx.set_tuning("pair_gs", key)
+        try:
+            eng.run(-5.0j, d_in, out=d_out)
+            ctx.synchronize()
+            tf = time.perf_counter()
+            itf = 0
+            for _ in range(5):
+                itf += eng.run(-5.0j, d_in, out=d_out)[1]
+            ctx.synchronize()
+            tf = time.perf_counter() - tf
+            full[label] = {"value": itf / tf, "iterations_per_step": itf / 5, "ms_per_step": tf / 5 * 1e3,
+                           "pair_iterations_last_step": int(eng.last_stats["pair_iterations"])}
+        finally:
+            ctx.set_tuning("pair_gs", None)
+    o_full, o_full_it, _ = (oracle_lib.reference() if oracle_lib.have_reference() else oracle_lib.oracle()).expo(
+        csr, -5.0j, init, full_orthogonalize=True)
+    g_full, g_full_it = eng.run(-5.0j, init)
+    full["parity"] = {"iterations_cpu": int(o_full_it), "iterations_gpu": int(g_full_it),
+                      "max_abs_diff_over_input_norm": float(np.max(np.abs(g_full - o_full)) / np.linalg.norm(init))}
+    full["parity"]["ok"] = bool(full["parity"]["max_abs_diff_over_input_norm"] <= 1e-10 and abs(int(o_full_it) - int(g_full_it)) <= 1)
+    eng.full_orthogonalize = False
     kind = "reference" if oracle_lib.have_reference() else "port"
     chk = oracle_lib.reference() if kind == "reference" else oracle_lib.oracle()
     o_out, o_it, o_t = chk.expo(csr, -5.0j, init)
@@ -254,6 +280,7 @@ def other_config_c5(ctx, L, G):
            "spmv": {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac_of_8TBps": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "kernel": {L.capi.SPMV_CSR_STREAM: "spmv_stream", L.capi.SPMV_PB: "pb_phase1+pb_phase2_fixed",
                                L.capi.SPMV_TILED: "tl_xmax+tl_spmv"}.get(op.selected_spmv())},
+           "full_orthogonalize": full,
            "cpu_whole_run": {"kind": kind, "value": o_it / o_t["t_total"], "seconds": o_t["t_total"], "iterations": int(o_it), "cores": 1},
            "parity_whole_run": {"iterations_cpu": int(o_it), "iterations_gpu": int(g_it), "max_abs_diff_over_input_norm": err,
                                 "one_minus_overlap": ovl, "norm_drift": unit,

@@ -924,24 +924,39 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
   if (op->ctx->tune.pb_placement_trace) std::fprintf(stderr, "[ll placement] draw 0 at %p: %.4f ms\n", op->d_pb_arena, best);
   void* best_arena = op->d_pb_arena;
   std::vector<void*> losers;
+  // The candidates that lose are not returned to the device: sized like a Krylov-basis slab of a default run on this operator
+  // (when that is at least the arena's size), they go into the context's slab cache and become the first basis slabs.  A process
+  // that starts on a GPU another process has just left pays ~120 ms per fresh 4 GiB hipMalloc: config 3's
+  // first run() to convergence needs seven slabs — the search has already paid for seven allocations.
+  const size_t slab_hint = (size_t)default_slab_bytes(op->n, op->n_local, op->n_shard, op->elem_bytes, ctx->tune);
+  const size_t cand_bytes = slab_hint >= op->pb_arena_bytes && slab_hint <= 2 * op->pb_arena_bytes ? slab_hint : op->pb_arena_bytes;
+  void* const first_arena = op->d_pb_arena;
+  bool finished = false;
   // Unwinding (a failed copy or launch, thrown through LL_HIP): the operator goes back to the best image found so far and
   // every other copy is freed exactly once — `losers` never contains the arena the operator is bound to at that point.
   struct Guard {
     std::vector<void*>& v;
     void*& best;
     decltype(rebase)& rb;
+    ll_context* ctx;
+    void* first;
+    size_t cand_bytes, slab_hint;
+    bool& finished;
     ~Guard() {
       rb(best);
-      for (void* p : v)
-        if (p != best) (void)hipFree(p);
+      for (void* p : v) {
+        if (p == best) continue;
+        if (finished && p != first && cand_bytes == slab_hint) ctx->cache_put(p, cand_bytes);
+        else (void)hipFree(p);
+      }
     }
-  } guard{losers, best_arena, rebase};
+  } guard{losers, best_arena, rebase, ctx, first_arena, cand_bytes, slab_hint, finished};
   // candidates come from the context's allocator: under memory pressure it releases the cached Krylov slabs once before
   // giving up, so a large matrix is not silently left with fewer draws
   for (int t = 1; t < ctx->tune.pb_placements; ++t) {
     void* cand = nullptr;
     try {
-      ctx->dev_malloc(&cand, op->pb_arena_bytes, "PB placement candidate");
+      ctx->dev_malloc(&cand, cand_bytes, "PB placement candidate");
     } catch (const Failure&) {  // no room for another copy: decide among what we have
       (void)hipGetLastError();
       break;
@@ -958,6 +973,7 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
     }
     rebase(best_arena);
   }
+  finished = true;
   return best;
 }
 

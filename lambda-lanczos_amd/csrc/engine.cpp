@@ -724,6 +724,7 @@ template <typename T> struct LoopState {
   int prec_set = 0;           // records prec[2 * prec_set], prec[2 * prec_set + 1] hold the pending pair's coefficients
   bool slot_pair[4] = {false, false, false, false};  // the scalars of this ring slot came from a pair fold (its gate is valid)
   static constexpr size_t kPairRec = (size_t)kLaggedMaxCols + 32;
+  static constexpr int64_t kPairSmallMinBytes = (int64_t)512 << 10;  // shortest vector of the pair form (small-vector geometry; enqueue_pair)
   // Pointer table of the software-pipelined sweep (kernels.hip, pair_sweep_pipe_kernel): entry c = stored column c of this pass —
   // the locked eigenvectors, then u_0, u_1, ... — written on the device, slab by slab (launch_fill_ptrs), when a pass starts and
   // whenever the basis has grown by a slab.
@@ -828,7 +829,10 @@ template <typename T> struct LoopState {
     pair_pending = false;
     pair_allowed = true;
     for (auto& b : slot_pair) b = false;
-    lag_ok = lagged && (n_lock == 0 || (lambda_shifted != nullptr && n_lock <= kLaggedMaxLocked));
+    // (lambda_shifted == nullptr with locked vectors — a caller's orthogonalizeTo list, run_iteration LL:216-220,259: their Rayleigh
+    // quotients theta_i = <z_i, (A + offset) z_i> are MEASURED below and take the eigenvalues' place; the residual gate then decides
+    // whether the list consists of eigenvectors to the accuracy the one-sweep forms need)
+    lag_ok = lagged && n_lock <= kLaggedMaxLocked;
     lag_beta2_min = 0.0;
     if (lag_ok) vtab_begin_pass();
     if (lagged) {
@@ -844,8 +848,11 @@ template <typename T> struct LoopState {
       E.ctx->ensure_partials((size_t)kMaxGrid * cols);
     }
     if (!lag_ok || n_lock == 0) return;
-    LL_HIP(hipMemcpyAsync(d_lambda, lambda_shifted, (size_t)n_lock * sizeof(double), hipMemcpyHostToDevice, s));
-    LL_HIP(hipStreamSynchronize(s));  // (pageable source: the caller's array may go away)
+    const bool measure_theta = lambda_shifted == nullptr;
+    if (!measure_theta) {
+      LL_HIP(hipMemcpyAsync(d_lambda, lambda_shifted, (size_t)n_lock * sizeof(double), hipMemcpyHostToDevice, s));
+      LL_HIP(hipStreamSynchronize(s));  // (pageable source: the caller's array may go away)
+    }
     BasisSegs<T> none;
     none.nseg = 0;
     none.ld = ld;
@@ -854,14 +861,19 @@ template <typename T> struct LoopState {
     for (int64_t i = 0; i < n_lock; ++i) {
       const T* z = locked + i * ld;
       T* y = work[0].p;
-      E.apply(z, y, offset, nullptr, true);
+      E.apply(z, y, offset, measure_theta ? d_lambda + i : nullptr, true);  // (theta_i = Re <z_i, y>: the fused dot of the operator kernel)
       const ThreeTerm<T> tt{nullptr, z, d_lambda + i, NormRefs{nullptr, nullptr, nullptr, 0}};  // y <- y - lambda_i z, ||y||^2
       const int grid = launch_mdot<T>(nl, y, none, tt, nullptr, E.ctx->d_partials, small_bytes, s);
       launch_reduce_cols(E.ctx->d_partials, grid, 1, r2_dev + i, nullptr, s);
     }
     E.all_reduce(r2_dev, (size_t)n_lock);  // one collective and one fetch for all locked vectors
-    std::vector<double> r2((size_t)n_lock);
+    std::vector<double> r2((size_t)n_lock), theta;
     E.fetch(r2_dev, r2.data(), (size_t)n_lock);
+    if (measure_theta) {
+      theta.resize((size_t)n_lock);
+      E.fetch(d_lambda, theta.data(), (size_t)n_lock);
+      lambda_shifted = theta.data();
+    }
     double scale = norm_scale, worst = 0.0;
     for (int64_t i = 0; i < n_lock; ++i) {
       worst = std::max(worst, std::sqrt(std::max(r2[(size_t)i], 0.0)));
@@ -987,13 +999,21 @@ template <typename T> struct LoopState {
     const int64_t len = E.ctx->comm != nullptr ? E.op->n_shard : nl;  // (sharded: decided on the shard stride, the same on every rank)
     // the coefficient records hold reals * (K + 2) (+ reals) numbers, the recorded tridiagonal kLaggedMaxCols + 8 entries; the
     // sweep's 2 reals K + 5 reals + 1 columns are summed in as many launches as one workgroup's LDS asks for (pair_sweep_max_vecs)
-    if ((int64_t)R * (K + 8) > kLaggedMaxCols || len * (int64_t)sizeof(T) < stream_bytes) return false;
+    // below the streaming geometry, down to the one-sweep form's lower limit (320 KiB by default), the sweep runs in the small-vector
+    // geometry (pair_small_kernel: four waves per 1 KiB strip split the stored vectors), one launch, as many columns as 64 KiB of LDS hold
+    // (Laplacian, window 100, it/s with / without the pair form: n = 5.0e4 (401 KB) 25.8 k / 26.3 k, n = 1.0e5 (800 KB) 24.3 k / 20.9 k:
+    // seven launches per pair against four per iteration, half the basis traffic — the pair form takes over from 512 KiB)
+    const int64_t min_default = std::min<int64_t>(stream_bytes, kPairSmallMinBytes);
+    const int64_t min_bytes = E.ctx->tune.lagged_min_bytes >= 0 ? std::min<int64_t>(E.ctx->tune.lagged_min_bytes, stream_bytes) : min_default;
+    const bool small_geometry = len * (int64_t)sizeof(T) < stream_bytes;
+    if ((int64_t)R * (K + 8) > kLaggedMaxCols || len * (int64_t)sizeof(T) < min_bytes) return false;
+    if (small_geometry && (!pair_small_fits<T>((int)K) || K > max_vecs_per_launch<T>() || basis_runs(P).runs.size() > (size_t)kMaxSegs)) return false;
     if (E.ctx->tune.pair_max_stored > 0 && K > E.ctx->tune.pair_max_stored) return false;  // (test hook: the hand-over to the one-sweep form)
     const RunList<T> stored = basis_runs(P);
     int per_launch = pair_sweep_max_vecs<T>();
     if (E.ctx->tune.pair_split_vecs > 0) per_launch = std::min(per_launch, std::max(1, E.ctx->tune.pair_split_vecs));
     const std::vector<BasisSegs<T>> groups = stored.groups(per_launch);
-    if (groups.size() > 1 && !psplit.p) psplit.alloc(E.ctx, (size_t)ld);
+    if (!small_geometry && groups.size() > 1 && !psplit.p) psplit.alloc(E.ctx, (size_t)ld);
     const double te0 = now_s();
     T* r3 = out_set ? pwork[0].p : work[0].p;
     T* r4 = out_set ? pwork[1].p : work[1].p;
@@ -1040,8 +1060,18 @@ template <typename T> struct LoopState {
                         e1, e2, da2.nparts > 0 ? da2.partials : nullptr, da2.nparts, hist_alpha, hist_beta, d_lambda, pp3, pp4, s);
     T* const uP = U.vec(P);
     T* const uQ = U.vec(P + 1);  // (may add a slab: the pointer table is brought up to date after it)
-    grid = launch_pair_sweep<T>(nl, groups, (int)K, r1, r2, r3, r4, uP, uQ, psplit.p, g1, g2, gam, pp4, rho1sq, rho2sq, e2, t3,
-                                E.ctx->d_partials, E.ctx->tune.lagged_pieces, s, vtab_sync());
+    if (small_geometry) {
+      BasisSegs<T> none;
+      none.nseg = 0;
+      none.ld = ld;
+      const std::vector<BasisSegs<T>> one = stored.groups(max_vecs_per_launch<T>());  // a single group (checked above)
+      LL_REQUIRE(launch_pair_sweep_small<T>(nl, one.empty() ? none : one[0], (int)K, r1, r2, r3, r4, uP, uQ, g1, g2, gam, pp4, rho1sq, rho2sq,
+                                            e2, t3, E.ctx->d_partials, &grid, s),
+                 "internal: the small-geometry pair sweep refused a launch that was checked to fit");
+    } else {
+      grid = launch_pair_sweep<T>(nl, groups, (int)K, r1, r2, r3, r4, uP, uQ, psplit.p, g1, g2, gam, pp4, rho1sq, rho2sq, e2, t3,
+                                  E.ctx->d_partials, E.ctx->tune.lagged_pieces, s, vtab_sync());
+    }
     launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
     // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits
     if (E.ctx->comm != nullptr) E.all_reduce(pcols, (size_t)ncols);
@@ -1260,6 +1290,14 @@ int64_t pick_chunk_vecs(int64_t initial_vector_size, int64_t max_iteration, int6
 
 }  // namespace
 
+// Bytes of one Krylov-basis slab of a run with default parameters on this operator (initial_vector_size = 200, max_iteration = n):
+// what operator creation sizes its spare placement candidates to, so that they can serve as the first basis slabs (capi.cpp).
+int64_t default_slab_bytes(int64_t n, int64_t n_local, int64_t n_shard, int elem_bytes, const Tuning& tune) {
+  const int64_t ld = round_up(std::max(n_local, n_shard), 256);
+  const int64_t vec_bytes = ld * (int64_t)elem_bytes;
+  return pick_chunk_vecs(200, std::max<int64_t>(n, 1), vec_bytes, tune.slab_bytes) * vec_bytes;
+}
+
 // ================================================================= LambdaLanczos<T>::run
 template <typename T>
 void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in, double* eigvals, T* eigvecs,
@@ -1323,9 +1361,12 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
   LS.max_k_hint = P.max_iteration;
   if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && mode == LL_ORTH_CGS_DGKS) LS.enable_lagged(ld);
   // two iterations per sweep (device operators, streaming vectors, no locked vectors; LoopState::enqueue_pair decides per iteration)
-  if (LS.lagged && ctx->tune.pair_gs &&
-      (ctx->comm != nullptr ? op->n_shard : nl) * (int64_t)sizeof(T) >= std::min<int64_t>(ctx->tune.blas_small_bytes, (int64_t)1 << 20))
-    LS.enable_pair();
+  {
+    const int64_t stream_bytes = std::min<int64_t>(ctx->tune.blas_small_bytes, (int64_t)1 << 20);
+    const int64_t pair_min = ctx->tune.lagged_min_bytes >= 0 ? std::min<int64_t>(ctx->tune.lagged_min_bytes, stream_bytes)
+                                                             : std::min<int64_t>(stream_bytes, LoopState<T>::kPairSmallMinBytes);
+    if (LS.lagged && ctx->tune.pair_gs && (ctx->comm != nullptr ? op->n_shard : nl) * (int64_t)sizeof(T) >= pair_min) LS.enable_pair();
+  }
   std::vector<double> alpha, beta;
   // Pinned staging buffer owned by the context (reused across runs): the init_vector hook fills it directly and the
   // Ritz vectors land in it, so n-sized host<->device copies run at full PCIe rate and nothing n-sized is zero-filled
@@ -1773,7 +1814,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   Basis<T> U;
   U.init(ctx, nl, ld, pick_chunk_vecs(P.initial_vector_size, P.max_iteration, ld * (int64_t)sizeof(T), ctx->tune.slab_bytes));
   st.at("basis");
-  ctx->ensure_pinned(16);
+  ctx->ensure_pinned(32);  // 4 ring slots of 4 scalars, then the 4 gate values of the pair form
   EventRing ring;
   PhaseTimer timer(ctx, s);
   double t_tridiag = 0.0;
@@ -1804,12 +1845,21 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   if (E.can_defer_scale() && fuse_launches && (!P.full_orthogonalize || P.orth_mode == LL_ORTH_CGS_DGKS)) LS.enable_defer(ld);
   if (E.can_scale_input() && fuse_launches && ctx->tune.lagged_gs && P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS)
     LS.enable_lagged(ld);
+  // two iterations per sweep with full_orthogonalize (EX:120-122), exactly as in the eigen-solver loop (LoopState::enqueue_pair)
+  {
+    const int64_t stream_bytes = std::min<int64_t>(ctx->tune.blas_small_bytes, (int64_t)1 << 20);
+    const int64_t pair_min = ctx->tune.lagged_min_bytes >= 0 ? std::min<int64_t>(ctx->tune.lagged_min_bytes, stream_bytes)
+                                                             : std::min<int64_t>(stream_bytes, LoopState<T>::kPairSmallMinBytes);
+    if (LS.lagged && ctx->tune.pair_gs && (ctx->comm != nullptr ? op->n_shard : nl) * (int64_t)sizeof(T) >= pair_min) LS.enable_pair();
+  }
   LS.begin_pass(nullptr, 0);
-  auto enqueue = [&](int64_t k) {  // EX:107-118 (+ EX:120-122 with full_orthogonalize), EX:145, EX:160
+  auto enqueue = [&](int64_t k) -> int64_t {  // EX:107-118 (+ EX:120-122 with full_orthogonalize), EX:145, EX:160
+    if (P.full_orthogonalize && P.orth_mode == LL_ORTH_CGS_DGKS && !LS.pending && LS.enqueue_pair(k, 0.0)) return 2;
     RunList<T> runs;
     runs.ld = ld;
     if (P.full_orthogonalize) runs.add_basis(U, k);
     LS.enqueue(k, 0.0, runs, P.orth_mode);
+    return 1;
   };
   // Host half of iteration j, part 1 (this thread): the four scalars, the DGKS decision, alpha_j / beta_j; part 2 (EX:124-158:
   // exp(a T_j) e_1 and the overlap test, O(j^3)) runs on the helper thread like the eigen-solver's Ritz step.
@@ -1829,6 +1879,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     last = std::move(o);
     return last.stop;
   };
+  const double pair_gate = sizeof(typename scalar_traits<T>::real) == 4 ? 2e-4 : kPairGate;
   auto collect = [&](int64_t j) -> int {
     const int slot = (int)(j % 4);
     const double tw0 = now_s();
@@ -1851,11 +1902,24 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
         LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
         LS.pending = false;  // (see lanczos_run)
         LS.lag_pending = false;
+        LS.pair_pending = false;
         LS.set_beta(j - 1, std::sqrt(beta2_j));
         verdict = kRedone;
       } else {
         beta2_j = 0.0;
       }
+    }
+    if (verdict == kContinue && LS.slot_pair[slot] && !(ctx->h_pinned[16 + slot] <= pair_gate)) {  // the pair form's gate (see lanczos_run)
+      LS.pair_allowed = false;
+      ++LS.n_gate_trips;
+      LS.make_final(j);
+      LS.pending = false;
+      LS.lag_pending = false;
+      LS.pair_pending = false;
+      double* cj = E.S(kScalNorms + 3 * slot);
+      launch_set_scalar(cj + 1, beta2_j, s);
+      LS.refs_prev = NormRefs{cj, cj + 1, cj + 1, 0};
+      verdict = kRedone;
     }
     alpha.push_back(alpha_j);
     beta.push_back(std::sqrt(beta2_j));  // EX:145
@@ -1863,16 +1927,31 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     return verdict;
   };
   if (speculate) {
-    for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
-      enqueue(k);
-      if (k > 1) {
-        if (collect(k - 1) == kRedone) enqueue(k);
-        stopped = worker.consume(k - 1, lockstep_lag, kMaxLag, absorb);
+    // One group of iterations (one, or the two of a pair) is enqueued ahead of the group whose scalars are collected (lanczos_run).
+    int64_t enq = 0, col = 0;
+    int64_t ahead_first = 1, ahead_last = 0;
+    while (!stopped && col < P.max_iteration) {
+      const int64_t grp_first = ahead_first, grp_last = ahead_last;
+      if (enq < P.max_iteration) {
+        ahead_first = enq + 1;
+        enq += enqueue(enq + 1);
+        ahead_last = enq;
+      } else {
+        LS.flush();
+        ahead_first = 1;
+        ahead_last = 0;
       }
-    }
-    if (!stopped) {
-      LS.flush();
-      collect(P.max_iteration);
+      for (int64_t j = grp_first; j <= std::min(grp_last, P.max_iteration) && !stopped; ++j) {
+        const bool redo = collect(j) == kRedone;
+        col = j;
+        if (redo) {
+          enq = j;
+          ahead_first = 1;
+          ahead_last = 0;
+        }
+        stopped = worker.consume(j, lockstep_lag, kMaxLag, absorb);
+        if (redo) break;
+      }
     }
   } else {
     for (int64_t k = 1; k <= P.max_iteration && !stopped; ++k) {
@@ -1884,6 +1963,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   while (!stopped && worker.wait_pop(r)) stopped = absorb(r);
   itern = last.m;
   coeff_prev = last.coeff;
+  LS.pair_flush((int64_t)coeff_prev.size());  // (a pending pair: the output below needs u_0 .. u_{m-1} complete in the basis)
   alpha.resize((size_t)itern);
   beta.resize((size_t)itern);
   st.at("loop");
@@ -1914,6 +1994,8 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
     stats->last_alpha_len = (int64_t)alpha.size();
     stats->second_passes = second_passes;
     stats->lagged_iterations = LS.n_lagged;
+    stats->pair_iterations = LS.n_pair;
+    stats->pair_gate_trips = LS.n_gate_trips;
     stats->seconds_host_enqueue = LS.t_enqueue;
     stats->seconds_host_wait = t_wait;
     timer.collect(stats->seconds_spmv, stats->seconds_orth);

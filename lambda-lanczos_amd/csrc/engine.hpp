@@ -155,6 +155,9 @@ template <typename T> struct IterationSpec {
   const T* orth_host;
 };
 
+// Bytes of one Krylov-basis slab of a default run on an operator of this shape (engine.cpp)
+int64_t default_slab_bytes(int64_t n, int64_t n_local, int64_t n_shard, int elem_bytes, const Tuning& tune);
+
 // Whole-loop drivers
 template <typename T>
 void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P, double* eigvals, T* eigvecs,

@@ -2079,6 +2079,234 @@ __global__ __launch_bounds__(kBlock) void lagged_small_kernel(int64_t n, T* __re
   for (int i = tid; i < ncols; i += kBlock) out[i] = cols[i];
 }
 
+// The pair sweep (pair_sweep_kernel's algebra, see there) in the SMALL-VECTOR geometry — vectors of 320 KiB .. 1 MiB, where the
+// reference's users live (n = 4e4 .. 1.3e5 doubles): four waves share a strip of 64 lanes x 16 B and split the stored vectors
+// between them (trips of kSmallJB vectors dealt round-robin).  Every wave takes the measured coefficients <u_j, r3>, <u_j, r4 raw>
+// of its vectors (LDS-transposed column sums, as in mdot_small_kernel) and accumulates its shares of the three updates
+// sum g1_j u_j, sum g2_j u_j (late updates of u_P, u_{P+1}) and sum p4_j u_j (compensation of the next operator input); wave 0
+// adds the four shares in a fixed order, finishes the three strips and takes the in-strip dots.  One launch (no split: the
+// launcher refuses more columns than the LDS holds and the loop keeps the one-sweep form there).  Partial columns in the layout
+// of pair_sweep_kernel: [m3: R P][m4: R P][<u_P,r3>][<u_{P+1},r3>][<u_P,r4>][<u_{P+1},r4>][<r3,r4>] (R each) [|r4|^2].
+int small_pair_lds_doubles(int ncols, int ept_times_reals) {
+  return ((ncols + 15) & ~15) + 4 * 16 * kSmallTileRow + 3 * kBlock * ept_times_reals;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pair_small_kernel(int64_t n, BasisSegs<T> segs, int P, const T* r1, const T* __restrict__ r2,
+                                                            const T* __restrict__ r3, T* __restrict__ r4, T* uP_out,
+                                                            T* __restrict__ uQ_out, const double* __restrict__ g1,
+                                                            const double* __restrict__ g2, const double* __restrict__ gam,
+                                                            const double* __restrict__ p4, const double* __restrict__ rho1sq,
+                                                            const double* __restrict__ rho2sq, const double* __restrict__ e2,
+                                                            const double* __restrict__ n3sq, double* __restrict__ partials) {
+  // (r1 may alias uP_out: entering the pair form, u_{k-2} is already complete and is rewritten with zero coefficients)
+  constexpr int EPT = small_geom<T>::EPT;
+  constexpr int ELEMS = small_geom<T>::ELEMS;
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = 2 * R * P + 5 * R + 1;
+  extern __shared__ double lds[];  // [ncols] column sums, one [16][65] tile per wave, the waves' shares of the three updates
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* cols = lds;
+  double* tile = lds + ((ncols + 15) & ~15) + wave * (16 * kSmallTileRow);
+  double* share1 = lds + ((ncols + 15) & ~15) + 4 * (16 * kSmallTileRow);
+  double* share2 = share1 + (size_t)kBlock * EPT * R;
+  double* share4 = share2 + (size_t)kBlock * EPT * R;
+  for (int i = tid; i < ncols; i += kBlock) cols[i] = 0.0;
+  const double s1 = 1.0 / sqrt(*rho1sq), s2 = 1.0 / sqrt(*rho2sq);
+  const double n3 = sqrt(*n3sq);
+  const double ca = *e2 / n3, cb = n3 * s2;
+  acc_t<T> gm;
+  if constexpr (scalar_traits<T>::is_complex) gm = zc{gam[0], gam[1]};
+  else gm = gam[0];
+  double* tail = cols + 2 * R * P;
+  __syncthreads();
+
+  const int64_t nstrips = (n + ELEMS - 1) / ELEMS;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {  // same trip count for every wave of the workgroup
+    const int64_t i0 = sidx * ELEMS + (int64_t)lane * EPT;
+    T a1[EPT], a2[EPT], b3[EPT], b4r[EPT];
+    load_small<T>(r1, i0, n, a1);
+    load_small<T>(r2, i0, n, a2);
+    load_small<T>(r3, i0, n, b3);
+    load_small<T>(r4, i0, n, b4r);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) b4r[e] = sub(sub(b4r[e], rmul(ca, b3[e])), rmul(cb, a2[e]));
+    acc_t<T> d1[EPT], d2[EPT], d4[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) d1[e] = d2[e] = d4[e] = zero<acc_t<T>>();
+    int trip = 0, col0 = 0;
+    for (int sg = 0; sg < segs.nseg; ++sg) {
+      const T* ub = segs.base[sg];
+      const int cnt = segs.count[sg];
+      for (int j = 0; j < cnt; j += kSmallJB, ++trip) {
+        if ((trip & 3) != wave) continue;
+        const int nv = min(kSmallJB, cnt - j);
+        T ur[kSmallJB][EPT];
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b)
+          if (b < nv) load_small<T>(ub + (int64_t)(j + b) * segs.ld, i0, n, ur[b]);
+        acc_t<T> s3[kSmallJB], s4[kSmallJB];
+#pragma unroll
+        for (int b = 0; b < kSmallJB; ++b) {
+          s3[b] = zero<acc_t<T>>();
+          s4[b] = zero<acc_t<T>>();
+          if (b < nv) {
+            const int c = col0 + R * (j + b);
+            acc_t<T> c1, c2, c4;
+            if constexpr (scalar_traits<T>::is_complex) {
+              c1 = zc{g1[c], g1[c + 1]};
+              c2 = zc{g2[c], g2[c + 1]};
+              c4 = zc{p4[c], p4[c + 1]};
+            } else {
+              c1 = g1[c];
+              c2 = g2[c];
+              c4 = p4[c];
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+              cfma_acc(s3[b], ur[b][e], b3[e]);
+              cfma_acc(s4[b], ur[b][e], b4r[e]);
+              fma_acc(d1[e], c1, to_acc(ur[b][e]));
+              fma_acc(d2[e], c2, to_acc(ur[b][e]));
+              fma_acc(d4[e], c4, to_acc(ur[b][e]));
+            }
+          }
+        }
+        // the trip's column sums through the wave's transpose tile (16 rows): <u_j, r3> first, then <u_j, r4 raw>
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+          for (int b = 0; b < kSmallJB; ++b) {
+            const acc_t<T> v = which == 0 ? s3[b] : s4[b];
+            if constexpr (scalar_traits<T>::is_complex) {
+              tile[(2 * b) * kSmallTileRow + lane] = v.re;
+              tile[(2 * b + 1) * kSmallTileRow + lane] = v.im;
+            } else {
+              tile[b * kSmallTileRow + lane] = v;
+            }
+          }
+          wave_lds_handover();
+          const int i = lane >> 2, q = lane & 3;
+          double sum = 0.0;
+          if (i < nv * R) {
+            const double* row = tile + i * kSmallTileRow + q * 16;
+#pragma unroll
+            for (int t2 = 0; t2 < 16; ++t2) sum += row[t2];
+          }
+          sum += __shfl_xor(sum, 1, 64);
+          sum += __shfl_xor(sum, 2, 64);
+          if (q == 0 && i < nv * R) cols[which * R * P + col0 + R * j + i] += sum;  // this column belongs to this wave alone
+          wave_lds_handover();
+        }
+      }
+      col0 += R * cnt;
+    }
+    double* m1 = share1 + ((size_t)wave * 64 + lane) * (EPT * R);
+    double* m2 = share2 + ((size_t)wave * 64 + lane) * (EPT * R);
+    double* m4 = share4 + ((size_t)wave * 64 + lane) * (EPT * R);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      if constexpr (scalar_traits<T>::is_complex) {
+        m1[2 * e] = d1[e].re;
+        m1[2 * e + 1] = d1[e].im;
+        m2[2 * e] = d2[e].re;
+        m2[2 * e + 1] = d2[e].im;
+        m4[2 * e] = d4[e].re;
+        m4[2 * e + 1] = d4[e].im;
+      } else {
+        m1[e] = d1[e];
+        m2[e] = d2[e];
+        m4[e] = d4[e];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      T u1[EPT], u2[EPT], b4[EPT];
+      acc_t<T> t3p = zero<acc_t<T>>(), t3q = zero<acc_t<T>>(), t4p = zero<acc_t<T>>(), t4q = zero<acc_t<T>>(),
+               d34 = zero<acc_t<T>>();
+      double nn = 0.0;
+      auto total = [&](const double* base, int idx) {
+        auto at = [&](int wv) { return base[((size_t)wv * 64 + lane) * (EPT * R) + idx]; };
+        return (at(0) + at(1)) + (at(2) + at(3));
+      };
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        acc_t<T> t1, t2, t4;
+        if constexpr (scalar_traits<T>::is_complex) {
+          t1 = zc{total(share1, 2 * e), total(share1, 2 * e + 1)};
+          t2 = zc{total(share2, 2 * e), total(share2, 2 * e + 1)};
+          t4 = zc{total(share4, 2 * e), total(share4, 2 * e + 1)};
+        } else {
+          t1 = total(share1, e);
+          t2 = total(share2, e);
+          t4 = total(share4, e);
+        }
+        u1[e] = rmul(s1, narrow<T>(sub(to_acc(a1[e]), t1)));
+        T h2 = narrow<T>(sub(to_acc(a2[e]), t2));
+        fnma_acc(h2, gm, u1[e]);
+        u2[e] = rmul(s2, h2);
+        b4[e] = narrow<T>(sub(to_acc(b4r[e]), t4));
+        cfma_acc(t3p, u1[e], b3[e]);
+        cfma_acc(t3q, u2[e], b3[e]);
+        cfma_acc(t4p, u1[e], b4[e]);
+        cfma_acc(t4q, u2[e], b4[e]);
+        cfma_acc(d34, b3[e], b4[e]);
+        nn += abs2(b4[e]);
+      }
+      store_small<T>(uP_out, i0, n, u1);
+      store_small<T>(uQ_out, i0, n, u2);
+      store_small<T>(r4, i0, n, b4);
+      const acc_t<T> sums[5] = {wave_sum(t3p), wave_sum(t3q), wave_sum(t4p), wave_sum(t4q), wave_sum(d34)};
+      nn = wave_sum(nn);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          if constexpr (scalar_traits<T>::is_complex) {
+            tail[2 * c] += sums[c].re;
+            tail[2 * c + 1] += sums[c].im;
+          } else {
+            tail[c] += sums[c];
+          }
+        }
+        tail[5 * R] += nn;
+      }
+    }
+    __syncthreads();  // the shares are rewritten by the next strip
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * ncols;
+  for (int i = tid; i < ncols; i += kBlock) out[i] = cols[i];
+}
+template <typename T> bool pair_small_fits(int P) {
+  constexpr int R = scalar_traits<T>::reals;
+  return (size_t)small_pair_lds_doubles(2 * R * P + 5 * R + 1, (int)(16 / sizeof(T)) * R) * sizeof(double) <= (size_t)64 * 1024;
+}
+template bool pair_small_fits<double>(int);
+template bool pair_small_fits<zc>(int);
+template bool pair_small_fits<float>(int);
+template bool pair_small_fits<cf>(int);
+// false: more columns than one workgroup's LDS holds in this geometry (nothing was launched)
+template <typename T>
+bool launch_pair_sweep_small(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
+                             T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
+                             const double* rho2sq, const double* e2, const double* n3sq, double* partials, int* grid_out,
+                             hipStream_t s) {
+  constexpr int R = scalar_traits<T>::reals;
+  const int ncols = 2 * R * P + 5 * R + 1;
+  const size_t lds_bytes = (size_t)small_pair_lds_doubles(ncols, (int)(16 / sizeof(T)) * R) * sizeof(double);
+  if (!pair_small_fits<T>(P)) return false;  // (64 KiB, the default limit: no opt-in needed; P <= ~1240 real columns)
+  const int grid = strip_grid(n, (int)(64 * (16 / sizeof(T))));
+  hipLaunchKernelGGL((pair_small_kernel<T>), dim3(grid), dim3(kBlock), lds_bytes, s, n, segs, P, r1, r2, r3, r4, uP_out, uQ_out, g1, g2,
+                     gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
+  LL_HIP(hipGetLastError());
+  *grid_out = grid;
+  return true;
+}
+#define LL_INST_PAIR_SMALL(T)                                                                                                    \
+  template bool launch_pair_sweep_small<T>(int64_t, const BasisSegs<T>&, int, const T*, const T*, const T*, T*, T*, T*,         \
+                                           const double*, const double*, const double*, const double*, const double*,          \
+                                           const double*, const double*, const double*, double*, int*, hipStream_t);
+LL_INST_PAIR_SMALL(double) LL_INST_PAIR_SMALL(zc) LL_INST_PAIR_SMALL(float) LL_INST_PAIR_SMALL(cf)
+
 template <typename T>
 int launch_mdot(int64_t n, T* w, const BasisSegs<T>& segs, const ThreeTerm<T>& tt, const NormRefs* pred,
                 double* partials, int64_t small_bytes, hipStream_t s) {

@@ -507,6 +507,14 @@ int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P,
                       const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
                       hipStream_t s, const T* const* vtab = nullptr);  // vtab (device; column c -> pointer of stored vector c): the software-
                                                                        // pipelined kernel; null: the reference kernel over the segment lists
+// The same sweep in the small-vector geometry (pair_small_kernel: four waves per 1 KiB strip split the stored vectors; vectors of
+// 320 KiB .. 1 MiB).  One launch over ONE group of segments; false when the columns do not fit one workgroup's LDS (nothing launched).
+template <typename T>
+bool launch_pair_sweep_small(int64_t n, const BasisSegs<T>& segs, int P, const T* r1, const T* r2, const T* r3, T* r4, T* uP_out,
+                             T* uQ_out, const double* g1, const double* g2, const double* gam, const double* p4, const double* rho1sq,
+                             const double* rho2sq, const double* e2, const double* n3sq, double* partials, int* grid_out,
+                             hipStream_t s);
+template <typename T> bool pair_small_fits(int P);  // P stored columns fit the small-geometry sweep's LDS
 // tab[start + i] = base + i * ld, i < count (the pointer table of the pipelined sweeps; one launch per slab)
 template <typename T> void launch_fill_ptrs(const T** tab, int start, int count, const T* base, int64_t ld, hipStream_t s);
 void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,

@@ -164,15 +164,17 @@ def test_misconvergence_of_the_reference_is_reproduced(ctx, path):
 
 
 # ------------------------------------------------------------------ one-sweep form, run to convergence
-@pytest.mark.parametrize("name", ["randsym1e5_converge", "laplace200_converge"])
-def test_one_sweep_form_to_convergence_matches_the_reference(ctx, name):
+@pytest.mark.parametrize("name,pair", [("randsym1e5_converge", "1"), ("randsym1e5_converge", "0"), ("laplace200_converge", "1")])
+def test_one_sweep_form_to_convergence_matches_the_reference(ctx, llenv, name, pair):
     """randsym n = 1e5 (352 reference iterations) and the 200 x 200 Laplacian with offset -8 (729), default geometry.  The 800 KB
-    vectors of the first take the one-sweep kernel of the small-vector geometry (lagged_small_kernel) in every iteration but the
-    first; the 320 000-byte vectors of the second sit just below the 320 KiB switch and keep the two-sweep small-vector kernels
-    (block CGS + DGKS) for all 729 iterations — both forms against the reference's sequential MGS."""
+    vectors of the first take the SMALL-VECTOR geometry of the one-sweep forms: two iterations per sweep (pair_small_kernel, round 6;
+    the default) or one (lagged_small_kernel, LL_PAIR_GS=0) in every iteration but the first ones; the 320 000-byte vectors of the
+    second sit just below the 320 KiB switch and keep the two-sweep small-vector kernels (block CGS + DGKS) for all 729 iterations —
+    all three forms against the reference's sequential MGS."""
     gold = GOLD[name]
     csr = MG.long_run_matrix(gold)
     n = gold["n"]
+    llenv.setenv("LL_PAIR_GS", pair)
     op = L.CsrOperator(ctx, *csr)
     eng = L.LambdaLanczos(op, n, gold["find_max"], 1)
     eng.eigenvalue_offset = gold["offset"]
@@ -181,6 +183,10 @@ def test_one_sweep_form_to_convergence_matches_the_reference(ctx, name):
     itern = eng.getIterationCounts()[0]
     if n * 8 >= 320 << 10 or os.environ.get("LL_BLAS_SMALL_BYTES") == "0":   # (the suite is also run with the streaming geometry forced)
         assert eng.last_stats["lagged_iterations"] >= itern - 3, eng.last_stats
+        if pair == "1":
+            assert eng.last_stats["pair_iterations"] >= itern - 3 - 4 * eng.last_stats["second_passes"], eng.last_stats
+        else:
+            assert eng.last_stats["pair_iterations"] == 0
     else:
         assert eng.last_stats["lagged_iterations"] == 0, eng.last_stats
     check_counts(eng.getIterationCounts(), gold)

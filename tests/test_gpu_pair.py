@@ -284,6 +284,45 @@ def test_software_pipelined_sweep_changes_no_bit(ctx, name, split):
     op.close()
 
 
+@pytest.mark.parametrize("name,n", [("randsym", 70001), ("randsym", 100003), ("laplace", 260), ("torus", 190)])
+def test_pair_form_in_the_small_vector_geometry(ctx, oracle, llenv, name, n):
+    """Vectors of 512 KiB .. 1 MiB (n = 6.6e4 .. 1.3e5 doubles — the reference's everyday sizes) take the pair form in the small-vector
+    geometry (pair_small_kernel: four waves per 1 KiB strip split the stored vectors; round 6).  Default switches, whole runs to
+    convergence with two or three roots (restart passes behind locked eigenvectors included): alpha / beta / counts / eigenpairs
+    against the oracle's sequential MGS, and against the one-sweep form of the same geometry (LL_PAIR_GS=0) to 1e-11 ||A||."""
+    if name == "randsym":
+        csr, init, find_max, offset, dim = G.randsym_np(n), G.start_vector(n, 1), True, 0.0, n
+    elif name == "laplace":
+        csr, init, find_max, offset, dim = G.laplace2d_np(n), G.start_vector(n * n, 2), True, 0.0, n * n
+    else:
+        csr, init, find_max, offset, dim = G.torus_np(n), G.start_vector(n * n, 3, np.complex128), False, -10.0, n * n
+    assert (512 << 10) <= dim * csr[2].dtype.itemsize < (1 << 20)
+    op = L.CsrOperator(ctx, *csr)
+    num_eigs = 2 if n == 70001 else 1
+    pair = _run(ctx, op, dim, find_max, offset, init, num_eigs=num_eigs)
+    llenv.setenv("LL_PAIR_GS", "0")
+    one = _run(ctx, op, dim, find_max, offset, init, num_eigs=num_eigs)
+    llenv.delenv("LL_PAIR_GS")
+    ora = oracle.lanczos(csr, init, find_max, num_eigs=num_eigs, offset=offset)
+    norm = inf_norm(csr) + abs(offset)
+    assert one["stats"]["pair_iterations"] == 0
+    total = sum(pair["iters"])
+    assert pair["stats"]["pair_iterations"] >= total - 3 * len(pair["iters"]) - 4 * pair["stats"]["second_passes"] - 2 * pair["stats"]["pair_gate_trips"], pair["stats"]
+    assert len(pair["iters"]) == len(ora["iter_counts"]) == len(one["iters"])
+    for a, b, c in zip(pair["iters"], ora["iter_counts"], one["iters"]):
+        assert abs(a - b) <= 2 and abs(c - b) <= 2, (pair["iters"], ora["iter_counts"], one["iters"])
+    m = min(len(pair["alpha"]), len(one["alpha"]), 200)
+    if len(pair["iters"]) == 1:   # (the trace of the LAST pass: comparable with the oracle's when there is one pass)
+        mo = min(m, len(ora["alpha"]))
+        assert np.max(np.abs(pair["alpha"][:mo] - ora["alpha"][:mo])) <= 1e-10 * norm
+        assert np.max(np.abs(pair["beta"][:mo - 1] - ora["beta"][:mo - 1])) <= 1e-10 * norm
+        assert np.max(np.abs(pair["alpha"][:m] - one["alpha"][:m])) <= 1e-11 * norm
+    for i in range(num_eigs):
+        assert abs(pair["vals"][i] - ora["eigenvalues"][i]) <= 1e-10 * max(1.0, abs(ora["eigenvalues"][i] + offset))
+        assert 1 - overlap(pair["vecs"][i], ora["eigenvectors"][i]) <= 1e-8
+    op.close()
+
+
 @pytest.mark.parametrize("name,limit", [("laplace", 100), ("laplace", 101), ("torus", 77)])
 def test_pair_form_hands_over_to_the_one_sweep_form_at_its_column_limit(ctx, oracle, llenv, name, limit):
     """The coefficient records of the pair form end at 4 992 real (2 492 complex) stored vectors; beyond that the loop completes the

@@ -105,3 +105,79 @@ def test_pair_form_honours_an_odd_max_iteration(ctx, oracle, window):
     assert abs(vals[0] - ora["eigenvalues"][0]) <= 1e-10 * 30
     assert np.all(np.isfinite(vecs[0]))
     op.close()
+
+
+# ------------------------------------------------------------------ the pair form where it did not run
+@pytest.mark.parametrize("side,dt", [(300, 5.0), (190, 5.0), (300, 1.0)])
+def test_exponentiator_with_full_orthogonalize_takes_two_iterations_per_sweep(ctx, oracle, side, dt):
+    """Exponentiator<T>::run with full_orthogonalize (EX:63,120-122) on config 5's matrix in small — complex torus 300 x 300 (1.44 MB
+    vectors: streaming geometry) and 190 x 190 (577 KB: small-vector geometry): the loop enqueues two iterations per sweep like the
+    eigen-solver's; exp(-i dt H) v, the iteration count and the norm against the oracle's Exponentiator::run with the same flag."""
+    n = side * side
+    csr = G.torus_np(side)
+    v = G.start_vector(n, 1, np.complex128)
+    op = L.CsrOperator(ctx, *csr)
+    eng = L.Exponentiator(op, n)
+    eng.full_orthogonalize = True
+    out, itern = eng.run(-1j * dt, v)
+    st = eng.last_stats
+    o_out, o_it, _ = oracle.expo(csr, -1j * dt, v, full_orthogonalize=True)
+    assert abs(itern - o_it) <= 1, (itern, o_it)
+    assert st["pair_iterations"] >= itern - 4, st
+    nv = np.linalg.norm(v)
+    assert np.max(np.abs(out - o_out)) <= 1e-10 * nv
+    assert 1.0 - abs(np.vdot(o_out, out)) / (np.linalg.norm(o_out) * np.linalg.norm(out)) <= 10 * np.finfo(float).eps + 1e-15
+    assert abs(np.linalg.norm(out) / nv - 1.0) <= 1e-12
+    # and the switch: LL_PAIR_GS=0 keeps the one-sweep form, same output to rounding
+    ctx.set_tuning("pair_gs", "0")
+    try:
+        out1, it1 = eng.run(-1j * dt, v)
+    finally:
+        ctx.set_tuning("pair_gs", None)
+    assert eng.last_stats["pair_iterations"] == 0 and it1 == itern
+    assert np.max(np.abs(out - out1)) <= 1e-12 * nv
+    op.close()
+
+
+def test_run_iteration_with_eigenvectors_in_orthogonalize_to_takes_the_one_sweep_forms(ctx, oracle):
+    """LambdaLanczos::run_iteration with a caller's orthogonalizeTo list (LL:216-220,259).  The list carries no eigenvalues, so the
+    one-sweep / pair forms — whose compensation needs the image of every column under the operator — used to be off for such passes.
+    Now the Rayleigh quotients theta_i = <z_i, A z_i> and the residuals ||A z_i - theta_i z_i|| are measured at pass start
+    (LoopState::begin_pass) and a list of EIGENvectors takes the locked-column path: the two largest pairs of randsym n = 1e5 as the
+    list, three further pairs against the oracle's run_iteration.  A list that is orthonormal but NOT made of eigenvectors fails the
+    residual gate and keeps the two-sweep form — same answers."""
+    n = 100_003
+    csr = G.randsym_np(n)
+    init = G.start_vector(n, 1)
+    op = L.CsrOperator(ctx, *csr)
+    top = L.LambdaLanczos(op, n, True, 2)
+    top.init_vector = fixed_init(init)
+    lam, lock = top.run()
+    lock = np.ascontiguousarray(lock)
+    eng = L.LambdaLanczos(op, n, True, 1)
+    eng.init_vector = fixed_init(G.start_vector(n, 7))
+    vals, vecs, itern = eng.run_iteration(3, lock)
+    st = eng.last_stats
+    ora = oracle.run_iteration(csr, G.start_vector(n, 7), True, 3, orth=lock)
+    assert abs(itern - ora["itern"]) <= 2, (itern, ora["itern"])
+    assert st["lagged_iterations"] >= itern - 3 and st["pair_iterations"] >= itern - 6 - 4 * st["second_passes"], st
+    for got, ref in zip(vals, ora["eigenvalues"]):
+        assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref))
+    for i in range(3):
+        assert 1 - abs(np.vdot(vecs[i], ora["eigenvectors"][i])) <= 1e-8
+        assert np.max(np.abs(lock.conj() @ vecs[i])) <= 1e-9          # orthogonal to the list
+    assert vals[0] < lam[1] - 1e-6                                     # the list's pairs are not found again
+    # ---- an orthonormal list that is not made of eigenvectors: gate -> two-sweep form, still the oracle's answers
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.standard_normal((n, 2)))
+    junk = np.ascontiguousarray(q.T)
+    eng2 = L.LambdaLanczos(op, n, True, 1)
+    eng2.init_vector = fixed_init(G.start_vector(n, 7))
+    eng2.max_iteration = 60
+    v2, w2, it2 = eng2.run_iteration(2, junk)
+    assert eng2.last_stats["lagged_iterations"] == 0 and eng2.last_stats["pair_iterations"] == 0, eng2.last_stats
+    ora2 = oracle.run_iteration(csr, G.start_vector(n, 7), True, 2, orth=junk, max_iteration=60)
+    assert it2 == ora2["itern"] == 60
+    for got, ref in zip(v2, ora2["eigenvalues"]):
+        assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref))
+    op.close()
