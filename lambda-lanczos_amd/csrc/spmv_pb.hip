@@ -1324,8 +1324,11 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const int t0 = tfirst[rb], t1 = tfirst[rb + 1];
   const double xs_fac = xnorm2 ? 1.0 / sqrt(*xnorm2) : 1.0;  // unnormalised input (see pb_phase1)
-  const long long q_begin = tquad[t0], q_end = tquad[t1];
-  const long long q_last = q_end > q_begin ? q_end - 1 : q_begin;  // (the image is padded by one quad behind its end)
+  const long long q_begin = tquad[t0];
+  // (the planner works on 32-bit quad numbers RELATIVE to the row block's first quad: its comparisons are scalar instructions;
+  // 64-bit compares go through vector-register temporaries)
+  const int q_end = (int)(tquad[t1] - q_begin);
+  const int q_last = q_end > 0 ? q_end - 1 : 0;  // (the image is padded by one quad behind its end)
 
   // ---- trips.  A trip is kPbThreads consecutive quads of the row block's stream, WHEREVER the tile boundaries fall: a lane's
   // quad belongs to one tile (tiles are whole quads), the lanes of a trip to up to three consecutive tiles of the block's list.
@@ -1337,15 +1340,16 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   // slots; a trip that would need more ends early, at a tile boundary.  ONE barrier per trip (new tiles visible; every wave has left
   // the trip before the previous one).  The planner below is uniform over the workgroup and runs at REQUEST time, D - 1 trips ahead.
   struct Plan {
-    long long q0, q1;  // quads [q0, q1) of the stream
-    long long e1, e2;  // ends of tiles a and a + 1: a lane's tile is a + (g >= e1) + (g >= e2)
-    int a;             // tile of the trip's first quad
+    int q0, q1;  // quads [q0, q1) of the stream (relative to q_begin)
+    int e1, e2;  // ends of tiles a and a + 1: a lane's tile is a + (g >= e1) + (g >= e2)
+    int a;       // tile of the trip's first quad
     int first_new, n_new;
   };
-  long long pq = q_begin;  // next quad to plan
-  int pcur = t0;           // tile that holds pq
-  int pb = t0 - 1;         // last tile some earlier trip brought in
-  int pspan = 0;           // tiles of the trip before
+  int pq = 0;       // next quad to plan
+  int pcur = t0;    // tile that holds pq
+  int pb = t0 - 1;  // last tile some earlier trip brought in
+  int pspan = 0;    // tiles of the trip before
+  auto tq = [&](int t) { return (int)(tquad[t] - q_begin); };
   auto plan = [&]() {
     Plan p;
     p.q0 = pq;
@@ -1359,10 +1363,10 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     }
     const int cap = min(kTlNewPerTrip, kTlSlots - pspan);  // >= 1: a trip spans at most three tiles
     const int bmax = min(t1 - 1, pb + cap);
-    const long long end = min(pq + (long long)kPbThreads, q_end);
-    const long long e1 = tquad[min(pcur + 1, t1)], e2 = tquad[min(pcur + 2, t1)], e3 = tquad[min(pcur + 3, t1)];
+    const int end = min(pq + kPbThreads, q_end);
+    const int e1 = tq(min(pcur + 1, t1)), e2 = tq(min(pcur + 2, t1)), e3 = tq(min(pcur + 3, t1));
     int b = pcur;
-    long long eb = e1;
+    int eb = e1;
     if (b < bmax && eb < end) {
       ++b;
       eb = e2;
@@ -1383,7 +1387,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   };
   quad<T> v[D];
   uint4 ix[D], xp[D][kTlNewPerTrip];
-  long long gq[D];
+  int gq[D];
   Plan pl[D];
   int ctn[D][kTlNewPerTrip];  // column tiles of the (up to) two new tiles of the trip
   // Every trip requests the SAME loads, unconditionally and in straight-line code — the lane's quad of values (2 x 16 B), its packed
@@ -1392,8 +1396,8 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   auto issue = [&](int slot) {
     const Plan p = plan();
     pl[slot] = p;
-    const long long g = p.q0 + tid;
-    const long long gc = g < q_last ? g : q_last;
+    const int g = p.q0 + tid;
+    const long long gc = q_begin + (g < q_last ? g : q_last);
     gq[slot] = g;
     v[slot] = load_quad<T>(val + 4 * gc);
     ix[slot] = idx[gc];
@@ -1525,7 +1529,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     if (p.n_new > 0) store_piece(p.first_new, ctn[PH][0], xp[PH][0]);
     if (p.n_new > 1) store_piece(p.first_new + 1, ctn[PH][1], xp[PH][1]);
     __syncthreads();
-    const long long g = gq[PH];
+    const int g = gq[PH];
     const bool valid = g < p.q1;
     const int buf = (p.a - t0 + (g >= p.e1 ? 1 : 0) + (g >= p.e2 ? 1 : 0)) & (kTlSlots - 1);
     const quad<T> vv = v[PH];
