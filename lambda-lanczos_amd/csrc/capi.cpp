@@ -69,7 +69,7 @@ bool tuning_apply(Tuning& t, const std::string& key, const std::string& v) {
   else if (key == "tl_force") t.tl_force = e ? false : to_flag(v);
   else if (key == "tl_xcd") t.tl_xcd_order = e ? d.tl_xcd_order : to_flag(v);
   else if (key == "tl_walk") t.tl_walk_modulo = e ? d.tl_walk_modulo : to_flag(v);
-  else if (key == "sweep_pipeline") t.sweep_pipeline = e ? d.sweep_pipeline : to_flag(v);
+  else if (key == "sweep_pipeline") t.sweep_pipeline = e ? d.sweep_pipeline : (int)std::max<long long>(0, std::min<long long>(2, to_ll(v)));
   else if (key == "pair_split") t.pair_split_vecs = e ? 0 : (int)std::max<long long>(0, to_ll(v));
   else if (key == "pair_max_stored") t.pair_max_stored = e ? 0 : (int)std::max<long long>(0, to_ll(v));
   else if (key == "lagged_pieces") t.lagged_pieces = e ? 0 : (int)to_ll(v);
@@ -1102,8 +1102,7 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     (void)hipFree(d);
     return sum == 0.0;
   };
-  // 0 auto, 1 csr, 2 pb, 3 tiled.  The tiled kernel sums in fixed point only (norm-wise class): a caller or an environment
-  // that asks for component-wise sums does not get it.
+  // 0 auto, 1 csr, 2 pb, 3 tiled.
   const bool componentwise = op->accuracy_req == LL_ACCURACY_COMPONENTWISE ||
                              (op->accuracy_req == LL_ACCURACY_DEFAULT && ctx->tune.pb_phase2 != LL_PB_FIXED);
   bool pb_ok = false, tl_ok = false;
@@ -1126,17 +1125,16 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     if (built && !pb_ok) release_pb_image(op.get());  // some rank could not build it: nobody uses it
   }
   if ((want == 0 || want == 3) && nnz > 0 && ctx->comm == nullptr) {
-    // the 2-D tiled image: only for matrices whose row blocks touch few column tiles (tl_build_device decides)
-    LL_REQUIRE(!(want == 3 && componentwise), "the tiled SpMV kernel sums in fixed point: not available with component-wise accuracy");
-    if (!componentwise) {
-      try {
-        tl_ok = tl_build_device<T>(op.get());
-      } catch (const Failure& f) {
-        if (!(f.code == LL_ERR_ALLOC && want == 0)) throw;
-        (void)hipGetLastError();
-        tl_release(op.get());
-        tl_ok = false;
-      }
+    // the 2-D tiled image: only for matrices whose row blocks touch few column tiles (tl_build_device decides).  One image serves
+    // both accuracy classes: fixed-point sums (norm-wise) or the waves adding in turn in floating point (component-wise).
+    op->tl_ordered = componentwise;
+    try {
+      tl_ok = tl_build_device<T>(op.get());
+    } catch (const Failure& f) {
+      if (!(f.code == LL_ERR_ALLOC && want == 0)) throw;
+      (void)hipGetLastError();
+      tl_release(op.get());
+      tl_ok = false;
     }
     LL_REQUIRE(!(want == 3 && !tl_ok), "this matrix is not eligible for the tiled SpMV kernel (its row blocks touch too many column tiles)");
   }
@@ -1412,16 +1410,9 @@ int ll_op_set_accuracy(ll_operator* op, int accuracy) {
     LL_REQUIRE(op != nullptr && op->kind == ll_operator::CSR, "not a CSR operator");
     LL_REQUIRE(accuracy == LL_ACCURACY_NORMWISE || accuracy == LL_ACCURACY_COMPONENTWISE,
                "accuracy must be LL_ACCURACY_NORMWISE or LL_ACCURACY_COMPONENTWISE");
-    if (accuracy == LL_ACCURACY_COMPONENTWISE && op->spmv_kind == LL_SPMV_TILED) {
-      // the tiled kernel has the fixed-point sums only: move to an image with floating-point sums, if one was kept
-      if (op->d_row_ptr != nullptr && (op->d_col != nullptr || op->nnz == 0)) op->spmv_kind = LL_SPMV_CSR_STREAM;
-      else if (op->d_pb_val != nullptr) op->spmv_kind = LL_SPMV_PB;
-      else
-        LL_REQUIRE(false, "this operator kept only its tiled image (fixed-point sums): ask for LL_ACCURACY_COMPONENTWISE when it is "
-                          "created (ll_csr_options.accuracy), or keep every image with LL_SPMV_KEEP_BOTH=1");
-    }
+    if (op->tl_nrb > 0) op->tl_ordered = accuracy == LL_ACCURACY_COMPONENTWISE;  // the tiled image serves both classes
     op->accuracy_req = accuracy;
-    if (op->d_pb_val == nullptr) return;  // no PB image: CSR-stream is component-wise, the tiled kernel norm-wise, whatever is asked
+    if (op->d_pb_val == nullptr) return;  // no PB image: CSR-stream is component-wise whatever is asked, the tiled kernel was set above
     if (accuracy == LL_ACCURACY_COMPONENTWISE) {
       if (op->pb_phase2 == LL_PB_FIXED) op->pb_phase2 = LL_PB_ORDERED;
     } else {
@@ -1435,7 +1426,7 @@ int ll_op_accuracy(const ll_operator* op, int* accuracy_out) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && accuracy_out != nullptr, "null argument");
     const bool fixed = op->kind == ll_operator::CSR && ((op->spmv_kind == LL_SPMV_PB && op->pb_phase2 == LL_PB_FIXED) ||
-                                                        op->spmv_kind == LL_SPMV_TILED);
+                                                        (op->spmv_kind == LL_SPMV_TILED && !op->tl_ordered));
     *accuracy_out = fixed ? LL_ACCURACY_NORMWISE : LL_ACCURACY_COMPONENTWISE;
   });
 }

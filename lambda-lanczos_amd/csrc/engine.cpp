@@ -755,7 +755,7 @@ template <typename T> struct LoopState {
       if (!w.p) w.alloc(E.ctx, (size_t)ld);
     // 4 records + zero record + p3 + p4 + fold scratch + folded columns (two per stored vector: twice a record) + 64 scalars
     pbuf.alloc(E.ctx, 10 * kPairRec + 64);
-    if (E.ctx->tune.sweep_pipeline) vtab.alloc(E.ctx, kVtabCap);
+    if (E.ctx->tune.sweep_pipeline > 0) vtab.alloc(E.ctx, kVtabCap);
     double* b = pbuf.p;
     for (int i = 0; i < 4; ++i) prec[i] = b + (size_t)i * kPairRec;
     pzero = b + 4 * kPairRec;
@@ -1070,7 +1070,7 @@ template <typename T> struct LoopState {
                  "internal: the small-geometry pair sweep refused a launch that was checked to fit");
     } else {
       grid = launch_pair_sweep<T>(nl, groups, (int)K, r1, r2, r3, r4, uP, uQ, psplit.p, g1, g2, gam, pp4, rho1sq, rho2sq, e2, t3,
-                                  E.ctx->d_partials, E.ctx->tune.lagged_pieces, s, vtab_sync());
+                                  E.ctx->d_partials, E.ctx->tune.lagged_pieces, s, vtab_sync(), E.ctx->tune.sweep_pipeline >= 2);
     }
     launch_reduce_cols(E.ctx->d_partials, grid, ncols, pcols, nullptr, s);
     // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits

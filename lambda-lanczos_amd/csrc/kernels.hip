@@ -1420,7 +1420,7 @@ template <typename T>
 int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P, const T* r1, const T* r2, const T* r3, T* r4,
                       T* uP_out, T* uQ_out, T* part4, const double* g1, const double* g2, const double* gam, const double* p4,
                       const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
-                      hipStream_t s, const T* const* vtab) {
+                      hipStream_t s, const T* const* vtab, bool force_pipeline) {
   constexpr int R = scalar_traits<T>::reals;
   const int64_t strips16k = (n * (int64_t)sizeof(T) + 16383) / 16384;
   int pc = strips16k >= kLaggedFullStrips ? 4 : 2;
@@ -1437,7 +1437,13 @@ int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P,
     for (int i = 0; i < segs.nseg; ++i) Pl += segs.count[i];
     const int flags = (gi == 0 ? kPairFirst : 0) | (gi + 1 == ng ? kPairLast : 0);
     const size_t lds_bytes = (size_t)4 * (size_t)(2 * R * Pl + ((flags & kPairLast) ? 5 * R + 1 : 0)) * sizeof(double);
-    if (vtab != nullptr) {  // software-pipelined form: the stored vectors through the pointer table (columns [col0, col0 + Pl))
+    // The software-pipelined form where the sweep is a STREAM: vectors of more than ~9 MiB, every workgroup walking several strips
+    // back to back (strip_grid's one-workgroup-per-CU mode).  Config 3 (80 MB vectors, k <= 300): 822 -> 808 us per sweep.  Shorter
+    // vectors have one strip per workgroup and more workgroups than CUs: their sweeps are latency chains of k / JB trips, and two
+    // vectors per trip instead of four cost more than the prefetch brings — config 2 (8 MB vectors, 3 368 iterations to
+    // convergence): 4.76 s of sweeps with the reference kernel, 5.09 s pipelined (profiles/r06_pair_sweep_pipeline_ab.txt).
+    const bool streaming = force_pipeline || strips16k > 2 * kCUs + kCUs / 4;  // (force: key sweep_pipeline = 2, parity tests on small cases)
+    if (vtab != nullptr && streaming) {  // the stored vectors through the pointer table (columns [col0, col0 + Pl))
       if (pc == 4)
         hipLaunchKernelGGL((pair_sweep_pipe_kernel<T, 4, kPipeJB>), dim3(grid), dim3(kBlock), lds_bytes, s, n, vtab, P, col0, Pl, flags, r1, r2, r3,
                            r4, uP_out, uQ_out, part4, g1, g2, gam, p4, rho1sq, rho2sq, e2, n3sq, partials);
@@ -1617,7 +1623,7 @@ void launch_pair_fold(const double* m, int P, int L, int reals, const double* la
                                          const double*, double*, bool, hipStream_t);                                             \
   template int launch_pair_sweep<T>(int64_t, const std::vector<BasisSegs<T>>&, int, const T*, const T*, const T*, T*, T*, T*, T*, \
                                     const double*, const double*, const double*, const double*, const double*, const double*,    \
-                                    const double*, const double*, double*, int, hipStream_t, const T* const*);                    \
+                                    const double*, const double*, double*, int, hipStream_t, const T* const*, bool);              \
   template void launch_fill_ptrs<T>(const T**, int, int, const T*, int64_t, hipStream_t);
 LL_INST_PAIR(double) LL_INST_PAIR(zc) LL_INST_PAIR(float) LL_INST_PAIR(cf)
 

@@ -179,7 +179,7 @@ struct Tuning {
   long long lagged_min_bytes = -1; // key lagged_min_bytes: shortest vector of the one-sweep form (-1 = default)
   int lagged_pieces = 0;           // key lagged_pieces: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
-  bool sweep_pipeline = true;      // key sweep_pipeline = 0: the Gram-Schmidt sweeps request a trip's strips only when they consume it (A/B of the software pipeline; same bits)
+  int sweep_pipeline = 1;          // key sweep_pipeline: 1 (default) the software-pipelined pair sweep on streaming vectors (> ~9 MiB), 0 never (A/B: same bits), 2 on every length (parity tests on small cases)
   bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
   // --- test hooks (not for users)
   bool force_rp64 = false;         // LL_FORCE_RP64=1: 64-bit row offsets on small matrices
@@ -326,6 +326,7 @@ struct ll_operator {
   uint32_t* d_tl_idx = nullptr;      // local column | local row << 16
   int16_t* d_tl_rexp = nullptr;      // exponent of every row's absolute sum (the scale the values were divided by)
   double* d_tl_xmax = nullptr;       // per-workgroup maxima of |x| left by the pre-pass of every launch
+  bool tl_ordered = false;           // the tiled kernel sums in floating point, the waves in turn (component-wise class) instead of in fixed point
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
   // gathered buffer).  One phase-1 launch per range, so own-column work runs under the all-gather.
@@ -505,8 +506,8 @@ template <typename T>
 int launch_pair_sweep(int64_t n, const std::vector<BasisSegs<T>>& groups, int P, const T* r1, const T* r2, const T* r3, T* r4,
                       T* uP_out, T* uQ_out, T* part4, const double* g1, const double* g2, const double* gam, const double* p4,
                       const double* rho1sq, const double* rho2sq, const double* e2, const double* n3sq, double* partials, int pieces,
-                      hipStream_t s, const T* const* vtab = nullptr);  // vtab (device; column c -> pointer of stored vector c): the software-
-                                                                       // pipelined kernel; null: the reference kernel over the segment lists
+                      hipStream_t s, const T* const* vtab = nullptr,  // vtab (device; column c -> pointer of stored vector c): the software-
+                      bool force_pipeline = false);                   // pipelined kernel on streaming vectors (force: on any); null: the reference kernel
 // The same sweep in the small-vector geometry (pair_small_kernel: four waves per 1 KiB strip split the stored vectors; vectors of
 // 320 KiB .. 1 MiB).  One launch over ONE group of segments; false when the columns do not fit one workgroup's LDS (nothing launched).
 template <typename T>

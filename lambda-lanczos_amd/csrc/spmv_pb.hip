@@ -1290,7 +1290,12 @@ __global__ __launch_bounds__(256) void tl_xmax_kernel(long long n, const T* __re
   if (threadIdx.x == 0) parts[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-template <typename T, int D, bool ALIGNED>
+// ORDERED: component-wise accurate floating-point sums (ll_csr_options.accuracy = LL_ACCURACY_COMPONENTWISE, LL_PB_PHASE2=ordered)
+// instead of the fixed-point ones — the y slice holds doubles, every product fl(a_ij 2^-e_i x_j) is added with ds_add_f64, the 16 waves
+// of the workgroup in turn (a barrier between turns, as in pb_phase2<ORDERED>): a fixed order, so the result is the same bits on every
+// launch, and its error is the reference's own fp64 row loop's, gamma_n sum_j |a_ij x_j| (the row's power-of-two scale is exact).  No
+// max|x| pre-pass, no grid scale on the staged x.
+template <typename T, int D, bool ALIGNED, bool ORDERED>
 __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_t n_local, int64_t n_cols,
                                                              const int32_t* __restrict__ tfirst,   // [nrb + 1]
                                                              const int32_t* __restrict__ tcol,     // [ntiles]
@@ -1425,7 +1430,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   // element and tile instead of one v_ldexp_f64 per entry; |kx| <= 1000 and every product below 2^-1022 rounds to the integer 0
   // either way, so the integers are the same.  The float types keep the scaling behind their float product, whose underflow
   // threshold is within reach of the scale.)
-  constexpr bool kFoldScale = sizeof(typename scalar_traits<T>::real) == 8;
+  constexpr bool kFoldScale = sizeof(typename scalar_traits<T>::real) == 8 && !ORDERED;
   int kx = 0;  // set below, before the first tile is staged
   auto store_piece = [&](int tile, int ct, uint4 piece) {
     const int buf = (tile - t0) & (kTlSlots - 1);
@@ -1461,21 +1466,38 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   for (int i = tid; i < rb_rows * R; i += kPbThreads) acc[i] = 0;
   for (int i = tid; i < (rb_rows + 31) / 32; i += kPbThreads) bad[i] = 0u;
   int e_x = -2000;  // x == 0: any scale does
-  {
+  if constexpr (!ORDERED) {
     double m = 0.0;
     for (int i = tid; i < n_xmax; i += kPbThreads) m = fmax(m, xmax_parts[i]);
     const double t = pb_block_max(m, red) * xs_fac;  // (ends with a barrier: the LDS stores above are visible)
     if (t > 0.0 && isfinite(t)) (void)frexp(t, &e_x);
     else if (!(t == 0.0)) e_x = kPbXInf;
+    // integer = (PRE-SCALED value * x) * 2^kx; row i's sum is acc_i * 2^(er_i - kx)   (pb_phase2_fixed: k = 62 - (er + e_x + 1))
+    kx = e_x == kPbXInf ? 0 : max(-1000, min(1000, 61 - e_x));
+  } else {
+    __syncthreads();  // the accumulators are zero before the first add
   }
-  // integer = (PRE-SCALED value * x) * 2^kx; row i's sum is acc_i * 2^(er_i - kx)   (pb_phase2_fixed: k = 62 - (er + e_x + 1))
-  kx = e_x == kPbXInf ? 0 : max(-1000, min(1000, 61 - e_x));
+  double* const accd = reinterpret_cast<double*>(acc);  // ORDERED: the same slice as doubles
+  const int wave = tid >> 6;
 
   // (No branch on `valid`: a lane beyond the end of its trip holds a re-read of a valid quad and adds ZERO to that quad's
   // rows — every trip then waits for and uses its loads on every path, which keeps the wait counts of the ring exact.)
   auto consume = [&](const quad<T>& vv, const uint4& ii, bool valid, int buf) {
     const T* xb = xs + (size_t)buf * C;
     const unsigned w4[4] = {ii.x, ii.y, ii.z, ii.w};
+    if constexpr (ORDERED) {
+      T pe[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pe[e] = mul(vv.e[e], xb[w4[e] & 0xffffu]);
+      for (int w = 0; w < kPbWaves; ++w) {  // the waves add in turn: a fixed order (Inf / NaN travel through the sums by themselves)
+        if (wave == w && valid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lds_add_elem<T>(accd, (int)(w4[e] >> 16), pe[e]);
+        }
+        __syncthreads();
+      }
+      return;
+    }
     // the four x elements first, in one batch of LDS reads: behind the first atomic the compiler may not move a read of the
     // same LDS array forward (it cannot prove that xs and acc do not overlap), and entry by entry every read's latency is exposed
     T xe[4];
@@ -1555,6 +1577,14 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
   __syncthreads();
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
   auto value = [&](int i, const T&, int er) {  // er: the row's exponent (requested ahead, see the epilogue)
+    if constexpr (ORDERED) {  // 2^er restores the row's scale (exact); a row whose absolute sum is not finite has no usable image
+      acc_t<T> a;
+      if constexpr (scalar_traits<T>::is_complex)
+        a = er == 32767 ? zc{nan, nan} : zc{ldexp(accd[2 * i], er), ldexp(accd[2 * i + 1], er)};
+      else
+        a = er == 32767 ? nan : ldexp(accd[i], er);
+      return a;
+    }
     const bool unusable = er == 32767 || e_x == kPbXInf || ((bad[i >> 5] >> (i & 31)) & 1u);
     const int back = er - kx;  // 2^back restores the row's scale (empty rows: er = -1100, acc = 0)
     acc_t<T> a;
@@ -1578,8 +1608,10 @@ template <typename T> void tl_opt_in_lds() {
   LL_HIP(hipGetDevice(&dev));
   const unsigned long long bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
-  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, true>);
-  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, false>);
+  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, true, false>);
+  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, false, false>);
+  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, true, true>);
+  pb_opt_in(&tl_spmv_kernel<T, kTlDepth, false, true>);
   mask.fetch_or(bit, std::memory_order_release);
 }
 }  // namespace
@@ -1590,20 +1622,21 @@ int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, do
   if (op.tl_nrb <= 0) return 0;
   tl_opt_in_lds<T>();
   const int xgrid = (int)std::max<int64_t>(1, std::min<int64_t>(kTlXmaxParts, (op.n + 255) / 256));
-  hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(xgrid), dim3(256), 0, s, (long long)op.n, x, op.d_tl_xmax,
-                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0);
+  if (!op.tl_ordered)  // (the component-wise form has no fixed-point grid to scale: no max|x| pre-pass)
+    hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(xgrid), dim3(256), 0, s, (long long)op.n, x, op.d_tl_xmax,
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0);
   // 16-byte pieces of x: the fast form needs an aligned vector of at least one piece
   const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && op.n >= (int64_t)(16 / sizeof(T));
-  if (aligned)
-    hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, true>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,
-                       op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,
-                       (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset,
-                       dot_partials, xnorm2, op.ctx->tune.tl_xcd_order ? 1 : 0);
-  else
-    hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, false>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,
-                       op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,
-                       (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset,
-                       dot_partials, xnorm2, op.ctx->tune.tl_xcd_order ? 1 : 0);
+#define LL_TL_LAUNCH(AL, ORD)                                                                                                         \
+  hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, AL, ORD>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,      \
+                     op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,                \
+                     (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset, dot_partials, xnorm2, \
+                     op.ctx->tune.tl_xcd_order ? 1 : 0)
+  if (aligned && op.tl_ordered) LL_TL_LAUNCH(true, true);
+  else if (aligned) LL_TL_LAUNCH(true, false);
+  else if (op.tl_ordered) LL_TL_LAUNCH(false, true);
+  else LL_TL_LAUNCH(false, false);
+#undef LL_TL_LAUNCH
   LL_HIP(hipGetLastError());
   return op.tl_nrb;
 }

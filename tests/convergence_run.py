@@ -23,6 +23,8 @@ from lambda_lanczos_amd import generators as G  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else None   # None: the library default (LL_TRIDIAG_AUTO)
 ctx = L.Context(0)
+for kv in filter(None, os.environ.get("DEMO_TUNING", "").split(",")):   # per-context settings for A/B runs: key=value,key=value
+    ctx.set_tuning(*kv.split("=", 1))
 if wl == "c3":
     n = int(os.environ.get("DEMO_N", "10000000"))
     csr = G.randsym(n)

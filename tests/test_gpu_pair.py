@@ -259,8 +259,8 @@ def test_split_sweeps_change_no_bit(ctx, llenv, name, split):
 def test_software_pipelined_sweep_changes_no_bit(ctx, name, split):
     """The production sweep (pair_sweep_pipe_kernel: the next trip's strips requested before the current trip is consumed, stored
     vectors addressed through a device pointer table, two vectors per trip, trips across slab boundaries, dummy columns with zero
-    coefficients behind the last stored vector) performs the additions of the reference kernel (pair_sweep_kernel, setting
-    sweep_pipeline = 0: four vectors per trip over the segment lists) in the same order: whole runs — restart passes behind locked
+    coefficients behind the last stored vector; the default on vectors of more than ~9 MiB) performs the additions of the reference
+    kernel (pair_sweep_kernel, setting sweep_pipeline = 0: four vectors per trip over the segment lists) in the same order: whole runs — restart passes behind locked
     vectors, ragged last strips, split sweeps included — agree bit for bit: alpha, beta, counts, eigenvalues, eigenvectors."""
     n, csr, init, find_max, offset = _case(name)
     ctx.set_tuning("blas_small_bytes", "0")
@@ -269,6 +269,7 @@ def test_software_pipelined_sweep_changes_no_bit(ctx, name, split):
     try:
         op = L.CsrOperator(ctx, *csr)
         num_eigs = 2 if name == "randsym" else 1
+        ctx.set_tuning("sweep_pipeline", "2")      # (by itself only on vectors of more than ~9 MiB: forced onto these small cases)
         piped = _run(ctx, op, n, find_max, offset, init, num_eigs=num_eigs)
         ctx.set_tuning("sweep_pipeline", "0")
         plain = _run(ctx, op, n, find_max, offset, init, num_eigs=num_eigs)

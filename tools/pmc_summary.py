@@ -57,11 +57,12 @@ def main():
         res["windows"] = windows
         res["window_iterations"] = window_iterations
         loop = ("mdot_kernel", "mdot_small_kernel", "lagged_kernel", "lagged_small_kernel", "lagged_fold_kernel", "reduce_cols_kernel",
-                "pair_sweep_kernel", "pair_three_term_kernel", "pair_predict_kernel", "pair_fold_kernel")
+                "pair_sweep_kernel", "pair_sweep_pipe_kernel", "pair_small_kernel", "pair_three_term_kernel", "pair_predict_kernel",
+                "pair_fold_kernel")
         two_sweep = ("maxpy_kernel", "maxpy_small_kernel", "scale_kernel", "scale_publish_kernel")
         # pair form: the multi-axpy / scale kernels only complete the pending vector at the END of a pass (LoopState::pair_flush,
         # outside the per-iteration phase timers): reported separately, not part of the Gram-Schmidt sweeps' traffic
-        pair_form = any(k.split("<")[0] == "pair_sweep_kernel" for k in res["kernels"])
+        pair_form = any(k.split("<")[0] in ("pair_sweep_kernel", "pair_sweep_pipe_kernel", "pair_small_kernel") for k in res["kernels"])
         names = loop if pair_form else loop + two_sweep
         orth = [v for k, v in res["kernels"].items() if k.split("<")[0] in names]
         if pair_form:
@@ -77,7 +78,7 @@ def main():
     print(json.dumps(res["calibration"]))
     for k, v in res["kernels"].items():
         if k.startswith(("pb_phase1<", "pb_phase2<", "pb_phase2_fixed<", "spmv_stream<", "mdot_kernel<", "maxpy_kernel<", "lagged_kernel<", "stencil", "dense_mv", "gemv_basis",
-                         "tl_spmv_kernel<", "tl_xmax_kernel<", "pair_sweep_kernel<", "pair_three_term_kernel<")):
+                         "tl_spmv_kernel<", "tl_xmax_kernel<", "pair_sweep_kernel<", "pair_sweep_pipe_kernel<", "pair_three_term_kernel<", "bw_read_kernel<", "bw_copy_kernel<")):
             print(k, {kk: (round(vv / 1e9, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()})
     if windows:
         print("orth_bytes_per_window_GB", res["orth_bytes_per_window"] / 1e9)
