@@ -197,7 +197,9 @@ template <typename T> class LambdaLanczos {
 // (lambda_lanczos_tridiagonal_impl.hpp:290-361; called directly by the reference's own tests, test/lambda_lanczos_test.cpp:765,795):
 // all eigenvalues (ascending) and, on request, the eigenvectors (eigenvectors[k] = k-th vector) of the symmetric tridiagonal
 // matrix with diagonal alpha and sub-diagonal beta, by the library's host solver (ll_tridiag_eig: the reference's implicit-QR
-// arithmetic step for step, bit-identical results); returns the count of forced breaks.  Host code, no device needed.
+// arithmetic step for step, in DOUBLE: bit-identical results for T = double; for T = float the solver still runs in double and the
+// results are rounded to float at the end, so they are at least as accurate as — but need not equal — what the reference's QR in
+// float arithmetic returns, and the count of forced breaks may differ); returns that count.  Host code, no device needed.
 namespace tridiagonal_impl {
 template <typename T>
 inline size_t tridiagonal_eigenpairs(const std::vector<T>& alpha, const std::vector<T>& beta, std::vector<T>& eigenvalues,

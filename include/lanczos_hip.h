@@ -249,17 +249,18 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  *                       itself ships, sample3_dynamic.cpp:17-22): one workgroup per row block keeps the y slice AND, tile by
  *                       tile, the x slice in LDS and streams 12 B per nonzero (fp64) — no global gather, no product buffer.
  *                       Built only when the row blocks touch few column tiles (a random matrix is not eligible); single
- *                       GPU; sums in fixed point like LL_SPMV_PB's default form (same integers: the result does not depend
- *                       on the tiling), i.e. the NORM-wise accuracy class below — not offered with LL_ACCURACY_COMPONENTWISE.
+ *                       GPU.  By default it sums in fixed point like LL_SPMV_PB's default form (same integers: the result does
+ *                       not depend on the tiling), i.e. the NORM-wise accuracy class below; with LL_ACCURACY_COMPONENTWISE the same
+ *                       image is summed in floating point, the waves of a workgroup adding in turn (a fixed order).
  * ll_op_create_csr_{d,z} and _csr_dev_ build the images, time them on the device with the actual matrix (sharded
  * contexts: summed over the ranks, so every rank takes the same decision), keep the fastest and RELEASE the others
  * (for BASELINE config 3 that returns 1.8 GB of CSR arrays).  Environment: LL_SPMV_KERNEL=csr|pb|tiled skips the timing,
  * LL_SPMV_KEEP_BOTH=1 keeps every image so that ll_op_select_spmv can switch later (A/B timing, tests).
  *
  * ACCURACY of y = A x (this is what replaces the user's fp64 mv_mul, LL:243 / EX:108):
- *   LL_SPMV_CSR_STREAM and LL_SPMV_PB with floating-point sums (LL_ACCURACY_COMPONENTWISE; LL_PB_PHASE2=ordered|atomic):
+ *   LL_SPMV_CSR_STREAM, and LL_SPMV_PB / LL_SPMV_TILED with floating-point sums (LL_ACCURACY_COMPONENTWISE; LL_PB_PHASE2=ordered|atomic):
  *     |y_i - (A x)_i| <= ~nnz_i * eps * sum_j |a_ij| |x_j|             (COMPONENT-wise, like a plain fp64 row loop).
- *   LL_SPMV_PB in its default form (LL_PB_PHASE2=fixed) and LL_SPMV_TILED round every product to a per-row fixed-point grid and add
+ *   LL_SPMV_PB and LL_SPMV_TILED in their default form (LL_PB_PHASE2=fixed) round every product to a per-row fixed-point grid and add
  *   64-bit integers (order-independent: same bits for every launch, block geometry and partition of the matrix):
  *     |y_i - (A x)_i| <= eps * sum_j |a_ij| |x_j|  +  nnz_i * 2^-60 * (sum_j |a_ij|) * max_k |x_k|   (NORM-wise)
  *   where max_k runs over the WHOLE input vector.  For vectors whose entries are of comparable size (Lanczos vectors of
@@ -286,7 +287,8 @@ enum { LL_SPMV_CSR_STREAM = 0, LL_SPMV_PB = 1, LL_SPMV_TILED = 2 };
 enum { LL_ACCURACY_DEFAULT = 0, LL_ACCURACY_NORMWISE = 1, LL_ACCURACY_COMPONENTWISE = 2 };
 typedef struct ll_csr_options {
   int32_t accuracy;          /* LL_ACCURACY_* */
-  int32_t kernel;            /* -1: the environment decides (timing of both unless LL_SPMV_KERNEL); LL_SPMV_CSR_STREAM / LL_SPMV_PB */
+  int32_t kernel;            /* -1: the environment decides (timing of the candidates unless LL_SPMV_KERNEL); LL_SPMV_CSR_STREAM / LL_SPMV_PB /
+                              * LL_SPMV_TILED (an error when the matrix is not eligible or has no entries: never a silent fallback) */
   int32_t arrays_on_device;  /* 0: row_ptr / col / val are host arrays (copied); 1: device arrays as in ll_op_create_csr_dev_* */
   int32_t reserved[5];       /* zero */
 } ll_csr_options;

@@ -208,7 +208,8 @@ class CsrOperator(_Operator):
 
     def __init__(self, ctx, row_ptr, col, val, n_cols=None, row_begin=0, accuracy=None, kernel=None):
         """accuracy: None (the environment decides), capi.ACCURACY_NORMWISE or capi.ACCURACY_COMPONENTWISE — the accuracy class
-        of y = A x (include/lanczos_hip.h, ll_csr_options); kernel: None (timed at creation), capi.SPMV_CSR_STREAM / SPMV_PB."""
+        of y = A x (include/lanczos_hip.h, ll_csr_options); kernel: None (timed at creation), capi.SPMV_CSR_STREAM / SPMV_PB / SPMV_TILED
+        (SPMV_TILED: an error for a matrix that is not eligible or has no entries, never a silent fallback)."""
         self.ctx = ctx
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
         col = np.ascontiguousarray(col, dtype=np.int32)

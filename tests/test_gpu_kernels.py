@@ -54,7 +54,9 @@ KERNELS = {"csr_stream": ("csr", None, None),
            # the 2-D tiled kernel (LL_TL_FORCE: these small matrices are not all eligible on their own): default row blocks,
            # tiny and ragged row blocks (many row blocks per column tile, empty tiles, one-quad tiles)
            "tiled": ("tiled", None, None), "tiled_small_blocks": ("tiled", "37", None),
-           "tiled_ragged_blocks": ("tiled", "53", None)}
+           "tiled_ragged_blocks": ("tiled", "53", None),
+           # ... and in the component-wise class (round 6: the waves add in turn in floating point, like pb_phase2<ORDERED>)
+           "tiled_ordered": ("tiled", None, "ordered"), "tiled_ordered_ragged_blocks": ("tiled", "53", "ordered")}
 KIND = {"csr": 0, "pb": 1, "tiled": 2}
 
 

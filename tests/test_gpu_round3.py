@@ -113,6 +113,24 @@ def test_fixed_point_spmv_meets_its_stated_normwise_bound(ctx, llenv, kind, dtyp
         assert np.array_equal(yd.get(), got[name])
         op.close()
     assert np.array_equal(got["fixed_switched"], got["ordered"]) and np.array_equal(got["ordered_switched"], got["fixed"])
+    # the 2-D tiled kernel serves both classes out of ONE image (round 6): fixed-point sums = the PB kernel's bits, or the waves adding
+    # in turn in floating point (component-wise); an operator moves between them like a PB operator
+    llenv.setenv("LL_TL_FORCE", "1")
+    op = L.CsrOperator(ctx, *csr, accuracy=capi.ACCURACY_COMPONENTWISE, kernel=capi.SPMV_TILED)
+    assert op.selected_spmv() == capi.SPMV_TILED and op.accuracy() == capi.ACCURACY_COMPONENTWISE
+    L.spmv(op, xd, yd)
+    got["tiled_ordered"] = yd.get()
+    L.spmv(op, xd, yd)
+    assert np.array_equal(yd.get(), got["tiled_ordered"])          # a fixed order: the same bits on every launch
+    op.set_accuracy(capi.ACCURACY_NORMWISE)
+    assert op.accuracy() == capi.ACCURACY_NORMWISE
+    L.spmv(op, xd, yd)
+    assert np.array_equal(yd.get(), got["fixed"])                  # the integers of the PB kernel
+    op.set_accuracy(capi.ACCURACY_COMPONENTWISE)
+    L.spmv(op, xd, yd)
+    assert np.array_equal(yd.get(), got["tiled_ordered"])
+    op.close()
+    llenv.delenv("LL_TL_FORCE")
     op = L.CsrOperator(ctx, *csr, kernel=capi.SPMV_CSR_STREAM)
     assert op.selected_spmv() == capi.SPMV_CSR_STREAM and op.accuracy() == capi.ACCURACY_COMPONENTWISE
     L.spmv(op, xd, yd)
@@ -131,6 +149,7 @@ def test_fixed_point_spmv_meets_its_stated_normwise_bound(ctx, llenv, kind, dtyp
     componentwise = 8 * EPS * (nnz_i + 2) * absrow + tiny
     normwise = 2 * EPS * absrow + nnz_i * np.longdouble(2.0) ** -60 * rowsum * xmax + tiny
     assert np.all(err_of(got["ordered"]) <= componentwise)
+    assert np.all(err_of(got["tiled_ordered"]) <= componentwise)
     assert np.all(err_of(got["csr"]) <= componentwise)
     assert np.all(err_of(got["fixed"]) <= normwise), float(np.max(err_of(got["fixed"]) / normwise))
     if kind == "decades":   # the inputs separate the two classes: fixed point is norm-wise accurate only
