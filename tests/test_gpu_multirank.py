@@ -101,9 +101,9 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
         # the one-sweep Gram-Schmidt form runs on sharded contexts too (streaming geometry: forced by the *-one-sweep cases)
         one_sweep = extra.get("LL_BLAS_SMALL_BYTES") == "0" or extra.get("LL_TEST_LAGGED_MIN_BYTES") == "0"
         assert all((r[key]["lagged"] > 0) == one_sweep for r in ranks)
-        # ... and, in the streaming geometry, its first pass (no locked vectors) takes TWO iterations per sweep: one all-reduce
-        # carries both iterations' columns, every rank folds the same numbers
-        assert all((r[key]["pair"] > 0) == (extra.get("LL_BLAS_SMALL_BYTES") == "0") for r in ranks)
+        # ... and takes TWO iterations per sweep — in the streaming geometry and, since round 6, in the small-vector geometry
+        # (pair_small_kernel) as well: one all-reduce carries both iterations' columns, every rank folds the same numbers
+        assert all((r[key]["pair"] > 0) == one_sweep for r in ranks)
         vals = np.array(ranks[0][key]["vals"])
         assert np.max(np.abs(vals - ora["eigenvalues"])) <= 1e-10 * np.max(np.abs(vals))
         assert ranks[0][key]["iters"] == ora["iter_counts"]          # fixed windows: identical pass structure
