@@ -96,6 +96,15 @@ class Context {
     return id;
   }
   void init_comm(const std::vector<char>& id, int rank, int n_ranks) { check(ll_comm_init(get(), id.data(), rank, n_ranks)); }
+  // Which transport answers the collectives: "rccl", "plugin:<path>", "attached" or "none" (ll_comm_transport).
+  std::string transport() const {
+    char buf[512];
+    check(ll_comm_transport(get(), buf, sizeof(buf)));
+    return std::string(buf);
+  }
+  // UNSTABLE: one tuning field of this context by key, on top of the environment switches (ll_ctx_set_tuning; value nullptr removes
+  // the setting).  The environment carries only the user-facing switches of INTEGRATION.md section 8.
+  void set_tuning(const char* key, const char* value) { check(ll_ctx_set_tuning(get(), key, value)); }
   static Context& default_context() {
     static Context ctx(0);
     return ctx;

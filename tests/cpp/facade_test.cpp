@@ -360,8 +360,25 @@ static void device_resident_io() {
   }
 }
 
+// The context's round-6 additions: which transport answers the collectives, and the per-context tuning keys (unknown keys throw).
+static void context_queries() {
+  std::printf("[case] Context::transport / set_tuning\n");
+  ll::Context ctx(0);
+  expect(ctx.transport() == "none", "no communicator: transport() == \"none\"");
+  ctx.set_tuning("pair_gs", "0");
+  ctx.set_tuning("pair_gs", nullptr);
+  bool threw = false;
+  try {
+    ctx.set_tuning("no_such_key", "1");
+  } catch (const std::exception& e) {
+    threw = std::string(e.what()).find("unknown key") != std::string::npos;
+  }
+  expect(threw, "an unknown tuning key is an error");
+}
+
 int main() {
   try {
+    context_queries();
     eigen_cases();
     api_shapes();
     run_iteration_direct();
