@@ -955,6 +955,36 @@ template <typename T> struct LoopState {
     lag_pending = false;
     refs_prev = NormRefs{rho2p, rho2p, rho2p, 0};  // beta^2 of the last completed vector, for the next three-term update
   }
+  // End of a pass with a pair pending: the Ritz vectors need u_0 .. u_{count-1}, of which u_P (and u_{P+1}) exist only as raw
+  // vectors with their measured coefficients.  Instead of completing them with a sweep of their own (pair_flush: the whole basis
+  // read once per pending vector — 1.4 ms of a 131 ms step on config 3), the caller folds the late update into the COEFFICIENTS of the
+  // Ritz GEMV:  u_P = (r1 - S g1) / rho1,  u_{P+1} = (r2 - S g2 - gam u_P) / rho2  =>  sum_k s_k u_k is a combination of S, r1, r2.
+  struct PairTail {
+    bool active = false;
+    int64_t P = 0;            // Lanczos vectors complete in the basis
+    int nvec = 0;             // pending vectors the result needs (1: u_P; 2: u_P and u_{P+1})
+    const T* src[2] = {nullptr, nullptr};
+    const double* g[2] = {nullptr, nullptr};     // reals * K coefficients each; g[1] is followed by gam (reals)
+    const double* rho2[2] = {nullptr, nullptr};  // squared norms of the orthogonal parts
+  };
+  PairTail take_tail(int64_t count) {
+    PairTail t;
+    if (!pair_pending) return t;
+    const int nv = (int)std::max<int64_t>(0, std::min<int64_t>(2, count - pair_P));
+    pair_pending = false;
+    lag_pending = false;
+    if (nv == 0) return t;
+    t.active = true;
+    t.P = pair_P;
+    t.nvec = nv;
+    t.src[0] = pr1;
+    t.src[1] = pr2;
+    t.g[0] = g1p;
+    t.g[1] = g2p;
+    t.rho2[0] = rho1p;
+    t.rho2[1] = rho2p;
+    return t;
+  }
   // Iterations k and k + 1 in the pair form.  Entered from the one-sweep state (iteration k - 1 pending with its measured
   // coefficients: u_{k-2} plays the part of an already complete first vector, g1 = 0, rho1 = 1) or continued from a pair.
   bool enqueue_pair(int64_t k, double offset) {
@@ -1591,7 +1621,9 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     }
     while (!stopped && worker.wait_pop(r)) stopped = absorb(r);  // the first stop verdict wins; else the last iteration's values
     itern = last.m;  // == max_iteration without a stop (LL:239,312)
-    LS.pair_flush(itern);  // (a pending pair: the Ritz vectors below need u_0 .. u_{itern-1} complete in the basis)
+    // (a pending pair: the Ritz vectors below need u_0 .. u_{itern-1}; the pending ones enter the GEMV through their raw vectors)
+    if (!ctx->tune.ritz_tail) LS.pair_flush(itern);  // (A/B: complete the pending vectors with a sweep of their own)
+    const typename LoopState<T>::PairTail tail = LS.take_tail(itern);
     if (trace_file) {
       std::fprintf(trace_file, "stop %lld %lld %d collected %zu\n", (long long)passes, (long long)itern, (int)stopped, alpha.size());
       std::fflush(trace_file);
@@ -1677,12 +1709,64 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
       }
       RunList<T> basis;
       basis.ld = ld;
-      basis.add_basis(U, m);
+      int64_t mm = m;
+      if (!tail.active) {
+        basis.add_basis(U, m);
+      } else {
+        // x = sum_{k<m} s_k u_k with the pending vectors expanded (LoopState::PairTail): columns = the stored columns of the last
+        // sweep (locked vectors first, then u_0 .. u_{P-1}), then r1 (and r2)
+        typedef std::complex<double> Z;
+        const int64_t Pt = tail.P, K = L + Pt;
+        std::vector<double> g1h((size_t)R * K + 1), g2h((size_t)R * (K + 1) + 1), rho(2, 1.0);
+        if (K > 0) E.fetch(tail.g[0], g1h.data(), (size_t)R * K);
+        E.fetch(tail.g[1], g2h.data(), (size_t)R * (K + 1));
+        E.fetch(tail.rho2[0], &rho[0], 1);
+        E.fetch(tail.rho2[1], &rho[1], 1);
+        const double rho1 = std::sqrt(rho[0]), rho2 = std::sqrt(rho[1]);
+        auto gz = [&](const std::vector<double>& g, int64_t j) { return R == 2 ? Z(g[(size_t)2 * j], g[(size_t)2 * j + 1]) : Z(g[(size_t)j], 0.0); };
+        auto to_t = [&](Z v, T* o) {
+          if constexpr (scalar_traits<T>::is_complex) {
+            o->re = (decltype(o->re))v.real();
+            o->im = (decltype(o->im))v.imag();
+          } else {
+            *o = (T)v.real();
+          }
+        };
+        auto from_t = [&](const T& v) {
+          if constexpr (scalar_traits<T>::is_complex) return Z((double)v.re, (double)v.im);
+          else return Z((double)v, 0.0);
+        };
+        mm = K + tail.nvec;
+        std::vector<T> c2((size_t)nw * mm);
+        std::vector<Z> cs((size_t)K);
+        for (int64_t w = 0; w < nw; ++w) {
+          const T* sw = coeff.data() + (size_t)w * m;
+          for (int64_t j = 0; j < K; ++j) cs[(size_t)j] = j < L ? Z(0.0, 0.0) : from_t(sw[j - L]);
+          Z a = from_t(sw[Pt]);                                              // coefficient of u_P
+          Z b = tail.nvec == 2 ? from_t(sw[Pt + 1]) : Z(0.0, 0.0);           // ... of u_{P+1}
+          Z on_r2(0.0, 0.0);
+          if (tail.nvec == 2) {
+            on_r2 = b / rho2;
+            for (int64_t j = 0; j < K; ++j) cs[(size_t)j] -= on_r2 * gz(g2h, j);
+            a -= on_r2 * gz(g2h, K);                                         // gam = <u_P, r2>
+          }
+          const Z on_r1 = a / rho1;
+          for (int64_t j = 0; j < K; ++j) cs[(size_t)j] -= on_r1 * gz(g1h, j);
+          T* out = c2.data() + (size_t)w * mm;
+          for (int64_t j = 0; j < K; ++j) to_t(cs[(size_t)j], out + j);
+          to_t(on_r1, out + K);
+          if (tail.nvec == 2) to_t(on_r2, out + K + 1);
+        }
+        coeff.swap(c2);
+        basis = LS.basis_runs(Pt);
+        basis.add(tail.src[0], 1);
+        if (tail.nvec == 2) basis.add(tail.src[1], 1);
+      }
       if (!d_ritz.p || d_ritz_cap < nw) {  // only the surviving vectors are formed; sized by what a pass can return at
         d_ritz_cap = std::max<int64_t>(nw, std::min<int64_t>(nroot_max, spec ? spec->nroot : P.num_eigs));  // most, so that
         d_ritz.alloc(ctx, (size_t)d_ritz_cap * ld);  // repeated runs of one problem reuse ONE cached buffer size
       }
-      E.gemv(basis, m, (int)nw, coeff.data(), d_ritz.p, ld);
+      E.gemv(basis, mm, (int)nw, coeff.data(), d_ritz.p, ld);
       for (int64_t w = 0; w < nw; ++w) {
         E.norm2_dev(d_ritz.p + w * ld, E.S(kScalScratch) + 1);
         const NormRefs nr = E.plain_norm(E.S(kScalScratch) + 1);

@@ -179,6 +179,7 @@ struct Tuning {
   long long lagged_min_bytes = -1; // key lagged_min_bytes: shortest vector of the one-sweep form (-1 = default)
   int lagged_pieces = 0;           // key lagged_pieces: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
+  bool ritz_tail = true;           // key ritz_tail = 0: a pair pending at the end of a pass is completed by sweeps of its own instead of entering the Ritz GEMV through its raw vectors (A/B)
   int sweep_pipeline = 1;          // key sweep_pipeline: 1 (default) the software-pipelined pair sweep on streaming vectors (> ~9 MiB), 0 never (A/B: same bits), 2 on every length (parity tests on small cases)
   bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
   // --- test hooks (not for users)

@@ -116,4 +116,4 @@ def test_reference_tests_through_the_facade():
     build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "PASSED" in r.stdout and r.stdout.count("[case]") == 16
+    assert "PASSED" in r.stdout and r.stdout.count("[case]") == 17
