@@ -181,3 +181,49 @@ def test_run_iteration_with_eigenvectors_in_orthogonalize_to_takes_the_one_sweep
     for got, ref in zip(v2, ora2["eigenvalues"]):
         assert abs(got - ref) <= 1e-10 * max(1.0, abs(ref))
     op.close()
+
+
+@pytest.mark.parametrize("name,window,num_eigs", [("randsym", 40, 1), ("randsym", 41, 1), ("randsym", None, 3), ("torus", 37, 1),
+                                                   ("torus", 38, 1), ("laplace", None, 1)])
+def test_pending_pair_enters_the_ritz_gemv_through_its_raw_vectors(ctx, oracle, name, window, num_eigs):
+    """At the end of a pass the last pair's vectors u_P (and u_{P+1}) exist only as raw vectors with their measured coefficients.
+    They are not completed by sweeps of their own any more: the late update is folded into the coefficients of the Ritz GEMV
+    (LoopState::PairTail; compute_eigenvectors, LL:33-62).  Windows that end on the first and on the second vector of a pair, runs
+    to convergence, restart passes behind locked eigenvectors, real and complex: the eigenvectors equal those of the flush path
+    (setting ritz_tail = 0) to rounding and the oracle's to the usual tolerance; eigenvalues and traces are the same bits."""
+    if name == "randsym":
+        n = 200_003
+        csr, init, find_max, offset = G.randsym_np(n), G.start_vector(n, 1), True, 0.0
+    elif name == "laplace":
+        m = 400
+        n = m * m
+        csr, init, find_max, offset = G.laplace2d_np(m), G.start_vector(n, 2), True, 0.0
+    else:
+        m = 300
+        n = m * m
+        csr, init, find_max, offset = G.torus_np(m), G.start_vector(n, 3, np.complex128), False, -10.0
+    op = L.CsrOperator(ctx, *csr)
+    got = {}
+    for tail in ("1", "0"):
+        ctx.set_tuning("ritz_tail", tail)
+        try:
+            eng = L.LambdaLanczos(op, n, find_max, num_eigs)
+            eng.eigenvalue_offset = offset
+            eng.init_vector = fixed_init(init)
+            if window:
+                eng.max_iteration = window
+            vals, vecs = eng.run()
+            got[tail] = (vals, vecs, eng.getIterationCounts(), eng.last_alpha.copy(), dict(eng.last_stats))
+        finally:
+            ctx.set_tuning("ritz_tail", None)
+    a, b = got["1"], got["0"]
+    assert a[4]["pair_iterations"] > 0
+    assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    for va, vb in zip(a[1], b[1]):
+        assert abs(abs(np.vdot(va, vb)) - 1.0) <= 1e-13 and np.max(np.abs(va - vb * np.vdot(vb, va))) <= 1e-12
+    ora = oracle.lanczos(csr, init, find_max, num_eigs=num_eigs, offset=offset, max_iteration=window)
+    assert a[2] == ora["iter_counts"] or all(abs(x - y) <= 2 for x, y in zip(a[2], ora["iter_counts"]))
+    for i in range(num_eigs):
+        assert abs(a[0][i] - ora["eigenvalues"][i]) <= 1e-10 * max(1.0, abs(ora["eigenvalues"][i] + offset))
+        assert 1 - abs(np.vdot(a[1][i], ora["eigenvectors"][i])) <= 1e-8
+    op.close()
