@@ -947,7 +947,11 @@ template <typename T> double tune_pb_placement(ll_operator* op) {
       rb(best);
       for (void* p : v) {
         if (p == best) continue;
-        if (finished && p != first && cand_bytes == slab_hint) ctx->cache_put(p, cand_bytes);
+        // (at most eight slabs of that size are kept this way: a context on which many operators are created must not pile up
+        // a placement search's worth of HBM per operator)
+        size_t same = 0;
+        for (auto& c : ctx->slab_cache) same += c.second == cand_bytes;
+        if (finished && p != first && cand_bytes == slab_hint && same < 8) ctx->cache_put(p, cand_bytes);
         else (void)hipFree(p);
       }
     }
