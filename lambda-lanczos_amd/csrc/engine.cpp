@@ -723,6 +723,7 @@ template <typename T> struct LoopState {
          *pcols = nullptr, *pscal = nullptr;
   int prec_set = 0;           // records prec[2 * prec_set], prec[2 * prec_set + 1] hold the pending pair's coefficients
   bool slot_pair[4] = {false, false, false, false};  // the scalars of this ring slot came from a pair fold (its gate is valid)
+  int ev_of_slot[4] = {0, 1, 2, 3};                   // the event that covers a ring slot's scalars (a pair's two slots share one)
   static constexpr size_t kPairRec = (size_t)kLaggedMaxCols + 32;
   static constexpr int64_t kPairSmallMinBytes = (int64_t)512 << 10;  // shortest vector of the pair form (small-vector geometry; enqueue_pair)
   // Pointer table of the software-pipelined sweep (kernels.hip, pair_sweep_pipe_kernel): entry c = stored column c of this pass —
@@ -1107,8 +1108,10 @@ template <typename T> struct LoopState {
     if (E.ctx->comm != nullptr) E.all_reduce(pcols, (size_t)ncols);
     launch_pair_fold(pcols, (int)P, (int)Lk, R, d_lambda, pp4, g2, gam, rho2sq, t3, e1, e2, rec3, rec4, nxt, hist_alpha, hist_beta, pfold,
                      E.ctx->h_pinned + 4 * sa, E.ctx->h_pinned + 4 * sb, E.ctx->h_pinned + 16 + sa, E.ctx->h_pinned + 16 + sb, s);
-    LL_HIP(hipEventRecord(ring.ev[sa], s));
+    // ONE event for both iterations of the pair (their scalars are published by the same fold kernel): every event record is a marker
+    // packet between two dependent kernels of a loop that is bound by exactly those gaps at small sizes
     LL_HIP(hipEventRecord(ring.ev[sb], s));
+    ev_of_slot[sa] = ev_of_slot[sb] = sb;
     timer.mark();
     slot_pair[sa] = slot_pair[sb] = true;
     pair_pending = true;
@@ -1191,6 +1194,7 @@ template <typename T> struct LoopState {
     const double* pg = lag_pending ? hbuf[(k - 1) & 1] : nullptr;
     launch_lagged_fold(hb, (int)nb_total, (int)n_locked, R, hb + t_off, c0, c, c + 1, E.S(kScalAlpha + slot), pg,
                        pg ? pg + t_off : nullptr, lag_c1, hist_alpha, hist_beta, d_lambda, E.ctx->h_pinned + 4 * slot, s);
+    ev_of_slot[slot] = slot;
     LL_HIP(hipEventRecord(ring.ev[slot], s));
     timer.mark();
     lag_pending = true;
@@ -1225,6 +1229,7 @@ template <typename T> struct LoopState {
     typename Engine<T>::DeferredAlpha da;
     E.apply(x, y, offset, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr, pending ? &sc : nullptr);  // P0-P3
     if (pending) {
+      ev_of_slot[pend_slot] = pend_slot;
       LL_HIP(hipEventRecord(ring.ev[pend_slot], s));  // iteration k-1's scalars are on their way to the host
       pending = false;
     }
@@ -1245,13 +1250,16 @@ template <typename T> struct LoopState {
       pend_k = k;
     } else if (pub.deferred) {  // norm fold + publish + normalisation in one launch (P8)
       launch_scale_publish<T>(nl, y, pub.partials, pub.nparts, pub.c1, pub.alpha, pub.c0, pub.host, s);
+      ev_of_slot[slot] = slot;
       LL_HIP(hipEventRecord(ring.ev[slot], s));
     } else if (pub.derive) {  // sharded: derived norm + publish + normalisation in one launch
       launch_scale_derive<T>(nl, y, pub.derive_c0, pub.derive_h, pub.derive_count, pub.c0_out, pub.c1, pub.alpha, pub.host, s);
+      ev_of_slot[slot] = slot;
       LL_HIP(hipEventRecord(ring.ev[slot], s));
     } else {
       LL_REQUIRE(!defer, "internal: deferred normalisation needs the fused norm fold");
       if (!pub.done) launch_publish(pub.host, pub.alpha, refs, s);
+      ev_of_slot[slot] = slot;
       LL_HIP(hipEventRecord(ring.ev[slot], s));
       launch_scale<T>(nl, y, 0.0, &refs, s);  // P8
     }
@@ -1264,6 +1272,7 @@ template <typename T> struct LoopState {
     if (!pending) return;
     launch_scale_publish<T>(nl, U.vec(pend_k), pend.partials, pend.nparts, pend.c1, pend.alpha, pend.c0, pend.host, s,
                             work[pend_k & 1].p);
+    ev_of_slot[pend_slot] = pend_slot;
     LL_HIP(hipEventRecord(ring.ev[pend_slot], s));
     pending = false;
   }
@@ -1520,7 +1529,7 @@ void lanczos_run(ll_context* ctx, ll_operator* op, const ll_lanczos_params& P_in
     auto collect = [&](int64_t j) -> int {
       const int slot = (int)(j % 4);
       const double tw0 = now_s();
-      LL_HIP(hipEventSynchronize(ring.ev[slot]));
+      LL_HIP(hipEventSynchronize(ring.ev[LS.ev_of_slot[slot]]));
       t_wait += now_s() - tw0;
       const volatile double* hp = ctx->h_pinned + 4 * slot;
       const double alpha_j = hp[0], c0_j = hp[2], c1_j = hp[3];
@@ -1967,7 +1976,7 @@ void expo_run(ll_context* ctx, ll_operator* op, const ll_expo_params& P_in, type
   auto collect = [&](int64_t j) -> int {
     const int slot = (int)(j % 4);
     const double tw0 = now_s();
-    LL_HIP(hipEventSynchronize(ring.ev[slot]));
+    LL_HIP(hipEventSynchronize(ring.ev[LS.ev_of_slot[slot]]));
     t_wait += now_s() - tw0;
     const volatile double* hp = ctx->h_pinned + 4 * slot;
     const double alpha_j = hp[0], c0_j = hp[2], c1_j = hp[3];
