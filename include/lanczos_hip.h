@@ -50,7 +50,7 @@ extern "C" {
                              * 4: additive — ll_csr_options / ll_op_create_csr_opt_*, ll_op_set_accuracy, ll_op_accuracy, the tiled
                              *    SpMV kernel id; no struct changed, callers built against minor 3 keep working
                              * 5: additive — ll_ctx_set_tuning (the test hooks and geometry overrides left the environment),
-                             *    ll_comm_transport, ll_bandwidth_probe; no struct changed */
+                             *    ll_comm_transport, ll_bandwidth_probe, ll_op_tiled_layout; no struct changed */
 
 enum {
   LL_OK = 0,
@@ -248,8 +248,11 @@ int ll_op_create_stencil_z(ll_context* ctx, const ll_stencil_desc* desc, int64_t
  *   LL_SPMV_TILED       2-D tiling for matrices WITH column locality (bands, stencils, lattices — the operators the reference
  *                       itself ships, sample3_dynamic.cpp:17-22): one workgroup per row block keeps the y slice AND, tile by
  *                       tile, the x slice in LDS and streams 12 B per nonzero (fp64) — no global gather, no product buffer.
- *                       Built only when the row blocks touch few column tiles (a random matrix is not eligible); single
- *                       GPU.  By default it sums in fixed point like LL_SPMV_PB's default form (same integers: the result does
+ *                       Built only when the row blocks touch few column tiles (a random matrix is not eligible).  Sharded
+ *                       contexts launch it twice per product: the row blocks whose tiles all lie inside the rank's own columns
+ *                       run under the all-gather, the others when the vector has arrived (ll_op_tiled_layout reports the
+ *                       split); the ranks' maxima of |x| travel in an 8-byte all-gather in front of the vector's, so the
+ *                       shards stitch to the bits of the single-GPU product.  By default it sums in fixed point like LL_SPMV_PB's default form (same integers: the result does
  *                       not depend on the tiling), i.e. the NORM-wise accuracy class below; with LL_ACCURACY_COMPONENTWISE the same
  *                       image is summed in floating point, the waves of a workgroup adding in turn (a fixed order).
  * ll_op_create_csr_{d,z} and _csr_dev_ build the images, time them on the device with the actual matrix (sharded
@@ -308,6 +311,8 @@ int ll_op_selected_spmv(const ll_operator* op, int* kind_out);
 /* Milliseconds the creation-time timing measured per kernel on this rank (-1: that kernel was not timed). */
 int ll_op_autotune_ms(const ll_operator* op, double* csr_stream_ms, double* pb_ms);
 int ll_op_autotune_ms_of(const ll_operator* op, int kind /* LL_SPMV_* */, double* ms);
+/* The tiled image's row blocks (0: no tiled image) and how many of them need no column of another rank (all of them on one GPU). */
+int ll_op_tiled_layout(const ll_operator* op, int* row_blocks, int* own_column_row_blocks);
 int ll_op_destroy(ll_operator* op);
 /* Global dimension n, local rows, nnz held locally (0 for callbacks). */
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz_local);

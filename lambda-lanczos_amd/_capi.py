@@ -162,6 +162,7 @@ PROTOTYPES = {
     "ll_op_selected_spmv": (C.c_int, [vp, P(C.c_int)]),
     "ll_op_autotune_ms": (C.c_int, [vp, P(f64), P(f64)]),
     "ll_op_autotune_ms_of": (C.c_int, [vp, C.c_int, P(f64)]),
+    "ll_op_tiled_layout": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
     "ll_op_destroy": (C.c_int, [vp]),
     "ll_op_info": (C.c_int, [vp, P(i64), P(i64), P(i64)]),
     "ll_spmv_d": (C.c_int, [vp, vp, vp, vp, f64, P(f64)]),

@@ -233,7 +233,7 @@ ll_operator::~ll_operator() {
                   (void*)d_pb_rptr, (void*)d_pb_xoff, (void*)d_pb_ncols, d_pb_arena, (void*)d_pb_rexp, d_pb_diag,
                   (void*)d_pb_blockmax, d_rp_own, d_rp_rem, (void*)d_col_own, (void*)d_col_rem, d_val_own, d_val_rem,
                   (void*)d_tiles_own, (void*)d_tiles_rem, (void*)d_tl_first, (void*)d_tl_col, (void*)d_tl_quad, d_tl_val,
-                  (void*)d_tl_idx, (void*)d_tl_rexp, (void*)d_tl_xmax})
+                  (void*)d_tl_idx, (void*)d_tl_rexp, (void*)d_tl_xmax, (void*)d_tl_rbmap})
     if (q) (void)hipFree(q);
   if (owns_arrays) {
     if (d_col) (void)hipFree(d_col);
@@ -1003,7 +1003,7 @@ template <typename T> void autotune_spmv(ll_operator* op) {
   } w;
   ctx->dev_malloc((void**)&w.x, xn * sizeof(T), "autotune x");
   ctx->dev_malloc((void**)&w.y, (size_t)std::max<int64_t>(op->n_local, 1) * sizeof(T), "autotune y");
-  ctx->dev_malloc((void**)&w.t, 2 * sizeof(double), "autotune scalars");
+  ctx->dev_malloc((void**)&w.t, 3 * sizeof(double), "autotune scalars");
   LL_HIP(hipMemsetAsync(w.x, 0, xn * sizeof(T), s));
   LL_HIP(hipEventCreate(&w.e0));
   LL_HIP(hipEventCreate(&w.e1));
@@ -1029,10 +1029,10 @@ template <typename T> void autotune_spmv(ll_operator* op) {
     }
   }
   for (int k = 0; k < 3; ++k) op->tune_ms[k] = t_kind[k] < 1e29 ? (float)t_kind[k] : -1.f;
-  if (ctx->comm != nullptr) {  // (the tiled kernel is single-GPU only: never a candidate here)
-    LL_HIP(hipMemcpyAsync(w.t, t_kind, 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    comm_allreduce_sum(ctx->comm, w.t, 2, s);
-    LL_HIP(hipMemcpyAsync(t_kind, w.t, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (ctx->comm != nullptr) {
+    LL_HIP(hipMemcpyAsync(w.t, t_kind, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    comm_allreduce_sum(ctx->comm, w.t, 3, s);
+    LL_HIP(hipMemcpyAsync(t_kind, w.t, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     LL_HIP(hipStreamSynchronize(s));
   }
   op->spmv_kind = LL_SPMV_CSR_STREAM;
@@ -1129,18 +1129,22 @@ void create_csr(ll_context* ctx, int64_t nr, int64_t nc, int64_t row_begin, cons
     pb_ok = all_ranks_agree(built);
     if (built && !pb_ok) release_pb_image(op.get());  // some rank could not build it: nobody uses it
   }
-  if ((want == 0 || want == 3) && nnz > 0 && ctx->comm == nullptr) {
+  if ((want == 0 || want == 3) && (nnz > 0 || ctx->comm != nullptr)) {
     // the 2-D tiled image: only for matrices whose row blocks touch few column tiles (tl_build_device decides).  One image serves
     // both accuracy classes: fixed-point sums (norm-wise) or the waves adding in turn in floating point (component-wise).
     op->tl_ordered = componentwise;
+    bool built = false;
     try {
-      tl_ok = tl_build_device<T>(op.get());
+      built = nnz > 0 && tl_build_device<T>(op.get());
     } catch (const Failure& f) {
-      if (!(f.code == LL_ERR_ALLOC && want == 0)) throw;
+      if (!(f.code == LL_ERR_ALLOC && (want == 0 || ctx->comm != nullptr))) throw;
       (void)hipGetLastError();
       tl_release(op.get());
-      tl_ok = false;
+      built = false;
     }
+    // (sharded contexts: the kernel choice is collective — the exchange in front of the tiled kernel carries the ranks' maxima)
+    tl_ok = all_ranks_agree(built);
+    if (built && !tl_ok) tl_release(op.get());
     LL_REQUIRE(!(want == 3 && !tl_ok), "this matrix is not eligible for the tiled SpMV kernel (its row blocks touch too many column tiles)");
   }
   // Asked for by name, the tiled kernel is an error where no tiled image exists (a matrix without entries) — never a silent
@@ -1452,6 +1456,13 @@ int ll_op_autotune_ms_of(const ll_operator* op, int kind, double* ms) {
   return guarded([&] {
     LL_REQUIRE(op != nullptr && ms != nullptr && kind >= LL_SPMV_CSR_STREAM && kind <= LL_SPMV_TILED, "bad argument");
     *ms = (double)op->tune_ms[kind];
+  });
+}
+int ll_op_tiled_layout(const ll_operator* op, int* row_blocks, int* own_column_row_blocks) {
+  return guarded([&] {
+    LL_REQUIRE(op != nullptr, "null operator");
+    if (row_blocks) *row_blocks = op->tl_nrb;
+    if (own_column_row_blocks) *own_column_row_blocks = op->ctx->nranks > 1 ? op->tl_n_interior : op->tl_nrb;
   });
 }
 int ll_op_info(const ll_operator* op, int64_t* n, int64_t* n_local, int64_t* nnz) {

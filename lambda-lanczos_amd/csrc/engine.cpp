@@ -247,7 +247,8 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
     // parts would take the scalar path of dense_mv_kernel, and gather-then-multiply, which vectorises whole rows, is faster)
     constexpr int64_t V = (int64_t)(16 / sizeof(T)) > 0 ? (int64_t)(16 / sizeof(T)) : 1;
     const bool dense_split_ok = op->n % V == 0 && op->row_begin % V == 0 && (op->row_begin + op->n_local) % V == 0;
-    const bool split = ctx->comm != nullptr && ((op->kind == ll_operator::CSR && !pb && op->csr_split) ||
+    const bool tiled = op->kind == ll_operator::CSR && op->spmv_kind == LL_SPMV_TILED;
+    const bool split = ctx->comm != nullptr && ((op->kind == ll_operator::CSR && !pb && !tiled && op->csr_split) ||
                                                 (op->kind == ll_operator::DENSE && ctx->tune.csr_split && dense_split_ok));
     const T* x_full = x_local;
     const T* x_own = x_local;  // what the own-column blocks of the PB kernels read
@@ -278,12 +279,20 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
         plan.start[0] = 0;
         plan.len[0] = op->n_shard;
       }
-      const bool overlap = (pb || split) && ctx->tune.comm_overlap && ctx->comm_stream != nullptr;
+      const bool overlap = (pb || split || tiled) && ctx->tune.comm_overlap && ctx->comm_stream != nullptr;
       hipStream_t cs = overlap ? ctx->comm_stream : s;
+      // tiled, fixed-point class: the grid's scale needs max |x| over the WHOLE vector before the first launch — every rank's own
+      // maximum (two small kernels) travels in an 8-byte all-gather in front of the vector's
+      const bool tl_max = tiled && !op->tl_ordered;
+      if (tl_max) launch_tl_xmax_local<T>(*op, send, s);
       comm_timer_begin(cs);
       if (overlap) {
         LL_HIP(hipEventRecord(ctx->ev_x_ready, s));  // everything enqueued so far (x final, previous readers of the
         LL_HIP(hipStreamWaitEvent(cs, ctx->ev_x_ready, 0));  // gathered buffer done) precedes the gather
+      }
+      if (tl_max) {
+        comm_allgather(ctx->comm, op->d_tl_xmax + tl_xmax_local_slot(), op->d_tl_xmax, sizeof(double), cs);
+        if (overlap) LL_HIP(hipEventRecord(ctx->ev_chunk[1], cs));
       }
       for (int c = 0; c < plan.nchunks; ++c) {
         comm_allgather(ctx->comm, send + plan.start[c], gathered + (int64_t)P * plan.start[c],
@@ -304,6 +313,14 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
           nparts = launch_spmv<T>(*op, gathered, x_local, y, offset, dotp, s, sc, 2);
         }
         remote_done = true;
+      } else if (tiled) {
+        // the row blocks whose tiles are all own-column tiles run under the gather (x = the own shard), the others when the
+        // vector has arrived; LL_COMM_OVERLAP=0 issues the same two launches behind the gather on one stream
+        if (overlap && tl_max) LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[1], 0));
+        launch_spmv_tiled_pass<T>(*op, 0, send, op->row_begin, op->row_begin + op->n_shard, x_local, y, offset, dotp, s, xnorm2, P);
+        if (overlap) LL_HIP(hipStreamWaitEvent(s, ctx->ev_chunk[0], 0));
+        nparts = launch_spmv_tiled_pass<T>(*op, 1, gathered, 0, op->n, x_local, y, offset, dotp, s, xnorm2, P);
+        remote_done = true;
       } else if (overlap) {
         // own-column blocks run under the gather; every chunk's remote blocks start when that chunk has arrived
         launch_pb_phase1<T>(*op, 0, op->pb_own_count, x_own, s, xnorm2);
@@ -320,7 +337,7 @@ void Engine<T>::apply(const T* x_local, T* y, double offset, double* d_alpha, bo
       nparts = launch_dense_mv<T>(*op, x_full, x_local, y, offset, dotp, s, sc);
     else if (pb)
       nparts = launch_spmv_pb<T>(*op, x_full, x_own, x_local, y, offset, dotp, s, xnorm2);
-    else if (op->spmv_kind == LL_SPMV_TILED)  // single GPU only (never selected on a sharded context): x_local is the whole x
+    else if (op->spmv_kind == LL_SPMV_TILED)  // single GPU (sharded contexts took the two-launch form above): x_local is the whole x
       nparts = launch_spmv_tiled<T>(*op, x_local, y, offset, dotp, s, xnorm2);
     else {
       LL_REQUIRE(op->d_col != nullptr || op->nnz == 0,

@@ -319,6 +319,8 @@ struct ll_operator {
   // 2-D tiled image (spmv_pb.hip, tl_*; LL_SPMV_TILED): row blocks with the y slice in LDS, each walking its non-empty
   // column tiles of 16 KiB of x; entries = value (pre-scaled by the row's exponent) + packed 16-bit local column / row
   int tl_nrb = 0, tl_rb_rows = 0, tl_ncb = 0;
+  int tl_n_interior = 0;             // sharded: row blocks whose tiles are all own-column tiles (first in d_tl_rbmap; they run under the all-gather)
+  int32_t* d_tl_rbmap = nullptr;     // sharded: [nrb] row blocks in launch order (interior first); nullptr on one GPU
   int64_t tl_entries = 0, tl_tiles = 0;
   int32_t* d_tl_first = nullptr;     // [nrb + 1]     first tile of each row block in the tile list
   int32_t* d_tl_col = nullptr;       // [ntiles]      column tile index
@@ -326,7 +328,7 @@ struct ll_operator {
   void* d_tl_val = nullptr;          // values in tile order
   uint32_t* d_tl_idx = nullptr;      // local column | local row << 16
   int16_t* d_tl_rexp = nullptr;      // exponent of every row's absolute sum (the scale the values were divided by)
-  double* d_tl_xmax = nullptr;       // per-workgroup maxima of |x| left by the pre-pass of every launch
+  double* d_tl_xmax = nullptr;       // maxima of |x| the kernel folds (per workgroup of the pre-pass; sharded: one per rank), then scratch of the own-shard pre-pass
   bool tl_ordered = false;           // the tiled kernel sums in floating point, the waves in turn (component-wise class) instead of in fixed point
   // Column-block table order: the blocks over the rank's OWN columns first (their x slice is the local shard, no
   // exchange needed), then, gather chunk by gather chunk, the blocks over the other ranks' columns (x slice in the
@@ -410,6 +412,12 @@ void tl_release(ll_operator* op);
 template <typename T>
 int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, double* dot_partials, hipStream_t s,
                       const double* xnorm2 = nullptr);
+// Sharded form (engine.cpp): own-shard maximum, then the two launches (own-column row blocks under the all-gather, the rest behind it).
+template <typename T> void launch_tl_xmax_local(const ll_operator& op, const T* x_own, hipStream_t s);
+int tl_xmax_local_slot();
+template <typename T>
+int launch_spmv_tiled_pass(const ll_operator& op, int pass, const T* x, int64_t col0, int64_t col_end, const T* x_local, T* y,
+                           double offset, double* dot_partials, hipStream_t s, const double* xnorm2, int n_xmax);
 // Column range check + max absolute row sum of the local rows (sets op->inf_norm), on the device.
 template <typename T> void csr_check_device(ll_operator* op);
 // Same contract for the dense row block (op.kind == DENSE).

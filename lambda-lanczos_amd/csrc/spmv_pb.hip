@@ -1306,7 +1306,11 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
                                                              const T* __restrict__ x, const T* __restrict__ xl,
                                                              T* __restrict__ y, double offset,
                                                              double* __restrict__ dot_partials,
-                                                             const double* __restrict__ xnorm2, int xcd_order) {
+                                                             const double* __restrict__ xnorm2, int xcd_order,
+                                                             const int32_t* __restrict__ rb_map, int rb_first, int64_t col0) {
+  // Sharded contexts launch the kernel twice: x holds the global columns [col0, n_cols) — the rank's own shard
+  // for the row blocks whose tiles are all own-column tiles (they run under the all-gather), the gathered vector (col0 = 0) for
+  // the others — and rb_map[rb_first + i] is the i-th row block of the launch.  Single GPU: rb_map = nullptr, col0 = 0.
   constexpr int R = scalar_traits<T>::reals;
   constexpr int C = kTlTileBytes / (int)sizeof(T);  // columns per tile
   constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte piece
@@ -1325,6 +1329,7 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
     const int x = blockIdx.x % kXcds, l = blockIdx.x / kXcds;
     rb = x * q + min(x, r) + l;  // XCD x owns q + (x < r) consecutive blocks; a bijection on [0, nb)
   }
+  if (rb_map) rb = rb_map[rb_first + rb];
   const int64_t row0 = (int64_t)rb * rb_rows;
   const int rows = (int)min((int64_t)rb_rows, n_local - row0);
   const int t0 = tfirst[rb], t1 = tfirst[rb + 1];
@@ -1416,12 +1421,17 @@ __global__ __launch_bounds__(kPbThreads) void tl_spmv_kernel(int rb_rows, int64_
       if constexpr (ALIGNED) {
         // a piece that would reach beyond the end is read V-aligned from the last whole piece position that is still inside
         // (n_cols >= V is guaranteed by the launcher) and shifted into place below (store_piece)
+        // (... and never from in front of the buffer: only a re-requested or padding tile can lie there, and it is never stored)
         const long long lim = n_cols - V;
-        xp[slot][j] = *reinterpret_cast<const uint4*>(x + (off <= lim ? off : lim));
+        const long long o = off <= lim ? off : lim;
+        xp[slot][j] = *reinterpret_cast<const uint4*>(x + ((o >= col0 ? o : col0) - col0));
       } else {
         T el[V];
 #pragma unroll
-        for (int q = 0; q < V; ++q) el[q] = x[off + q < n_cols ? off + q : n_cols - 1];
+        for (int q = 0; q < V; ++q) {
+          const long long o = off + q < n_cols ? off + q : n_cols - 1;
+          el[q] = x[(o >= col0 ? o : col0) - col0];
+        }
         __builtin_memcpy(&xp[slot][j], el, sizeof(uint4));
       }
     }
@@ -1616,6 +1626,31 @@ template <typename T> void tl_opt_in_lds() {
 }
 }  // namespace
 
+namespace {
+// One launch over the row blocks [rb_first, rb_first + rb_count) of the image's order (op.d_tl_rbmap; identity without a map); x holds the
+// global columns [col0, col_end), x_local the rank's own rows; the fixed-point class reads n_xmax maxima of |x| from op.d_tl_xmax.
+template <typename T>
+void tl_launch_rows(const ll_operator& op, int rb_first, int rb_count, const T* x, int64_t col0, int64_t col_end, const T* x_local, T* y,
+                    double offset, double* dot_partials, hipStream_t s, const double* xnorm2, int n_xmax) {
+  if (rb_count <= 0) return;
+  constexpr int64_t V = (int64_t)(16 / sizeof(T));
+  // 16-byte pieces of x: the fast form needs an aligned window of at least one piece that starts on a piece boundary
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && col0 % V == 0 && col_end - col0 >= V;
+#define LL_TL_LAUNCH(AL, ORD)                                                                                                         \
+  hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, AL, ORD>), dim3(rb_count), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,      \
+                     op.tl_rb_rows, op.n_local, col_end, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,              \
+                     (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, n_xmax, x, x_local, y, offset, dot_partials, xnorm2,       \
+                     op.ctx->tune.tl_xcd_order ? 1 : 0, (const int32_t*)op.d_tl_rbmap, rb_first, col0)
+  if (aligned && op.tl_ordered) LL_TL_LAUNCH(true, true);
+  else if (aligned) LL_TL_LAUNCH(true, false);
+  else if (op.tl_ordered) LL_TL_LAUNCH(false, true);
+  else LL_TL_LAUNCH(false, false);
+#undef LL_TL_LAUNCH
+  LL_HIP(hipGetLastError());
+}
+}  // namespace
+
+// x = the WHOLE vector (single GPU; sharded: the gathered vector, x + row_begin the rank's own rows): max |x|, then every row block.
 template <typename T>
 int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, double* dot_partials, hipStream_t s,
                       const double* xnorm2) {
@@ -1625,19 +1660,34 @@ int launch_spmv_tiled(const ll_operator& op, const T* x, T* y, double offset, do
   if (!op.tl_ordered)  // (the component-wise form has no fixed-point grid to scale: no max|x| pre-pass)
     hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(xgrid), dim3(256), 0, s, (long long)op.n, x, op.d_tl_xmax,
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0);
-  // 16-byte pieces of x: the fast form needs an aligned vector of at least one piece
-  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && op.n >= (int64_t)(16 / sizeof(T));
-#define LL_TL_LAUNCH(AL, ORD)                                                                                                         \
-  hipLaunchKernelGGL((tl_spmv_kernel<T, kTlDepth, AL, ORD>), dim3(op.tl_nrb), dim3(kPbThreads), tl_lds_bytes<T>(op.tl_rb_rows), s,      \
-                     op.tl_rb_rows, op.n_local, op.n, op.d_tl_first, op.d_tl_col, op.d_tl_quad, (const T*)op.d_tl_val,                \
-                     (const uint4*)op.d_tl_idx, op.d_tl_rexp, op.d_tl_xmax, xgrid, x, x + op.row_begin, y, offset, dot_partials, xnorm2, \
-                     op.ctx->tune.tl_xcd_order ? 1 : 0)
-  if (aligned && op.tl_ordered) LL_TL_LAUNCH(true, true);
-  else if (aligned) LL_TL_LAUNCH(true, false);
-  else if (op.tl_ordered) LL_TL_LAUNCH(false, true);
-  else LL_TL_LAUNCH(false, false);
-#undef LL_TL_LAUNCH
+  tl_launch_rows<T>(op, 0, op.tl_nrb, x, 0, op.n, x + op.row_begin, y, offset, dot_partials, s, xnorm2, xgrid);
+  return op.tl_nrb;
+}
+
+// Sharded contexts (engine.cpp apply_operator): the maximum of |x| over the rank's own shard, one double at
+// op.d_tl_xmax[tl_xmax_local_slot()] — the ranks' maxima are then all-gathered into op.d_tl_xmax[0, nranks), the table the kernel
+// folds (a maximum does not depend on how the vector is cut, so every partition scales its fixed-point grid exactly like one GPU).
+template <typename T> void launch_tl_xmax_local(const ll_operator& op, const T* x_own, hipStream_t s) {
+  if (op.tl_nrb <= 0 || op.tl_ordered) return;
+  double* parts = op.d_tl_xmax + kTlXmaxParts;
+  const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kTlXmaxParts, (op.n_local + 255) / 256));
+  hipLaunchKernelGGL((tl_xmax_kernel<T>), dim3(g), dim3(256), 0, s, (long long)op.n_local, x_own, parts,
+                     (reinterpret_cast<uintptr_t>(x_own) & 15) == 0 ? 1 : 0);
+  hipLaunchKernelGGL((tl_xmax_kernel<double>), dim3(1), dim3(256), 0, s, (long long)g, (const double*)parts, parts + kTlXmaxParts, 1);
   LL_HIP(hipGetLastError());
+}
+int tl_xmax_local_slot() { return 2 * kTlXmaxParts; }
+
+// pass 0: the row blocks whose tiles are all own-column tiles (x = the rank's shard, global columns [col0, col_end));
+// pass 1: the others (x = the gathered vector, col0 = 0).  n_xmax maxima (one per rank) wait in op.d_tl_xmax.
+template <typename T>
+int launch_spmv_tiled_pass(const ll_operator& op, int pass, const T* x, int64_t col0, int64_t col_end, const T* x_local, T* y,
+                           double offset, double* dot_partials, hipStream_t s, const double* xnorm2, int n_xmax) {
+  if (op.tl_nrb <= 0) return 0;
+  tl_opt_in_lds<T>();
+  const int first = pass == 0 ? 0 : op.tl_n_interior;
+  const int count = pass == 0 ? op.tl_n_interior : op.tl_nrb - op.tl_n_interior;
+  tl_launch_rows<T>(op, first, count, x, col0, col_end, x_local, y, offset, dot_partials, s, xnorm2, n_xmax);
   return op.tl_nrb;
 }
 
@@ -1648,7 +1698,7 @@ template <typename T> bool tl_build_device(ll_operator* op) {
   ll_context* ctx = op->ctx;
   hipStream_t s = ctx->stream;
   const int64_t nr = op->n_local;
-  if (ctx->nranks > 1 || nr <= 0 || op->nnz <= 0) return false;  // single GPU (sharded contexts keep CSR-stream / PB)
+  if (nr <= 0 || op->nnz <= 0 || ctx->nranks > kTlXmaxParts) return false;
   const Tuning& tune = ctx->tune;
   constexpr int C = tl_cols<T>();
   // ---- row blocks: as long as the LDS allows (the longer the block, the smaller the share of re-staged x per entry),
@@ -1730,6 +1780,23 @@ template <typename T> bool tl_build_device(ll_operator* op) {
   }
   tfirst[(size_t)nrb] = (int32_t)tcol.size();
   tquad.push_back(q >> 2);
+  // Sharded contexts: the row blocks whose tiles all lie inside the rank's OWN columns come first — their launch needs nothing from
+  // the other ranks and runs under the all-gather; the rest follows behind it (banded matrices: the blocks next to the shard's ends).
+  std::vector<int32_t> rbmap;
+  int n_interior = 0;
+  if (ctx->nranks > 1) {
+    std::vector<int32_t> rest;
+    for (int64_t r = 0; r < nrb; ++r) {
+      bool own = true;
+      for (int32_t t = tfirst[(size_t)r]; t < tfirst[(size_t)r + 1] && own; ++t) {
+        const int64_t c0 = (int64_t)tcol[(size_t)t] * C, c1 = std::min<int64_t>(c0 + C, op->n);
+        own = c0 >= op->row_begin && c1 <= op->row_begin + nr;
+      }
+      (own ? rbmap : rest).push_back((int32_t)r);
+    }
+    n_interior = (int)rbmap.size();
+    rbmap.insert(rbmap.end(), rest.begin(), rest.end());
+  }
   const int64_t entries = q;
   const int64_t ntiles = (int64_t)tcol.size();
   tcol.push_back(tcol.empty() ? 0 : tcol.back());  // padding entry: what a row block without tiles reads (and ignores)
@@ -1743,6 +1810,7 @@ template <typename T> bool tl_build_device(ll_operator* op) {
   op->tl_ncb = (int)ncb;
   op->tl_entries = entries;
   op->tl_tiles = ntiles;
+  op->tl_n_interior = n_interior;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     ctx->dev_malloc(dst, std::max<size_t>(bytes, 16), "tiled-image tables");
     LL_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
@@ -1759,14 +1827,16 @@ template <typename T> bool tl_build_device(ll_operator* op) {
     up((void**)&op->d_tl_col, tcol.data(), tcol.size() * sizeof(int32_t));
     up((void**)&op->d_tl_quad, tquad.data(), tquad.size() * sizeof(int64_t));
     up((void**)&d_segq, segq.data(), segq.size() * sizeof(int64_t));
+    if (!rbmap.empty()) up((void**)&op->d_tl_rbmap, rbmap.data(), rbmap.size() * sizeof(int32_t));
     const size_t cap = (size_t)entries + 16;  // one quad behind the image: clamped reads of lanes beyond the end
     ctx->dev_malloc(&op->d_tl_val, cap * sizeof(T), "tiled image (values)");
     ctx->dev_malloc((void**)&op->d_tl_idx, cap * sizeof(uint32_t), "tiled image (local indices)");
     ctx->dev_malloc((void**)&op->d_tl_rexp, std::max<size_t>((size_t)nr, 8) * sizeof(int16_t), "row exponents");
-    ctx->dev_malloc((void**)&op->d_tl_xmax, (size_t)kTlXmaxParts * sizeof(double), "x maxima");
+    // [0, parts): what the kernel folds; [parts, 2 parts): the own shard's partial maxima; [2 parts]: the own shard's maximum
+    ctx->dev_malloc((void**)&op->d_tl_xmax, (size_t)(2 * kTlXmaxParts + 8) * sizeof(double), "x maxima");
     LL_HIP(hipMemsetAsync(op->d_tl_val, 0, cap * sizeof(T), s));  // padding entries: value 0, local indices 0
     LL_HIP(hipMemsetAsync(op->d_tl_idx, 0, cap * sizeof(uint32_t), s));
-    LL_HIP(hipMemsetAsync(op->d_tl_xmax, 0, (size_t)kTlXmaxParts * sizeof(double), s));
+    LL_HIP(hipMemsetAsync(op->d_tl_xmax, 0, (size_t)(2 * kTlXmaxParts + 8) * sizeof(double), s));
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (nr + 255) / 256));
     if (op->rp64)
       hipLaunchKernelGGL((pb_rowexp_kernel<T, int64_t>), dim3(g), dim3(256), 0, s, (long long)nr, (const int64_t*)op->d_row_ptr,
@@ -1804,7 +1874,9 @@ void tl_release(ll_operator* op) {
   drop(op->d_tl_idx);
   drop(op->d_tl_rexp);
   drop(op->d_tl_xmax);
+  drop(op->d_tl_rbmap);
   op->tl_nrb = 0;
+  op->tl_n_interior = 0;
 }
 
 #define LL_INST_PB(T)                                                                                              \
@@ -1815,6 +1887,9 @@ void tl_release(ll_operator* op) {
   template bool pb_build_device<T>(ll_operator*);                                                                   \
   template bool tl_build_device<T>(ll_operator*);                                                                   \
   template int launch_spmv_tiled<T>(const ll_operator&, const T*, T*, double, double*, hipStream_t, const double*);  \
+  template void launch_tl_xmax_local<T>(const ll_operator&, const T*, hipStream_t);                                 \
+  template int launch_spmv_tiled_pass<T>(const ll_operator&, int, const T*, int64_t, int64_t, const T*, T*, double, \
+                                         double*, hipStream_t, const double*, int);                                 \
   template void csr_check_device<T>(ll_operator*);
 LL_INST_PB(double) LL_INST_PB(zc) LL_INST_PB(float) LL_INST_PB(cf)
 

@@ -279,6 +279,12 @@ class CsrOperator(_Operator):
         check(lib().ll_op_autotune_ms_of(self.handle, int(kind), C.byref(a)))
         return a.value
 
+    def tiled_layout(self):
+        """(row blocks of the tiled image, those of them whose tiles all lie inside the rank's own columns) — (0, 0) without a tiled image."""
+        a, b = C.c_int(), C.c_int()
+        check(lib().ll_op_tiled_layout(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def selected_spmv(self):
         k = C.c_int()
         check(lib().ll_op_selected_spmv(self.handle, C.byref(k)))

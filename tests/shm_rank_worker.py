@@ -134,6 +134,31 @@ def main():
     v9, x9 = e9.run()
     res["dense_aligned"] = {"vals": v9.tolist(), "vecs": [x9[0].tolist()], "iters": e9.getIterationCounts()}
     dn9.close()
+    # --- banded random matrix (the band wraps around: first and last rank need each other's columns) through the 2-D tiled
+    #     kernel: the row blocks whose tiles are all own-column tiles run under the all-gather, the others behind it
+    n10, band = 30011, 700
+    rb10, nl10 = ctx.partition(n10)
+    ctx.set_tuning("tl_force", "1")          # (a matrix this small is not eligible by itself: 16 KiB tiles)
+    ctx.set_tuning("pb_row_block", "96")
+    csr10 = G.randsym(n10, band=band, row_begin=rb10, n_local=nl10)
+    x10 = G.start_vector(nl10, 7, np.float64, rb10)
+    res["tiled"] = {}
+    for acc, label in ((L.capi.ACCURACY_NORMWISE, "fixed"), (L.capi.ACCURACY_COMPONENTWISE, "ordered")):
+        op = L.CsrOperator(ctx, *csr10, n_cols=n10, row_begin=rb10, accuracy=acc, kernel=L.capi.SPMV_TILED)
+        assert op.selected_spmv() == L.capi.SPMV_TILED
+        xd, yd = ctx.to_device(x10), ctx.empty(nl10)
+        dot = L.spmv(op, xd, yd, offset=-0.25, want_dot=True)
+        rec = {"y": yd.get().tolist(), "dot": dot, "layout": list(op.tiled_layout()), "n_local": nl10}
+        if label == "fixed":
+            eng = L.LambdaLanczos(op, n10, True, 1)
+            eng.max_iteration = 40
+            eng.init_vector = lambda v, row_begin: np.copyto(v, G.start_vector(v.shape[0], 1, np.float64, row_begin))
+            vals, vecs = eng.run()
+            rec.update(vals=vals.tolist(), alpha=eng.last_alpha.tolist(), iters=eng.getIterationCounts(), vecs=[vecs[0].tolist()])
+        res["tiled"][label] = rec
+        op.close()
+    ctx.set_tuning("tl_force", None)
+    ctx.set_tuning("pb_row_block", None)
     # --- fewer rows than ranks: the last shard(s) are empty
     tiny = np.array([[2.0, 1.0], [1.0, 3.0]])
     rb8, nl8 = ctx.partition(2)

@@ -167,6 +167,41 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
     out5 = np.concatenate([list2c(r["stencil_3d"]["out"]) for r in ranks])
     assert abs(ranks[0]["stencil_3d"]["itern"] - it5) <= 1
     assert np.max(np.abs(out5 - o5)) <= 1e-10 * np.linalg.norm(x5)
+    # ---- banded matrix through the 2-D tiled kernel, sharded: two launches per product, the own-column row blocks under the gather
+    n10 = 30011
+    band = G.randsym_np(n10, band=700)
+    x10 = G.start_vector(n10, 7)
+    y10 = oracle.spmv(band, x10) - 0.25 * x10
+    for label in ("fixed", "ordered"):
+        recs = [r["tiled"][label] for r in ranks]
+        assert sum(r["n_local"] for r in recs) == n10
+        for r in recs:   # row blocks in the shard's middle need no column of another rank; the ones at its ends do (the band wraps around)
+            nrb, own = r["layout"]
+            assert 0 < own < nrb, r["layout"]
+        y = np.concatenate([np.asarray(r["y"]) for r in recs])
+        assert np.max(np.abs(y - y10)) <= 1e-12 * 40, label
+        assert abs(recs[0]["dot"] - float(x10 @ y10)) <= 1e-9 * n10
+    if not os.environ.get("LL_PB_PHASE2"):
+        # fixed-point sums: the shards stitch to the BITS of the single-GPU product — of the tiled kernel and of the PB kernel alike
+        y = np.concatenate([np.asarray(r["tiled"]["fixed"]["y"]) for r in ranks])
+        llenv.setenv("LL_TL_FORCE", "1")
+        for kernel in (L.capi.SPMV_TILED, L.capi.SPMV_PB):
+            op1 = L.CsrOperator(ctx, *band, kernel=kernel, accuracy=L.capi.ACCURACY_NORMWISE)
+            x1, y1 = ctx.to_device(x10), ctx.empty(n10)
+            L.spmv(op1, x1, y1, offset=-0.25)
+            assert np.array_equal(y, y1.get()), kernel
+            op1.close()
+        llenv.delenv("LL_TL_FORCE")
+    ora10 = oracle.lanczos(band, G.start_vector(n10, 1), True, max_iteration=40)
+    t0 = ranks[0]["tiled"]["fixed"]
+    for r in ranks[1:]:
+        assert r["tiled"]["fixed"]["vals"] == t0["vals"] and r["tiled"]["fixed"]["alpha"] == t0["alpha"]
+    assert t0["iters"] == ora10["iter_counts"]
+    assert abs(t0["vals"][0] - ora10["eigenvalues"][0]) <= 1e-10 * abs(ora10["eigenvalues"][0])
+    m10 = len(ora10["alpha"])
+    assert np.max(np.abs(np.array(t0["alpha"])[:m10] - ora10["alpha"])) <= 1e-10 * 30
+    v10 = np.concatenate([np.asarray(r["tiled"]["fixed"]["vecs"][0]) for r in ranks])
+    assert 1 - overlap(v10, ora10["eigenvectors"][0]) <= 1e-8
     # ---- 2 x 2 problem on `world` ranks (empty shards beyond the second rank)
     assert [r["tiny"]["n_local"] for r in ranks] == [1, 1] + [0] * (world - 2)
     lam = (5 + np.sqrt(5)) / 2

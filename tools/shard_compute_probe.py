@@ -5,6 +5,8 @@ Everything else is the production sharded path: the row shard of the matrix with
 with own / remote column blocks, the chunked gather buffer, n/N-sized Gram-Schmidt sweeps, all-reduced coefficients.
 
     python tools/shard_compute_probe.py [N ...]      -> one JSON line per N (default 1 2 4 8)
+    SHARD_PROBE_BAND=65536 python tools/shard_compute_probe.py ...   the banded variant of config 3 (columns within +-2^16 of the row):
+                                                      eligible for the 2-D tiled kernel, sharded contexts included
 
 Feeds the strong-scaling model of DESIGN.md section 6: T_iter(N) = compute(N) [measured here] + exchange(N) [modelled]."""
 import json
@@ -23,12 +25,12 @@ os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import numpy as np
 import lambda_lanczos_amd as L
 from lambda_lanczos_amd import generators as G
-N = int(sys.argv[1]); n = 10_000_000; window = 100
+N = int(sys.argv[1]); n = 10_000_000; window = 100; band = int(os.environ.get('SHARD_PROBE_BAND', '0'))
 ctx = L.Context(0)
 if N > 1:
     ctx.init_comm(L.Context.unique_id(), 0, N)
 rb, nl = ctx.partition(n)
-csr = G.randsym(n, row_begin=rb, n_local=nl)
+csr = G.randsym(n, band=band, row_begin=rb, n_local=nl)
 nnz_local = int(csr[0][-1])
 op = L.CsrOperator(ctx, *csr, n_cols=n, row_begin=rb)
 init = G.start_vector_fast(nl, 1, np.float64, rb)
@@ -46,7 +48,8 @@ eng.run()
 ctx.synchronize(); t0 = time.perf_counter(); eng.run(); ctx.synchronize(); wall = time.perf_counter() - t0
 ctx.set_profiling(True); eng.run(); st = eng.last_stats
 it = eng.getIterationCounts()[0]
-print(json.dumps({"ranks": N, "rows_per_rank": nl, "nnz_per_rank": nnz_local, "spmv_kernel": op.selected_spmv(),
+print(json.dumps({"ranks": N, "band": band, "rows_per_rank": nl, "nnz_per_rank": nnz_local, "spmv_kernel": op.selected_spmv(),
+                  "creation_ms_csr_pb_tiled": [round(op.autotune_ms_of(k), 4) for k in (0, 1, 2)], "tiled_row_blocks_all_own": list(op.tiled_layout()),
                   "spmv_ms_incl_local_copies": sorted(rounds)[1], "iterations": it, "window_wall_ms": wall * 1e3,
                   "per_iteration_us": {"operator_incl_local_copies": st["seconds_spmv"] / it * 1e6,
                                        "gather_copies_of_the_stand_in": st["seconds_comm_gather"] / it * 1e6,
