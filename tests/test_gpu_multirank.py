@@ -51,6 +51,7 @@ def test_overlapped_exchange_is_bit_identical_to_the_serial_issue_order(tmp_path
             assert ra[key]["vecs"] == rb[key]["vecs"], key
         assert ra["spmv_pb"] == rb["spmv_pb"] and ra["spmv_csr"] == rb["spmv_csr"]
         assert ra["laplace"] == rb["laplace"]
+        assert ra["tiled"] == rb["tiled"]     # the tiled kernel's two launches: under the gather / behind it on one stream
 
 
 # The CSR-stream and dense operators of a sharded context multiply the rank's OWN columns under the all-gather and add the
