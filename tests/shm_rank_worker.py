@@ -73,6 +73,15 @@ def main():
     out, it = L.Exponentiator(top, n3).run(-1j, inp)
     res["torus_expo"] = {"out": c2list(out), "itern": it, "row_begin": rb3}
     top.close()
+    # ... and once more through the 2-D tiled kernel (complex entries, sharded: two launches per product)
+    ctx.set_tuning("tl_force", "1")
+    ctx.set_tuning("pb_row_block", "40")
+    top2 = L.CsrOperator(ctx, *G.torus(N, rb3, nl3), n_cols=n3, row_begin=rb3, kernel=L.capi.SPMV_TILED)
+    out2, it2 = L.Exponentiator(top2, n3).run(-1j, inp)
+    res["torus_expo_tiled"] = {"out": c2list(out2), "itern": it2, "layout": list(top2.tiled_layout())}
+    top2.close()
+    ctx.set_tuning("tl_force", None)
+    ctx.set_tuning("pb_row_block", None)
     # --- matrix-free lattice operators: halo exchange instead of the all-gather
     #     (a) open 2-D Laplacian, (b) 3-D complex hops, periodic in every dimension (ring neighbours wrap around)
     side = 24

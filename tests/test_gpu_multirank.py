@@ -146,6 +146,10 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
     out = np.concatenate([list2c(r["torus_expo"]["out"]) for r in ranks])
     assert abs(ranks[0]["torus_expo"]["itern"] - o_it) <= 1
     assert np.max(np.abs(out - o_out)) <= 1e-10 * np.linalg.norm(inp)
+    out_t = np.concatenate([list2c(r["torus_expo_tiled"]["out"]) for r in ranks])
+    assert abs(ranks[0]["torus_expo_tiled"]["itern"] - o_it) <= 1
+    assert np.max(np.abs(out_t - o_out)) <= 1e-10 * np.linalg.norm(inp)
+    assert all(r["torus_expo_tiled"]["layout"][0] > 0 for r in ranks)
     # ---- matrix-free lattice operators (halo exchange) and the dense row block
     key = "stencil_laplace"
     for r in ranks[1:]:
