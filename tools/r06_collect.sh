@@ -12,3 +12,4 @@ for w in c3 c2; do cp gpurun_out/r06_convergence_${w}_defaults.json profiles/ 2>
 cp gpurun_out/r06_tl_xcd_probe.txt profiles/ 2>/dev/null
 ls -la profiles/r06_* | awk '{print $5, $9}'
 cp gpurun_out/r06_shard_compute_probe.txt gpurun_out/r06_convergence_c3_after_seven_processes.json profiles/ 2>/dev/null
+cp gpurun_out/r06_shard_probe_banded.txt profiles/r06_shard_compute_probe_banded.txt 2>/dev/null
