@@ -197,16 +197,17 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
             assert np.array_equal(y, y1.get()), kernel
             op1.close()
         llenv.delenv("LL_TL_FORCE")
-    ora10 = oracle.lanczos(band, G.start_vector(n10, 1), True, max_iteration=40)
+    ora10 = oracle.lanczos(band, G.start_vector(n10, 1), True, num_eigs=2, max_iteration=40)
     t0 = ranks[0]["tiled"]["fixed"]
     for r in ranks[1:]:
         assert r["tiled"]["fixed"]["vals"] == t0["vals"] and r["tiled"]["fixed"]["alpha"] == t0["alpha"]
     assert t0["iters"] == ora10["iter_counts"]
-    assert abs(t0["vals"][0] - ora10["eigenvalues"][0]) <= 1e-10 * abs(ora10["eigenvalues"][0])
+    assert np.max(np.abs(np.array(t0["vals"]) - ora10["eigenvalues"])) <= 1e-10 * np.max(np.abs(ora10["eigenvalues"]))
     m10 = len(ora10["alpha"])
     assert np.max(np.abs(np.array(t0["alpha"])[:m10] - ora10["alpha"])) <= 1e-10 * 30
-    v10 = np.concatenate([np.asarray(r["tiled"]["fixed"]["vecs"][0]) for r in ranks])
-    assert 1 - overlap(v10, ora10["eigenvectors"][0]) <= 1e-8
+    for i in range(2):   # (fixed windows of 40 iterations: Ritz vectors of the same Krylov spaces, the second pass with the first one locked)
+        v10 = np.concatenate([np.asarray(r["tiled"]["fixed"]["vecs"][i]) for r in ranks])
+        assert 1 - overlap(v10, ora10["eigenvectors"][i]) <= 1e-8
     # ---- 2 x 2 problem on `world` ranks (empty shards beyond the second rank)
     assert [r["tiny"]["n_local"] for r in ranks] == [1, 1] + [0] * (world - 2)
     lam = (5 + np.sqrt(5)) / 2
