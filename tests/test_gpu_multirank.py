@@ -239,7 +239,10 @@ def test_sharded_engine_with_several_ranks_on_one_gpu(tmp_path, oracle, ctx, wor
     assert 1 - overlap(stitch("dense_aligned", "vecs", 0), ora9["eigenvectors"][0]) <= 1e-8
 
 
-def test_bench_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("extra,kernel", [([], None),
+                                          (["--workload", "c3band", "--tuning", "tl_force=1", "--tuning", "spmv_kernel=tiled"], "tl_")],
+                         ids=["config4-shape", "banded-through-the-tiled-kernel"])
+def test_bench_two_ranks_on_one_gpu(tmp_path, extra, kernel):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, gloo control plane, id broadcast,
     row shards, sharded SpMV timing, timed Lanczos windows, reductions over ranks, one JSON line from rank 0) — with
     both ranks on the test box's single GPU through the host-staged test transport."""
@@ -251,7 +254,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, LL_COMM_PLUGIN=SHM_TRANSPORT, LL_BENCH_DEVICE="0", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--size", "300000", "--window", "30", "--spmv-reps", "3"]
+           "--size", "300000", "--window", "30", "--spmv-reps", "3"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -260,3 +263,5 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["config"]["n"] == 300000 and d["config"]["nnz"] == 15 * 300000
     assert d["value"] > 0 and abs(d["config"]["iterations_per_step"] - 30) < 1e-9
     assert d["cpu_baseline"] is None                # rank 0 at N = 1 only
+    if kernel:   # the sharded form of the 2-D tiled kernel ran (tl_force: a band of +-65536 columns on 150 000 rows per rank is not eligible)
+        assert kernel in d["spmv"]["kernel"], d["spmv"]["kernel"]
