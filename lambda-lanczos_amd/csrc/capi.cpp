@@ -70,6 +70,7 @@ bool tuning_apply(Tuning& t, const std::string& key, const std::string& v) {
   else if (key == "tl_xcd") t.tl_xcd_order = e ? d.tl_xcd_order : to_flag(v);
   else if (key == "tl_walk") t.tl_walk_modulo = e ? d.tl_walk_modulo : to_flag(v);
   else if (key == "ritz_tail") t.ritz_tail = e ? d.ritz_tail : to_flag(v);
+  else if (key == "event_in_launch") t.event_in_launch = e ? d.event_in_launch : to_flag(v);
   else if (key == "sweep_pipeline") t.sweep_pipeline = e ? d.sweep_pipeline : (int)std::max<long long>(0, std::min<long long>(2, to_ll(v)));
   else if (key == "pair_split") t.pair_split_vecs = e ? 0 : (int)std::max<long long>(0, to_ll(v));
   else if (key == "pair_max_stored") t.pair_max_stored = e ? 0 : (int)std::max<long long>(0, to_ll(v));

@@ -1124,10 +1124,11 @@ template <typename T> struct LoopState {
     // sharded: ONE all-reduce carries both iterations' columns; every rank then folds the same numbers to the same bits
     if (E.ctx->comm != nullptr) E.all_reduce(pcols, (size_t)ncols);
     launch_pair_fold(pcols, (int)P, (int)Lk, R, d_lambda, pp4, g2, gam, rho2sq, t3, e1, e2, rec3, rec4, nxt, hist_alpha, hist_beta, pfold,
-                     E.ctx->h_pinned + 4 * sa, E.ctx->h_pinned + 4 * sb, E.ctx->h_pinned + 16 + sa, E.ctx->h_pinned + 16 + sb, s);
+                     E.ctx->h_pinned + 4 * sa, E.ctx->h_pinned + 4 * sb, E.ctx->h_pinned + 16 + sa, E.ctx->h_pinned + 16 + sb, s,
+                     E.ctx->tune.event_in_launch ? ring.ev[sb] : nullptr);
     // ONE event for both iterations of the pair (their scalars are published by the same fold kernel): every event record is a marker
     // packet between two dependent kernels of a loop that is bound by exactly those gaps at small sizes
-    LL_HIP(hipEventRecord(ring.ev[sb], s));
+    if (!E.ctx->tune.event_in_launch) LL_HIP(hipEventRecord(ring.ev[sb], s));
     ev_of_slot[sa] = ev_of_slot[sb] = sb;
     timer.mark();
     slot_pair[sa] = slot_pair[sb] = true;
@@ -1210,9 +1211,10 @@ template <typename T> struct LoopState {
     }
     const double* pg = lag_pending ? hbuf[(k - 1) & 1] : nullptr;
     launch_lagged_fold(hb, (int)nb_total, (int)n_locked, R, hb + t_off, c0, c, c + 1, E.S(kScalAlpha + slot), pg,
-                       pg ? pg + t_off : nullptr, lag_c1, hist_alpha, hist_beta, d_lambda, E.ctx->h_pinned + 4 * slot, s);
+                       pg ? pg + t_off : nullptr, lag_c1, hist_alpha, hist_beta, d_lambda, E.ctx->h_pinned + 4 * slot, s,
+                       E.ctx->tune.event_in_launch ? ring.ev[slot] : nullptr);
     ev_of_slot[slot] = slot;
-    LL_HIP(hipEventRecord(ring.ev[slot], s));
+    if (!E.ctx->tune.event_in_launch) LL_HIP(hipEventRecord(ring.ev[slot], s));
     timer.mark();
     lag_pending = true;
     lag_k = k;
@@ -1244,10 +1246,15 @@ template <typename T> struct LoopState {
     }
     timer.mark();
     typename Engine<T>::DeferredAlpha da;
+    // the operator kernel that publishes iteration k-1's scalars completes that iteration's event itself where its launcher can
+    // (LL_LAUNCH_STOP: no marker packet between it and the sweep's first kernel); otherwise the event is recorded behind it
+    const bool ev_in_launch = pending && E.ctx->tune.event_in_launch;
+    if (ev_in_launch) E.ctx->stop_next = ring.ev[pend_slot];
     E.apply(x, y, offset, E.S(kScalAlpha + slot), true, fuse_launches ? &da : nullptr, pending ? &sc : nullptr);  // P0-P3
     if (pending) {
       ev_of_slot[pend_slot] = pend_slot;
-      LL_HIP(hipEventRecord(ring.ev[pend_slot], s));  // iteration k-1's scalars are on their way to the host
+      if (!ev_in_launch || E.ctx->stop_next != nullptr) LL_HIP(hipEventRecord(ring.ev[pend_slot], s));  // iteration k-1's scalars are on their way to the host
+      E.ctx->stop_next = nullptr;
       pending = false;
     }
     timer.mark();

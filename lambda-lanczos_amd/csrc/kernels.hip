@@ -161,12 +161,15 @@ int launch_spmv(const ll_operator& op, const T* x_full, const T* x_local, T* y, 
   const void* va = part == 1 ? op.d_val_own : (part == 2 ? op.d_val_rem : op.d_val);
   const int grid = spmv_grid(ntiles, sizeof(T));
   const ScaleIn<T> sc = scp ? *scp : ScaleIn<T>{};
+  // (the kernel that publishes an iteration's scalars may complete that iteration's event itself: ll_context::stop_next)
+  hipEvent_t stop = part != 1 ? op.ctx->stop_next : nullptr;
+  op.ctx->stop_next = stop ? nullptr : op.ctx->stop_next;
   if (op.rp64)
-    hipLaunchKernelGGL((spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, ntiles, tiles, (const int64_t*)rp, ci,
-                       (const T*)va, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, sc, part);
+    LL_LAUNCH_STOP(stop, (spmv_stream<T, int64_t>), dim3(grid), dim3(kBlock), 0, s, ntiles, tiles, (const int64_t*)rp, ci,
+                   (const T*)va, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, sc, part);
   else
-    hipLaunchKernelGGL((spmv_stream<T, int32_t>), dim3(grid), dim3(kBlock), 0, s, ntiles, tiles, (const int32_t*)rp, ci,
-                       (const T*)va, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, sc, part);
+    LL_LAUNCH_STOP(stop, (spmv_stream<T, int32_t>), dim3(grid), dim3(kBlock), 0, s, ntiles, tiles, (const int32_t*)rp, ci,
+                   (const T*)va, x_full, x_local, y, offset, part == 1 ? nullptr : dot_partials, sc, part);
   LL_HIP(hipGetLastError());
   return grid;
 }
@@ -785,9 +788,9 @@ __global__ __launch_bounds__(256) void lagged_fold_kernel(double* __restrict__ m
 }
 void launch_lagged_fold(double* m, int K, int L, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
                         double* alpha, const double* prev_g, const double* prev_t, const double* prev_c1,
-                        double* hist_alpha, double* hist_beta, const double* lambda, double* host_mapped, hipStream_t s) {
-  hipLaunchKernelGGL(lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, K, L, reals, t_out, c0, c0_out, c1, alpha, prev_g, prev_t,
-                     prev_c1, hist_alpha, hist_beta, lambda, host_mapped);
+                        double* hist_alpha, double* hist_beta, const double* lambda, double* host_mapped, hipStream_t s, hipEvent_t stop) {
+  LL_LAUNCH_STOP(stop, lagged_fold_kernel, dim3(1), dim3(256), 0, s, m, K, L, reals, t_out, c0, c0_out, c1, alpha, prev_g, prev_t,
+                 prev_c1, hist_alpha, hist_beta, lambda, host_mapped);
   LL_HIP(hipGetLastError());
 }
 
@@ -1613,9 +1616,9 @@ __global__ __launch_bounds__(256) void pair_fold_kernel(const double* __restrict
 void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,
                       const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
                       double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,
-                      double* gate_a, double* gate_b, hipStream_t s) {
-  hipLaunchKernelGGL(pair_fold_kernel, dim3(1), dim3(256), 0, s, m, P, L, reals, lambda, p4, g2, gam, rho2sq, n3sq, e1, e2, rec3, rec4, nxt,
-                     hist_alpha, hist_beta, scratch, host_a, host_b, gate_a, gate_b);
+                      double* gate_a, double* gate_b, hipStream_t s, hipEvent_t stop) {
+  LL_LAUNCH_STOP(stop, pair_fold_kernel, dim3(1), dim3(256), 0, s, m, P, L, reals, lambda, p4, g2, gam, rho2sq, n3sq, e1, e2, rec3, rec4, nxt,
+                 hist_alpha, hist_beta, scratch, host_a, host_b, gate_a, gate_b);
   LL_HIP(hipGetLastError());
 }
 #define LL_INST_PAIR(T)                                                                                                          \

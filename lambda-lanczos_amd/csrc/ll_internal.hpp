@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -13,6 +14,15 @@
 
 #include "../../include/lanczos_hip.h"
 #include "../../include/lanczos_hip_transport.h"
+
+// A launch whose completion IS an event: hipExtLaunchKernelGGL hangs the event on the kernel's own dispatch packet; hipEventRecord
+// behind the launch is a marker packet of its own between two dependent kernels (config 5: 5.9 -> 4.5 us in front of the next kernel,
+// 16.5 k -> 16.9 k it/s; n = 1e5: + 1.4 %; same-box A/B through the key event_in_launch).
+#define LL_LAUNCH_STOP(stop, kernel, grid, block, lds, s, ...)                                      \
+  do {                                                                                              \
+    if (stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, stop, 0, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                              \
+  } while (0)
 
 namespace ll {
 
@@ -179,6 +189,7 @@ struct Tuning {
   long long lagged_min_bytes = -1; // key lagged_min_bytes: shortest vector of the one-sweep form (-1 = default)
   int lagged_pieces = 0;           // key lagged_pieces: strip geometry of the one-sweep kernel (0 = by length)
   bool lagged_gs = true;           // LL_FUSE_LAUNCHES=1: fused folds but the two-sweep Gram-Schmidt form; 2 (default): one sweep
+  bool event_in_launch = true;     // key event_in_launch = 0: iteration events as marker packets behind the publishing kernel (A/B)
   bool ritz_tail = true;           // key ritz_tail = 0: a pair pending at the end of a pass is completed by sweeps of its own instead of entering the Ritz GEMV through its raw vectors (A/B)
   int sweep_pipeline = 1;          // key sweep_pipeline: 1 (default) the software-pipelined pair sweep on streaming vectors (> ~9 MiB), 0 never (A/B: same bits), 2 on every length (parity tests on small cases)
   bool pair_gs = true;             // LL_PAIR_GS=0: never two iterations per sweep (the one-sweep form throughout; A/B and parity hunts)
@@ -264,6 +275,8 @@ struct ll_context {
   void* h_cb = nullptr;          // pinned [in | out] buffers of the host-callback operator
   size_t cb_cap = 0;
   hipEvent_t ev_cb = nullptr;    // recorded after the upload of a callback result
+  hipEvent_t stop_next = nullptr;  // set by the loop in front of an operator application whose kernel publishes an iteration's scalars: that
+                                   // launch completes the event itself (LL_LAUNCH_STOP) and clears the field; still set afterwards = not taken
   void* ensure_cb_stage(size_t bytes);
   void sync();
 };
@@ -530,14 +543,14 @@ template <typename T> void launch_fill_ptrs(const T** tab, int start, int count,
 void launch_pair_fold(const double* m, int P, int L, int reals, const double* lambda, const double* p4, const double* g2, const double* gam,
                       const double* rho2sq, const double* n3sq, const double* e1, const double* e2, double* rec3, double* rec4,
                       double* nxt, double* hist_alpha, double* hist_beta, double* scratch, double* host_a, double* host_b,
-                      double* gate_a, double* gate_b, hipStream_t s);
+                      double* gate_a, double* gate_b, hipStream_t s, hipEvent_t stop = nullptr);
 // Fold of a lagged iteration (K = L + k columns: L locked eigenvectors with eigenvalues lambda[0..L), then k Lanczos
 // vectors; m: reals * K folded columns, *c0 = ||w||^2, copied to *c0_out): compensated coefficients in place,
 // *c1 = *c0 - |g|^2, t_out (reals * (K + 1) + 1) for the next sweep, alpha / beta appended to hist_*[k - 1], *alpha
 // replaced by its corrected value, the iteration's four scalars published.  prev_* = nullptr after a clean iteration.
 void launch_lagged_fold(double* m, int K, int L, int reals, double* t_out, const double* c0, double* c0_out, double* c1,
                         double* alpha, const double* prev_g, const double* prev_t, const double* prev_c1,
-                        double* hist_alpha, double* hist_beta, const double* lambda, double* host_mapped, hipStream_t s);
+                        double* hist_alpha, double* hist_beta, const double* lambda, double* host_mapped, hipStream_t s, hipEvent_t stop = nullptr);
 // w -= sum_j h_j u_j over the segments; partial ||w||^2 per workgroup. h: reals*nb doubles on the device.
 template <typename T>
 int launch_maxpy(int64_t n, T* w, const BasisSegs<T>& segs, const double* h, const NormRefs* pred, double* partials,
