@@ -34,6 +34,9 @@ CASES = list(range(36))
 if os.environ.get("LL_FUZZ_SEEDS"):
     _a, _b = os.environ["LL_FUZZ_SEEDS"].split(":")
     CASES = CASES + [c for c in range(int(_a), int(_b)) if c >= 36]
+    EXTRA = [c for c in range(int(_a), int(_b)) if c >= 36]
+else:
+    EXTRA = []
 
 
 # geometry "streaming": LL_BLAS_SMALL_BYTES=0 puts these small problems on the streaming kernels, i.e. (orth mode 0) on the
@@ -93,7 +96,7 @@ def test_random_problem_matches_oracle(ctx, oracle, seed, geometry, llenv):
     op.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", list(range(8)) + EXTRA)
 def test_random_exponentiator_matches_oracle(ctx, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     n = int(rng.choice([1, 2, 9, 120, 1500]))
@@ -105,13 +108,26 @@ def test_random_exponentiator_matches_oracle(ctx, oracle, seed):
     op = L.CsrOperator(ctx, rp, ci, va)
     ex = L.Exponentiator(op, n)
     ex.full_orthogonalize = bool(rng.integers(2))
+    kw = {}
+    if seed >= 8:   # the extra seeds of a stress run: a real exponent never meets the reference's stop test (EX:154) and would run n
+        ex.max_iteration = min(n, 60)   # iterations with an O(k^3) host step each — bound the run on both sides
+        kw["max_iteration"] = min(n, 60)
     out, it = ex.run(a_coef, inp)
-    o_out, o_it, _ = oracle.expo((rp, ci, va), a_coef, inp, full_orthogonalize=ex.full_orthogonalize)
+    o_out, o_it, _ = oracle.expo((rp, ci, va), a_coef, inp, full_orthogonalize=ex.full_orthogonalize, **kw)
     assert abs(it - o_it) <= 1
-    assert np.linalg.norm(out - o_out) <= 1e-8 * max(np.linalg.norm(o_out), 1e-300)
+    if it == o_it:
+        assert np.linalg.norm(out - o_out) <= 1e-8 * max(np.linalg.norm(o_out), 1e-300)
+    else:
+        # The reference stops when SUCCESSIVE approximations overlap to eps = 1e2 * epsilon (EX:147-158) — a test that is quadratic in
+        # their difference, so two successive iterates differ by up to sqrt(2 eps) ~ 2e-7 of their norm; where rounding puts the stop one
+        # iteration apart (stress seed 239: 38 against 37 iterations, 6e-8 apart, each within 6e-8 of the exact exponential) the two
+        # outputs are held to the reference's own criterion.
+        ov = abs(np.vdot(out, o_out)) / (np.linalg.norm(out) * np.linalg.norm(o_out))
+        assert 1 - ov <= 10 * ex.eps
     wv, v = np.linalg.eigh(a.toarray())
     exact = v @ (np.exp(a_coef * wv) * (v.conj().T @ inp))
-    assert np.linalg.norm(out - exact) <= 1e-6 * np.linalg.norm(exact)
+    if "max_iteration" not in kw or it < kw["max_iteration"]:   # (a run cut off by the bound of the stress seeds is compared with the oracle only)
+        assert np.linalg.norm(out - exact) <= 1e-6 * np.linalg.norm(exact)
     op.close()
 
 
@@ -142,7 +158,7 @@ def test_full_krylov_space_many_basis_groups(ctx, oracle, dtype, side):
     op.close()
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(24)) + EXTRA)
 def test_random_lattice_operator_matches_oracle(ctx, oracle, seed):
     """Random lattices (1-3 dimensions, open/periodic mix, lengths from 1 up, complex hops, on-site terms, all four
     storage types): one apply of the matrix-free operator against the oracle's CSR row loop on the equivalent matrix,
