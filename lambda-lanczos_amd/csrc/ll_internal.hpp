@@ -3,7 +3,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
+#if defined(__HIPCC__)
+#include <hip/hip_ext.h>  // hipExtLaunchKernelGGL (device-code translation units only: the host-only sanitizer builds use g++)
+#endif
 
 #include <cstdint>
 #include <cstdio>
@@ -15,6 +17,7 @@
 #include "../../include/lanczos_hip.h"
 #include "../../include/lanczos_hip_transport.h"
 
+#if defined(__HIPCC__)
 // A launch whose completion IS an event: hipExtLaunchKernelGGL hangs the event on the kernel's own dispatch packet; hipEventRecord
 // behind the launch is a marker packet of its own between two dependent kernels (config 5: 5.9 -> 4.5 us in front of the next kernel,
 // 16.5 k -> 16.9 k it/s; n = 1e5: + 1.4 %; same-box A/B through the key event_in_launch).
@@ -23,6 +26,7 @@
     if (stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, stop, 0, __VA_ARGS__);    \
     else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                              \
   } while (0)
+#endif
 
 namespace ll {
 
